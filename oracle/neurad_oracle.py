@@ -1,0 +1,518 @@
+"""CPU restatement (numpy, fp32) of NeuRAD's volumetric ray-marching hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package (``neurad_studio_amd``)
+imports this module: it is the *checker* used by ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``.
+
+Every function restates one row of SURVEY.md §8(a) and cites the reference
+``file:line`` (paths relative to the neurad-studio tree) it follows.  The parity
+target is the reference's ``implementation="torch"`` branch (fp32), NOT tiny-cuda-nn.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against golden
+vectors produced by importing the reference itself (``oracle/make_golden.py`` ->
+``tests/golden/*.npz``).  Compositing (nerfacc 0.5.2, un-vendored, absent from the
+reference tree, and replaced by a 0.5 placeholder on CPU -- models/neurad.py:713-715)
+has no reference output to pin against: for those two functions parity is pinned only
+against the in-repo torch equivalents ``RaySamples.get_weights`` (cameras/rays.py:188-210)
+and is otherwise "parity unpinned" (see DESIGN.md).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+f32 = np.float32
+PRIME_Y = np.int64(2654435761)  # field_components/encodings.py:419
+PRIME_Z = np.int64(805459861)
+
+
+# --------------------------------------------------------------------------------------
+# H1  HashEncoding (field_components/encodings.py:326-471)
+# --------------------------------------------------------------------------------------
+def hash_scalings(num_levels: int, min_res: int, max_res: int) -> np.ndarray:
+    """``scalings_l = floor(min_res * g**l)``, ``g = exp((ln max - ln min)/(L-1))``.
+
+    encodings.py:347-350.  The reference evaluates ``growth_factor ** levels`` as
+    (numpy float64 scalar) ** (torch int64 tensor) -> torch promotes to the default
+    dtype float32, multiplies by ``min_res`` and floors, all in fp32.
+    """
+    if num_levels > 1:
+        growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1))
+    else:
+        growth = 1.0
+    levels = np.arange(num_levels)
+    # torch: (python float) ** (int64 tensor) -> float32 tensor computed by powf(float(g), float(l))
+    g = np.power(f32(growth), levels.astype(f32), dtype=f32)
+    return np.floor(f32(min_res) * g).astype(f32)
+
+
+def hash_indices(corner: np.ndarray, table_size: int, level_offset: np.ndarray) -> np.ndarray:
+    """``hash_fn`` (encodings.py:408-423): int32 corners * int64 primes, xor, mod T, + l*T."""
+    c = corner.astype(np.int64)
+    x = c[..., 0] ^ (c[..., 1] * PRIME_Y) ^ (c[..., 2] * PRIME_Z)
+    x = np.mod(x, np.int64(table_size))
+    return x + level_offset
+
+
+def hashgrid_corner_indices(x: np.ndarray, scalings: np.ndarray, table_size: int):
+    """All 8 corner indices + interpolation offsets of ``pytorch_fwd`` (encodings.py:425-444).
+
+    Returns (idx [N,L,8] int64 in the reference's corner order 0..7, offset [N,L,3] fp32).
+    """
+    x = np.asarray(x, f32)
+    L = scalings.shape[0]
+    scaled = x[:, None, :] * scalings.reshape(L, 1).astype(f32)  # [N,L,3]
+    c = np.ceil(scaled).astype(np.int32)
+    f = np.floor(scaled).astype(np.int32)
+    offset = scaled - f.astype(f32)
+    lo = (np.arange(L, dtype=np.int64) * table_size)[None, :]
+
+    def pick(sx, sy, sz):
+        return np.stack([sx[..., 0], sy[..., 1], sz[..., 2]], axis=-1)
+
+    combos = [  # encodings.py:437-444
+        (c, c, c), (c, f, c), (f, f, c), (f, c, c), (c, c, f), (c, f, f), (f, f, f), (f, c, f),
+    ]
+    idx = np.stack([hash_indices(pick(*cb), table_size, lo) for cb in combos], axis=-1)
+    return idx, offset
+
+
+def hashgrid_fwd(x: np.ndarray, table: np.ndarray, scalings: np.ndarray, table_size: int) -> np.ndarray:
+    """``HashEncoding.pytorch_fwd`` (encodings.py:425-466).  x [N,3] in [0,1] -> [N, L*F]."""
+    idx, o = hashgrid_corner_indices(x, scalings, table_size)
+    t = np.asarray(table, f32)
+    fc = [t[idx[..., k]] for k in range(8)]  # each [N,L,F]
+    ox, oy, oz = o[..., 0:1], o[..., 1:2], o[..., 2:3]
+    one = f32(1.0)
+    f03 = fc[0] * ox + fc[3] * (one - ox)
+    f12 = fc[1] * ox + fc[2] * (one - ox)
+    f56 = fc[5] * ox + fc[6] * (one - ox)
+    f47 = fc[4] * ox + fc[7] * (one - ox)
+    f0312 = f03 * oy + f12 * (one - oy)
+    f4756 = f47 * oy + f56 * (one - oy)
+    enc = f0312 * oz + f4756 * (one - oz)
+    return enc.reshape(x.shape[0], -1).astype(f32)
+
+
+def hashgrid_bwd(x, grad_out, scalings, table_size, n_rows, n_feat) -> np.ndarray:
+    """dL/d(hash_table) of :func:`hashgrid_fwd` (autograd of encodings.py:446-464): scatter-add of
+    the 8 trilinear corner weights times the upstream gradient.  Accumulates in float64."""
+    idx, o = hashgrid_corner_indices(x, scalings, table_size)
+    N, L = idx.shape[:2]
+    g = np.asarray(grad_out, np.float64).reshape(N, L, n_feat)
+    ox, oy, oz = (o[..., k].astype(np.float64) for k in range(3))
+    wx = {"c": ox, "f": 1 - ox}
+    wy = {"c": oy, "f": 1 - oy}
+    wz = {"c": oz, "f": 1 - oz}
+    order = ["ccc", "cfc", "ffc", "fcc", "ccf", "cff", "fff", "fcf"]
+    out = np.zeros((n_rows, n_feat), np.float64)
+    for k, s in enumerate(order):
+        w = wx[s[0]] * wy[s[1]] * wz[s[2]]
+        np.add.at(out, idx[..., k].reshape(-1), (w[..., None] * g).reshape(-1, n_feat))
+    return out.astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# F3  SHEncoding (encodings.py:797-805 -> utils/math.py:31-94), levels=4
+# --------------------------------------------------------------------------------------
+def sh_deg4(d: np.ndarray) -> np.ndarray:
+    """16 real SH components of ``d`` -- NB the torch path feeds ``(dir+1)/2`` unchanged
+    (fields/base_field.py:136-142, neurad_field.py:140)."""
+    d = np.asarray(d, f32)
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    xx, yy, zz = x * x, y * y, z * z
+    c = np.zeros(d.shape[:-1] + (16,), f32)
+    c[..., 0] = 0.28209479177387814
+    c[..., 1] = f32(0.4886025119029199) * y
+    c[..., 2] = f32(0.4886025119029199) * z
+    c[..., 3] = f32(0.4886025119029199) * x
+    c[..., 4] = f32(1.0925484305920792) * x * y
+    c[..., 5] = f32(1.0925484305920792) * y * z
+    c[..., 6] = f32(0.9461746957575601) * zz - f32(0.31539156525251999)
+    c[..., 7] = f32(1.0925484305920792) * x * z
+    c[..., 8] = f32(0.5462742152960396) * (xx - yy)
+    c[..., 9] = f32(0.5900435899266435) * y * (f32(3) * xx - yy)
+    c[..., 10] = f32(2.890611442640554) * x * y * z
+    c[..., 11] = f32(0.4570457994644658) * y * (f32(5) * zz - f32(1))
+    c[..., 12] = f32(0.3731763325901154) * z * (f32(5) * zz - f32(3))
+    c[..., 13] = f32(0.4570457994644658) * x * (f32(5) * zz - f32(1))
+    c[..., 14] = f32(1.445305721320277) * z * (xx - yy)
+    c[..., 15] = f32(0.5900435899266435) * x * (xx - f32(3) * yy)
+    return c
+
+
+# --------------------------------------------------------------------------------------
+# F2  MLP.pytorch_fwd (field_components/mlp.py:159-178): Linear(+bias)+ReLU ... Linear
+# --------------------------------------------------------------------------------------
+def mlp_fwd(x: np.ndarray, weights: Sequence[np.ndarray], biases: Sequence[Optional[np.ndarray]],
+            return_hidden: bool = False):
+    """weights[i] is ``[out,in]`` like ``nn.Linear.weight``; ReLU between layers, none at the end."""
+    h = np.asarray(x, f32)
+    hidden = [h]
+    n = len(weights)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        h = h @ np.asarray(w, f32).T
+        if b is not None:
+            h = h + np.asarray(b, f32)
+        if i < n - 1:
+            h = np.maximum(h, f32(0))
+        hidden.append(h)
+    return (h, hidden) if return_hidden else h
+
+
+def mlp_bwd(hidden: List[np.ndarray], weights, grad_out):
+    """Backward of :func:`mlp_fwd` -> (dx, [dW], [db]) in float64 accumulate."""
+    g = np.asarray(grad_out, np.float64)
+    n = len(weights)
+    dWs, dbs = [None] * n, [None] * n
+    for i in reversed(range(n)):
+        if i < n - 1:
+            g = g * (hidden[i + 1] > 0)
+        dWs[i] = (g.T @ hidden[i].astype(np.float64)).astype(f32)
+        dbs[i] = g.sum(0).astype(f32)
+        g = g @ np.asarray(weights[i], np.float64)
+    return g.astype(f32), dWs, dbs
+
+
+# --------------------------------------------------------------------------------------
+# H2  Frustums.get_fast_isotropic_gaussian(M=1) (cameras/rays.py:109-124)
+# --------------------------------------------------------------------------------------
+def fast_isotropic_gaussian(origins, directions, pixel_area, starts, ends):
+    """origins/directions [R,3], pixel_area [R], starts/ends [R,S] -> mean [R,S,3], std [R,S]."""
+    o, d = np.asarray(origins, f32), np.asarray(directions, f32)
+    s, e = np.asarray(starts, f32), np.asarray(ends, f32)
+    dist = (e - s) / f32(2)
+    t = s + f32(1) * dist
+    mean = o[:, None, :] + d[:, None, :] * t[..., None]
+    area = np.asarray(pixel_area, f32).reshape(-1, 1) * np.power(t, f32(2))
+    std = np.power(area * dist, f32(1 / 3), dtype=f32)
+    return mean.astype(f32), std.astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# H3  ScaledSceneContraction(order=inf) on GaussiansStd (spatial_distortions.py:103-141)
+# --------------------------------------------------------------------------------------
+def contract_gaussian(mean, std, scale: float):
+    """-> positions in [0,1]^3 and contracted std."""
+    m = np.asarray(mean, f32) / f32(scale)
+    s = np.asarray(std, f32) / f32(scale)
+    mag = np.max(np.abs(m), axis=-1, keepdims=True)
+    mask = mag < 1
+    cm = np.maximum(mag, f32(1))
+    m2 = np.where(mask, m, (f32(2) - (f32(1) / cm)) * (m / cm))
+    sc = (np.power(f32(2) * cm - f32(1), f32(1 / 3), dtype=f32) / cm) ** 2
+    s2 = np.where(mask[..., 0], s, s * sc[..., 0])
+    m2 = (m2 + f32(2)) / f32(4)
+    s2 = s2 / f32(4)
+    return m2.astype(f32), s2.astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# H4  NeuRADHashEncoding._rescale_grid_features (field_components/neurad_encoding.py:297-304), M=1
+# --------------------------------------------------------------------------------------
+def rescale_grid_features(feat, std, scalings, n_feat: int):
+    """feat [N, L*F], std [N] -> feat * 1/max(1, 2*scalings_l*std)."""
+    L = scalings.shape[0]
+    w = f32(1) / np.maximum(scalings[None, :].astype(f32) * f32(2) * np.asarray(std, f32).reshape(-1, 1), f32(1))
+    return (feat.reshape(-1, L, n_feat) * w[..., None]).reshape(-1, L * n_feat).astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# Parameter containers (state_dict layout of SURVEY.md Appendix B)
+# --------------------------------------------------------------------------------------
+@dataclass
+class GridParams:
+    table: np.ndarray  # [L*T, F]
+    num_levels: int
+    min_res: int
+    max_res: int
+    log2_hashmap_size: int
+
+    @property
+    def table_size(self):
+        return 1 << self.log2_hashmap_size
+
+    @property
+    def n_feat(self):
+        return self.table.shape[1]
+
+    @property
+    def scalings(self):
+        return hash_scalings(self.num_levels, self.min_res, self.max_res)
+
+
+@dataclass
+class FieldParams:
+    """NeuRADField (fields/neurad_field.py:78-152) parameters, no actors."""
+
+    grid: GridParams
+    static_scale: float
+    geo_w: List[np.ndarray]
+    geo_b: List[np.ndarray]
+    feat_w: List[np.ndarray]
+    feat_b: List[np.ndarray]
+    beta: float = 20.0
+    beta_min: float = 1e-4
+    use_sdf: bool = True
+
+
+@dataclass
+class ProposalParams:
+    """NeuRADProposalField (fields/neurad_field.py:182-216)."""
+
+    grid: GridParams
+    static_scale: float
+    decoder_w: np.ndarray  # [1, L*F], no bias
+
+
+def encode_static(grid: GridParams, static_scale, origins, directions, pixel_area, starts, ends):
+    """H2 -> H3 -> H1 -> H4 (neurad_encoding.py:164-169,265-268).  -> [R*S, L*F]"""
+    mean, std = fast_isotropic_gaussian(origins, directions, pixel_area, starts, ends)
+    pos, cstd = contract_gaussian(mean, std, static_scale)
+    feat = hashgrid_fwd(pos.reshape(-1, 3), grid.table, grid.scalings, grid.table_size)
+    return rescale_grid_features(feat, cstd.reshape(-1), grid.scalings, grid.n_feat)
+
+
+def sigmoid(x):
+    x = np.asarray(x, f32)
+    return (f32(1) / (f32(1) + np.exp(-x))).astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# F1/F4  NeuRADField.forward (fields/neurad_field.py:128-152), SigmoidDensity (model_components/utils.py:21-41)
+# --------------------------------------------------------------------------------------
+def field_fwd(p: FieldParams, origins, directions, pixel_area, starts, ends) -> Dict[str, np.ndarray]:
+    """-> {"feature" [R,S,C], "sdf" [R,S], "alpha" [R,S]}  (or "density" when use_sdf=False)."""
+    R, S = np.asarray(starts).shape
+    enc = encode_static(p.grid, p.static_scale, origins, directions, pixel_area, starts, ends)
+    geo = mlp_fwd(enc, p.geo_w, p.geo_b)
+    geo_out, geo_emb = geo[:, :1], geo[:, 1:]
+    d01 = (np.asarray(directions, f32) + f32(1)) / f32(2)  # base_field.py:136-142
+    sh = sh_deg4(np.broadcast_to(d01[:, None, :], (R, S, 3)).reshape(-1, 3))
+    feat = geo_emb + mlp_fwd(np.concatenate([geo_emb, sh], -1), p.feat_w, p.feat_b)
+    out = {"feature": feat.reshape(R, S, -1).astype(f32)}
+    if p.use_sdf:
+        beta = f32(abs(p.beta) + p.beta_min)
+        out["sdf"] = geo_out.reshape(R, S)
+        out["alpha"] = sigmoid(-geo_out.reshape(R, S) * beta)
+    else:
+        out["density"] = np.exp(geo_out.reshape(R, S)).astype(f32)  # trunc_exp fwd, activations.py:33-35
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# S2  NeuRADProposalField.get_density (fields/neurad_field.py:208-213)
+# --------------------------------------------------------------------------------------
+def proposal_density(p: ProposalParams, origins, directions, pixel_area, starts, ends) -> np.ndarray:
+    R, S = np.asarray(starts).shape
+    enc = encode_static(p.grid, p.static_scale, origins, directions, pixel_area, starts, ends)
+    return np.exp(enc @ np.asarray(p.decoder_w, f32).T).reshape(R, S).astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# S3  RaySamples.get_weights (cameras/rays.py:188-210)
+# --------------------------------------------------------------------------------------
+def weights_from_density(deltas, densities) -> np.ndarray:
+    dd = np.asarray(deltas, f32) * np.asarray(densities, f32)
+    alphas = f32(1) - np.exp(-dd)
+    # torch.cumsum on CPU accumulates fp32 in float64 (at::acc_type<float,false>) and rounds each output
+    cs = np.cumsum(dd[..., :-1].astype(np.float64), axis=-1).astype(f32)
+    trans = np.exp(-np.concatenate([np.zeros_like(dd[..., :1]), cs], -1))
+    return np.nan_to_num(alphas * trans).astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# C1  nerfacc 0.5.2 dense-mode restatement (un-vendored; call sites models/neurad.py:716-723)
+# --------------------------------------------------------------------------------------
+def render_weight_from_alpha(alphas):
+    """``T_i = prod_{j<i}(1-a_j)``, ``w = T a``  (exclusive cumprod).  -> (weights, trans)"""
+    a = np.asarray(alphas, f32)
+    om = (f32(1) - a).astype(np.float64)
+    trans = np.concatenate([np.ones_like(om[..., :1]), np.cumprod(om[..., :-1], axis=-1)], -1).astype(f32)
+    return (trans * a).astype(f32), trans
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas):
+    """``T_i = exp(-sum_{j<i} s_j d_j)``, ``a = 1-exp(-s d)``.  -> (weights, trans, alphas)"""
+    sd = np.asarray(sigmas, f32) * (np.asarray(t_ends, f32) - np.asarray(t_starts, f32))
+    alphas = f32(1) - np.exp(-sd)
+    cs = np.cumsum(sd[..., :-1].astype(np.float64), axis=-1).astype(f32)
+    trans = np.exp(-np.concatenate([np.zeros_like(sd[..., :1]), cs], -1)).astype(f32)
+    return (trans * alphas).astype(f32), trans, alphas.astype(f32)
+
+
+def accumulate_along_rays(weights, values=None):
+    """dense mode (ray_indices=None): ``sum_S w * v`` -> [R,C] (C=1 when values is None)."""
+    w = np.asarray(weights, f32)
+    if values is None:
+        return w.astype(np.float64).sum(-1, keepdims=True).astype(f32)
+    return (w[..., None].astype(np.float64) * np.asarray(values, np.float64)).sum(-2).astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# C2  get_nff_outputs compositing (models/neurad.py:377-395,727-734; renderers.py:59-90,322-350)
+# --------------------------------------------------------------------------------------
+def composite(weights, features, starts, ends):
+    """weights [R,S] (from C1), features [R,S,C] -> features [R,C], depth [R,1], accumulation [R,1].
+
+    acc = sum(w); the residual 1-acc goes onto the last (sky) sample; features use all S samples;
+    depth drops the sky sample and is NOT normalised (render_depth_simple).
+    """
+    w = np.asarray(weights, f32)
+    acc = w.astype(np.float64).sum(-1, keepdims=True).astype(f32)
+    w2 = np.concatenate([w[..., :-1], w[..., -1:] + f32(1) - acc], -1)
+    feat = (w2[..., None].astype(np.float64) * np.asarray(features, np.float64)).sum(-2).astype(f32)
+    steps = (np.asarray(starts, f32) + np.asarray(ends, f32)) / f32(2)
+    depth = (w2[..., :-1].astype(np.float64) * steps[..., :-1]).sum(-1, keepdims=True).astype(f32)
+    return feat, depth, acc
+
+
+def depth_expected(weights, starts, ends):
+    """DepthRenderer("expected") dense branch (model_components/renderers.py:398-416)."""
+    w = np.asarray(weights, f32)
+    steps = (np.asarray(starts, f32) + np.asarray(ends, f32)) / f32(2)
+    d = (w * steps).sum(-1, keepdims=True) / (w.sum(-1, keepdims=True) + f32(1e-10))
+    return np.clip(d, steps.min(), steps.max()).astype(f32)
+
+
+# --------------------------------------------------------------------------------------
+# S1  SpacedSampler / PowerSampler (ray_samplers.py:80-132,838-852; utils/math.py:541-579)
+# --------------------------------------------------------------------------------------
+def power_fn(x, lam: float):
+    x = np.asarray(x, f32)
+    lam_1 = abs(lam - 1)
+    return (f32(lam_1 / lam) * (np.power(x / f32(lam_1) + f32(1), f32(lam), dtype=f32) - f32(1))).astype(f32)
+
+
+def inv_power_fn(x, lam: float, eps: float = 1e-10):
+    x = np.asarray(x, f32)
+    lam_1 = abs(lam - 1)
+    base = np.maximum(x * f32(lam) / f32(lam_1) + f32(1), f32(eps))
+    return ((np.power(base, f32(1 / lam), dtype=f32) - f32(1)) * f32(lam_1)).astype(f32)
+
+
+@dataclass
+class Spacing:
+    """the ``spacing_to_euclidean_fn`` closure of ray_samplers.py:117-118."""
+
+    s_near: np.ndarray  # [R,1]
+    s_far: np.ndarray
+    lam: float
+    scaling: float
+
+    def __call__(self, x):
+        x = np.asarray(x, f32)
+        return (inv_power_fn(x * self.s_far + (f32(1) - x) * self.s_near, self.lam) / f32(self.scaling)).astype(f32)
+
+
+def power_sampler(nears, fars, num_samples: int, lam: float = -1.0, scaling: float = 0.1, t_rand=None):
+    """-> (spacing bins [R,S+1], euclidean bins [R,S+1], Spacing).  ``t_rand`` [R,S+1] injects the
+    training-mode stratified jitter (ray_samplers.py:104-112); None = eval mode."""
+    nears = np.asarray(nears, f32).reshape(-1, 1)
+    fars = np.asarray(fars, f32).reshape(-1, 1)
+    bins = np.linspace(0.0, 1.0, num_samples + 1, dtype=f32)[None, :]
+    if t_rand is not None:
+        centers = (bins[..., 1:] + bins[..., :-1]) / f32(2)
+        upper = np.concatenate([centers, bins[..., -1:]], -1)
+        lower = np.concatenate([bins[..., :1], centers], -1)
+        bins = lower + (upper - lower) * np.asarray(t_rand, f32)
+    sp = Spacing(power_fn(nears * f32(scaling), lam), power_fn(fars * f32(scaling), lam), lam, scaling)
+    bins = np.broadcast_to(bins, (nears.shape[0], num_samples + 1)).astype(f32)
+    return bins, sp(bins), sp
+
+
+# --------------------------------------------------------------------------------------
+# S4  PDFSampler.generate_ray_samples (ray_samplers.py:280-376), include_original=False
+# --------------------------------------------------------------------------------------
+def pdf_sample(weights, spacing_bins, num_samples: int, spacing: Spacing, histogram_padding: float = 0.01,
+               eps: float = 1e-5, rand=None):
+    """weights [R,Sp], spacing_bins [R,Sp+1] -> (new spacing bins [R,num_samples+1], euclidean bins).
+    ``rand`` [R,1] (single_jitter) or [R,num_samples+1] = training-mode jitter in [0,1); None = eval."""
+    w = np.asarray(weights, f32) + f32(histogram_padding)
+    wsum = w.sum(-1, keepdims=True, dtype=f32)
+    padding = np.maximum(f32(eps) - wsum, f32(0))
+    w = w + padding / f32(w.shape[-1])
+    wsum = wsum + padding
+    pdf = w / wsum
+    cdf = np.minimum(f32(1), np.cumsum(pdf.astype(np.float64), -1).astype(f32))
+    cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf], -1)
+    nb = num_samples + 1
+    u = np.linspace(0.0, 1.0 - (1.0 / nb), nb, dtype=f32)
+    if rand is not None:
+        u = u[None, :] + np.asarray(rand, f32) / f32(nb)
+    else:
+        u = u + f32(1.0 / (2 * nb))
+    u = np.broadcast_to(u, (cdf.shape[0], nb)).astype(f32)
+    existing = np.asarray(spacing_bins, f32)
+    inds = np.stack([np.searchsorted(cdf[r], u[r], side="right") for r in range(cdf.shape[0])])
+    hi = existing.shape[-1] - 1
+    below = np.clip(inds - 1, 0, hi)
+    above = np.clip(inds, 0, hi)
+    cdf0 = np.take_along_axis(cdf, below, -1)
+    b0 = np.take_along_axis(existing, below, -1)
+    cdf1 = np.take_along_axis(cdf, above, -1)
+    b1 = np.take_along_axis(existing, above, -1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = (u - cdf0) / (cdf1 - cdf0)
+    t = np.clip(np.nan_to_num(t, nan=0.0), 0, 1).astype(f32)
+    bins = (b0 + t * (b1 - b0)).astype(f32)
+    return bins, spacing(bins)
+
+
+# --------------------------------------------------------------------------------------
+# S5 + M1  ProposalNetworkSampler (ray_samplers.py:623-666) driven as NeuRADModel._get_ray_samples
+#          (models/neurad.py:443-459), incl. the late-binding quirk of models/neurad.py:248
+# --------------------------------------------------------------------------------------
+@dataclass
+class SamplerOutput:
+    starts: np.ndarray  # [R,S] final euclidean starts (sky-stretched)
+    ends: np.ndarray
+    spacing_starts: np.ndarray
+    spacing_ends: np.ndarray
+    prop_weights: List[np.ndarray] = field(default_factory=list)
+    prop_starts: List[np.ndarray] = field(default_factory=list)
+    prop_ends: List[np.ndarray] = field(default_factory=list)
+    prop_spacing: List[np.ndarray] = field(default_factory=list)
+
+
+def proposal_sampler(props: Sequence[ProposalParams], origins, directions, pixel_area, nears, fars,
+                     num_proposal_samples=(128, 64), num_nerf_samples=32, lam=-1.0, scaling=0.1,
+                     sky_distance=20000.0, late_binding_quirk=True, stretch_sky=True, rands=None) -> SamplerOutput:
+    """eval-mode (deterministic) sampler chain unless ``rands`` = [t_rand0, rand1, rand2] is given.
+
+    ``late_binding_quirk``: the reference's ``density_fns`` list comprehension closes over the loop
+    variable, so BOTH rounds evaluate ``proposal_fields[-1]`` (models/neurad.py:248).
+    """
+    fars = np.minimum(np.asarray(fars, f32), f32(sky_distance))  # neurad.py:445-446
+    n = len(num_proposal_samples)
+    rands = rands if rands is not None else [None] * (n + 1)
+    bins, eu, sp = power_sampler(nears, fars, num_proposal_samples[0], lam, scaling, rands[0])
+    out_w, out_s, out_e, out_sp = [], [], [], []
+    for i in range(n):
+        p = props[-1] if late_binding_quirk else props[i]
+        dens = proposal_density(p, origins, directions, pixel_area, eu[:, :-1], eu[:, 1:])
+        w = weights_from_density(eu[:, 1:] - eu[:, :-1], dens)
+        out_w.append(w), out_s.append(eu[:, :-1]), out_e.append(eu[:, 1:]), out_sp.append(bins)
+        ns = num_proposal_samples[i + 1] if i + 1 < n else num_nerf_samples
+        bins, eu = pdf_sample(w, bins, ns, sp, rand=rands[i + 1])  # anneal = 1 -> pow(w,1) no-op
+    starts, ends = eu[:, :-1].copy(), eu[:, 1:].copy()
+    sps, spe = bins[:, :-1].copy(), bins[:, 1:].copy()
+    if stretch_sky:  # neurad.py:451-455
+        ends[:, -1] += f32(sky_distance) - ends[:, -1]
+        spe[:, -1] = f32(1 - 1e-7)
+    return SamplerOutput(starts, ends, sps, spe, out_w, out_s, out_e, out_sp)
+
+
+# --------------------------------------------------------------------------------------
+# get_nff_outputs end to end (models/neurad.py:368-398), no appearance embedding
+# --------------------------------------------------------------------------------------
+def render_rays(p: FieldParams, origins, directions, pixel_area, starts, ends):
+    f = field_fwd(p, origins, directions, pixel_area, starts, ends)
+    if p.use_sdf:
+        w, _ = render_weight_from_alpha(f["alpha"])
+    else:
+        w, _, _ = render_weight_from_density(starts, ends, f["density"])
+    feat, depth, acc = composite(w, f["feature"], starts, ends)
+    return {"features": feat, "depth": depth, "accumulation": acc, "weights": w, **f}

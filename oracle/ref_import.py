@@ -1,0 +1,90 @@
+"""Import the read-only reference (neurad-studio) torch path in THIS container only.
+
+TEST INFRASTRUCTURE -- never imported by the product path.  Used by
+``oracle/make_golden.py`` to generate the fixtures under ``tests/golden/`` and by
+``tests/test_oracle_vs_reference.py`` (skipped when /root/reference is absent, e.g.
+on the GPU box).
+
+The reference needs a handful of pure-import dependencies that are not installed
+here: they are stubbed.  ``tinycudann`` must stay absent so that
+``nerfstudio.utils.external.TCNN_EXISTS`` is False and every component takes its
+``implementation="torch"`` branch -- that branch is the parity target.
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import os
+import sys
+import types
+from unittest import mock
+
+REFERENCE_ROOT = os.environ.get("NEURAD_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "nerfstudio"))
+
+
+class _Anno:
+    """jaxtyping-style annotation stub: Float[Tensor, "..."] -> object."""
+
+    def __class_getitem__(cls, item):
+        return object
+
+
+def _stub(name: str, **attrs) -> types.ModuleType:
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Magic(types.ModuleType):
+    """Module whose every attribute is a MagicMock (for import-only deps)."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        self.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        self.__path__ = []
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        v = mock.MagicMock(name=f"{self.__name__}.{item}")
+        setattr(self, item, v)
+        return v
+
+
+def install() -> None:
+    """Make ``import nerfstudio...`` work from the read-only reference tree."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    assert "tinycudann" not in sys.modules, "tinycudann must stay absent for the torch oracle"
+    if "jaxtyping" not in sys.modules:
+        _stub("jaxtyping", **{k: _Anno for k in ("Float", "Int", "Shaped", "Bool", "UInt8", "Num", "Integer")})
+    for name in (
+        "viser", "viser.transforms", "viser.theme", "viser.infra",
+        "torch.utils.tensorboard", "cv2", "nerfacc", "torchmetrics", "torchmetrics.functional",
+        "torchmetrics.image", "torchmetrics.image.lpip", "torchvision", "torchvision.models",
+        "torchvision.transforms", "tyro", "tyro.conf", "tyro.extras", "wandb", "comet_ml", "mediapy", "open3d",
+        "pyquaternion", "trimesh", "plotly", "plotly.graph_objects", "imageio", "gsplat", "gsplat.strategy",
+        "pytorch_msssim", "lpips", "pymeshlab", "xatlas", "splines", "splines.quaternion", "msgpack_numpy",
+        "nuscenes", "av2", "zod", "pandaset", "pathos", "appdirs", "gdown", "ninja", "h5py", "rawpy", "newrawpy",
+        "pyarrow", "tensorboard", "timm", "kornia", "opencv", "torchtyping", "typeguard", "awscli", "scikit-image",
+        "skimage", "skimage.metrics", "cryptography", "nodeenv", "protobuf", "ipywidgets", "jupyterlab", "matplotlib",
+        "matplotlib.pyplot", "matplotlib.cm", "matplotlib.colors", "PIL.ImageFont",
+    ):
+        if name in sys.modules:
+            continue
+        try:
+            if "." not in name:
+                __import__(name)
+                continue
+        except Exception:
+            pass
+        sys.modules[name] = _Magic(name)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
