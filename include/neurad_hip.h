@@ -1,0 +1,218 @@
+/*
+ * neurad_hip.h -- C ABI of libneurad_hip.so: NeuRAD's volumetric ray-marching hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the path named by BASELINE.json:north_star.  Every entry point
+ * replaces one reference interface (cited as file:line relative to the neurad-studio tree); the
+ * reference-side binding (ctypes) a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers (HBM) unless the comment says "host".  Buffers are owned by
+ *    the caller (PyTorch allocates them); the library never allocates, frees or retains device memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only enqueues
+ *    kernels on that stream; nothing synchronises the device.
+ *  - Return value: 0 = NRHIP_OK, otherwise an NRHIP_ERR_* code; nrhip_last_error() returns a
+ *    thread-local human-readable message for the last failing call on this thread.
+ *  - Floating point is fp32 end to end (the parity target is the reference's implementation="torch"
+ *    path).  Hash tables may be stored as fp32 (param_dtype 0) or fp16 (param_dtype 1, BASELINE config 5).
+ *  - Row-major, innermost dimension last.  R = rays, S = samples per ray, N = R*S, L = levels,
+ *    F = features per level, T = 2^log2_table_size entries per level.
+ */
+#ifndef NEURAD_HIP_H_
+#define NEURAD_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRHIP_OK 0
+#define NRHIP_ERR_INVALID_ARG 1  /* bad size / NULL pointer / unsupported configuration */
+#define NRHIP_ERR_UNSUPPORTED 2  /* configuration outside what the kernels are instantiated for */
+#define NRHIP_ERR_LAUNCH 3       /* hipLaunchKernel / hipGetLastError failure */
+
+#define NRHIP_MAX_LEVELS 32
+#define NRHIP_MAX_LAYERS 8
+
+/* ---- descriptors (plain C structs, passed by pointer from host memory) ------------------------- */
+
+/* Multi-resolution hash grid == HashEncoding(implementation="torch")
+ * (nerfstudio/field_components/encodings.py:326-384).  scalings[l] = floor(min_res * g^l) is computed
+ * by the host exactly as encodings.py:348-350 does, so the device never re-derives it.           */
+typedef struct {
+  int32_t num_levels;       /* L  */
+  int32_t n_features;       /* F in {1,2,4,8} */
+  int32_t log2_table_size;  /* T = 1 << log2_table_size (per level) */
+  int32_t param_dtype;      /* 0 = fp32 table, 1 = fp16 table */
+  float scalings[NRHIP_MAX_LEVELS];
+} nrhip_grid;
+
+/* MLP == MLP.pytorch_fwd (nerfstudio/field_components/mlp.py:142-178): Linear(+bias)+ReLU ... Linear.
+ * weight[k] is nn.Linear.weight of layer k ([out_k][in_k] row-major), bias[k] may be NULL.         */
+typedef struct {
+  int32_t in_dim;
+  int32_t hidden_dim;
+  int32_t out_dim;
+  int32_t num_layers;       /* number of Linear layers (>= 1) */
+  const float* weight[NRHIP_MAX_LAYERS];
+  const float* bias[NRHIP_MAX_LAYERS];
+} nrhip_mlp;
+
+/* A ray batch == the per-ray part of RayBundle/Frustums (nerfstudio/cameras/rays.py:33-59,251-357).
+ * Samples are described by per-ray origin/direction and per-sample [start,end]; the materialised
+ * [R,S,3] broadcast views of rays.py:336-355 are never built.                                       */
+typedef struct {
+  int64_t n_rays;           /* R */
+  int32_t n_samples;        /* S */
+  const float* origins;     /* [R,3] */
+  const float* directions;  /* [R,3] */
+  const float* pixel_area;  /* [R]   */
+  const float* starts;      /* [R,S] euclidean bin starts */
+  const float* ends;        /* [R,S] euclidean bin ends   */
+  int32_t sample_stride;    /* row stride (floats) of starts/ends; 0 = S.  With bin EDGES e[R,S+1] pass
+                               starts = e, ends = e + 1, sample_stride = S + 1 (no copies).            */
+} nrhip_rays;
+
+/* NeuRADField (nerfstudio/fields/neurad_field.py:78-152), static scene part.
+ *   geo:  L*F -> hidden -> 1 + geo_feat_dim   (neurad_field.py:98-106)
+ *   feat: geo_feat_dim + 16 (SH deg 4) -> hidden ... -> geo_feat_dim  (neurad_field.py:109-117)   */
+typedef struct {
+  nrhip_grid grid;
+  const void* table;        /* [L*T, F] level-major rows (encodings.py:382-384) */
+  float static_scale;       /* ScaledSceneContraction scale (neurad_encoding.py:99) */
+  nrhip_mlp geo;
+  nrhip_mlp feat;
+  int32_t use_sdf;          /* 1: ALPHA = sigmoid(-sdf*beta) ; 0: DENSITY = exp(geo_out) */
+  float beta;               /* |beta| + beta_min already applied (model_components/utils.py:38-41) */
+} nrhip_field;
+
+/* NeuRADProposalField (nerfstudio/fields/neurad_field.py:182-216): grid -> Linear(L*F,1,no bias) -> exp */
+typedef struct {
+  nrhip_grid grid;
+  const void* table;
+  float static_scale;
+  const float* decoder_weight; /* [L*F] */
+} nrhip_proposal;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+const char* nrhip_last_error(void);
+int nrhip_version(void);
+/* number of CUs / XCDs of the current device (host out-pointers) */
+int nrhip_device_info(int32_t* n_cus, int32_t* n_xcds, int64_t* hbm_bytes);
+
+/* ---- H1: hash grid (replaces HashEncoding.pytorch_fwd, encodings.py:425-466; tcnn.Encoding
+ *          {otype:"HashGrid"} call sites encodings.py:362-373,468-471) --------------------------- */
+int nrhip_hashgrid_fwd(const nrhip_grid* g, const void* table, const float* x /*[N,3] in [0,1]*/, int64_t n,
+                       float* out /*[N,L*F]*/, void* stream);
+/* grad_table [L*T,F] fp32 is ACCUMULATED into (caller zeroes it): autograd of encodings.py:446-464 */
+int nrhip_hashgrid_bwd(const nrhip_grid* g, const float* x, const float* grad_out /*[N,L*F]*/, int64_t n,
+                       float* grad_table, void* stream);
+
+/* ---- H2+H3+H1+H4: NeuRADHashEncoding static path (neurad_encoding.py:164-169,265-268,297-304;
+ *      cameras/rays.py:109-124; spatial_distortions.py:103-141) --------------------------------- */
+int nrhip_encode_fwd(const nrhip_grid* g, const void* table, float static_scale, const nrhip_rays* rays,
+                     float* out /*[N,L*F]*/, void* stream);
+int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
+                     const float* grad_out /*[N,L*F]*/, float* grad_table, void* stream);
+
+/* ---- F3: SHEncoding(levels=4) (encodings.py:797-805 -> utils/math.py:31-94) -------------------- */
+int nrhip_sh4_fwd(const float* dirs /*[N,3]*/, int64_t n, float* out /*[N,16]*/, void* stream);
+
+/* ---- F2: MLP (mlp.py:142-183; tcnn.Network call sites mlp.py:102-113,180-183) ------------------
+ * hidden (optional, may be NULL): [N, (num_layers-1)*hidden_dim] post-ReLU activations, saved for bwd */
+int nrhip_mlp_fwd(const nrhip_mlp* m, const float* x /*[N,in]*/, int64_t n, float* y /*[N,out]*/,
+                  float* hidden, void* stream);
+/* Backward.  grad_x may be NULL.  grad_weight[k] ([out_k][in_k]) and grad_bias[k] (may be NULL) are
+ * ACCUMULATED into.  workspace: [N, (num_layers-1)*hidden_dim] floats of scratch (same shape as hidden). */
+int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_y, int64_t n,
+                  float* grad_x, float* const* grad_weight /*host array*/, float* const* grad_bias /*host array*/,
+                  float* workspace, void* stream);
+
+/* ---- F1+F4: NeuRADField.forward, per-sample outputs (neurad_field.py:128-152) ------------------
+ * feature [R,S,C], sdf_or_raw [R,S] (sdf when use_sdf else the pre-exp geo output), alpha_or_density [R,S] */
+int nrhip_field_fwd(const nrhip_field* f, const nrhip_rays* rays, float* feature, float* sdf, float* alpha,
+                    void* stream);
+
+/* ---- C1: nerfacc 0.5.2 dense-mode (call sites models/neurad.py:716-723,734; renderers.py:88,345) */
+int nrhip_render_weight_from_alpha(const float* alphas /*[R,S]*/, int64_t r, int32_t s, float* weights,
+                                   float* trans, void* stream);
+int nrhip_render_weight_from_alpha_bwd(const float* alphas, const float* grad_w, const float* grad_t, int64_t r,
+                                       int32_t s, float* grad_alphas, void* stream);
+int nrhip_render_weight_from_density(const float* t_starts, const float* t_ends, const float* sigmas, int64_t r,
+                                     int32_t s, float* weights, float* trans, float* alphas, void* stream);
+int nrhip_render_weight_from_density_bwd(const float* t_starts, const float* t_ends, const float* sigmas,
+                                         const float* grad_w, int64_t r, int32_t s, float* grad_sigmas,
+                                         void* stream);
+/* values may be NULL (accumulation only, C=1) */
+int nrhip_accumulate_along_rays(const float* weights /*[R,S]*/, const float* values /*[R,S,C]*/, int64_t r,
+                                int32_t s, int32_t c, float* out /*[R,C]*/, void* stream);
+
+/* ---- C2: get_nff_outputs compositing (models/neurad.py:377-395,727-734) ------------------------
+ * weights [R,S] come from C1; the residual 1-acc goes on the last (sky) sample; depth drops it.     */
+int nrhip_composite_fwd(const float* weights, const float* features /*[R,S,C]*/, const float* starts,
+                        const float* ends, int64_t r, int32_t s, int32_t c, float* out_features /*[R,C]*/,
+                        float* out_depth /*[R]*/, float* out_acc /*[R]*/, void* stream);
+int nrhip_composite_bwd(const float* weights, const float* features, const float* starts, const float* ends,
+                        const float* g_features, const float* g_depth, const float* g_acc, int64_t r, int32_t s,
+                        int32_t c, float* grad_weights /*[R,S]*/, float* grad_features /*[R,S,C]*/, void* stream);
+
+/* ---- F1+C1+C2 fused: the headline kernel -- hash lookup + MLPs + compositing per ray -----------
+ * (NeuRADModel.get_nff_outputs minus sampling, models/neurad.py:373-395).  Optional per-sample
+ * outputs (may be NULL): weights [R,S] (pre sky residual, as returned by C1).                       */
+int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features /*[R,C]*/,
+                     float* out_depth /*[R]*/, float* out_acc /*[R]*/, float* out_weights /*[R,S] or NULL*/,
+                     void* stream);
+
+/* ---- S2: NeuRADProposalField.get_density (neurad_field.py:208-213) ----------------------------- */
+int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, float* density /*[R,S]*/,
+                               void* stream);
+/* grad_table / grad_decoder are accumulated into */
+int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
+                               const float* grad_density, float* grad_table, float* grad_decoder, void* stream);
+
+/* ---- S3: RaySamples.get_weights (cameras/rays.py:188-210) -------------------------------------- */
+int nrhip_weights_from_density(const float* deltas, const float* densities, int64_t r, int32_t s, float* weights,
+                               void* stream);
+int nrhip_weights_from_density_bwd(const float* deltas, const float* densities, const float* grad_w, int64_t r,
+                                   int32_t s, float* grad_densities, void* stream);
+
+/* ---- S1: PowerSampler / SpacedSampler (ray_samplers.py:80-132,838-852; utils/math.py:541-579) ---
+ * t_rand [R,S+1] = injected stratified jitter (training) or NULL (eval).  Outputs are bin EDGES.     */
+int nrhip_power_sampler(const float* nears /*[R]*/, const float* fars /*[R]*/, int64_t r, int32_t s, float lam,
+                        float scaling, const float* t_rand, float* spacing_bins /*[R,S+1]*/,
+                        float* euclid_bins /*[R,S+1]*/, void* stream);
+
+/* ---- S4: PDFSampler (ray_samplers.py:280-376), include_original=False -------------------------
+ * rand: NULL (eval) or [R] (single_jitter) / [R,S_new+1] (rand_stride = 1 / S_new+1)               */
+int nrhip_pdf_sample(const float* weights /*[R,S_prev]*/, const float* spacing_bins /*[R,S_prev+1]*/,
+                     const float* nears, const float* fars, int64_t r, int32_t s_prev, int32_t s_new, float lam,
+                     float scaling, float histogram_padding, const float* rand, int32_t rand_stride,
+                     float* new_spacing_bins /*[R,S_new+1]*/, float* new_euclid_bins /*[R,S_new+1]*/,
+                     void* stream);
+
+/* ---- S5+M1 fused: ProposalNetworkSampler as driven by NeuRADModel._get_ray_samples
+ *      (ray_samplers.py:623-666, models/neurad.py:443-459).  One wave marches one ray through
+ *      power bins -> (density -> weights -> pdf resample) x n_rounds, entirely on chip.
+ *      props[i] is the field evaluated in round i (the caller reproduces the late-binding quirk of
+ *      models/neurad.py:248 by passing the same field twice).
+ *      Outputs: final bins [R,S_final+1] (spacing + euclid, NOT sky-stretched -- M1's stretch is applied
+ *      by the host mirror) and per-round weights / bins for the proposal losses.                     */
+typedef struct {
+  int32_t n_rounds;                 /* <= 2 */
+  int32_t n_samples[3];             /* e.g. {128, 64, 32} */
+  float lam, scaling;               /* PowerSampler(lambda_, scaling) */
+  float histogram_padding;          /* 0.01 */
+  float sky_distance;               /* fars are clamped to this (neurad.py:445-446) */
+} nrhip_sampler_cfg;
+int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props /*host array[n_rounds]*/,
+                               const float* origins, const float* directions, const float* pixel_area,
+                               const float* nears, const float* fars, int64_t r,
+                               float* const* round_weights /*host array[n_rounds] of [R,S_i]*/,
+                               float* const* round_spacing /*host array[n_rounds+1] of [R,S_i+1]*/,
+                               float* const* round_euclid  /*host array[n_rounds+1] of [R,S_i+1]*/,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURAD_HIP_H_ */

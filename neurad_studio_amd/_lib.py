@@ -1,0 +1,115 @@
+"""ctypes binding of libneurad_hip.so (the C ABI declared in include/neurad_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol cannot be resolved,
+loading raises.  Mirrors the behaviour of the reference's tcnn import gate
+(nerfstudio/utils/external.py:18-58), except that nothing is lazily swallowed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_LEVELS = 32
+MAX_LAYERS = 8
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("NEURAD_HIP_LIB", os.path.join(_HERE, "lib", "libneurad_hip.so"))
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class Grid(C.Structure):
+    _fields_ = [("num_levels", C.c_int32), ("n_features", C.c_int32), ("log2_table_size", C.c_int32),
+                ("param_dtype", C.c_int32), ("scalings", C.c_float * MAX_LEVELS)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden_dim", C.c_int32), ("out_dim", C.c_int32), ("num_layers", C.c_int32),
+                ("weight", C.c_void_p * MAX_LAYERS), ("bias", C.c_void_p * MAX_LAYERS)]
+
+
+class Rays(C.Structure):
+    _fields_ = [("n_rays", C.c_int64), ("n_samples", C.c_int32), ("origins", C.c_void_p),
+                ("directions", C.c_void_p), ("pixel_area", C.c_void_p), ("starts", C.c_void_p),
+                ("ends", C.c_void_p), ("sample_stride", C.c_int32)]
+
+
+class Field(C.Structure):
+    _fields_ = [("grid", Grid), ("table", C.c_void_p), ("static_scale", C.c_float), ("geo", Mlp), ("feat", Mlp),
+                ("use_sdf", C.c_int32), ("beta", C.c_float)]
+
+
+class Proposal(C.Structure):
+    _fields_ = [("grid", Grid), ("table", C.c_void_p), ("static_scale", C.c_float), ("decoder_weight", C.c_void_p)]
+
+
+class SamplerCfg(C.Structure):
+    _fields_ = [("n_rounds", C.c_int32), ("n_samples", C.c_int32 * 3), ("lam", C.c_float), ("scaling", C.c_float),
+                ("histogram_padding", C.c_float), ("sky_distance", C.c_float)]
+
+
+P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes : exactly the prototypes of include/neurad_hip.h (tests/test_abi.py cross-checks this
+# table against the header so the two cannot drift)
+PROTOTYPES = {
+    "nrhip_version": [],
+    "nrhip_device_info": [C.POINTER(I32), C.POINTER(I32), C.POINTER(I64)],
+    "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
+    "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
+    "nrhip_encode_fwd": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P],
+    "nrhip_encode_bwd": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P],
+    "nrhip_sh4_fwd": [P, I64, P, P],
+    "nrhip_mlp_fwd": [C.POINTER(Mlp), P, I64, P, P, P],
+    "nrhip_mlp_bwd": [C.POINTER(Mlp), P, P, P, I64, P, C.POINTER(P), C.POINTER(P), P, P],
+    "nrhip_field_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P],
+    "nrhip_render_weight_from_alpha": [P, I64, I32, P, P, P],
+    "nrhip_render_weight_from_alpha_bwd": [P, P, P, I64, I32, P, P],
+    "nrhip_render_weight_from_density": [P, P, P, I64, I32, P, P, P, P],
+    "nrhip_render_weight_from_density_bwd": [P, P, P, P, I64, I32, P, P],
+    "nrhip_accumulate_along_rays": [P, P, I64, I32, I32, P, P],
+    "nrhip_composite_fwd": [P, P, P, P, I64, I32, I32, P, P, P, P],
+    "nrhip_composite_bwd": [P, P, P, P, P, P, P, I64, I32, I32, P, P, P],
+    "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
+    "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P],
+    "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
+    "nrhip_weights_from_density": [P, P, I64, I32, P, P],
+    "nrhip_weights_from_density_bwd": [P, P, P, I64, I32, P, P],
+    "nrhip_power_sampler": [P, P, I64, I32, F32, F32, P, P, P, P],
+    "nrhip_pdf_sample": [P, P, P, P, I64, I32, I32, F32, F32, F32, P, I32, P, P, P],
+    "nrhip_proposal_sampler_fwd": [C.POINTER(SamplerCfg), C.POINTER(Proposal), P, P, P, P, P, I64, C.POINTER(P),
+                                   C.POINTER(P), C.POINTER(P), P],
+}
+
+_lib = None
+
+
+class NeuradHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and bind every prototype; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NeuradHipError(
+            f"libneurad_hip.so not found at {LIB_PATH}: build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.nrhip_last_error.restype = C.c_char_p
+    lib.nrhip_last_error.argtypes = []
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise NeuradHipError(f"{name} failed (code {rc}): {lib.nrhip_last_error().decode()}")

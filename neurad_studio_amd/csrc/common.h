@@ -1,0 +1,258 @@
+// Shared device/host helpers for libneurad_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/neurad_hip.h"
+
+namespace nrhip {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define NR_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      ::nrhip::set_error(__VA_ARGS__); \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+constexpr uint32_t kPrimeY = 2654435761u;  // encodings.py:419
+constexpr uint32_t kPrimeZ = 805459861u;
+
+// Device-side copy of nrhip_grid (kernel argument, by value).
+struct GridDev {
+  int L, F, log2T, dtype;
+  float scal[NRHIP_MAX_LEVELS];
+};
+
+inline GridDev to_dev(const nrhip_grid& g) {
+  GridDev d;
+  d.L = g.num_levels;
+  d.F = g.n_features;
+  d.log2T = g.log2_table_size;
+  d.dtype = g.param_dtype;
+  for (int i = 0; i < NRHIP_MAX_LEVELS; ++i) d.scal[i] = i < g.num_levels ? g.scalings[i] : 0.f;
+  return d;
+}
+
+int validate_grid(const nrhip_grid* g);
+
+struct RaysDev {
+  int64_t R;
+  int S;
+  int stride;  // row stride of starts/ends
+  const float* o;
+  const float* d;
+  const float* area;
+  const float* starts;
+  const float* ends;
+};
+inline RaysDev to_dev(const nrhip_rays& r) {
+  return RaysDev{r.n_rays, r.n_samples, r.sample_stride > 0 ? r.sample_stride : r.n_samples, r.origins, r.directions,
+                 r.pixel_area, r.starts, r.ends};
+}
+int validate_rays(const nrhip_rays* r);
+
+// ---------------------------------------------------------------------------------------------
+// Table element loads: F features of one entry, fp32 or fp16 storage, one vector load each.
+// ---------------------------------------------------------------------------------------------
+template <int F, bool HALF>
+struct Entry;
+
+template <int F>
+struct Entry<F, false> {
+  static __device__ __forceinline__ void load(const void* table, uint32_t row, float (&v)[F]) {
+    // 32-bit byte offset from a wave-uniform base -> global_load with an SGPR base + one VGPR offset
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + row * (uint32_t)(F * 4));
+    if constexpr (F == 1) {
+      v[0] = *p;
+    } else if constexpr (F == 2) {
+      float2 t = *reinterpret_cast<const float2*>(p);
+      v[0] = t.x, v[1] = t.y;
+    } else if constexpr (F == 4) {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    } else {
+      static_assert(F == 8, "F in {1,2,4,8}");
+      float4 a = *reinterpret_cast<const float4*>(p);
+      float4 b = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    }
+  }
+};
+
+template <int F>
+struct Entry<F, true> {
+  static __device__ __forceinline__ void load(const void* table, uint32_t row, float (&v)[F]) {
+    const __half* p =
+        reinterpret_cast<const __half*>(reinterpret_cast<const char*>(table) + row * (uint32_t)(F * 2));
+    if constexpr (F == 1) {
+      v[0] = __half2float(*p);
+    } else if constexpr (F == 2) {
+      float2 t = __half22float2(*reinterpret_cast<const __half2*>(p));
+      v[0] = t.x, v[1] = t.y;
+    } else if constexpr (F == 4) {
+      uint2 raw = *reinterpret_cast<const uint2*>(p);
+      float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+      float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+      v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
+    } else {
+      static_assert(F == 8, "F in {1,2,4,8}");
+      uint4 raw = *reinterpret_cast<const uint4*>(p);
+      const __half2* h = reinterpret_cast<const __half2*>(&raw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float2 t = __half22float2(h[i]);
+        v[2 * i] = t.x, v[2 * i + 1] = t.y;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// One hash-grid level: HashEncoding.pytorch_fwd for a single (point, level)
+// (encodings.py:425-464).  x in [0,1]^3, `scale` = scalings[l], table_l = base row of the level.
+// The lerp tree and corner pairing follow the reference exactly (f03/f12/f56/f47 -> f0312/f4756).
+// ---------------------------------------------------------------------------------------------
+struct Corners {
+  uint32_t idx[8];  // reference corner order 0..7 (encodings.py:437-444), already masked (no level offset)
+  float ox, oy, oz;
+};
+
+__device__ __forceinline__ Corners hash_corners(float x, float y, float z, float scale, uint32_t mask) {
+  Corners c;
+  // __fmul_rn / __fsub_rn: the product must be ROUNDED before floor/ceil and before the offset is taken,
+  // exactly like torch's separate mul and sub.  Letting the compiler contract x*scale - floor(..) into an
+  // fma changes the offset by up to half an ulp of sx (~5e-4 at scale 8192) -- measured 7e-5 rel-L2.
+  const float sx = __fmul_rn(x, scale), sy = __fmul_rn(y, scale), sz = __fmul_rn(z, scale);
+  const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  const uint32_t ifx = (uint32_t)(int)fx, ify = (uint32_t)(int)fy, ifz = (uint32_t)(int)fz;
+  const uint32_t icx = (uint32_t)(int)ceilf(sx), icy = (uint32_t)(int)ceilf(sy), icz = (uint32_t)(int)ceilf(sz);
+  c.ox = __fsub_rn(sx, fx), c.oy = __fsub_rn(sy, fy), c.oz = __fsub_rn(sz, fz);
+  // int32*int64 products in the reference never wrap in 64 bit; their low log2(T) bits equal the
+  // uint32-wrapped products (T is a power of two), verified in tests against exact golden indices.
+  const uint32_t hyc = icy * kPrimeY, hyf = ify * kPrimeY, hzc = icz * kPrimeZ, hzf = ifz * kPrimeZ;
+  c.idx[0] = (icx ^ hyc ^ hzc) & mask;  // c c c
+  c.idx[1] = (icx ^ hyf ^ hzc) & mask;  // c f c
+  c.idx[2] = (ifx ^ hyf ^ hzc) & mask;  // f f c
+  c.idx[3] = (ifx ^ hyc ^ hzc) & mask;  // f c c
+  c.idx[4] = (icx ^ hyc ^ hzf) & mask;  // c c f
+  c.idx[5] = (icx ^ hyf ^ hzf) & mask;  // c f f
+  c.idx[6] = (ifx ^ hyf ^ hzf) & mask;  // f f f
+  c.idx[7] = (ifx ^ hyc ^ hzf) & mask;  // f c f
+  return c;
+}
+
+template <int F, bool HALF>
+__device__ __forceinline__ void hash_level(const void* table, uint32_t level_row0, float x, float y, float z,
+                                           float scale, uint32_t mask, float (&out)[F]) {
+  const Corners c = hash_corners(x, y, z, scale, mask);
+  float f[8][F];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(table, level_row0 + c.idx[k], f[k]);
+  const float ox = c.ox, oy = c.oy, oz = c.oz;
+  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+#pragma unroll
+  for (int i = 0; i < F; ++i) {
+    const float f03 = f[0][i] * ox + f[3][i] * mx;
+    const float f12 = f[1][i] * ox + f[2][i] * mx;
+    const float f56 = f[5][i] * ox + f[6][i] * mx;
+    const float f47 = f[4][i] * ox + f[7][i] * mx;
+    const float f0312 = f03 * oy + f12 * my;
+    const float f4756 = f47 * oy + f56 * my;
+    out[i] = f0312 * oz + f4756 * mz;
+  }
+}
+
+// Trilinear corner weights in the same corner order (for the scatter-add backward).
+__device__ __forceinline__ void corner_weights(const Corners& c, float (&w)[8]) {
+  const float ox = c.ox, oy = c.oy, oz = c.oz, mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+  w[0] = ox * oy * oz;
+  w[1] = ox * my * oz;
+  w[2] = mx * my * oz;
+  w[3] = mx * oy * oz;
+  w[4] = ox * oy * mz;
+  w[5] = ox * my * mz;
+  w[6] = mx * my * mz;
+  w[7] = mx * oy * mz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// H2 + H3: sample -> gaussian (mean,std) -> contracted position in [0,1]^3 and contracted std
+// (cameras/rays.py:109-124, M=1; spatial_distortions.py:103-113,126-141, order=inf)
+// ---------------------------------------------------------------------------------------------
+struct SamplePos {
+  float x, y, z, std;
+};
+
+__device__ __forceinline__ SamplePos sample_position(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                     float area, float t0, float t1, float inv_scale_dummy,
+                                                     float scale) {
+  // Position arithmetic mirrors torch op for op (separately rounded mul/add/div, no fma): one ulp of the
+  // contracted coordinate is 8192 * 6e-8 = 5e-4 of a cell at the finest level, so rounding-order matters.
+#pragma clang fp contract(off)
+  (void)inv_scale_dummy;
+  const float dist = (t1 - t0) / 2.f;
+  const float t = t0 + 1.f * dist;
+  float mx = ox + dx * t, my = oy + dy * t, mz = oz + dz * t;
+  float std = powf((area * (t * t)) * dist, 1.0f / 3.0f);
+  // ScaledSceneContraction: divide by scale, contract (inf-norm), map [-2,2] -> [0,1]
+  mx /= scale, my /= scale, mz /= scale, std /= scale;
+  const float mag = fmaxf(fabsf(mx), fmaxf(fabsf(my), fabsf(mz)));
+  if (!(mag < 1.f)) {
+    const float cm = fmaxf(mag, 1.f);
+    const float k = 2.f - (1.f / cm);
+    mx = k * (mx / cm), my = k * (my / cm), mz = k * (mz / cm);
+    const float sc = powf(2.f * cm - 1.f, 1.0f / 3.0f) / cm;
+    std = std * (sc * sc);
+  }
+  SamplePos p;
+  p.x = (mx + 2.f) / 4.f, p.y = (my + 2.f) / 4.f, p.z = (mz + 2.f) / 4.f;
+  p.std = std / 4.f;
+  return p;
+}
+
+// H4: 1 / max(1, 2*scalings_l*std)   (neurad_encoding.py:302)
+__device__ __forceinline__ float rescale_weight(float scale_l, float std) {
+  return 1.f / fmaxf(scale_l * 2.f * std, 1.f);
+}
+
+// F3: 16 real SH components (utils/math.py:31-94) of a direction given as (dir+1)/2 -- the torch path
+// evaluates the polynomials on that [0,1]-normalised vector directly (base_field.py:136-142).
+__device__ __forceinline__ void sh4(float x, float y, float z, float (&c)[16]) {
+  const float xx = x * x, yy = y * y, zz = z * z;
+  c[0] = 0.28209479177387814f;
+  c[1] = 0.4886025119029199f * y;
+  c[2] = 0.4886025119029199f * z;
+  c[3] = 0.4886025119029199f * x;
+  c[4] = 1.0925484305920792f * x * y;
+  c[5] = 1.0925484305920792f * y * z;
+  c[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+  c[7] = 1.0925484305920792f * x * z;
+  c[8] = 0.5462742152960396f * (xx - yy);
+  c[9] = 0.5900435899266435f * y * (3.f * xx - yy);
+  c[10] = 2.890611442640554f * x * y * z;
+  c[11] = 0.4570457994644658f * y * (5.f * zz - 1.f);
+  c[12] = 0.3731763325901154f * z * (5.f * zz - 3.f);
+  c[13] = 0.4570457994644658f * x * (5.f * zz - 1.f);
+  c[14] = 1.445305721320277f * z * (xx - yy);
+  c[15] = 0.5900435899266435f * x * (xx - 3.f * yy);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// DPP helpers over rows of 16 lanes -------------------------------------------------------------
+// row_shr:n  = 0x110+n ; bound_ctrl=false keeps `old` for lanes shifted in from outside the row.
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v, float fill) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x110 + N, 0xf,
+                                         0xf, false));
+}
+
+inline int grid_for(int64_t threads, int block) { return (int)((threads + block - 1) / block); }
+
+}  // namespace nrhip

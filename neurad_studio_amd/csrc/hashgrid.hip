@@ -1,0 +1,326 @@
+// H1 / H2-H4 / F3 / S2 standalone kernels: hash-grid lookup (fwd + scatter-add bwd), the fused
+// "encode" (gaussian -> contraction -> lookup -> rescale), SH deg-4 and the proposal density head.
+//
+// Thread mapping for the lookups: one thread per (sample, level), LEVEL FASTEST.  Adjacent lanes are
+// adjacent levels of the same sample, so the [N, L*F] output row is written fully coalesced
+// (L*F*4 contiguous bytes per sample) while every lane issues its 8 independent corner gathers.
+#include "common.h"
+
+namespace nrhip {
+
+// --------------------------------------------------------------------------------------------
+template <int F, bool HALF>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const void* __restrict__ table,
+                                                            const float* __restrict__ x, int64_t n,
+                                                            float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * g.L) return;
+  const int64_t i = t / g.L;
+  const int l = (int)(t - i * g.L);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  float v[F];
+  hash_level<F, HALF>(table, (uint32_t)l << g.log2T, x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask, v);
+  float* o = out + t * F;
+#pragma unroll
+  for (int k = 0; k < F; ++k) o[k] = v[k];
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_kernel(GridDev g, const float* __restrict__ x,
+                                                            const float* __restrict__ go, int64_t n,
+                                                            float* __restrict__ gt) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * g.L) return;
+  const int64_t i = t / g.L;
+  const int l = (int)(t - i * g.L);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  const Corners c = hash_corners(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask);
+  float w[8];
+  corner_weights(c, w);
+  float gv[F];
+#pragma unroll
+  for (int k = 0; k < F; ++k) gv[k] = go[t * F + k];
+  float* base = gt + ((size_t)l << g.log2T) * F;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float* p = base + (size_t)c.idx[k] * F;
+#pragma unroll
+    for (int j = 0; j < F; ++j) unsafeAtomicAdd(p + j, w[k] * gv[j]);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// encode: H2 -> H3 -> H1 -> H4, thread per (sample, level)
+template <int F, bool HALF>
+__global__ __launch_bounds__(256) void encode_fwd_kernel(GridDev g, const void* __restrict__ table, float scale,
+                                                          RaysDev r, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = r.R * r.S;
+  if (t >= n * g.L) return;
+  const int64_t i = t / g.L;
+  const int l = (int)(t - i * g.L);
+  const int64_t ray = i / r.S;
+  const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], 0.f,
+                                      scale);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  float v[F];
+  hash_level<F, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
+  const float w = rescale_weight(g.scal[l], p.std);
+  float* o = out + t * F;
+#pragma unroll
+  for (int k = 0; k < F; ++k) o[k] = v[k] * w;
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void encode_bwd_kernel(GridDev g, float scale, RaysDev r,
+                                                          const float* __restrict__ go, float* __restrict__ gt) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = r.R * r.S;
+  if (t >= n * g.L) return;
+  const int64_t i = t / g.L;
+  const int l = (int)(t - i * g.L);
+  const int64_t ray = i / r.S;
+  const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], 0.f,
+                                      scale);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  const Corners c = hash_corners(p.x, p.y, p.z, g.scal[l], mask);
+  float w[8];
+  corner_weights(c, w);
+  const float rw = rescale_weight(g.scal[l], p.std);
+  float gv[F];
+#pragma unroll
+  for (int k = 0; k < F; ++k) gv[k] = go[t * F + k] * rw;
+  float* base = gt + ((size_t)l << g.log2T) * F;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float* q = base + (size_t)c.idx[k] * F;
+#pragma unroll
+    for (int j = 0; j < F; ++j) unsafeAtomicAdd(q + j, w[k] * gv[j]);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sh4_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float c[16];
+  sh4(d[3 * i], d[3 * i + 1], d[3 * i + 2], c);
+  float4* o = reinterpret_cast<float4*>(out + 16 * i);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = make_float4(c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]);
+}
+
+// --------------------------------------------------------------------------------------------
+// S2: proposal density = exp( sum_l w_l * rescaled_feature_l )  (F == 1).  Thread per sample; the L
+// levels x 8 gathers of a sample are all independent loads issued back to back.
+template <bool HALF>
+__global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, const void* __restrict__ table,
+                                                                    float scale, const float* __restrict__ dec,
+                                                                    RaysDev r, float* __restrict__ dens) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= r.R * r.S) return;
+  const int64_t ray = i / r.S;
+  const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], 0.f,
+                                      scale);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  float acc = 0.f;
+  for (int l = 0; l < g.L; ++l) {
+    float v[1];
+    hash_level<1, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
+    acc += (v[0] * rescale_weight(g.scal[l], p.std)) * dec[l];
+  }
+  dens[i] = expf(acc);
+}
+
+// backward of S2 through trunc_exp (activations.py:37-41: g * exp(clamp(x,-15,15))) into the decoder
+// weight and the table.  x = log(density) is recovered from the saved forward output.
+__global__ __launch_bounds__(256) void proposal_density_bwd_kernel(GridDev g, const void* __restrict__ table,
+                                                                    float scale, const float* __restrict__ dec,
+                                                                    RaysDev r, const float* __restrict__ dens,
+                                                                    const float* __restrict__ gd,
+                                                                    float* __restrict__ gt,
+                                                                    float* __restrict__ gdec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < r.R * r.S;
+  float gl[NRHIP_MAX_LEVELS > 8 ? 8 : NRHIP_MAX_LEVELS];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) gl[l] = 0.f;
+  if (live) {
+    const int64_t ray = i / r.S;
+    const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)],
+                                        0.f, scale);
+    const uint32_t mask = (1u << g.log2T) - 1u;
+    const float xlog = logf(dens[i]);
+    const float gx = gd[i] * expf(fminf(fmaxf(xlog, -15.f), 15.f));
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      if (l < g.L) {
+        const Corners c = hash_corners(p.x, p.y, p.z, g.scal[l], mask);
+        float w[8];
+        corner_weights(c, w);
+        const float rw = rescale_weight(g.scal[l], p.std);
+        const uint32_t row0 = (uint32_t)l << g.log2T;
+        float f = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v[1];
+          Entry<1, false>::load(table, row0 + c.idx[k], v);
+          f += w[k] * v[0];
+          unsafeAtomicAdd(gt + row0 + c.idx[k], w[k] * (gx * dec[l] * rw));
+        }
+        gl[l] = gx * f * rw;
+      }
+    }
+  }
+  // block-reduce the decoder gradient: wave shuffle -> LDS -> one atomic per level per block
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    float v = gl[l];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wid][l] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && threadIdx.x < g.L) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    unsafeAtomicAdd(gdec + threadIdx.x, s);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+template <template <int, bool> class K>
+struct Dummy {};
+
+#define DISPATCH_F_HALF(F_, HALF_, CALL)                                   \
+  do {                                                                     \
+    const int f__ = (F_);                                                  \
+    const bool h__ = (HALF_);                                              \
+    if (f__ == 1) { if (h__) { CALL(1, true); } else { CALL(1, false); } } \
+    else if (f__ == 2) { if (h__) { CALL(2, true); } else { CALL(2, false); } } \
+    else if (f__ == 4) { if (h__) { CALL(4, true); } else { CALL(4, false); } } \
+    else { if (h__) { CALL(8, true); } else { CALL(8, false); } }          \
+  } while (0)
+
+#define DISPATCH_F(F_, CALL)         \
+  do {                               \
+    const int f__ = (F_);            \
+    if (f__ == 1) { CALL(1); }       \
+    else if (f__ == 2) { CALL(2); }  \
+    else if (f__ == 4) { CALL(4); }  \
+    else { CALL(8); }                \
+  } while (0)
+
+}  // namespace nrhip
+
+using namespace nrhip;
+
+extern "C" int nrhip_hashgrid_fwd(const nrhip_grid* g, const void* table, const float* x, int64_t n, float* out,
+                                  void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_fwd: negative n");
+  if (n == 0) return NRHIP_OK;
+  NR_REQUIRE(table && x && out, NRHIP_ERR_INVALID_ARG, "hashgrid_fwd: null pointer");
+  const GridDev gd = to_dev(*g);
+  const int blocks = grid_for(n * gd.L, 256);
+#define CALL(F, H) hashgrid_fwd_kernel<F, H><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, table, x, n, out)
+  DISPATCH_F_HALF(gd.F, gd.dtype == 1, CALL);
+#undef CALL
+  return check_launch("hashgrid_fwd");
+}
+
+extern "C" int nrhip_hashgrid_bwd(const nrhip_grid* g, const float* x, const float* grad_out, int64_t n,
+                                  float* grad_table, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(x && grad_out && grad_table && n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd: null pointer");
+  if (n == 0) return NRHIP_OK;
+  const GridDev gd = to_dev(*g);
+  const int blocks = grid_for(n * gd.L, 256);
+#define CALL(F) hashgrid_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, x, grad_out, n, grad_table)
+  DISPATCH_F(gd.F, CALL);
+#undef CALL
+  return check_launch("hashgrid_bwd");
+}
+
+extern "C" int nrhip_encode_fwd(const nrhip_grid* g, const void* table, float static_scale, const nrhip_rays* rays,
+                                float* out, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(table && out && static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "encode_fwd: bad argument");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  const GridDev gd = to_dev(*g);
+  const RaysDev rd = to_dev(*rays);
+  const int blocks = grid_for(n * gd.L, 256);
+#define CALL(F, H) encode_fwd_kernel<F, H><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, table, static_scale, rd, out)
+  DISPATCH_F_HALF(gd.F, gd.dtype == 1, CALL);
+#undef CALL
+  return check_launch("encode_fwd");
+}
+
+extern "C" int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
+                                const float* grad_out, float* grad_table, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(grad_out && grad_table && static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "encode_bwd: bad argument");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  const GridDev gd = to_dev(*g);
+  const RaysDev rd = to_dev(*rays);
+  const int blocks = grid_for(n * gd.L, 256);
+#define CALL(F) encode_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, static_scale, rd, grad_out, grad_table)
+  DISPATCH_F(gd.F, CALL);
+#undef CALL
+  return check_launch("encode_bwd");
+}
+
+extern "C" int nrhip_sh4_fwd(const float* dirs, int64_t n, float* out, void* stream) {
+  NR_REQUIRE(dirs && out && n >= 0, NRHIP_ERR_INVALID_ARG, "sh4_fwd: null pointer");
+  if (n == 0) return NRHIP_OK;
+  sh4_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(dirs, n, out);
+  return check_launch("sh4_fwd");
+}
+
+extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, float* density,
+                                          void* stream) {
+  NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_fwd: null descriptor");
+  if (int e = validate_grid(&p->grid)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(p->grid.n_features == 1, NRHIP_ERR_UNSUPPORTED,
+             "proposal_density: features_per_level must be 1 (neurad_field.py:166), got %d", p->grid.n_features);
+  NR_REQUIRE(p->table && p->decoder_weight && density && p->static_scale > 0.f, NRHIP_ERR_INVALID_ARG,
+             "proposal_density_fwd: bad argument");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  const GridDev gd = to_dev(p->grid);
+  const RaysDev rd = to_dev(*rays);
+  if (gd.dtype == 1)
+    proposal_density_fwd_kernel<true><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+        gd, p->table, p->static_scale, p->decoder_weight, rd, density);
+  else
+    proposal_density_fwd_kernel<false><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+        gd, p->table, p->static_scale, p->decoder_weight, rd, density);
+  return check_launch("proposal_density_fwd");
+}
+
+extern "C" int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
+                                          const float* grad_density, float* grad_table, float* grad_decoder,
+                                          void* stream) {
+  NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_bwd: null descriptor");
+  if (int e = validate_grid(&p->grid)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(p->grid.n_features == 1 && p->grid.num_levels <= 8 && p->grid.param_dtype == 0, NRHIP_ERR_UNSUPPORTED,
+             "proposal_density_bwd: needs F=1, L<=8, fp32 table");
+  NR_REQUIRE(p->table && p->decoder_weight && density && grad_density && grad_table && grad_decoder,
+             NRHIP_ERR_INVALID_ARG, "proposal_density_bwd: null pointer");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  proposal_density_bwd_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+      to_dev(p->grid), p->table, p->static_scale, p->decoder_weight, to_dev(*rays), density, grad_density, grad_table,
+      grad_decoder);
+  return check_launch("proposal_density_bwd");
+}

@@ -1,0 +1,447 @@
+// F1 (+C1+C2) fused: multi-resolution hash-grid lookup -> tiny MLPs on the matrix cores -> SDF/density
+// head -> transmittance scan -> feature/depth/accumulation compositing, one wavefront per ray.
+//
+// Wave layout (tile = 16 consecutive samples of one ray):   lane = 16*g + j
+//     j = lane & 15  : sample inside the tile          g = lane >> 4 : "k-group" (0..3)
+//   * gather: the 4 lanes (j, g=0..3) of a sample each look up L/4 levels  -> 8 features per lane.  Those 8
+//     registers ARE the MFMA B-fragments of geo-layer 1 (v_mfma_f32_16x16x4_f32: B[k = lane>>4][n = lane&15]),
+//     the weight matrix is the A operand with its K axis permuted to match (done once, at LDS staging).
+//   * transposed chaining H^T = W . X^T : the D tile comes out as D[neuron = 4g + r][sample = j]  (r = 0..3),
+//     i.e. lane (j,g) again holds 4 activations of ITS sample per 16-neuron block -> they feed the next layer's
+//     B operand directly.  No cross-lane traffic, no LDS round trip between the five layers.
+//   * compositing: the 16 samples of a tile live in one DPP row (16 lanes) -> exclusive transmittance scan
+//     with row_shr DPP ops; the four rows (g) carry identical copies, each accumulates w*feature for its
+//     own 8 feature channels.
+// Exact fp32 (f32-input MFMA == fmaf chain): the parity target is the reference's fp32 torch path.
+#include "common.h"
+
+namespace nrhip {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct FieldDev {
+  GridDev grid;
+  const void* table;
+  float scale;
+  const float* gw0; const float* gb0;   // geo layer 0: [H][32], [H]
+  const float* gw1; const float* gb1;   // geo layer 1: [33][H], [33]
+  const float* fw0; const float* fb0;   // feat layer 0: [H][48]
+  const float* fw1; const float* fb1;   // feat layer 1: [H][H]
+  const float* fw2; const float* fb2;   // feat layer 2: [32][H]
+  int use_sdf;
+  float beta;
+};
+
+// LDS carve (floats), H = hidden width.  Fragment-ordered weights use [mb][s/4][lane][s%4] so that one
+// ds_read_b128 fetches the A fragments of 4 consecutive k-steps.
+template <int H>
+struct Lds {
+  static constexpr int NB = H / 16;        // 16-neuron blocks of a hidden layer
+  static constexpr int G0 = 0;             // geo L0 : NB blocks x 8 steps
+  static constexpr int G1 = G0 + H * 32;   // geo L1 (rows 1..32): 2 blocks x H/4 steps
+  static constexpr int F0 = G1 + 32 * H;   // feat L0 (geo part): NB blocks x 8 steps
+  static constexpr int F1 = F0 + H * 32;   // feat L1: NB blocks x H/4 steps
+  static constexpr int F2 = F1 + H * H;    // feat L2: 2 blocks x H/4 steps
+  static constexpr int SHW = F2 + 32 * H;  // feat L0 SH part: [16 c][NB][4 g][4 r]
+  static constexpr int SDFW = SHW + 16 * H;  // geo L1 row 0: [NB][4 g][4 r]
+  static constexpr int BG0 = SDFW + H;     // biases, [blk][g][r] == natural order
+  static constexpr int BG1 = BG0 + H;      // 33 -> [0] = sdf bias, [1..32]
+  static constexpr int BF0 = BG1 + 36;
+  static constexpr int BF1 = BF0 + H;
+  static constexpr int BF2 = BF1 + H;
+  static constexpr int SCAL = BF2 + 32;    // per-level scalings
+  static constexpr int TOTAL = SCAL + NRHIP_MAX_LEVELS;
+};
+
+// stage W[row_off + 16mb + i][col(g,s)] into fragment order; CHAIN: col = 16*(s/4) + 4g + s%4 (input is a D
+// tile of the previous layer), else col = 8g + s (input is the gathered feature registers).
+template <bool CHAIN>
+__device__ void stage_frag(float* dst, const float* __restrict__ W, int ldw, int row_off, int nblk, int nstep) {
+  const int total = nblk * nstep * 64;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int s3 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;  // [mb][s4][lane][s3]
+    const int s4 = rest % (nstep / 4), mb = rest / (nstep / 4);
+    const int s = 4 * s4 + s3, i = lane & 15, g = lane >> 4;
+    const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
+    dst[e] = W[(size_t)(row_off + 16 * mb + i) * ldw + col];
+  }
+}
+
+// one MFMA layer: acc[mb] += Σ_s A[mb][s] * B[s],  NS k-steps, NBLK output blocks, all statically unrolled.
+template <int NBLK, int NS>
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ wf, int lane, const float (&b)[NS],
+                                           f32x4 (&acc)[NBLK]) {
+#pragma unroll
+  for (int s4 = 0; s4 < NS / 4; ++s4) {
+    f32x4 a[NBLK];
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb)
+      a[mb] = *reinterpret_cast<const f32x4*>(wf + ((mb * (NS / 4) + s4) * 64 + lane) * 4);
+#pragma unroll
+    for (int s3 = 0; s3 < 4; ++s3)
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][s3], b[4 * s4 + s3], acc[mb], 0, 0, 0);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float fill) {
+  return dpp_row_shr<N>(v, fill);
+}
+// sum over the 16 lanes of a DPP row (result valid in every lane of the row)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2.
+template <int L, int F, int H, bool HALF, bool COMPOSITE>
+__global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev rays, float* __restrict__ out_feat,
+                                                        float* __restrict__ out_depth, float* __restrict__ out_acc,
+                                                        float* __restrict__ out_w, float* __restrict__ out_sdf,
+                                                        float* __restrict__ out_alpha) {
+  static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
+  static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
+  using Ld = Lds<H>;
+  constexpr int NB = H / 16;
+  constexpr int LPL = L / 4;  // levels per lane
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
+  stage_frag<false>(lds + Ld::G0, fd.gw0, 32, 0, NB, 8);
+  stage_frag<true>(lds + Ld::G1, fd.gw1, H, 1, 2, H / 4);
+  stage_frag<true>(lds + Ld::F0, fd.fw0, 48, 0, NB, 8);
+  stage_frag<true>(lds + Ld::F1, fd.fw1, H, 0, NB, H / 4);
+  stage_frag<true>(lds + Ld::F2, fd.fw2, H, 0, 2, H / 4);
+  for (int e = threadIdx.x; e < 16 * H; e += blockDim.x) {  // SHW[c][n] = fw0[n][32+c]
+    const int c = e / H, n = e - c * H;
+    lds[Ld::SHW + e] = fd.fw0[(size_t)n * 48 + 32 + c];
+  }
+  for (int e = threadIdx.x; e < H; e += blockDim.x) {
+    lds[Ld::SDFW + e] = fd.gw1[e];
+    lds[Ld::BG0 + e] = fd.gb0 ? fd.gb0[e] : 0.f;
+    lds[Ld::BF0 + e] = fd.fb0 ? fd.fb0[e] : 0.f;
+    lds[Ld::BF1 + e] = fd.fb1 ? fd.fb1[e] : 0.f;
+  }
+  for (int e = threadIdx.x; e < 33; e += blockDim.x) lds[Ld::BG1 + e] = fd.gb1 ? fd.gb1[e] : 0.f;
+  for (int e = threadIdx.x; e < 32; e += blockDim.x) {
+    lds[Ld::BF2 + e] = fd.fb2 ? fd.fb2[e] : 0.f;
+    lds[Ld::SCAL + e] = fd.grid.scal[e];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const uint32_t mask = (1u << fd.grid.log2T) - 1u;
+  const int S = rays.S;
+  const int ntile = (S + 15) >> 4;
+
+  float scal_l[LPL];
+#pragma unroll
+  for (int q = 0; q < LPL; ++q) scal_l[q] = lds[Ld::SCAL + LPL * g + q];
+
+  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < rays.R; ray += (int64_t)gridDim.x * 4) {
+    const float ox = rays.o[3 * ray], oy = rays.o[3 * ray + 1], oz = rays.o[3 * ray + 2];
+    const float dx = rays.d[3 * ray], dy = rays.d[3 * ray + 1], dz = rays.d[3 * ray + 2];
+    const float area = rays.area[ray];
+
+    // per-ray part of feat layer 0:  rb[n] = fb0[n] + Σ_c fw0[n][32+c] * SH_c((d+1)/2)   (neurad_field.py:140-141)
+    f32x4 rb[NB];
+    {
+      float sh[16];
+      sh4((dx + 1.f) / 2.f, (dy + 1.f) / 2.f, (dz + 1.f) / 2.f, sh);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) rb[mb] = *reinterpret_cast<const f32x4*>(lds + Ld::BF0 + 16 * mb + 4 * g);
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(lds + Ld::SHW + c * H + 16 * mb + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rb[mb][r] = fmaf(w[r], sh[c], rb[mb][r]);
+        }
+    }
+
+    float carry = COMPOSITE ? (fd.use_sdf ? 1.f : 0.f) : 0.f;  // running transmittance (product) / optical depth (sum)
+    float acc_w = 0.f, acc_d = 0.f;
+    f32x4 fa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 flast[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+    for (int t = 0; t < ntile; ++t) {
+      // The weights in LDS are loop invariant: without this opaque offset the compiler hoists ~200 LDS
+      // loads out of the tile loop and spills them.  `lw` re-derives the LDS base once per tile.
+      int opaque = 0;
+      asm volatile("" : "+v"(opaque));
+      const float* lw = lds + opaque;
+      const int s = 16 * t + j;
+      const bool live = s < S;
+      const int64_t si = ray * rays.stride + (live ? s : S - 1);
+      const float t0 = rays.starts[si], t1 = rays.ends[si];
+      const SamplePos p = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, 0.f, fd.scale);
+
+      // ---- gather: LPL levels x 8 corners, rescaled (H1 + H4) ------------------------------------
+      float feat[8];
+#pragma unroll
+      for (int q = 0; q < LPL; ++q) {
+        const int l = LPL * g + q;
+        float v[F];
+        hash_level<F, HALF>(fd.table, (uint32_t)l << fd.grid.log2T, p.x, p.y, p.z, scal_l[q], mask, v);
+        const float w = rescale_weight(scal_l[q], p.std);
+#pragma unroll
+        for (int f = 0; f < F; ++f) feat[q * F + f] = v[f] * w;
+      }
+
+      // ---- geo MLP layer 0 (32 -> H, ReLU) ---------------------------------------------------------
+      f32x4 h[NB];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BG0 + 16 * mb + 4 * g);
+      mfma_layer<NB, 8>(lw + Ld::G0, lane, feat, h);
+      float hb[H / 4];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+
+      // ---- geo MLP layer 1 (H -> 1 + 32): row 0 (sdf / raw density) on the VALU, rows 1..32 on MFMA --
+      float sdf = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lw + Ld::SDFW + 16 * mb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sdf = fmaf(w[r], hb[4 * mb + r], sdf);
+      }
+      sdf += __shfl_xor(sdf, 16, 64);
+      sdf += __shfl_xor(sdf, 32, 64);
+      sdf += lw[Ld::BG1];
+      f32x4 e[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float* bp = lw + Ld::BG1 + 1 + 16 * mb + 4 * g;
+        e[mb] = f32x4{bp[0], bp[1], bp[2], bp[3]};
+      }
+      mfma_layer<2, H / 4>(lw + Ld::G1, lane, hb, e);
+      float eb[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) eb[k] = e[k >> 2][k & 3];
+
+      // ---- feature MLP (32 [+16 SH folded into rb] -> H -> H -> 32), residual add -------------------
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) h[mb] = rb[mb];
+      mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF1 + 16 * mb + 4 * g);
+      mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+      f32x4 o[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) o[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF2 + 16 * mb + 4 * g);
+      mfma_layer<2, H / 4>(lw + Ld::F2, lane, hb, o);
+      o[0] += e[0];
+      o[1] += e[1];  // feature = geo_embedding + mlp_feature(...)   (neurad_field.py:141)
+
+      // ---- head (F4 / trunc_exp) -------------------------------------------------------------------
+      float a_or_d;  // alpha (sdf mode) or density
+      if (fd.use_sdf) a_or_d = 1.f / (1.f + expf(sdf * fd.beta));  // sigmoid(-sdf*beta)
+      else a_or_d = expf(sdf);
+
+      if constexpr (!COMPOSITE) {
+        if (live) {
+          float* fp = out_feat + (ray * S + s) * 32;
+          *reinterpret_cast<f32x4*>(fp + 4 * g) = o[0];
+          *reinterpret_cast<f32x4*>(fp + 16 + 4 * g) = o[1];
+          if (g == 0) {
+            out_sdf[ray * S + s] = sdf;
+            out_alpha[ray * S + s] = a_or_d;
+          }
+        }
+      } else {
+        // ---- C1: transmittance scan over the 16 samples of the DPP row, carried across tiles -------
+        float w, T;
+        if (fd.use_sdf) {
+          const float alpha = live ? a_or_d : 0.f;
+          float incl = 1.f - alpha;
+          incl *= row_shr<1>(incl, 1.f);
+          incl *= row_shr<2>(incl, 1.f);
+          incl *= row_shr<4>(incl, 1.f);
+          incl *= row_shr<8>(incl, 1.f);
+          const float excl = row_shr<1>(incl, 1.f);
+          T = carry * excl;
+          w = T * alpha;
+          carry *= __shfl(incl, (lane & 48) | 15, 64);
+        } else {
+          const float sd = live ? a_or_d * (t1 - t0) : 0.f;
+          float incl = sd;
+          incl += row_shr<1>(incl, 0.f);
+          incl += row_shr<2>(incl, 0.f);
+          incl += row_shr<4>(incl, 0.f);
+          incl += row_shr<8>(incl, 0.f);
+          const float excl = row_shr<1>(incl, 0.f);
+          T = expf(-(carry + excl));
+          w = T * (1.f - expf(-sd));
+          carry += __shfl(incl, (lane & 48) | 15, 64);
+        }
+        if (out_w && live && g == 0) out_w[ray * S + s] = w;
+        // ---- C2 accumulation ------------------------------------------------------------------------
+        acc_w += w;
+        if (s < S - 1) acc_d += w * ((t0 + t1) / 2.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          fa[0][r] = fmaf(o[0][r], w, fa[0][r]);
+          fa[1][r] = fmaf(o[1][r], w, fa[1][r]);
+        }
+        if (s == S - 1) flast[0] = o[0], flast[1] = o[1];
+      }
+    }
+
+    if constexpr (COMPOSITE) {
+      const float acc = row_sum16(acc_w);
+      const float dep = row_sum16(acc_d);
+      const float resid = 1.f - acc;  // goes onto the last (sky) sample (models/neurad.py:381)
+      fa[0] += flast[0] * resid;      // flast is non-zero only in the lane that owns sample S-1
+      fa[1] += flast[1] * resid;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fa[mb][r] = row_sum16(fa[mb][r]);
+      if (j == 0) {
+        float* fp = out_feat + ray * 32;
+        *reinterpret_cast<f32x4*>(fp + 4 * g) = fa[0];
+        *reinterpret_cast<f32x4*>(fp + 16 + 4 * g) = fa[1];
+        if (g == 0) {
+          out_acc[ray] = acc;
+          out_depth[ray] = dep;
+        }
+      }
+    }
+  }
+}
+
+static int validate_field(const nrhip_field* f) {
+  NR_REQUIRE(f, NRHIP_ERR_INVALID_ARG, "field descriptor is NULL");
+  if (int e = validate_grid(&f->grid)) return e;
+  NR_REQUIRE(f->table && f->static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "field: NULL table or non-positive scale");
+  const nrhip_mlp& a = f->geo;
+  const nrhip_mlp& b = f->feat;
+  const int in = f->grid.num_levels * f->grid.n_features;
+  NR_REQUIRE(in == 32 && f->grid.num_levels % 4 == 0, NRHIP_ERR_UNSUPPORTED,
+             "fused field kernel needs L*F == 32 with L %% 4 == 0 (got L=%d F=%d); use the unfused ops",
+             f->grid.num_levels, f->grid.n_features);
+  NR_REQUIRE(a.num_layers == 2 && b.num_layers == 3 && a.in_dim == 32 && a.out_dim == 33 && b.in_dim == 48 &&
+                 b.out_dim == 32 && a.hidden_dim == b.hidden_dim,
+             NRHIP_ERR_UNSUPPORTED,
+             "fused field kernel needs geo 32->H->33 (2 layers) and feat 48->H->H->32 (3 layers); use the unfused ops");
+  NR_REQUIRE(a.hidden_dim == 32 || a.hidden_dim == 64, NRHIP_ERR_UNSUPPORTED,
+             "fused field kernel is instantiated for hidden width 32 and 64 (got %d)", a.hidden_dim);
+  for (int l = 0; l < 2; ++l) NR_REQUIRE(a.weight[l], NRHIP_ERR_INVALID_ARG, "geo weight %d is NULL", l);
+  for (int l = 0; l < 3; ++l) NR_REQUIRE(b.weight[l], NRHIP_ERR_INVALID_ARG, "feat weight %d is NULL", l);
+  return NRHIP_OK;
+}
+
+static FieldDev to_dev(const nrhip_field& f) {
+  FieldDev d;
+  d.grid = to_dev(f.grid);
+  d.table = f.table;
+  d.scale = f.static_scale;
+  d.gw0 = f.geo.weight[0], d.gb0 = f.geo.bias[0];
+  d.gw1 = f.geo.weight[1], d.gb1 = f.geo.bias[1];
+  d.fw0 = f.feat.weight[0], d.fb0 = f.feat.bias[0];
+  d.fw1 = f.feat.weight[1], d.fb1 = f.feat.bias[1];
+  d.fw2 = f.feat.weight[2], d.fb2 = f.feat.bias[2];
+  d.use_sdf = f.use_sdf;
+  d.beta = f.beta;
+  return d;
+}
+
+template <int L, int F, int H, bool HALF, bool COMPOSITE>
+static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
+                         float* oal, hipStream_t st) {
+  constexpr size_t lds = Lds<H>::TOTAL * sizeof(float);
+  auto kern = render_kernel<L, F, H, HALF, COMPOSITE>;
+  static bool configured = false;
+  if (lds > 64 * 1024 && !configured) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  int n_cu = 256;
+  {
+    static int cached = 0;
+    if (!cached) {
+      int dev = 0;
+      hipDeviceProp_t p;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+        cached = p.multiProcessorCount;
+      else
+        cached = 256;
+    }
+    n_cu = cached;
+  }
+  int64_t blocks = (rd.R + 3) / 4;
+  static int per_cu = 0;  // persistent grid: as many workgroups per CU as registers + LDS admit
+  if (!per_cu) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+    per_cu = nb > 4 ? 4 : nb;
+  }
+  const int64_t cap = (int64_t)n_cu * per_cu;
+  if (blocks > cap) blocks = cap;
+  kern<<<(int)blocks, 256, lds, st>>>(fd, rd, of, od, oa, ow, os, oal);
+  return check_launch("render/field fused kernel");
+}
+
+template <bool COMPOSITE>
+static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
+                           float* os, float* oal, void* stream) {
+  const FieldDev fd = to_dev(*f);
+  const RaysDev rd = to_dev(*rays);
+  const hipStream_t st = (hipStream_t)stream;
+  const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
+  const bool half = f->grid.param_dtype == 1;
+#define CASE(L_, F_, H_)                                                                                   \
+  if (L == L_ && F == F_ && H == H_) {                                                                     \
+    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, st)          \
+                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, st);        \
+  }
+  CASE(16, 2, 64)
+  CASE(16, 2, 32)
+  CASE(8, 4, 32)
+  CASE(8, 4, 64)
+  CASE(4, 8, 32)
+  CASE(4, 8, 64)
+#undef CASE
+  set_error("fused field kernel: no instantiation for L=%d F=%d H=%d", L, F, H);
+  return NRHIP_ERR_UNSUPPORTED;
+}
+
+}  // namespace nrhip
+
+using namespace nrhip;
+
+extern "C" int nrhip_field_fwd(const nrhip_field* f, const nrhip_rays* rays, float* feature, float* sdf, float* alpha,
+                               void* stream) {
+  if (int e = validate_field(f)) return e;
+  if (int e = validate_rays(rays)) return e;
+  if (rays->n_rays == 0 || rays->n_samples == 0) return NRHIP_OK;
+  NR_REQUIRE(feature && sdf && alpha, NRHIP_ERR_INVALID_ARG, "field_fwd: NULL output");
+  return dispatch_render<false>(f, rays, feature, nullptr, nullptr, nullptr, sdf, alpha, stream);
+}
+
+extern "C" int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
+                                float* out_acc, float* out_weights, void* stream) {
+  if (int e = validate_field(f)) return e;
+  if (int e = validate_rays(rays)) return e;
+  if (rays->n_rays == 0) return NRHIP_OK;
+  NR_REQUIRE(out_features && out_depth && out_acc, NRHIP_ERR_INVALID_ARG, "render_fwd: NULL output");
+  NR_REQUIRE(rays->n_samples >= 1, NRHIP_ERR_INVALID_ARG, "render_fwd: needs >= 1 sample per ray");
+  return dispatch_render<true>(f, rays, out_features, out_depth, out_acc, out_weights, nullptr, nullptr, stream);
+}

@@ -1,0 +1,328 @@
+// S1 / S4 / S5+M1: PowerSampler bins, PDF resampling and the fused proposal sampler.
+// One wavefront marches one ray; bin edges, the CDF and the weights of a round live in a per-wave LDS
+// slab, the exclusive sum scans are wave shuffles, the inverse-CDF lookups are per-lane binary searches
+// in LDS (the 65 / 33 query points of a round fit one / two passes of the 64 lanes).
+#include "common.h"
+
+namespace nrhip {
+
+constexpr int kSMax = 512;  // max samples per ray per round handled by the LDS slabs
+
+// ZipNeRF power transform (utils/math.py:541-579) as used by PowerSampler (ray_samplers.py:838-852)
+__device__ __forceinline__ float power_fn(float x, float lam) {
+  if (lam == 1.f) return x;
+  if (lam == 0.f) return log1pf(x);
+  const float lam_1 = fabsf(lam - 1.f);
+  return (lam_1 / lam) * (powf(x / lam_1 + 1.f, lam) - 1.f);
+}
+__device__ __forceinline__ float inv_power_fn(float x, float lam) {
+  if (lam == 1.f) return x;
+  if (lam == 0.f) return expm1f(x);
+  const float lam_1 = fabsf(lam - 1.f);
+  return (powf(fmaxf(x * lam / lam_1 + 1.f, 1e-10f), 1.f / lam) - 1.f) * lam_1;
+}
+struct Spacing {
+  float s_near, s_far, lam, scaling;
+  __device__ __forceinline__ float to_euclid(float b) const {
+    return inv_power_fn(b * s_far + (1.f - b) * s_near, lam) / scaling;
+  }
+};
+__device__ __forceinline__ Spacing make_spacing(float near, float far, float lam, float scaling) {
+  return Spacing{power_fn(near * scaling, lam), power_fn(far * scaling, lam), lam, scaling};
+}
+
+// torch.linspace(start, end, steps)[i] in fp32 (symmetric evaluation used by ATen)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  const float step = (end - start) / (float)(steps - 1);
+  return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+// S1 for one ray: edges k = lane, lane+64, ... of the S+1 bins (ray_samplers.py:100-119)
+__device__ __forceinline__ float power_bin(int k, int S, const float* t_rand_row) {
+  float b = linspace_at(0.f, 1.f, S + 1, k);
+  if (t_rand_row) {
+    const float bm = k > 0 ? linspace_at(0.f, 1.f, S + 1, k - 1) : b;
+    const float bp = k < S ? linspace_at(0.f, 1.f, S + 1, k + 1) : b;
+    const float upper = k < S ? (bp + b) / 2.f : b;
+    const float lower = k > 0 ? (b + bm) / 2.f : b;
+    b = lower + (upper - lower) * t_rand_row[k];
+  }
+  return b;
+}
+
+__global__ __launch_bounds__(256) void power_sampler_kernel(const float* __restrict__ nears,
+                                                             const float* __restrict__ fars, int64_t R, int S,
+                                                             float lam, float scaling,
+                                                             const float* __restrict__ t_rand,
+                                                             float* __restrict__ sp, float* __restrict__ eu) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= R * (S + 1)) return;
+  const int64_t ray = t / (S + 1);
+  const int k = (int)(t - ray * (S + 1));
+  const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
+  const float b = power_bin(k, S, t_rand ? t_rand + ray * (S + 1) : nullptr);
+  sp[t] = b;
+  eu[t] = spc.to_euclid(b);
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wscan_add(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// S4 for one ray (ray_samplers.py:306-366).  w_lds[Sp] raw weights, bins_lds[Sp+1] existing spacing bins,
+// cdf_lds[Sp+1] scratch.  Writes the Sn+1 new spacing bins to new_bins (LDS or global) and, if eu_out, the
+// euclidean bins.  rand_row: NULL (eval) / jitter values, rand_stride 0 = single jitter.
+__device__ __forceinline__ void pdf_resample_ray(const float* w_lds, const float* bins_lds, float* cdf_lds, int Sp,
+                                                 int Sn, float pad, const float* rand_row, int rand_stride,
+                                                 const Spacing& spc, float* new_bins, float* eu_out, int lane) {
+  constexpr float eps = 1e-5f;
+  // weights + histogram padding, their sum
+  float tot = 0.f;
+  for (int k = lane; k < Sp; k += 64) tot += w_lds[k] + pad;
+  tot = wsum(tot);
+  const float padding = fmaxf(eps - tot, 0.f);
+  const float add = padding / (float)Sp;
+  tot += padding;
+  // cdf = min(1, cumsum(pdf)), cdf[0] = 0
+  float carry = 0.f;
+  for (int k0 = 0; k0 < Sp; k0 += 64) {
+    const int k = k0 + lane;
+    const float pdf = k < Sp ? ((w_lds[k] + pad) + add) / tot : 0.f;
+    const float incl = wscan_add(pdf, lane);
+    if (k < Sp) cdf_lds[k + 1] = fminf(1.f, carry + incl);
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cdf_lds[0] = 0.f;
+  wave_fence();
+  const int nb = Sn + 1;
+  for (int i = lane; i < nb; i += 64) {
+    float u = linspace_at(0.f, 1.f - (1.f / (float)nb), nb, i);
+    if (rand_row) u += rand_row[rand_stride ? i : 0] / (float)nb;
+    else u += 1.f / (float)(2 * nb);
+    // searchsorted(cdf, u, side="right") over Sp+1 entries = #{cdf <= u}
+    int lo = 0, hi = Sp + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf_lds[mid] <= u) lo = mid + 1;
+      else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), Sp), above = min(max(lo, 0), Sp);
+    const float c0 = cdf_lds[below], c1 = cdf_lds[above];
+    const float b0 = bins_lds[below], b1 = bins_lds[above];
+    float tt = (u - c0) / (c1 - c0);
+    if (tt != tt) tt = 0.f;  // nan_to_num(nan=0); +-inf are clipped below
+    tt = fminf(fmaxf(tt, 0.f), 1.f);
+    const float nbv = b0 + tt * (b1 - b0);
+    new_bins[i] = nbv;
+    if (eu_out) eu_out[i] = spc.to_euclid(nbv);
+  }
+}
+
+__global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict__ weights,
+                                                          const float* __restrict__ bins,
+                                                          const float* __restrict__ nears,
+                                                          const float* __restrict__ fars, int64_t R, int Sp, int Sn,
+                                                          float lam, float scaling, float pad,
+                                                          const float* __restrict__ rand, int rand_stride,
+                                                          float* __restrict__ new_sp, float* __restrict__ new_eu) {
+  __shared__ float slab[4][3 * (kSMax + 1)];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wid;
+  if (ray >= R) return;
+  float* w_lds = slab[wid];
+  float* b_lds = w_lds + kSMax + 1;
+  float* c_lds = b_lds + kSMax + 1;
+  for (int k = lane; k < Sp; k += 64) w_lds[k] = weights[ray * Sp + k];
+  for (int k = lane; k <= Sp; k += 64) b_lds[k] = bins[ray * (Sp + 1) + k];
+  wave_fence();
+  const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
+  pdf_resample_ray(w_lds, b_lds, c_lds, Sp, Sn, pad, rand ? rand + ray * (rand_stride ? rand_stride : 1) : nullptr,
+                   rand_stride, spc, new_sp + ray * (Sn + 1), new_eu + ray * (Sn + 1), lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// S5 + M1 fused.  Per ray: power bins -> [density (S2) -> weights (S3) -> pdf resample (S4)] x rounds.
+struct PropDev {
+  GridDev grid;
+  const void* table;
+  float scale;
+  const float* dec;
+};
+struct SamplerDev {
+  int n_rounds;
+  int ns[3];
+  float lam, scaling, pad, sky;
+  PropDev prop[2];
+  float* w_out[2];
+  float* sp_out[3];
+  float* eu_out[3];
+};
+
+template <bool HALF>
+__device__ __forceinline__ float prop_density(const PropDev& p, float ox, float oy, float oz, float dx, float dy,
+                                              float dz, float area, float t0, float t1) {
+  const SamplePos q = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, 0.f, p.scale);
+  const uint32_t mask = (1u << p.grid.log2T) - 1u;
+  float acc = 0.f;
+  for (int l = 0; l < p.grid.L; ++l) {
+    float v[1];
+    hash_level<1, HALF>(p.table, (uint32_t)l << p.grid.log2T, q.x, q.y, q.z, p.grid.scal[l], mask, v);
+    acc += (v[0] * rescale_weight(p.grid.scal[l], q.std)) * p.dec[l];
+  }
+  return expf(acc);
+}
+
+__global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, const float* __restrict__ o,
+                                                                const float* __restrict__ d,
+                                                                const float* __restrict__ area,
+                                                                const float* __restrict__ nears,
+                                                                const float* __restrict__ fars, int64_t R) {
+  // per wave: spacing bins (2 buffers), euclid bins, weights, cdf
+  __shared__ float slab[4][5 * (kSMax + 1)];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* spA = slab[wid];
+  float* spB = spA + kSMax + 1;
+  float* eu = spB + kSMax + 1;
+  float* wl = eu + kSMax + 1;
+  float* cdf = wl + kSMax + 1;
+  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < R; ray += (int64_t)gridDim.x * 4) {
+    const float ox = o[3 * ray], oy = o[3 * ray + 1], oz = o[3 * ray + 2];
+    const float dx = d[3 * ray], dy = d[3 * ray + 1], dz = d[3 * ray + 2];
+    const float ar = area[ray];
+    const Spacing spc =
+        make_spacing(nears ? nears[ray] : 0.f, fminf(fars ? fars[ray] : sd.sky, sd.sky), sd.lam, sd.scaling);
+    wave_fence();
+    // round 0 bins (eval mode: no jitter inside the fused kernel)
+    int S = sd.ns[0];
+    for (int k = lane; k <= S; k += 64) {
+      const float b = power_bin(k, S, nullptr);
+      const float e = spc.to_euclid(b);
+      spA[k] = b;
+      eu[k] = e;
+      sd.sp_out[0][ray * (S + 1) + k] = b;
+      sd.eu_out[0][ray * (S + 1) + k] = e;
+    }
+    wave_fence();
+    float* cur = spA;
+    float* nxt = spB;
+    for (int rd = 0; rd < sd.n_rounds; ++rd) {
+      // S2 + S3: density -> delta*density -> exclusive-sum transmittance -> weights
+      float carry = 0.f;
+      for (int k0 = 0; k0 < S; k0 += 64) {
+        const int k = k0 + lane;
+        const bool live = k < S;
+        const float t0 = eu[live ? k : 0], t1 = eu[live ? k + 1 : 1];
+        float dens = sd.prop[rd].grid.dtype == 1
+                         ? prop_density<true>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1)
+                         : prop_density<false>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
+        const float dd = live ? (t1 - t0) * dens : 0.f;
+        const float incl = wscan_add(dd, lane);
+        float w = (1.f - expf(-dd)) * expf(-(carry + incl - dd));
+        if (w != w) w = 0.f;  // nan_to_num
+        w = fminf(fmaxf(w, -3.4028234663852886e38f), 3.4028234663852886e38f);
+        if (live) {
+          wl[k] = w;
+          sd.w_out[rd][ray * S + k] = w;
+        }
+        carry += __shfl(incl, 63, 64);
+      }
+      wave_fence();
+      // S4: resample into the next round's bins
+      const int Sn = sd.ns[rd + 1];
+      pdf_resample_ray(wl, cur, cdf, S, Sn, sd.pad, nullptr, 0, spc, nxt, eu, lane);
+      wave_fence();
+      for (int k = lane; k <= Sn; k += 64) {
+        sd.sp_out[rd + 1][ray * (Sn + 1) + k] = nxt[k];
+        sd.eu_out[rd + 1][ray * (Sn + 1) + k] = eu[k];
+      }
+      float* tsw = cur;
+      cur = nxt;
+      nxt = tsw;
+      S = Sn;
+    }
+  }
+}
+
+}  // namespace nrhip
+
+using namespace nrhip;
+
+extern "C" int nrhip_power_sampler(const float* nears, const float* fars, int64_t r, int32_t s, float lam,
+                                   float scaling, const float* t_rand, float* spacing_bins, float* euclid_bins,
+                                   void* stream) {
+  NR_REQUIRE(fars && spacing_bins && euclid_bins && r >= 0 && s >= 1, NRHIP_ERR_INVALID_ARG,
+             "power_sampler: bad argument");
+  NR_REQUIRE(lam != 0.f || true, NRHIP_ERR_INVALID_ARG, "unreachable");
+  if (r == 0) return NRHIP_OK;
+  power_sampler_kernel<<<grid_for(r * (s + 1), 256), 256, 0, (hipStream_t)stream>>>(nears, fars, r, s, lam, scaling,
+                                                                                    t_rand, spacing_bins, euclid_bins);
+  return check_launch("power_sampler");
+}
+
+extern "C" int nrhip_pdf_sample(const float* weights, const float* spacing_bins, const float* nears, const float* fars,
+                                int64_t r, int32_t s_prev, int32_t s_new, float lam, float scaling,
+                                float histogram_padding, const float* rand, int32_t rand_stride,
+                                float* new_spacing_bins, float* new_euclid_bins, void* stream) {
+  NR_REQUIRE(weights && spacing_bins && fars && new_spacing_bins && new_euclid_bins && r >= 0, NRHIP_ERR_INVALID_ARG,
+             "pdf_sample: null pointer");
+  NR_REQUIRE(s_prev >= 1 && s_prev <= kSMax && s_new >= 1 && s_new <= kSMax, NRHIP_ERR_UNSUPPORTED,
+             "pdf_sample: sample counts (%d -> %d) outside [1,%d]", s_prev, s_new, kSMax);
+  NR_REQUIRE(rand_stride == 0 || rand_stride == s_new + 1, NRHIP_ERR_INVALID_ARG,
+             "pdf_sample: rand_stride must be 0 (single jitter) or s_new+1");
+  if (r == 0) return NRHIP_OK;
+  pdf_sample_kernel<<<(int)((r + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      weights, spacing_bins, nears, fars, r, s_prev, s_new, lam, scaling, histogram_padding, rand, rand_stride,
+      new_spacing_bins, new_euclid_bins);
+  return check_launch("pdf_sample");
+}
+
+extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props,
+                                          const float* origins, const float* directions, const float* pixel_area,
+                                          const float* nears, const float* fars, int64_t r,
+                                          float* const* round_weights, float* const* round_spacing,
+                                          float* const* round_euclid, void* stream) {
+  NR_REQUIRE(cfg && props && origins && directions && pixel_area && round_weights && round_spacing && round_euclid,
+             NRHIP_ERR_INVALID_ARG, "proposal_sampler_fwd: null pointer");
+  NR_REQUIRE(cfg->n_rounds >= 1 && cfg->n_rounds <= 2, NRHIP_ERR_UNSUPPORTED,
+             "proposal_sampler_fwd: n_rounds %d outside [1,2]", cfg->n_rounds);
+  SamplerDev sd;
+  sd.n_rounds = cfg->n_rounds;
+  sd.lam = cfg->lam, sd.scaling = cfg->scaling, sd.pad = cfg->histogram_padding, sd.sky = cfg->sky_distance;
+  for (int i = 0; i <= cfg->n_rounds; ++i) {
+    NR_REQUIRE(cfg->n_samples[i] >= 1 && cfg->n_samples[i] <= kSMax, NRHIP_ERR_UNSUPPORTED,
+               "proposal_sampler_fwd: n_samples[%d]=%d outside [1,%d]", i, cfg->n_samples[i], kSMax);
+    sd.ns[i] = cfg->n_samples[i];
+    NR_REQUIRE(round_spacing[i] && round_euclid[i], NRHIP_ERR_INVALID_ARG, "proposal_sampler_fwd: null bins output");
+    sd.sp_out[i] = round_spacing[i];
+    sd.eu_out[i] = round_euclid[i];
+  }
+  for (int i = 0; i < cfg->n_rounds; ++i) {
+    if (int e = validate_grid(&props[i].grid)) return e;
+    NR_REQUIRE(props[i].grid.n_features == 1, NRHIP_ERR_UNSUPPORTED, "proposal field needs features_per_level == 1");
+    NR_REQUIRE(props[i].table && props[i].decoder_weight && props[i].static_scale > 0.f && round_weights[i],
+               NRHIP_ERR_INVALID_ARG, "proposal_sampler_fwd: bad proposal field %d", i);
+    sd.prop[i] = PropDev{to_dev(props[i].grid), props[i].table, props[i].static_scale, props[i].decoder_weight};
+    sd.w_out[i] = round_weights[i];
+  }
+  if (r == 0) return NRHIP_OK;
+  int64_t blocks = (r + 3) / 4;
+  if (blocks > 256 * 4) blocks = 256 * 4;
+  proposal_sampler_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(sd, origins, directions, pixel_area, nears,
+                                                                        fars, r);
+  return check_launch("proposal_sampler_fwd");
+}

@@ -1,0 +1,453 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see autograd.py).
+
+PyTorch is plumbing only: it owns the device buffers and the current HIP stream.  Every function
+launches hand-written HIP kernels from libneurad_hip.so on ``torch.cuda.current_stream()`` and fails
+loudly when given CPU tensors -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import call
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t: Tensor, name: str, dtype=torch.float32) -> Tensor:
+    if not isinstance(t, Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.NeuradHipError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def hash_scalings(num_levels: int, min_res: int, max_res: int) -> Tensor:
+    """scalings_l = floor(min_res * g**l) evaluated exactly like encodings.py:347-350 (fp32 torch ops on CPU)."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1.0
+    return torch.floor(min_res * growth**levels).to(torch.float32)
+
+
+@dataclass
+class GridSpec:
+    """Static description of one HashEncoding (encodings.py:326-352)."""
+
+    num_levels: int
+    features_per_level: int
+    log2_hashmap_size: int
+    min_res: int
+    max_res: int
+    scalings: Optional[Tensor] = None  # CPU fp32 [L]
+
+    def __post_init__(self):
+        if self.scalings is None:
+            self.scalings = hash_scalings(self.num_levels, self.min_res, self.max_res)
+
+    @property
+    def out_dim(self) -> int:
+        return self.num_levels * self.features_per_level
+
+    @property
+    def table_rows(self) -> int:
+        return self.num_levels << self.log2_hashmap_size
+
+    def c_grid(self, table: Tensor) -> _lib.Grid:
+        if table.dtype not in (torch.float32, torch.float16):
+            raise TypeError(f"hash table must be fp32 or fp16, got {table.dtype}")
+        if tuple(table.shape) != (self.table_rows, self.features_per_level):
+            raise ValueError(f"hash table shape {tuple(table.shape)} != {(self.table_rows, self.features_per_level)}")
+        g = _lib.Grid()
+        g.num_levels, g.n_features = self.num_levels, self.features_per_level
+        g.log2_table_size = self.log2_hashmap_size
+        g.param_dtype = 1 if table.dtype == torch.float16 else 0
+        sc = self.scalings.tolist()
+        for i, v in enumerate(sc):
+            g.scalings[i] = v
+        return g
+
+
+def _c_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]) -> Tuple[_lib.Mlp, list]:
+    n = len(weights)
+    if not 1 <= n <= _lib.MAX_LAYERS:
+        raise ValueError(f"MLP needs 1..{_lib.MAX_LAYERS} layers, got {n}")
+    keep = []
+    m = _lib.Mlp()
+    m.num_layers = n
+    m.in_dim = weights[0].shape[1]
+    m.out_dim = weights[-1].shape[0]
+    m.hidden_dim = weights[0].shape[0] if n > 1 else 0
+    for k, (w, b) in enumerate(zip(weights, biases)):
+        exp_in = m.in_dim if k == 0 else m.hidden_dim
+        exp_out = m.out_dim if k == n - 1 else m.hidden_dim
+        if tuple(w.shape) != (exp_out, exp_in):
+            raise ValueError(f"layer {k}: weight shape {tuple(w.shape)} != {(exp_out, exp_in)} (uniform hidden width)")
+        w = _chk(w, f"weight[{k}]")
+        keep.append(w)
+        m.weight[k] = w.data_ptr()
+        if b is not None:
+            b = _chk(b, f"bias[{k}]")
+            keep.append(b)
+            m.bias[k] = b.data_ptr()
+        else:
+            m.bias[k] = None
+    return m, keep
+
+
+def _c_rays(origins: Tensor, directions: Tensor, pixel_area: Tensor, starts: Tensor, ends: Tensor):
+    """starts/ends: [R,S] each, or views into one [R,S+1] edge tensor (stride S+1) -- no copies are made."""
+    o = _chk(origins, "origins")
+    d = _chk(directions, "directions")
+    a = _chk(pixel_area.reshape(-1), "pixel_area")
+    R = o.shape[0]
+    if starts.dim() != 2 or starts.shape != ends.shape or starts.shape[0] != R:
+        raise ValueError(f"starts/ends must be [R,S] with R={R}; got {tuple(starts.shape)}, {tuple(ends.shape)}")
+    if not (starts.is_cuda and ends.is_cuda and starts.dtype == torch.float32 and ends.dtype == torch.float32):
+        raise _lib.NeuradHipError("starts/ends must be fp32 GPU tensors")
+    S = starts.shape[1]
+    if starts.stride(1) != 1 or ends.stride(1) != 1 or starts.stride(0) != ends.stride(0):
+        starts, ends = starts.contiguous(), ends.contiguous()
+    r = _lib.Rays()
+    r.n_rays, r.n_samples = R, S
+    r.origins, r.directions, r.pixel_area = o.data_ptr(), d.data_ptr(), a.data_ptr()
+    r.starts, r.ends = starts.data_ptr(), ends.data_ptr()
+    r.sample_stride = starts.stride(0) if R > 1 else max(S, 1)
+    return r, (o, d, a, starts, ends)
+
+
+# ------------------------------------------------------------------------------------------------
+def hashgrid_fwd(spec: GridSpec, table: Tensor, x: Tensor) -> Tensor:
+    x = _chk(x, "x")
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise ValueError(f"x must be [N,3], got {tuple(x.shape)}")  # encodings.py:428
+    table = table if table.is_contiguous() else table.contiguous()
+    out = torch.empty((x.shape[0], spec.out_dim), device=x.device, dtype=torch.float32)
+    g = spec.c_grid(table)
+    call("nrhip_hashgrid_fwd", C.byref(g), _ptr(table), _ptr(x), x.shape[0], _ptr(out), _stream())
+    return out
+
+
+def hashgrid_bwd(spec: GridSpec, table_like: Tensor, x: Tensor, grad_out: Tensor) -> Tensor:
+    x, grad_out = _chk(x, "x"), _chk(grad_out, "grad_out")
+    gt = torch.zeros((spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
+    g = spec.c_grid(gt)
+    call("nrhip_hashgrid_bwd", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), _stream())
+    return gt
+
+
+def encode_fwd(spec: GridSpec, table: Tensor, static_scale: float, origins, directions, pixel_area, starts, ends):
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    out = torch.empty((r.n_rays * r.n_samples, spec.out_dim), device=origins.device, dtype=torch.float32)
+    g = spec.c_grid(table)
+    call("nrhip_encode_fwd", C.byref(g), _ptr(table), float(static_scale), C.byref(r), _ptr(out), _stream())
+    return out
+
+
+def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_area, starts, ends, grad_out):
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    grad_out = _chk(grad_out, "grad_out")
+    gt = torch.zeros((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
+    g = spec.c_grid(gt)
+    call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), _stream())
+    return gt
+
+
+def sh4_fwd(dirs01: Tensor) -> Tensor:
+    d = _chk(dirs01, "dirs")
+    out = torch.empty((d.shape[0], 16), device=d.device, dtype=torch.float32)
+    call("nrhip_sh4_fwd", _ptr(d), d.shape[0], _ptr(out), _stream())
+    return out
+
+
+def mlp_fwd(x: Tensor, weights, biases, save_hidden: bool = False):
+    x = _chk(x, "x")
+    m, keep = _c_mlp(weights, biases)
+    if x.dim() != 2 or x.shape[1] != m.in_dim:
+        raise ValueError(f"x must be [N,{m.in_dim}], got {tuple(x.shape)}")
+    n = x.shape[0]
+    y = torch.empty((n, m.out_dim), device=x.device, dtype=torch.float32)
+    hidden = None
+    if save_hidden and m.num_layers > 1:
+        hidden = torch.empty((n, (m.num_layers - 1) * m.hidden_dim), device=x.device, dtype=torch.float32)
+    call("nrhip_mlp_fwd", C.byref(m), _ptr(x), n, _ptr(y), _ptr(hidden), _stream())
+    return (y, hidden) if save_hidden else y
+
+
+def mlp_bwd(x: Tensor, hidden: Optional[Tensor], grad_y: Tensor, weights, biases, need_grad_x: bool = True):
+    x, grad_y = _chk(x, "x"), _chk(grad_y, "grad_y")
+    m, keep = _c_mlp(weights, biases)
+    n = x.shape[0]
+    gx = torch.empty_like(x) if need_grad_x else None
+    gws = [torch.zeros_like(w, dtype=torch.float32) for w in weights]
+    gbs = [None if b is None else torch.zeros_like(b, dtype=torch.float32) for b in biases]
+    ws = torch.empty_like(hidden) if hidden is not None else None
+    pw = (C.c_void_p * _lib.MAX_LAYERS)(*[g.data_ptr() for g in gws])
+    pb = (C.c_void_p * _lib.MAX_LAYERS)(*[(0 if g is None else g.data_ptr()) for g in gbs])
+    call("nrhip_mlp_bwd", C.byref(m), _ptr(x), _ptr(hidden), _ptr(grad_y), n, _ptr(gx),
+         C.cast(pw, C.POINTER(C.c_void_p)), C.cast(pb, C.POINTER(C.c_void_p)), _ptr(ws), _stream())
+    return gx, gws, gbs
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class FieldSpec:
+    """What the fused field/render kernels need (NeuRADField, neurad_field.py:78-152)."""
+
+    grid: GridSpec
+    table: Tensor
+    static_scale: float
+    geo_w: List[Tensor]
+    geo_b: List[Optional[Tensor]]
+    feat_w: List[Tensor]
+    feat_b: List[Optional[Tensor]]
+    use_sdf: bool = True
+    beta: float = 20.0 + 1e-4  # |beta| + beta_min (model_components/utils.py:38-41)
+
+    def c_field(self):
+        f = _lib.Field()
+        f.grid = self.grid.c_grid(self.table)
+        f.table = self.table.data_ptr()
+        f.static_scale = float(self.static_scale)
+        f.geo, k1 = _c_mlp(self.geo_w, self.geo_b)
+        f.feat, k2 = _c_mlp(self.feat_w, self.feat_b)
+        f.use_sdf = 1 if self.use_sdf else 0
+        f.beta = float(self.beta)
+        return f, (k1, k2)
+
+
+def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends):
+    """-> feature [R,S,32], sdf (or raw geo output) [R,S], alpha (or density) [R,S]"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    f, keep2 = fs.c_field()
+    R, S = r.n_rays, r.n_samples
+    dev = origins.device
+    feature = torch.empty((R, S, 32), device=dev, dtype=torch.float32)
+    sdf = torch.empty((R, S), device=dev, dtype=torch.float32)
+    alpha = torch.empty((R, S), device=dev, dtype=torch.float32)
+    call("nrhip_field_fwd", C.byref(f), C.byref(r), _ptr(feature), _ptr(sdf), _ptr(alpha), _stream())
+    return feature, sdf, alpha
+
+
+def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, return_weights: bool = False,
+               out: Optional[Tuple[Tensor, Tensor, Tensor]] = None):
+    """The fused headline kernel.  -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S])"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    f, keep2 = fs.c_field()
+    R, S = r.n_rays, r.n_samples
+    dev = origins.device
+    if out is None:
+        feats = torch.empty((R, 32), device=dev, dtype=torch.float32)
+        depth = torch.empty((R, 1), device=dev, dtype=torch.float32)
+        acc = torch.empty((R, 1), device=dev, dtype=torch.float32)
+    else:
+        feats, depth, acc = out
+    w = torch.empty((R, S), device=dev, dtype=torch.float32) if return_weights else None
+    call("nrhip_render_fwd", C.byref(f), C.byref(r), _ptr(feats), _ptr(depth), _ptr(acc), _ptr(w), _stream())
+    return (feats, depth, acc, w) if return_weights else (feats, depth, acc)
+
+
+# ------------------------------------------------------------------------------------------------
+def render_weight_from_alpha(alphas: Tensor):
+    a = _chk(alphas, "alphas")
+    R, S = a.shape
+    w, t = torch.empty_like(a), torch.empty_like(a)
+    call("nrhip_render_weight_from_alpha", _ptr(a), R, S, _ptr(w), _ptr(t), _stream())
+    return w, t
+
+
+def render_weight_from_alpha_bwd(alphas, grad_w, grad_t=None):
+    a, gw = _chk(alphas, "alphas"), _chk(grad_w, "grad_w")
+    gt = None if grad_t is None else _chk(grad_t, "grad_t")
+    ga = torch.empty_like(a)
+    call("nrhip_render_weight_from_alpha_bwd", _ptr(a), _ptr(gw), _ptr(gt), a.shape[0], a.shape[1], _ptr(ga), _stream())
+    return ga
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas):
+    s, e, sg = _chk(t_starts, "t_starts"), _chk(t_ends, "t_ends"), _chk(sigmas, "sigmas")
+    R, S = sg.shape
+    w, t, a = torch.empty_like(sg), torch.empty_like(sg), torch.empty_like(sg)
+    call("nrhip_render_weight_from_density", _ptr(s), _ptr(e), _ptr(sg), R, S, _ptr(w), _ptr(t), _ptr(a), _stream())
+    return w, t, a
+
+
+def render_weight_from_density_bwd(t_starts, t_ends, sigmas, grad_w):
+    s, e, sg, gw = (_chk(v, n) for v, n in ((t_starts, "t_starts"), (t_ends, "t_ends"), (sigmas, "sigmas"),
+                                            (grad_w, "grad_w")))
+    gs = torch.empty_like(sg)
+    call("nrhip_render_weight_from_density_bwd", _ptr(s), _ptr(e), _ptr(sg), _ptr(gw), sg.shape[0], sg.shape[1],
+         _ptr(gs), _stream())
+    return gs
+
+
+def accumulate_along_rays(weights, values=None):
+    w = _chk(weights, "weights")
+    R, S = w.shape
+    if values is None:
+        out = torch.empty((R, 1), device=w.device, dtype=torch.float32)
+        call("nrhip_accumulate_along_rays", _ptr(w), _ptr(None), R, S, 1, _ptr(out), _stream())
+        return out
+    v = _chk(values, "values")
+    Cc = v.shape[-1]
+    out = torch.empty((R, Cc), device=w.device, dtype=torch.float32)
+    call("nrhip_accumulate_along_rays", _ptr(w), _ptr(v), R, S, Cc, _ptr(out), _stream())
+    return out
+
+
+def composite_fwd(weights, features, starts, ends):
+    w, f, s, e = (_chk(v, n) for v, n in ((weights, "weights"), (features, "features"), (starts, "starts"),
+                                          (ends, "ends")))
+    R, S, Cc = f.shape
+    of = torch.empty((R, Cc), device=w.device, dtype=torch.float32)
+    od = torch.empty((R, 1), device=w.device, dtype=torch.float32)
+    oa = torch.empty((R, 1), device=w.device, dtype=torch.float32)
+    call("nrhip_composite_fwd", _ptr(w), _ptr(f), _ptr(s), _ptr(e), R, S, Cc, _ptr(of), _ptr(od), _ptr(oa), _stream())
+    return of, od, oa
+
+
+def composite_bwd(weights, features, starts, ends, g_feat, g_depth=None, g_acc=None, need_grad_features=True):
+    w, f, s, e, gf = (_chk(v, n) for v, n in ((weights, "weights"), (features, "features"), (starts, "starts"),
+                                              (ends, "ends"), (g_feat, "g_feat")))
+    gd = None if g_depth is None else _chk(g_depth.reshape(-1), "g_depth")
+    ga = None if g_acc is None else _chk(g_acc.reshape(-1), "g_acc")
+    R, S, Cc = f.shape
+    gw = torch.empty_like(w)
+    gfe = torch.empty_like(f) if need_grad_features else None
+    call("nrhip_composite_bwd", _ptr(w), _ptr(f), _ptr(s), _ptr(e), _ptr(gf), _ptr(gd), _ptr(ga), R, S, Cc, _ptr(gw),
+         _ptr(gfe), _stream())
+    return gw, gfe
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ProposalSpec:
+    grid: GridSpec
+    table: Tensor
+    static_scale: float
+    decoder_weight: Tensor  # [1, L] (nn.Linear(L,1,bias=False).weight)
+
+    def c_prop(self):
+        p = _lib.Proposal()
+        p.grid = self.grid.c_grid(self.table)
+        p.table = self.table.data_ptr()
+        p.static_scale = float(self.static_scale)
+        dw = _chk(self.decoder_weight.reshape(-1), "decoder_weight")
+        p.decoder_weight = dw.data_ptr()
+        return p, dw
+
+
+def proposal_density_fwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends) -> Tensor:
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    p, keep2 = ps.c_prop()
+    dens = torch.empty((r.n_rays, r.n_samples), device=origins.device, dtype=torch.float32)
+    call("nrhip_proposal_density_fwd", C.byref(p), C.byref(r), _ptr(dens), _stream())
+    return dens
+
+
+def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends, density, grad_density):
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    p, keep2 = ps.c_prop()
+    gt = torch.zeros((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
+    gdec = torch.zeros((1, ps.grid.num_levels), device=origins.device, dtype=torch.float32)
+    call("nrhip_proposal_density_bwd", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
+         _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _stream())
+    return gt, gdec
+
+
+def weights_from_density(deltas, densities) -> Tensor:
+    d, s = _chk(deltas, "deltas"), _chk(densities, "densities")
+    w = torch.empty_like(s)
+    call("nrhip_weights_from_density", _ptr(d), _ptr(s), s.shape[0], s.shape[1], _ptr(w), _stream())
+    return w
+
+
+def weights_from_density_bwd(deltas, densities, grad_w) -> Tensor:
+    d, s, g = _chk(deltas, "deltas"), _chk(densities, "densities"), _chk(grad_w, "grad_w")
+    gs = torch.empty_like(s)
+    call("nrhip_weights_from_density_bwd", _ptr(d), _ptr(s), _ptr(g), s.shape[0], s.shape[1], _ptr(gs), _stream())
+    return gs
+
+
+def power_sampler(nears: Optional[Tensor], fars: Tensor, num_samples: int, lam: float = -1.0, scaling: float = 0.1,
+                  t_rand: Optional[Tensor] = None):
+    f = _chk(fars.reshape(-1), "fars")
+    n = None if nears is None else _chk(nears.reshape(-1), "nears")
+    R = f.shape[0]
+    tr = None if t_rand is None else _chk(t_rand, "t_rand")
+    sp = torch.empty((R, num_samples + 1), device=f.device, dtype=torch.float32)
+    eu = torch.empty_like(sp)
+    call("nrhip_power_sampler", _ptr(n), _ptr(f), R, num_samples, float(lam), float(scaling), _ptr(tr), _ptr(sp),
+         _ptr(eu), _stream())
+    return sp, eu
+
+
+def pdf_sample(weights, spacing_bins, nears, fars, num_samples, lam=-1.0, scaling=0.1, histogram_padding=0.01,
+               rand: Optional[Tensor] = None):
+    w, b = _chk(weights, "weights"), _chk(spacing_bins, "spacing_bins")
+    f = _chk(fars.reshape(-1), "fars")
+    n = None if nears is None else _chk(nears.reshape(-1), "nears")
+    R, Sp = w.shape
+    stride = 0
+    if rand is not None:
+        rand = _chk(rand, "rand")
+        stride = 0 if rand.numel() == R else num_samples + 1
+    sp = torch.empty((R, num_samples + 1), device=w.device, dtype=torch.float32)
+    eu = torch.empty_like(sp)
+    call("nrhip_pdf_sample", _ptr(w), _ptr(b), _ptr(n), _ptr(f), R, Sp, num_samples, float(lam), float(scaling),
+         float(histogram_padding), _ptr(rand), stride, _ptr(sp), _ptr(eu), _stream())
+    return sp, eu
+
+
+def proposal_sampler_fwd(props: Sequence[ProposalSpec], origins, directions, pixel_area, nears, fars,
+                         num_samples=(128, 64, 32), lam=-1.0, scaling=0.1, histogram_padding=0.01,
+                         sky_distance=20000.0):
+    """Fused S5 (+ the far clamp of M1).  -> (weights per round, spacing bins per round+1, euclid bins per round+1)"""
+    n_rounds = len(props)
+    if len(num_samples) != n_rounds + 1:
+        raise ValueError("num_samples needs one entry per proposal round plus the final count")
+    o, d = _chk(origins, "origins"), _chk(directions, "directions")
+    a = _chk(pixel_area.reshape(-1), "pixel_area")
+    f = None if fars is None else _chk(fars.reshape(-1), "fars")
+    n = None if nears is None else _chk(nears.reshape(-1), "nears")
+    R = o.shape[0]
+    cfg = _lib.SamplerCfg()
+    cfg.n_rounds = n_rounds
+    for i, v in enumerate(num_samples):
+        cfg.n_samples[i] = v
+    cfg.lam, cfg.scaling, cfg.histogram_padding, cfg.sky_distance = lam, scaling, histogram_padding, sky_distance
+    cprops = (_lib.Proposal * n_rounds)()
+    keep = []
+    for i, p in enumerate(props):
+        cp, k = p.c_prop()
+        cprops[i] = cp
+        keep.append(k)
+    ws = [torch.empty((R, num_samples[i]), device=o.device, dtype=torch.float32) for i in range(n_rounds)]
+    sps = [torch.empty((R, num_samples[i] + 1), device=o.device, dtype=torch.float32) for i in range(n_rounds + 1)]
+    eus = [torch.empty((R, num_samples[i] + 1), device=o.device, dtype=torch.float32) for i in range(n_rounds + 1)]
+    pw = (C.c_void_p * n_rounds)(*[t.data_ptr() for t in ws])
+    psp = (C.c_void_p * (n_rounds + 1))(*[t.data_ptr() for t in sps])
+    peu = (C.c_void_p * (n_rounds + 1))(*[t.data_ptr() for t in eus])
+    call("nrhip_proposal_sampler_fwd", C.byref(cfg), cprops, _ptr(o), _ptr(d), _ptr(a), _ptr(n), _ptr(f), R,
+         C.cast(pw, C.POINTER(C.c_void_p)), C.cast(psp, C.POINTER(C.c_void_p)), C.cast(peu, C.POINTER(C.c_void_p)),
+         _stream())
+    return ws, sps, eus
+
+
+def device_info():
+    cus, xcds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
+    call("nrhip_device_info", C.byref(cus), C.byref(xcds), C.byref(hbm))
+    return {"cus": cus.value, "xcds": xcds.value, "hbm_bytes": hbm.value}

@@ -1,0 +1,79 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/neurad_hip.h declares, and the ctypes prototype table matches the header (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "neurad_hip.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(nrhip_\w+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    return ctypes.CDLL(ge.LIB)
+
+
+def test_header_declares_the_path():
+    fns = header_functions()
+    for needed in ["nrhip_hashgrid_fwd", "nrhip_hashgrid_bwd", "nrhip_field_fwd", "nrhip_render_fwd",
+                   "nrhip_proposal_density_fwd", "nrhip_pdf_sample", "nrhip_proposal_sampler_fwd",
+                   "nrhip_composite_fwd", "nrhip_render_weight_from_alpha", "nrhip_mlp_fwd", "nrhip_last_error"]:
+        assert needed in fns
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for fn in header_functions():
+        assert hasattr(lib, fn), f"{fn} declared in include/neurad_hip.h but not exported"
+
+
+def test_ctypes_prototypes_match_header():
+    from neurad_studio_amd import _lib
+
+    declared = set(header_functions()) - {"nrhip_last_error"}
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, argtypes in _lib.PROTOTYPES.items():
+        m = re.search(name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(args) == len(argtypes), f"{name}: header has {len(args)} args, ctypes table {len(argtypes)}"
+
+
+def test_struct_layouts_match_header_sizes(lib):
+    from neurad_studio_amd import _lib
+
+    assert ctypes.sizeof(_lib.Grid) == 16 + 4 * 32
+    assert ctypes.sizeof(_lib.Mlp) == 16 + 8 * 8 * 2
+    assert ctypes.sizeof(_lib.Rays) == 64
+
+
+def test_version_and_error_string(lib):
+    lib.nrhip_version.restype = ctypes.c_int
+    assert lib.nrhip_version() >= 100
+    lib.nrhip_last_error.restype = ctypes.c_char_p
+    # argument validation happens on the host before any launch: NULL descriptor -> INVALID_ARG + message
+    lib.nrhip_hashgrid_fwd.restype = ctypes.c_int
+    rc = lib.nrhip_hashgrid_fwd(None, None, None, ctypes.c_int64(0), None, None)
+    assert rc == 1 and b"NULL" in lib.nrhip_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+
+    from neurad_studio_amd import _lib, ops
+
+    spec = ops.GridSpec(4, 2, 8, 16, 128)
+    with pytest.raises(_lib.NeuradHipError):
+        ops.hashgrid_fwd(spec, torch.zeros(4 * 256, 2), torch.rand(5, 3))

@@ -1,0 +1,380 @@
+"""GPU parity tests: the hand-written HIP path (through the C ABI) vs the CPU oracle, plus the golden
+vectors the reference itself produced.  Bar: bit-exact for hash indices (checked through exact lattice
+lookups), <= 1e-4 rel-L2 for floating point (BASELINE.json north_star); most ops land near 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+import neurad_oracle as O
+import synth
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star tolerance (rel-L2 vs the reference's fp32 torch path)
+TIGHT = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from neurad_studio_amd import ops as _ops
+
+    return _ops
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+HASH_CFGS = {"c2small": (16, 16, 1024, 12, 2), "neurad": (8, 32, 8192, 12, 4), "prop": (6, 128, 4096, 11, 1),
+             "tiny": (1, 32, 32, 10, 4), "actor": (4, 64, 1024, 10, 4)}
+
+
+@pytest.mark.parametrize("tag", list(HASH_CFGS))
+def test_hashgrid_fwd_vs_reference_golden(ops, tag):
+    g = load_golden(f"hashgrid_{tag}")
+    L, mn, mx, lg, F = HASH_CFGS[tag]
+    spec = ops.GridSpec(L, F, lg, mn, mx)
+    np.testing.assert_array_equal(spec.scalings.numpy(), g["scalings"])
+    table = synth.hash_table(L * 2**lg, F, seed=11)
+    y = host(ops.hashgrid_fwd(spec, dev(table), dev(g["x"])))
+    assert rel_l2(y, g["y"]) < TIGHT  # fma contraction in the lerp tree vs torch's separate mul/add
+    # fp16 table storage (BASELINE config 5): same kernel, half loads; compare with the oracle on the rounded table
+    t16 = table.astype(np.float16)
+    y16 = host(ops.hashgrid_fwd(spec, dev(t16, torch.float16), dev(g["x"])))
+    ref16 = O.hashgrid_fwd(g["x"], t16.astype(np.float32), g["scalings"], 2**lg)
+    assert rel_l2(y16, ref16) < TIGHT
+
+
+def test_hash_indices_bit_exact(ops):
+    """One-hot tables: entry r of level l set to 1 -> the output equals the sum of trilinear weights that hit
+    r.  With x on lattice points (ceil == floor) the lookup returns exactly table[index] -> exact index check
+    against the oracle's int64 hash over many random lattice points, incl. large coordinates."""
+    L, mn, mx, lg, F = 8, 32, 8192, 14, 1
+    spec = ops.GridSpec(L, F, lg, mn, mx)
+    sc = spec.scalings.numpy()
+    rng = np.random.default_rng(0)
+    # table value = its own row index (exactly representable in fp32 below 2^24)
+    table = (np.arange(L * 2**lg) % 2**lg).astype(np.float32)[:, None]
+    lvl = 7
+    pts = rng.integers(0, int(sc[lvl]) + 1, size=(4096, 3)).astype(np.float32) / sc[lvl]
+    # keep points that are exact lattice points of level `lvl` after the fp32 multiply
+    keep = np.all((pts * sc[lvl]) == np.round(pts * sc[lvl]), axis=1)
+    pts = pts[keep]
+    y = host(ops.hashgrid_fwd(spec, dev(table), dev(pts)))[:, lvl]
+    idx, _ = O.hashgrid_corner_indices(pts, sc, 2**lg)
+    np.testing.assert_array_equal(y.astype(np.int64), idx[:, lvl, 6] - lvl * 2**lg)
+
+
+@pytest.mark.parametrize("tag", list(HASH_CFGS))
+def test_hashgrid_bwd(ops, tag):
+    g = load_golden(f"hashgrid_{tag}")
+    L, mn, mx, lg, F = HASH_CFGS[tag]
+    spec = ops.GridSpec(L, F, lg, mn, mx)
+    gt = host(ops.hashgrid_bwd(spec, None, dev(g["x"]), dev(g["grad_out"])))
+    ref = np.zeros_like(gt)
+    ref[g["grad_table_nz_idx"]] = g["grad_table_nz"]
+    assert rel_l2(gt, ref) < TIGHT
+
+
+def test_sh4(ops):
+    g = load_golden("sh")
+    assert rel_l2(host(ops.sh4_fwd(dev(g["d01"]))), g["y"]) < 1e-6
+
+
+def _mlp_params(cfg):
+    i, n, w, o = (int(v) for v in cfg)
+    dims = [i] + [w] * (n - 1) + [o]
+    ws, bs = [], []
+    for k in range(n):
+        wk, bk = synth.linear(dims[k + 1], dims[k], 100 + 10 * k)
+        ws.append(wk), bs.append(bk)
+    return ws, bs
+
+
+@pytest.mark.parametrize("tag", ["geo64", "feat64", "geo32", "lidar"])
+def test_mlp_fwd_bwd_vs_reference_golden(ops, tag):
+    g = load_golden(f"mlp_{tag}")
+    ws, bs = _mlp_params(g["cfg"])
+    dws, dbs = [dev(w) for w in ws], [dev(b) for b in bs]
+    x = dev(g["x"])
+    y, hidden = ops.mlp_fwd(x, dws, dbs, save_hidden=True)
+    assert rel_l2(host(y), g["y"]) < TIGHT
+    gx, gws, gbs = ops.mlp_bwd(x, hidden, dev(g["grad_out"]), dws, dbs)
+    assert rel_l2(host(gx), g["dx"]) < TIGHT
+    for k in range(len(ws)):
+        assert rel_l2(host(gws[k]), g[f"dw{k}"]) < TIGHT, k
+        assert rel_l2(host(gbs[k]), g[f"db{k}"]) < TIGHT, k
+
+
+@pytest.mark.parametrize("dims", [(3, 1, 7, 5), (13, 4, 24, 3), (48, 3, 128, 16), (32, 2, 16, 1), (5, 2, 100, 9)])
+def test_mlp_odd_shapes_and_ragged_batches(ops, dims):
+    i, n, w, o = dims
+    dd = [i] + [w] * (n - 1) + [o]
+    ws, bs = [], []
+    for k in range(n):
+        wk, bk = synth.linear(dd[k + 1], dd[k], 500 + k)
+        ws.append(wk), bs.append(bk if k % 2 == 0 else None)
+    for N in (1, 15, 16, 17, 1000):
+        x = synth.normal((N, i), seed=N)
+        y = host(ops.mlp_fwd(dev(x), [dev(a) for a in ws], [None if b is None else dev(b) for b in bs]))
+        ref = O.mlp_fwd(x, ws, bs)
+        assert rel_l2(y, ref) < TIGHT, (dims, N)
+    assert ops.mlp_fwd(dev(np.zeros((0, i), np.float32)), [dev(a) for a in ws],
+                       [None if b is None else dev(b) for b in bs]).shape == (0, o)
+
+
+def field_params(use_sdf=True, L=8, F=4, lg=11, H=32, mn=32, mx=8192, scale=0.5):
+    grid = O.GridParams(synth.hash_table(L * 2**lg, F, seed=51, scale=scale), L, mn, mx, lg)
+    gw, gb, fw, fb = [], [], [], []
+    for k, (o, i) in enumerate([(H, 32), (33, H)]):
+        w, b = synth.linear(o, i, 200 + 10 * k)
+        gw.append(w), gb.append(b)
+    for k, (o, i) in enumerate([(H, 48), (H, H), (32, H)]):
+        w, b = synth.linear(o, i, 300 + 10 * k)
+        fw.append(w), fb.append(b)
+    return O.FieldParams(grid, 100.0, gw, gb, fw, fb, use_sdf=use_sdf)
+
+
+def to_spec(ops, p: O.FieldParams, half=False):
+    g = p.grid
+    spec = ops.GridSpec(g.num_levels, g.n_feat, g.log2_hashmap_size, g.min_res, g.max_res)
+    table = dev(g.table, torch.float16 if half else torch.float32)
+    return ops.FieldSpec(spec, table, p.static_scale, [dev(w) for w in p.geo_w], [dev(b) for b in p.geo_b],
+                         [dev(w) for w in p.feat_w], [dev(b) for b in p.feat_b], use_sdf=p.use_sdf,
+                         beta=abs(p.beta) + p.beta_min)
+
+
+@pytest.mark.parametrize("tag", ["sdf", "density"])
+def test_field_fwd_vs_reference_golden(ops, tag):
+    g = load_golden(f"field_{tag}")
+    p = field_params(use_sdf=(tag == "sdf"))
+    fs = to_spec(ops, p)
+    feat, sdf, head = ops.field_fwd(fs, dev(g["o"]), dev(g["d"]), dev(g["area"]), dev(g["starts"]), dev(g["ends"]))
+    assert rel_l2(host(feat), g["feature"]) < TOL
+    if tag == "sdf":
+        assert rel_l2(host(sdf), g["sdf"]) < TOL
+        assert rel_l2(host(head), g["alpha"]) < TOL
+    else:
+        assert rel_l2(host(head), g["density"]) < TOL
+    # the unfused encode op (H2-H4) against the oracle
+    enc = host(ops.encode_fwd(fs.grid, fs.table, 100.0, dev(g["o"]), dev(g["d"]), dev(g["area"]), dev(g["starts"]),
+                              dev(g["ends"])))
+    ref = O.encode_static(p.grid, 100.0, g["o"], g["d"], g["area"], g["starts"], g["ends"])
+    assert rel_l2(enc, ref) < TIGHT
+
+
+def _sample_rays(R, S, seed, fars=200.0):
+    o, d, area, _ = synth.rays(R, seed)
+    bins, eu, _ = O.power_sampler(np.zeros(R), np.full(R, fars, np.float32), S)
+    return o, d, area, np.ascontiguousarray(eu[:, :-1]), np.ascontiguousarray(eu[:, 1:]), eu
+
+
+RENDER_CFGS = [  # (L, F, lg, min_res, max_res, H, use_sdf, R, S)
+    (16, 2, 12, 16, 1024, 64, True, 37, 128),   # BASELINE config 2 shape (small table)
+    (8, 4, 11, 32, 8192, 32, True, 50, 32),     # NeuRAD defaults
+    (8, 4, 11, 32, 8192, 32, False, 21, 33),    # density head, ragged S (not a multiple of 16)
+    (16, 2, 12, 16, 1024, 32, True, 5, 7),      # S < 16
+    (8, 4, 11, 32, 8192, 64, False, 9, 1),      # single sample per ray
+    (4, 8, 10, 64, 1024, 64, True, 13, 48),
+]
+
+
+@pytest.mark.parametrize("cfg", RENDER_CFGS)
+def test_render_fused_vs_oracle(ops, cfg):
+    L, F, lg, mn, mx, H, use_sdf, R, S = cfg
+    p = field_params(use_sdf=use_sdf, L=L, F=F, lg=lg, H=H, mn=mn, mx=mx, scale=2.0 if use_sdf else 0.5)
+    if use_sdf:
+        p.beta = 3.0  # keep alphas away from saturation so the compositing is exercised
+    fs = to_spec(ops, p)
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=R + S)
+    ref = O.render_rays(p, o, d, area, s, e)
+    edges = dev(eu)
+    # bin EDGES passed as strided views: starts = edges[:, :-1], ends = edges[:, 1:]  (no copies)
+    feats, depth, acc, w = ops.render_fwd(fs, dev(o), dev(d), dev(area), edges[:, :-1], edges[:, 1:],
+                                          return_weights=True)
+    assert rel_l2(host(w), ref["weights"]) < TOL
+    assert rel_l2(host(feats), ref["features"]) < TOL
+    assert rel_l2(host(depth), ref["depth"]) < TOL or np.abs(host(depth) - ref["depth"]).max() < 1e-5
+    assert rel_l2(host(acc), ref["accumulation"]) < TOL
+    # per-sample variant (Field.forward boundary) and the unfused C1+C2 ops composed by hand
+    f2, sdf2, head2 = ops.field_fwd(fs, dev(o), dev(d), dev(area), dev(s), dev(e))
+    assert rel_l2(host(f2), ref["feature"]) < TOL
+    if use_sdf:
+        w2, _ = ops.render_weight_from_alpha(head2)
+    else:
+        w2, _, _ = ops.render_weight_from_density(dev(s), dev(e), head2)
+    cf, cd, ca = ops.composite_fwd(w2, f2, dev(s), dev(e))
+    assert rel_l2(host(cf), host(feats)) < 1e-5 and rel_l2(host(ca), host(acc)) < 1e-5
+
+
+def test_render_fp16_table(ops):
+    p = field_params(use_sdf=True, L=8, F=4, lg=11, H=32)
+    p.beta = 3.0
+    p.grid.table = p.grid.table.astype(np.float16).astype(np.float32)  # oracle sees the rounded values
+    fs = to_spec(ops, p, half=True)
+    o, d, area, s, e, _ = _sample_rays(33, 32, seed=5)
+    ref = O.render_rays(p, o, d, area, s, e)
+    feats, depth, acc = ops.render_fwd(fs, dev(o), dev(d), dev(area), dev(s), dev(e))
+    assert rel_l2(host(feats), ref["features"]) < TOL and rel_l2(host(acc), ref["accumulation"]) < TOL
+
+
+def test_compositing_ops_fwd_bwd(ops):
+    R, S, Cc = 19, 70, 32  # S > 64 exercises the carried scan
+    alphas = synth.uniform((R, S), 0.0, 0.2, seed=1)
+    feats = synth.normal((R, S, Cc), seed=2)
+    s = np.sort(synth.uniform((R, S + 1), 0.0, 50.0, seed=3), -1)
+    st, en = np.ascontiguousarray(s[:, :-1]), np.ascontiguousarray(s[:, 1:])
+    w, t = ops.render_weight_from_alpha(dev(alphas))
+    rw, rt = O.render_weight_from_alpha(alphas)
+    assert rel_l2(host(w), rw) < TIGHT and rel_l2(host(t), rt) < TIGHT
+    sig = synth.uniform((R, S), 0.0, 0.3, seed=4)
+    w2, t2, a2 = ops.render_weight_from_density(dev(st), dev(en), dev(sig))
+    rw2, rt2, ra2 = O.render_weight_from_density(st, en, sig)
+    assert rel_l2(host(w2), rw2) < TIGHT and rel_l2(host(t2), rt2) < TIGHT and rel_l2(host(a2), ra2) < TIGHT
+    assert rel_l2(host(ops.weights_from_density(dev(en - st), dev(sig))), O.weights_from_density(en - st, sig)) < TIGHT
+    for Cv in (1, 3, 32, 48):
+        v = synth.normal((R, S, Cv), seed=5 + Cv)
+        assert rel_l2(host(ops.accumulate_along_rays(dev(rw), dev(v))), O.accumulate_along_rays(rw, v)) < TIGHT
+    assert rel_l2(host(ops.accumulate_along_rays(dev(rw))), O.accumulate_along_rays(rw)) < TIGHT
+    of, od, oa = ops.composite_fwd(dev(rw), dev(feats), dev(st), dev(en))
+    rf, rd, ra = O.composite(rw, feats, st, en)
+    assert rel_l2(host(of), rf) < TIGHT and rel_l2(host(od), rd) < TIGHT and rel_l2(host(oa), ra) < TIGHT
+    # backward vs torch autograd of the same dense formulas (fp64 on CPU)
+    ta = torch.tensor(alphas, dtype=torch.float64, requires_grad=True)
+    tf = torch.tensor(feats, dtype=torch.float64, requires_grad=True)
+    trans = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=torch.float64), 1 - ta[:, :-1]], -1), -1)
+    tw = trans * ta
+    acc = tw.sum(-1, keepdim=True)
+    tw2 = torch.cat([tw[:, :-1], tw[:, -1:] + 1 - acc], -1)
+    tfeat = (tw2[..., None] * tf).sum(1)
+    mid = torch.tensor((st + en) / 2, dtype=torch.float64)
+    tdepth = (tw2[:, :-1] * mid[:, :-1]).sum(-1, keepdim=True)
+    gF, gD, gA = synth.normal((R, Cc), 7), synth.normal((R, 1), 8), synth.normal((R, 1), 9)
+    (tfeat * torch.tensor(gF)).sum().add((tdepth * torch.tensor(gD)).sum()).add((acc * torch.tensor(gA)).sum()).backward()
+    gw, gf = ops.composite_bwd(dev(rw), dev(feats), dev(st), dev(en), dev(gF), dev(gD), dev(gA))
+    ga = ops.render_weight_from_alpha_bwd(dev(alphas), gw)
+    assert rel_l2(host(gf), tf.grad.numpy()) < TIGHT
+    assert rel_l2(host(ga), ta.grad.numpy()) < TOL
+    # density-mode backward
+    tsig = torch.tensor(sig, dtype=torch.float64, requires_grad=True)
+    dl = torch.tensor(en - st, dtype=torch.float64)
+    sd = tsig * dl
+    tr = torch.exp(-torch.cat([torch.zeros(R, 1, dtype=torch.float64), torch.cumsum(sd[:, :-1], -1)], -1))
+    twd = (1 - torch.exp(-sd)) * tr
+    gwd = synth.normal((R, S), 11)
+    (twd * torch.tensor(gwd)).sum().backward()
+    gs = ops.render_weight_from_density_bwd(dev(st), dev(en), dev(sig), dev(gwd))
+    assert rel_l2(host(gs), tsig.grad.numpy()) < TOL
+    gs2 = ops.weights_from_density_bwd(dev(en - st), dev(sig), dev(gwd))
+    assert rel_l2(host(gs2), tsig.grad.numpy()) < TOL
+
+
+def prop_params(seed, lg=11):
+    w, _ = synth.linear(1, 6, seed + 1, bias=False)
+    return O.ProposalParams(O.GridParams(synth.hash_table(6 * 2**lg, 1, seed=seed, scale=2.0), 6, 128, 4096, lg),
+                            100.0, w + np.float32(0.3))
+
+
+def to_pspec(ops, p):
+    g = p.grid
+    return ops.ProposalSpec(ops.GridSpec(g.num_levels, 1, g.log2_hashmap_size, g.min_res, g.max_res), dev(g.table),
+                            p.static_scale, dev(p.decoder_w))
+
+
+def test_sampler_pieces_vs_reference_golden(ops):
+    g = load_golden("sampler_parts")
+    R = g["o"].shape[0]
+    sp0, eu0 = ops.power_sampler(None, dev(g["fars"]), 128)
+    assert rel_l2(host(sp0), g["sp0"]) < 1e-6 and rel_l2(host(eu0), g["eu0"]) < TOL
+    ps = to_pspec(ops, prop_params(95))
+    e0 = dev(g["eu0"])
+    dens = ops.proposal_density_fwd(ps, dev(g["o"]), dev(g["d"]), dev(g["area"]), e0[:, :-1], e0[:, 1:])
+    assert rel_l2(host(dens), g["dens0"]) < TOL
+    w = ops.weights_from_density(dev(g["eu0"][:, 1:] - g["eu0"][:, :-1]), dev(g["dens0"]))
+    assert rel_l2(host(w), g["w0"]) < TIGHT
+    sp1, eu1 = ops.pdf_sample(dev(g["w0"]), dev(g["sp0"]), None, dev(g["fars"]), 64)
+    assert rel_l2(host(sp1), g["sp1"]) < TOL and rel_l2(host(eu1), g["eu1"]) < TOL
+    # training-mode jitter, injected
+    gt = load_golden("sampler_train")
+    sp0t, eu0t = ops.power_sampler(None, dev(gt["fars"]), 128, t_rand=dev(gt["t_rand"]))
+    assert rel_l2(host(sp0t), gt["sp0"]) < 1e-6 and rel_l2(host(eu0t), gt["eu0"]) < TOL
+    sp1t, eu1t = ops.pdf_sample(dev(gt["w0"]), dev(gt["sp0"]), None, dev(gt["fars"]), 64, rand=dev(gt["rand1"]))
+    assert rel_l2(host(sp1t), gt["sp1"]) < TOL and rel_l2(host(eu1t), gt["eu1"]) < TOL
+
+
+def test_fused_proposal_sampler_vs_reference_golden(ops):
+    g = load_golden("sampler_chain")
+    props = [prop_params(91), prop_params(95)]
+    # the reference's late-binding closure evaluates proposal_fields[1] in BOTH rounds (models/neurad.py:248)
+    specs = [to_pspec(ops, props[1]), to_pspec(ops, props[1])]
+    ws, sps, eus = ops.proposal_sampler_fwd(specs, dev(g["o"]), dev(g["d"]), dev(g["area"]), None, dev(g["fars"]))
+    assert rel_l2(host(ws[0]), g["w0"]) < TOL and rel_l2(host(ws[1]), g["w1"]) < TOL
+    assert rel_l2(host(eus[0][:, :-1]), g["s0"]) < TOL and rel_l2(host(eus[1][:, 1:]), g["e1"]) < TOL
+    assert rel_l2(host(eus[2][:, :-1]), g["starts"]) < TOL and rel_l2(host(eus[2][:, 1:]), g["ends"]) < TOL
+    assert rel_l2(host(sps[2][:, :-1]), g["sps"]) < TOL and rel_l2(host(sps[2][:, 1:]), g["spe"]) < TOL
+
+
+def test_proposal_density_bwd(ops):
+    p = prop_params(95)
+    ps = to_pspec(ops, p)
+    R, S = 11, 40
+    o, d, area, s, e, _ = _sample_rays(R, S, seed=3)
+    dens = ops.proposal_density_fwd(ps, dev(o), dev(d), dev(area), dev(s), dev(e))
+    gd = synth.normal((R, S), 12)
+    gt, gdec = ops.proposal_density_bwd(ps, dev(o), dev(d), dev(area), dev(s), dev(e), dens, dev(gd))
+    # oracle: d/dtable and d/ddecoder of sum(gd * exp(enc @ w))
+    enc = O.encode_static(p.grid, p.static_scale, o, d, area, s, e).astype(np.float64)
+    x = enc @ p.decoder_w.astype(np.float64).T
+    gx = gd.reshape(-1, 1) * np.exp(np.clip(x, -15, 15))
+    ref_dec = (gx * enc).sum(0)
+    assert rel_l2(host(gdec)[0], ref_dec) < TOL
+    mean, std = O.fast_isotropic_gaussian(o, d, area, s, e)
+    pos, cstd = O.contract_gaussian(mean, std, p.static_scale)
+    sc = p.grid.scalings
+    rw = 1.0 / np.maximum(sc[None, :] * 2 * cstd.reshape(-1, 1), 1.0)
+    g_enc = (gx * p.decoder_w.astype(np.float64)) * rw
+    ref_t = O.hashgrid_bwd(pos.reshape(-1, 3), g_enc, sc, p.grid.table_size, 6 * p.grid.table_size, 1)
+    assert rel_l2(host(gt), ref_t) < TOL
+
+
+def test_empty_batches(ops):
+    p = field_params()
+    fs = to_spec(ops, p)
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    f, dpt, a = ops.render_fwd(fs, z(0, 3), z(0, 3), z(0), z(0, 32), z(0, 32))
+    assert f.shape == (0, 32) and a.shape == (0, 1)
+    assert ops.hashgrid_fwd(fs.grid, fs.table, z(0, 3)).shape == (0, 32)
+
+
+def test_full_size_properties_config2(ops):
+    """BASELINE config 2 at full size (4096 x 128, L=16, T=2^19, 64-wide): size-independent properties.
+    (a) accumulation == 1 - prod(1 - alpha) and sum of returned weights, (b) features are an affine function of
+    the table restricted to what the MLP sees -> permuting rays permutes outputs, (c) fused == unfused ops."""
+    L, F, lg, H, R, S = 16, 2, 19, 64, 4096, 128
+    p = field_params(use_sdf=True, L=L, F=F, lg=lg, H=H, mn=16, mx=1024, scale=1.0)
+    p.beta = 2.0
+    fs = to_spec(ops, p)
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=77)
+    do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
+    feats, depth, acc, w = ops.render_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], return_weights=True)
+    f2, sdf2, alpha2 = ops.field_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:])
+    assert torch.isfinite(feats).all() and torch.isfinite(f2).all()
+    pa = 1 - torch.prod(1 - alpha2.double(), -1)
+    assert (acc[:, 0].double() - pa).abs().max() < 1e-5
+    assert (w.sum(-1).double() - pa).abs().max() < 1e-5
+    w2, _ = ops.render_weight_from_alpha(alpha2)
+    cf, cd, ca = ops.composite_fwd(w2, f2, edges[:, :-1].contiguous(), edges[:, 1:].contiguous())
+    assert rel_l2(host(cf), host(feats)) < 1e-5 and rel_l2(host(cd), host(depth)) < 1e-5
+    perm = torch.randperm(R, device="cuda")
+    fp, dp, ap = ops.render_fwd(fs, do[perm], dd[perm], da[perm], edges[perm][:, :-1], edges[perm][:, 1:])
+    assert torch.equal(fp, feats[perm]) and torch.equal(ap, acc[perm])
+    # oracle on a slice the CPU finishes quickly
+    sl = slice(100, 116)
+    ref = O.render_rays(p, o[sl], d[sl], area[sl], s[sl], e[sl])
+    assert rel_l2(host(feats[sl]), ref["features"]) < TOL and rel_l2(host(acc[sl]), ref["accumulation"]) < TOL
