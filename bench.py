@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on BASELINE.json config[1].
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic rays that is already resident in HBM:
+PowerSampler bins (S1) -> fused hash-grid lookup + tiny MLPs (fp32 MFMA) + transmittance/alpha compositing
+(F1+C1+C2, nrhip_render_fwd).  Workload = config[1]: 4096 rays x 128 samples, HashEncoding(16 levels, T=2^19,
+F=2) + 64-wide MLPs, fp32 table.  Rays shard across ranks with no data-path collective (inference needs none,
+SURVEY §8e) -> weak scaling, value = all ranks' ray-samples / max-over-ranks time.
+The JSON line also carries `roofline` (dominant kernel, HIP-event timed inside the timed region) and, at N=1,
+`cpu_baseline` (oracle/neurad_oracle_c.c on the host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_RAYS, N_SAMPLES = 4096, 128
+GRID = dict(num_levels=16, features_per_level=2, log2_hashmap_size=19, min_res=16, max_res=1024)  # encodings.py:326-333
+HIDDEN = 64
+STATIC_SCALE = 100.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured streaming ceiling)
+
+
+def algorithmic_bytes_per_sample(L, F, table_bytes, S):
+    """L*8*F*sizeof table reads + 8 B (t_start,t_end) + per-ray I/O (40 B in, 136 B out) / S."""
+    return L * 8 * F * table_bytes + 8 + (40 + 136) / S
+
+
+def make_workload(device, seed):
+    from neurad_studio_amd import ops
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    spec = ops.GridSpec(GRID["num_levels"], GRID["features_per_level"], GRID["log2_hashmap_size"], GRID["min_res"],
+                        GRID["max_res"])
+    table = (torch.rand((spec.table_rows, spec.features_per_level), device=device, generator=g) * 2 - 1) * 1e-3
+
+    def linear(o, i):
+        k = 1.0 / np.sqrt(i)
+        return ((torch.rand((o, i), device=device, generator=g) * 2 - 1) * k,
+                (torch.rand((o,), device=device, generator=g) * 2 - 1) * k)
+
+    H = HIDDEN
+    geo = [linear(H, 32), linear(33, H)]
+    feat = [linear(H, 48), linear(H, H), linear(32, H)]
+    fs = ops.FieldSpec(spec, table, STATIC_SCALE, [w for w, _ in geo], [b for _, b in geo], [w for w, _ in feat],
+                       [b for _, b in feat], use_sdf=True, beta=20.0 + 1e-4)
+    # SURVEY §8(d) synthetic rays
+    origins = torch.randn((R_RAYS, 3), device=device, generator=g) * 5.0
+    dirs = torch.randn((R_RAYS, 3), device=device, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    area = torch.full((R_RAYS,), 2.7e-7 * 9, device=device)
+    fars = torch.full((R_RAYS,), 20000.0, device=device)
+    return fs, origins.contiguous(), dirs.contiguous(), area, fars
+
+
+def cpu_baseline(fs, origins, dirs, area, edges, budget_s=12.0):
+    """The oracle's C/OpenMP port on the host cores, on a bounded slice of the SAME workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import neurad_oracle as O
+    import oracle_c
+
+    h = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    grid = O.GridParams(h(fs.table), GRID["num_levels"], GRID["min_res"], GRID["max_res"], GRID["log2_hashmap_size"])
+    p = O.FieldParams(grid, STATIC_SCALE, [h(w) for w in fs.geo_w], [h(b) for b in fs.geo_b], [h(w) for w in fs.feat_w],
+                      [h(b) for b in fs.feat_b], beta=20.0, use_sdf=True)
+    o, d, a, e = h(origins), h(dirs), h(area), h(edges)
+    s0, e0 = np.ascontiguousarray(e[:, :-1]), np.ascontiguousarray(e[:, 1:])
+
+    def run(n):
+        t0 = time.perf_counter()
+        out = oracle_c.render_fwd(p, o[:n], d[:n], a[:n], s0[:n], e0[:n])
+        return time.perf_counter() - t0, out
+
+    run(64)  # warm (page-in of the 64 MB table, OpenMP pool)
+    t_probe, _ = run(256)
+    n = int(min(R_RAYS, max(256, 256 * budget_s / max(t_probe, 1e-6))))
+    t, out = run(n)
+    return {"value": n * N_SAMPLES / t, "unit": "ray-samples/s", "cores": oracle_c.num_threads(), "kind": "port",
+            "sample": f"{n} rays x {N_SAMPLES} samples of the bench workload, {t:.1f} s, "
+                      "oracle/neurad_oracle_c.c (OpenMP, fp32)"}, (n, out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+
+    from neurad_studio_amd import ops
+
+    fs, origins, dirs, area, fars = make_workload(device, seed=1234 + rank)  # seed + rank like scripts/train.py:104
+    S = N_SAMPLES
+    feats = torch.empty((R_RAYS, 32), device=device)
+    depth = torch.empty((R_RAYS, 1), device=device)
+    acc = torch.empty((R_RAYS, 1), device=device)
+    state = {}
+
+    def step(ev=None):
+        sp, eu = ops.power_sampler(None, fars, S, lam=-1.0, scaling=0.1)
+        eu[:, -1] = 20000.0  # M1 sky stretch (models/neurad.py:451-455); no-op here since far == sky_distance
+        if ev is not None:
+            ev[0].record()
+        ops.render_fwd(fs, origins, dirs, area, eu[:, :-1], eu[:, 1:], out=(feats, depth, acc))
+        if ev is not None:
+            ev[1].record()
+        state["edges"] = eu
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(feats).all() and torch.isfinite(acc).all()
+
+    if rank == 0:
+        n_samples = R_RAYS * S
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        bytes_per = algorithmic_bytes_per_sample(GRID["num_levels"], GRID["features_per_level"], 4, S)
+        achieved = n_samples * bytes_per / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_render_kernel.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "ray-samples/sec (4096 rays x 128 samples)", "value": world * n_samples * args.steps / elapsed,
+            "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config[1]: NeuRAD hash-grid (16 levels, T=2^19, F=2, fp32) + 64-wide MLPs, "
+                                   "4096 rays x 128 samples per GPU, PowerSampler bins + fused field + compositing "
+                                   "(forward / render path)",
+                       "rays_per_gpu": R_RAYS, "samples_per_ray": S, "parallelism": f"rays sharded x{world}, no collective"},
+            "per_gpu_value": n_samples * args.steps / elapsed,
+            "target_per_gpu": 2e7,
+            "roofline": {"kernel": "nrhip::render_kernel<16,2,64,fp32,composite>", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": n_samples * bytes_per,
+                         "kernel_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, (n, ref) = cpu_baseline(fs, origins, dirs, area, state["edges"])
+            out["cpu_baseline"] = cb
+            err = float(np.linalg.norm(feats[:n].cpu().numpy() - ref["features"]) / np.linalg.norm(ref["features"]))
+            out["parity_rel_l2_vs_oracle"] = err
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
