@@ -1,0 +1,192 @@
+"""torch.autograd.Function wrappers over the HIP ops (operator-level training path).
+
+Every Function runs under ``custom_fwd(cast_inputs=float32)`` like the reference's ``trunc_exp``
+(field_components/activations.py:31-41), because the trainer runs under autocast + GradScaler
+(engine/trainer.py:550-553).  Gradients flow to hash tables, MLP weights/biases, the proposal decoder,
+densities/alphas and features; positions get no gradient (static samples carry none while
+camera_optimizer.mode == "off"; actor-pose gradients are a later row).
+"""
+from __future__ import annotations
+
+import torch
+from torch.amp import custom_bwd, custom_fwd
+
+from . import ops
+
+
+class HashGridFn(torch.autograd.Function):
+    """HashEncoding.pytorch_fwd (encodings.py:425-466): x [N,3] in [0,1], table [L*T,F] -> [N, L*F]."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, table, spec):
+        ctx.spec = spec
+        ctx.save_for_backward(x)
+        return ops.hashgrid_fwd(spec, table, x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gt = ops.hashgrid_bwd(ctx.spec, None, x, g.contiguous()) if ctx.needs_input_grad[1] else None
+        return None, gt, None
+
+
+class EncodeFn(torch.autograd.Function):
+    """NeuRADHashEncoding static path, fused H2->H3->H1->H4 (neurad_encoding.py:164-169,265-268,297-304)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, table, spec, static_scale, origins, directions, pixel_area, starts, ends):
+        ctx.spec, ctx.scale = spec, static_scale
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends)
+        return ops.encode_fwd(spec, table, static_scale, origins, directions, pixel_area, starts, ends)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        o, d, a, s, e = ctx.saved_tensors
+        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, g.contiguous())
+        return gt, None, None, None, None, None, None, None
+
+
+class MLPFn(torch.autograd.Function):
+    """MLP.pytorch_fwd (mlp.py:159-178).  args: x, n_layers, w0, b0, w1, b1, ... (b may be None)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, n_layers, *params):
+        ws, bs = list(params[0::2]), list(params[1::2])
+        y, hidden = ops.mlp_fwd(x, ws, bs, save_hidden=True)
+        ctx.n = n_layers
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.save_for_backward(x, hidden if hidden is not None else x.new_empty(0), *ws, *[b for b in bs if b is not None])
+        return y
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        n = ctx.n
+        x, hidden, *rest = ctx.saved_tensors
+        ws = rest[:n]
+        bit = iter(rest[n:])
+        bs = [next(bit) if hb else None for hb in ctx.has_bias]
+        gx, gws, gbs = ops.mlp_bwd(x, hidden if hidden.numel() else None, gy.contiguous(), ws, bs,
+                                   need_grad_x=ctx.needs_input_grad[0])
+        out = [gx, None]
+        for k in range(n):
+            out += [gws[k], gbs[k]]
+        return tuple(out)
+
+
+def mlp(x, weights, biases):
+    params = []
+    for w, b in zip(weights, biases):
+        params += [w, b]
+    return MLPFn.apply(x, len(weights), *params)
+
+
+class WeightFromAlphaFn(torch.autograd.Function):
+    """nerfacc.render_weight_from_alpha, dense mode (call site models/neurad.py:716-717)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, alphas):
+        ctx.save_for_backward(alphas)
+        w, t = ops.render_weight_from_alpha(alphas)
+        return w, t
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gw, gt):
+        (a,) = ctx.saved_tensors
+        return ops.render_weight_from_alpha_bwd(a, gw.contiguous(), None if gt is None else gt.contiguous())
+
+
+class WeightFromDensityFn(torch.autograd.Function):
+    """nerfacc.render_weight_from_density, dense mode (models/neurad.py:718-723).  Gradient w.r.t. sigmas."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, t_starts, t_ends, sigmas):
+        ctx.save_for_backward(t_starts, t_ends, sigmas)
+        w, t, a = ops.render_weight_from_density(t_starts, t_ends, sigmas)
+        ctx.mark_non_differentiable(t, a)
+        return w, t, a
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gw, gt, ga):
+        s, e, sg = ctx.saved_tensors
+        return None, None, ops.render_weight_from_density_bwd(s, e, sg, gw.contiguous())
+
+
+class WeightsFromDensityFn(torch.autograd.Function):
+    """RaySamples.get_weights (cameras/rays.py:188-210)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, deltas, densities):
+        ctx.save_for_backward(deltas, densities)
+        return ops.weights_from_density(deltas, densities)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gw):
+        d, s = ctx.saved_tensors
+        return None, ops.weights_from_density_bwd(d, s, gw.contiguous())
+
+
+class AccumulateFn(torch.autograd.Function):
+    """nerfacc.accumulate_along_rays dense mode: sum_S w * v."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, weights, values):
+        ctx.save_for_backward(weights, values)
+        return ops.accumulate_along_rays(weights, values)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        w, v = ctx.saved_tensors
+        gw = (g[:, None, :] * v).sum(-1) if v is not None else g.expand_as(w)
+        gv = w[..., None] * g[:, None, :] if (v is not None and ctx.needs_input_grad[1]) else None
+        return gw, gv
+
+
+class CompositeFn(torch.autograd.Function):
+    """get_nff_outputs compositing (models/neurad.py:377-395,727-734): -> features [R,C], depth [R,1], acc [R,1]."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, weights, features, starts, ends):
+        ctx.save_for_backward(weights, features, starts, ends)
+        return ops.composite_fwd(weights, features, starts, ends)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gf, gd, ga):
+        w, f, s, e = ctx.saved_tensors
+        gw, gfe = ops.composite_bwd(w, f, s, e, gf.contiguous(), gd, ga, need_grad_features=ctx.needs_input_grad[1])
+        return gw, gfe, None, None
+
+
+class ProposalDensityFn(torch.autograd.Function):
+    """NeuRADProposalField.get_density (fields/neurad_field.py:208-213), trunc_exp backward included."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, table, decoder_weight, spec, static_scale, origins, directions, pixel_area, starts, ends):
+        ps = ops.ProposalSpec(spec, table, static_scale, decoder_weight)
+        dens = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends)
+        ctx.ps = ps
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, dens)
+        return dens
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        o, d, a, s, e, dens = ctx.saved_tensors
+        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g.contiguous())
+        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None, None

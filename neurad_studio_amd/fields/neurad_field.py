@@ -1,0 +1,196 @@
+"""NeuRADField / NeuRADProposalField on the HIP path (mirror of nerfstudio/fields/neurad_field.py:43-216).
+
+Same constructor arguments, ``forward(ray_samples) -> Dict[FieldHeadNames, Tensor]``, ``get_density``,
+``get_param_groups`` and state_dict names (``hashgrid.static_grid.hash_table``, ``mlp_geo.layers.k.*``,
+``mlp_feature.layers.k.*``, ``sdf_to_density.beta``, ``density_decoder.weight``).
+
+Two execution paths, both pure HIP:
+  * no-grad (eval / render): ONE fused kernel -- nrhip_field_fwd per-sample, or nrhip_render_fwd when the
+    caller wants composited rays (``render``);
+  * grad-enabled (training): operator-level autograd chain encode -> MLP(MFMA) -> SH -> MLP -> head, each op
+    with its hand-written backward (hash scatter-add atomics, MFMA data/weight gradients).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import autograd as ag
+from .. import ops
+from ..cameras.rays import RaySamples
+from ..field_components.encodings import SHEncoding
+from ..field_components.field_heads import FieldHeadNames
+from ..field_components.mlp import MLP
+from ..field_components.neurad_encoding import (ActorSettings, NeuRADHashEncoding, NeuRADHashEncodingConfig,
+                                                StaticSettings)
+
+
+class _TruncExp(torch.autograd.Function):  # field_components/activations.py:28-41
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+class SigmoidDensity(nn.Module):  # model_components/utils.py:21-41
+    def __init__(self, init_val, beta_min=0.0001, learnable_beta=False):
+        super().__init__()
+        self.register_buffer("beta_min", torch.tensor(beta_min))
+        self.register_parameter("beta", nn.Parameter(init_val * torch.ones(1), requires_grad=learnable_beta))
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min
+
+    def forward(self, sdf: Tensor, beta=None) -> Tensor:
+        return torch.sigmoid(-sdf * (self.get_beta() if beta is None else beta))
+
+
+def get_normalized_directions(directions: Tensor) -> Tensor:  # fields/base_field.py:136-142
+    return (directions + 1.0) / 2.0
+
+
+@dataclass
+class NeuRADFieldConfig:  # neurad_field.py:43-75
+    grid: NeuRADHashEncodingConfig = field(
+        default_factory=lambda: NeuRADHashEncodingConfig(require_actor_grad=True, actor=ActorSettings(flip_prob=0.25)))
+    geo_hidden_dim: int = 32
+    geo_num_layers: int = 2
+    nff_hidden_dim: int = 32
+    nff_num_layers: int = 3
+    nff_out_dim: int = 32
+    num_multisamples: int = 1
+    use_sdf: bool = True
+    sdf_beta: float = 20.0
+    learnable_beta: bool = True
+
+    def setup(self, **kwargs):
+        return NeuRADField(self, **kwargs)
+
+
+class NeuRADField(nn.Module):
+    def __init__(self, config: NeuRADFieldConfig, actors=None, static_scale: float = 1.0,
+                 implementation: str = "hip") -> None:
+        super().__init__()
+        if config.num_multisamples != 1:
+            raise NotImplementedError("num_multisamples != 1 is not used by any NeuRAD config (neurad_field.py:67)")
+        self.config, self.implementation = config, implementation
+        self.hashgrid: NeuRADHashEncoding = config.grid.setup(dynamic_actors=actors, static_scale=static_scale,
+                                                              implementation=implementation)
+        self.geo_feat_dim = config.nff_out_dim
+        self.mlp_geo = MLP(in_dim=self.hashgrid.get_out_dim(), num_layers=config.geo_num_layers,
+                           layer_width=config.geo_hidden_dim, out_dim=self.geo_feat_dim + 1)
+        self.direction_encoding = SHEncoding(levels=4)
+        self.mlp_feature = MLP(in_dim=16 + self.geo_feat_dim, num_layers=config.nff_num_layers,
+                               layer_width=config.nff_hidden_dim, out_dim=config.nff_out_dim)
+        if config.use_sdf:
+            self.sdf_to_density = SigmoidDensity(config.sdf_beta, learnable_beta=config.learnable_beta)
+
+    def get_param_groups(self, param_groups: Dict):
+        self.hashgrid.get_param_groups(param_groups)
+        param_groups["fields"] += list(self.mlp_geo.parameters()) + list(self.mlp_feature.parameters())
+        if self.config.use_sdf:
+            param_groups["fields"] += list(self.sdf_to_density.parameters())
+
+    # ---- fused path -----------------------------------------------------------------------------
+    def fused_supported(self) -> bool:
+        c, g = self.config, self.hashgrid.static_grid
+        return (g.get_out_dim() == 32 and g.num_levels % 4 == 0 and c.geo_num_layers == 2 and c.nff_num_layers == 3
+                and c.geo_hidden_dim == c.nff_hidden_dim and c.geo_hidden_dim in (32, 64) and c.nff_out_dim == 32)
+
+    def field_spec(self) -> ops.FieldSpec:
+        g = self.hashgrid.static_grid
+        beta = float(self.sdf_to_density.get_beta()) if self.config.use_sdf else 0.0
+        return ops.FieldSpec(g.spec, g.hash_table.detach(), self.hashgrid.static_scale,
+                             [l.weight.detach() for l in self.mlp_geo.layers], [l.bias.detach() for l in self.mlp_geo.layers],
+                             [l.weight.detach() for l in self.mlp_feature.layers],
+                             [l.bias.detach() for l in self.mlp_feature.layers], use_sdf=self.config.use_sdf, beta=beta)
+
+    @torch.no_grad()
+    def render(self, origins, directions, pixel_area, starts, ends, return_weights=False):
+        """F1+C1+C2 in one kernel: -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S])."""
+        if not self.fused_supported():
+            raise NotImplementedError("fused render kernel: configuration not instantiated; use forward() + renderers")
+        return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights)
+
+    # ---- Field.forward (neurad_field.py:128-152) ------------------------------------------------
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[FieldHeadNames, Tensor]:
+        fr = ray_samples.frustums
+        o, d, a = fr.per_ray()
+        starts, ends = fr.starts[..., 0], fr.ends[..., 0]
+        R, S = starts.shape
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not needs_grad and self.fused_supported():
+            feature, sdf, head = ops.field_fwd(self.field_spec(), o, d, a, starts, ends)
+            out = {FieldHeadNames.FEATURE: feature}
+            if self.config.use_sdf:
+                out[FieldHeadNames.SDF], out[FieldHeadNames.ALPHA] = sdf[..., None], head[..., None]
+            else:
+                out[FieldHeadNames.DENSITY] = head[..., None]
+            return out
+        features = self.hashgrid.forward_rays(o, d, a, starts, ends)
+        geo = self.mlp_geo(features)
+        geo_out, geo_embedding = geo[:, :1], geo[:, 1:]
+        sh = self.direction_encoding(get_normalized_directions(d))  # per ray; broadcast over the samples
+        sh = sh[:, None, :].expand(R, S, 16).reshape(-1, 16)
+        feature = geo_embedding + self.mlp_feature(torch.cat([geo_embedding, sh], dim=-1))
+        out = {FieldHeadNames.FEATURE: feature.view(R, S, self.config.nff_out_dim)}
+        geo_out = geo_out.reshape(R, S, 1)
+        if self.config.use_sdf:
+            out[FieldHeadNames.SDF] = geo_out
+            out[FieldHeadNames.ALPHA] = self.sdf_to_density(geo_out)
+        else:
+            out[FieldHeadNames.DENSITY] = trunc_exp(geo_out)
+        return out
+
+
+@dataclass
+class NeuRADProposalFieldConfig:  # neurad_field.py:155-179
+    grid: NeuRADHashEncodingConfig = field(default_factory=lambda: NeuRADHashEncodingConfig(
+        static=StaticSettings(log2_hashmap_size=20, num_levels=6, max_res=4096, base_res=128, hashgrid_dim=1),
+        actor=ActorSettings(log2_hashmap_size=15, num_levels=4, base_res=64, max_res=1024, hashgrid_dim=1),
+        require_actor_grad=False))
+    hidden_dim: int = 16
+
+    def setup(self, **kwargs):
+        return NeuRADProposalField(self, **kwargs)
+
+
+class NeuRADProposalField(nn.Module):
+    def __init__(self, config: NeuRADProposalFieldConfig, actors=None, static_scale: float = 1.0,
+                 implementation: str = "hip") -> None:
+        super().__init__()
+        self.config, self.implementation = config, implementation
+        self.hashgrid: NeuRADHashEncoding = config.grid.setup(dynamic_actors=actors, static_scale=static_scale,
+                                                              implementation=implementation)
+        self.density_decoder = nn.Linear(self.hashgrid.get_out_dim(), 1, bias=False)
+
+    def get_param_groups(self, param_groups: Dict):
+        self.hashgrid.get_param_groups(param_groups)
+        param_groups["fields"] += list(self.density_decoder.parameters())
+
+    def proposal_spec(self) -> ops.ProposalSpec:
+        g = self.hashgrid.static_grid
+        return ops.ProposalSpec(g.spec, g.hash_table.detach(), self.hashgrid.static_scale,
+                                self.density_decoder.weight.detach())
+
+    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
+        """neurad_field.py:208-213, one kernel: gaussian -> contraction -> 6-level lookup -> rescale -> dot -> exp."""
+        fr = ray_samples.frustums
+        o, d, a = fr.per_ray()
+        g = self.hashgrid.static_grid
+        dens = ag.ProposalDensityFn.apply(g.hash_table, self.density_decoder.weight, g.spec, self.hashgrid.static_scale,
+                                          o, d, a, fr.starts[..., 0], fr.ends[..., 0])
+        return dens[..., None], None
+
+    def get_outputs(self, ray_samples, density_embedding=None) -> dict:
+        return {}

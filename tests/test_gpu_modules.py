@@ -1,0 +1,192 @@
+"""GPU tests of the host-side mirror (Field / Sampler / Renderer / hot-path model): the reference's plugin API
+driving the HIP kernels, incl. the hand-written backward passes against the reference's autograd goldens."""
+import numpy as np
+import pytest
+import torch
+
+import neurad_oracle as O
+import synth
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def make_field(use_sdf, lg=11):
+    from neurad_studio_amd.fields.neurad_field import NeuRADField, NeuRADFieldConfig
+
+    cfg = NeuRADFieldConfig(use_sdf=use_sdf)
+    cfg.grid.static.log2_hashmap_size = lg
+    f = NeuRADField(cfg, actors=None, static_scale=100.0).cuda()
+    with torch.no_grad():
+        f.hashgrid.static_grid.hash_table.copy_(dev(synth.hash_table(8 * 2**lg, 4, seed=51, scale=0.5)))
+        for k, l in enumerate(f.mlp_geo.layers):
+            w, b = synth.linear(l.out_features, l.in_features, 200 + 10 * k)
+            l.weight.copy_(dev(w)), l.bias.copy_(dev(b))
+        for k, l in enumerate(f.mlp_feature.layers):
+            w, b = synth.linear(l.out_features, l.in_features, 300 + 10 * k)
+            l.weight.copy_(dev(w)), l.bias.copy_(dev(b))
+    return f
+
+
+def bundle(o, d, area, fars=None):
+    from neurad_studio_amd.cameras.rays import RayBundle
+
+    R = o.shape[0]
+    return RayBundle(origins=dev(o), directions=dev(d), pixel_area=dev(area)[:, None],
+                     nears=torch.zeros(R, 1, device="cuda"),
+                     fars=torch.full((R, 1), 20000.0, device="cuda") if fars is None else dev(fars)[:, None])
+
+
+@pytest.mark.parametrize("tag", ["sdf", "density"])
+def test_field_forward_backward_vs_reference_autograd(tag):
+    """Same parameters, inputs and upstream gradients as oracle/make_golden.py::golden_field; the golden gradients
+    come from the reference's own autograd (B1)."""
+    from neurad_studio_amd.field_components.field_heads import FieldHeadNames
+    from neurad_studio_amd.model_components.ray_samplers import PowerSampler
+
+    g = load_golden(f"field_{tag}")
+    fld = make_field(tag == "sdf").eval()
+    rb = bundle(g["o"], g["d"], g["area"])
+    rs = PowerSampler(num_samples=12, lambda_=-1.0, scaling=0.1).eval()(rb)
+    assert rel_l2(host(rs.frustums.starts[..., 0]), g["starts"]) < 1e-5
+    key = FieldHeadNames.ALPHA if tag == "sdf" else FieldHeadNames.DENSITY
+    with torch.no_grad():  # fused kernel
+        out_f = fld(rs)
+    out = fld(rs)  # operator-level autograd path
+    assert rel_l2(host(out[FieldHeadNames.FEATURE]), g["feature"]) < TOL
+    assert rel_l2(host(out_f[FieldHeadNames.FEATURE]), g["feature"]) < TOL
+    assert rel_l2(host(out[key][..., 0]), g["alpha" if tag == "sdf" else "density"]) < TOL
+    assert rel_l2(host(out_f[key][..., 0]), host(out[key][..., 0])) < 1e-5
+    ((out[FieldHeadNames.FEATURE] * dev(g["g_feature"])).sum() + (out[key][..., 0] * dev(g["g_head"])).sum()).backward()
+    tg = np.zeros((8 * 2**11, 4), np.float32)
+    tg[g["tg_idx"]] = g["tg_val"]
+    assert rel_l2(host(fld.hashgrid.static_grid.hash_table.grad), tg) < TOL
+    for k, l in enumerate(fld.mlp_geo.layers):
+        assert rel_l2(host(l.weight.grad), g[f"geo_dw{k}"]) < TOL and rel_l2(host(l.bias.grad), g[f"geo_db{k}"]) < TOL
+    for k, l in enumerate(fld.mlp_feature.layers):
+        assert rel_l2(host(l.weight.grad), g[f"feat_dw{k}"]) < TOL and rel_l2(host(l.bias.grad), g[f"feat_db{k}"]) < TOL
+    if tag == "sdf":
+        assert rel_l2(host(fld.sdf_to_density.beta.grad), g["dbeta"]) < TOL
+
+
+def make_prop(seed, lg=11):
+    from neurad_studio_amd.fields.neurad_field import NeuRADProposalField, NeuRADProposalFieldConfig
+
+    c = NeuRADProposalFieldConfig()
+    c.grid.static.log2_hashmap_size = lg
+    p = NeuRADProposalField(c, actors=None, static_scale=100.0).cuda()
+    w, _ = synth.linear(1, 6, seed + 1, bias=False)
+    with torch.no_grad():
+        p.hashgrid.static_grid.hash_table.copy_(dev(synth.hash_table(6 * 2**lg, 1, seed=seed, scale=2.0)))
+        p.density_decoder.weight.copy_(dev(w + np.float32(0.3)))
+    return p
+
+
+def test_proposal_sampler_module_vs_reference_golden():
+    """ProposalNetworkSampler with the reference's orchestration (density_fns callables) AND the fused kernel,
+    against the chain the reference produced (incl. the late-binding quirk)."""
+    from neurad_studio_amd.model_components.ray_samplers import PowerSampler, ProposalNetworkSampler
+
+    g = load_golden("sampler_chain")
+    props = [make_prop(91), make_prop(95)]
+    sampler = ProposalNetworkSampler(num_proposal_samples_per_ray=(128, 64), num_nerf_samples_per_ray=32,
+                                     num_proposal_network_iterations=2, single_jitter=True,
+                                     initial_sampler=PowerSampler(lambda_=-1.0, scaling=0.1),
+                                     update_sched=lambda x: 0).eval()
+    density_fns = [lambda x: prop_field.get_density(x)[0] for prop_field in props]  # the reference's own idiom
+    rb = bundle(g["o"], g["d"], g["area"], np.minimum(g["fars"], 20000.0))
+    with torch.no_grad():
+        rs, wl, rsl = sampler(rb, density_fns, pass_ray_samples=True)
+        rs2, wl2, rsl2 = sampler.generate_fused(rb, [props[1], props[1]])
+    for r, w in ((rs, wl), (rs2, wl2)):
+        assert rel_l2(host(w[0][..., 0]), g["w0"]) < TOL and rel_l2(host(w[1][..., 0]), g["w1"]) < TOL
+        assert rel_l2(host(r.frustums.starts[..., 0]), g["starts"]) < TOL
+        assert rel_l2(host(r.frustums.ends[..., 0]), g["ends"]) < TOL
+        assert rel_l2(host(r.spacing_ends[..., 0]), g["spe"]) < TOL
+
+
+def small_model(use_sdf=True):
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    c = NeuRADHotPathConfig(appearance_dim=0)
+    c.field.use_sdf = use_sdf
+    c.field.sdf_beta = 3.0
+    c.field.grid.static.log2_hashmap_size = 12
+    c.sampling.proposal_field_1.grid.static.log2_hashmap_size = 11
+    c.sampling.proposal_field_2.grid.static.log2_hashmap_size = 11
+    torch.manual_seed(0)
+    m = NeuRADHotPath(c, static_scale=100.0).cuda()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(1000.0)  # O(1) features so alphas vary
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(2000.0)
+    return m
+
+
+@pytest.mark.parametrize("use_sdf", [True, False])
+def test_hot_path_model_eval_fused_vs_oracle_and_operator_path(use_sdf):
+    m = small_model(use_sdf).eval()
+    R = 48
+    o, d, area, _ = synth.rays(R, 9)
+    with torch.no_grad():
+        out = m.get_nff_outputs(bundle(o, d, area / 9))  # _scale_pixel_area multiplies camera rays by 3^2
+    # oracle chain with the same parameters
+    h = lambda t: host(t)  # noqa: E731
+    props = [O.ProposalParams(O.GridParams(h(p.hashgrid.static_grid.hash_table), 6, 128, 4096, 11), 100.0,
+                              h(p.density_decoder.weight)) for p in m.proposal_fields]
+    so = O.proposal_sampler(props, o, d, area, np.zeros(R), np.full(R, 20000.0, np.float32))
+    f = m.field
+    fp = O.FieldParams(O.GridParams(h(f.hashgrid.static_grid.hash_table), 8, 32, 8192, 12), 100.0,
+                       [h(l.weight) for l in f.mlp_geo.layers], [h(l.bias) for l in f.mlp_geo.layers],
+                       [h(l.weight) for l in f.mlp_feature.layers], [h(l.bias) for l in f.mlp_feature.layers],
+                       beta=3.0, use_sdf=use_sdf)
+    ref = O.render_rays(fp, o, d, area, so.starts, so.ends)
+    assert rel_l2(host(out["features"]), ref["features"]) < TOL
+    assert rel_l2(host(out["accumulation"]), ref["accumulation"]) < TOL
+    assert rel_l2(host(out["depth"]), ref["depth"]) < TOL
+    # operator-level (training) path in eval mode (no jitter) must agree with the fused kernels
+    out2 = m.get_nff_outputs(bundle(o, d, area / 9))
+    for k in ("features", "accumulation", "depth", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(host(out2[k]), host(out[k])) < 2e-5, k
+    # gradients reach every trainable tensor of the path that the reference trains
+    (out2["features"].sum() + out2["depth"].sum()).backward()
+    assert m.field.hashgrid.static_grid.hash_table.grad.abs().sum() > 0
+    assert all(l.weight.grad is not None for l in m.field.mlp_geo.layers)
+
+
+def test_training_mode_runs_with_jitter_and_proposal_grads():
+    m = small_model(True).train()
+    R = 64
+    o, d, area, _ = synth.rays(R, 11)
+    out = m.get_nff_outputs(bundle(o, d, area))
+    assert len(out["weights_list"]) == 3 and out["weights_list"][0].shape == (R, 128, 1)
+    loss = out["features"].square().mean() + sum(w.square().sum() for w in out["weights_list"][:2])
+    loss.backward()
+    # the late-binding quirk: only proposal_fields[1] is ever evaluated -> [0] gets no gradient
+    assert m.proposal_fields[0].hashgrid.static_grid.hash_table.grad is None
+    assert m.proposal_fields[1].hashgrid.static_grid.hash_table.grad.abs().sum() > 0
+    assert m.proposal_fields[1].density_decoder.weight.grad.abs().sum() > 0
+
+
+def test_nerfacc_shaped_shim_and_renderers():
+    from neurad_studio_amd.model_components.renderers import AccumulationRenderer, FeatureRenderer
+    from neurad_studio_amd.shims import nerfacc
+
+    a = dev(synth.uniform((9, 40), 0, 0.3, 1)).requires_grad_(True)
+    w, t = nerfacc.render_weight_from_alpha(a)
+    feats = dev(synth.normal((9, 40, 32), 2))
+    out = FeatureRenderer()(features=feats, weights=w[..., None])
+    acc = AccumulationRenderer()(weights=w[..., None])
+    (out.sum() + acc.sum()).backward()
+    rw, _ = O.render_weight_from_alpha(host(a))
+    assert rel_l2(host(out), O.accumulate_along_rays(rw, host(feats))) < 2e-5
+    assert a.grad is not None and torch.isfinite(a.grad).all()
