@@ -190,3 +190,28 @@ def test_nerfacc_shaped_shim_and_renderers():
     rw, _ = O.render_weight_from_alpha(host(a))
     assert rel_l2(host(out), O.accumulate_along_rays(rw, host(feats))) < 2e-5
     assert a.grad is not None and torch.isfinite(a.grad).all()
+
+
+def test_tinycudann_shaped_shim_matches_torch_path_oracle():
+    """tcnn.Encoding / Network / NetworkWithInputEncoding call forms of encodings.py:370-373, mlp.py:109-113,251-268."""
+    from neurad_studio_amd.shims import tinycudann as tcnn
+
+    growth = float(np.exp((np.log(1024) - np.log(16)) / 15))
+    enc_cfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 12,
+               "base_resolution": 16, "per_level_scale": growth}
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+               "n_hidden_layers": 1}
+    m = tcnn.NetworkWithInputEncoding(3, 16, enc_cfg, net_cfg).cuda()
+    x = synth.uniform((777, 3), 0, 1, 4)
+    y = m(dev(x))
+    table = host(m.encoding.params).reshape(-1, 2)
+    sc = O.hash_scalings(16, 16, 1024)
+    np.testing.assert_array_equal(m.encoding.spec.scalings.numpy(), sc)
+    ref = O.mlp_fwd(O.hashgrid_fwd(x, table, sc, 2**12), [host(l.weight) for l in m.network.layers],
+                    [host(l.bias) for l in m.network.layers])
+    assert rel_l2(host(y), ref) < TOL
+    y.square().sum().backward()
+    assert m.encoding.params.grad.abs().sum() > 0 and m.network.layers[0].weight.grad.abs().sum() > 0
+    sh = tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": 4}).cuda()
+    d = synth.uniform((50, 3), 0, 1, 5)
+    assert rel_l2(host(sh(dev(d))), O.sh_deg4(d)) < 1e-6
