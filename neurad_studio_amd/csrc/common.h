@@ -146,6 +146,23 @@ __device__ __forceinline__ Corners hash_corners(float x, float y, float z, float
   return c;
 }
 
+// trilinear blend of 8 loaded corner entries, reference lerp tree (encodings.py:454-464)
+template <int F>
+__device__ __forceinline__ void hash_lerp(const float (&f)[8][F], float ox, float oy, float oz, float (&out)[F]) {
+  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+#pragma unroll
+  for (int i = 0; i < F; ++i) {
+    // a*o + b*(1-o) as fma(a, o, b*(1-o)): 2 VALU ops per lerp; one rounding fewer than torch's mul,mul,add
+    const float f03 = fmaf(f[0][i], ox, f[3][i] * mx);
+    const float f12 = fmaf(f[1][i], ox, f[2][i] * mx);
+    const float f56 = fmaf(f[5][i], ox, f[6][i] * mx);
+    const float f47 = fmaf(f[4][i], ox, f[7][i] * mx);
+    const float f0312 = fmaf(f03, oy, f12 * my);
+    const float f4756 = fmaf(f47, oy, f56 * my);
+    out[i] = fmaf(f0312, oz, f4756 * mz);
+  }
+}
+
 template <int F, bool HALF>
 __device__ __forceinline__ void hash_level(const void* table, uint32_t level_row0, float x, float y, float z,
                                            float scale, uint32_t mask, float (&out)[F]) {
@@ -157,13 +174,14 @@ __device__ __forceinline__ void hash_level(const void* table, uint32_t level_row
   const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
 #pragma unroll
   for (int i = 0; i < F; ++i) {
-    const float f03 = f[0][i] * ox + f[3][i] * mx;
-    const float f12 = f[1][i] * ox + f[2][i] * mx;
-    const float f56 = f[5][i] * ox + f[6][i] * mx;
-    const float f47 = f[4][i] * ox + f[7][i] * mx;
-    const float f0312 = f03 * oy + f12 * my;
-    const float f4756 = f47 * oy + f56 * my;
-    out[i] = f0312 * oz + f4756 * mz;
+    // a*o + b*(1-o) as fma(a, o, b*(1-o)): 2 VALU ops per lerp; one rounding fewer than torch's mul,mul,add
+    const float f03 = fmaf(f[0][i], ox, f[3][i] * mx);
+    const float f12 = fmaf(f[1][i], ox, f[2][i] * mx);
+    const float f56 = fmaf(f[5][i], ox, f[6][i] * mx);
+    const float f47 = fmaf(f[4][i], ox, f[7][i] * mx);
+    const float f0312 = fmaf(f03, oy, f12 * my);
+    const float f4756 = fmaf(f47, oy, f56 * my);
+    out[i] = fmaf(f0312, oz, f4756 * mz);
   }
 }
 
@@ -188,6 +206,13 @@ struct SamplePos {
   float x, y, z, std;
 };
 
+// x^(1/3) for x >= 0 via v_log_f32 / v_exp_f32 (~1e-6 relative).  Only the gaussian std (which feeds the smooth
+// down-weighting 1/max(1, 2*s_l*std)) goes through it -- never a position -- so torch's pow(x, 1/3) need not be
+// matched to the ulp; a full powf costs ~40 VALU instructions twice per sample.
+__device__ __forceinline__ float fast_cbrt(float x) {
+  return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 3.0f));
+}
+
 __device__ __forceinline__ SamplePos sample_position(float ox, float oy, float oz, float dx, float dy, float dz,
                                                      float area, float t0, float t1, float inv_scale_dummy,
                                                      float scale) {
@@ -198,7 +223,7 @@ __device__ __forceinline__ SamplePos sample_position(float ox, float oy, float o
   const float dist = (t1 - t0) / 2.f;
   const float t = t0 + 1.f * dist;
   float mx = ox + dx * t, my = oy + dy * t, mz = oz + dz * t;
-  float std = powf((area * (t * t)) * dist, 1.0f / 3.0f);
+  float std = fast_cbrt((area * (t * t)) * dist);
   // ScaledSceneContraction: divide by scale, contract (inf-norm), map [-2,2] -> [0,1]
   mx /= scale, my /= scale, mz /= scale, std /= scale;
   const float mag = fmaxf(fabsf(mx), fmaxf(fabsf(my), fabsf(mz)));
@@ -206,7 +231,7 @@ __device__ __forceinline__ SamplePos sample_position(float ox, float oy, float o
     const float cm = fmaxf(mag, 1.f);
     const float k = 2.f - (1.f / cm);
     mx = k * (mx / cm), my = k * (my / cm), mz = k * (mz / cm);
-    const float sc = powf(2.f * cm - 1.f, 1.0f / 3.0f) / cm;
+    const float sc = fast_cbrt(2.f * cm - 1.f) / cm;
     std = std * (sc * sc);
   }
   SamplePos p;
@@ -217,7 +242,7 @@ __device__ __forceinline__ SamplePos sample_position(float ox, float oy, float o
 
 // H4: 1 / max(1, 2*scalings_l*std)   (neurad_encoding.py:302)
 __device__ __forceinline__ float rescale_weight(float scale_l, float std) {
-  return 1.f / fmaxf(scale_l * 2.f * std, 1.f);
+  return __builtin_amdgcn_rcpf(fmaxf(scale_l * 2.f * std, 1.f));  // v_rcp_f32 (1 ulp); weights are smooth in std
 }
 
 // F3: 16 real SH components (utils/math.py:31-94) of a direction given as (dir+1)/2 -- the torch path

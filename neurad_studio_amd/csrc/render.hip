@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
 
       // ---- head (F4 / trunc_exp) -------------------------------------------------------------------
       float a_or_d;  // alpha (sdf mode) or density
-      if (fd.use_sdf) a_or_d = 1.f / (1.f + expf(sdf * fd.beta));  // sigmoid(-sdf*beta)
+      if (fd.use_sdf) a_or_d = __builtin_amdgcn_rcpf(1.f + __expf(sdf * fd.beta));  // sigmoid(-sdf*beta)
       else a_or_d = expf(sdf);
 
       if constexpr (!COMPOSITE) {
