@@ -516,3 +516,146 @@ def render_rays(p: FieldParams, origins, directions, pixel_area, starts, ends):
         w, _, _ = render_weight_from_density(starts, ends, f["density"])
     feat, depth, acc = composite(w, f["feature"], starts, ends)
     return {"features": feat, "depth": depth, "accumulation": acc, "weights": w, **f}
+
+
+# --------------------------------------------------------------------------------------
+# H5  dynamic actors (field_components/neurad_encoding.py:150-295; model_components/dynamic_actors.py:106-108,
+#     251-268; utils/poses.py:42-55,90-150; cameras/camera_utils.py:422-443; cameras/lidars.py:550-564)
+# --------------------------------------------------------------------------------------
+def _normalize(v, eps=1e-12):  # torch.nn.functional.normalize
+    n = np.sqrt((v * v).sum(-1, keepdims=True, dtype=f32)).astype(f32)
+    return (v / np.maximum(n, f32(eps))).astype(f32)
+
+
+def rotation_6d_to_matrix(d6):
+    """camera_utils.py:422-443 (rows b1, b2, b3)."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = _normalize(a1)
+    b2 = _normalize(a2 - (b1 * a2).sum(-1, keepdims=True) * b1)
+    b3 = np.cross(b1, b2)
+    return np.stack([b1, b2, b3], axis=-2).astype(f32)
+
+
+@dataclass
+class ActorParams:
+    """state of DynamicActors (model_components/dynamic_actors.py:109-170) + the per-actor grids of the torch path."""
+
+    timestamps: np.ndarray        # [Tn]
+    positions: np.ndarray         # [Tn, A, 3]   actor_positions
+    rotations_6d: np.ndarray      # [Tn, A, 6]   actor_rotations_6d
+    present: np.ndarray           # [Tn, A] bool actor_present_at_time
+    sizes: np.ndarray             # [A, 3]       actor_sizes (wlh)
+    padding: np.ndarray           # [3]          actor_padding
+    grids: List[GridParams]       # one 3-D grid per actor (neurad_encoding.py:110-131)
+    actor_scale: float = 10.0
+
+    @property
+    def bounds(self):
+        return (self.sizes / f32(2) + self.padding).astype(f32)  # dynamic_actors.py:106-107
+
+
+def actor_boxes2world(a: ActorParams, query_times):
+    """DynamicActors.get_boxes2world(flatten=False) -> (boxes2world [R,A,4,4], valid [R,A]);
+    interpolate_trajectories_6d (utils/poses.py:90-150)."""
+    poses = np.concatenate([a.rotations_6d, a.positions], -1).astype(f32)  # [Tn,A,9]
+    a1 = _normalize(poses[..., :3])
+    a2 = poses[..., 3:6]
+    a2 = _normalize(a2 - (a1 * a2).sum(-1, keepdims=True) * a1)
+    poses = np.concatenate([a1, a2, poses[..., 6:9]], -1)
+    q = np.asarray(query_times, f32).reshape(-1)
+    right = np.searchsorted(a.timestamps, q, side="left")
+    left = np.clip(right - 1, 0, None)
+    right = np.clip(right, None, len(a.timestamps) - 1)
+    rt, lt = a.timestamps[right].astype(f32), a.timestamps[left].astype(f32)
+    frac = np.clip((q - lt) / (rt - lt + f32(1e-6)), 0, 1).astype(f32)
+    valid = a.present[left] | a.present[right]
+    pl, pr = poses[left], poses[right]
+    interp = (pl + (pr - pl) * frac[:, None, None]).astype(f32)  # [R,A,9]
+    rot = rotation_6d_to_matrix(interp[..., :6])
+    b2w = np.zeros(interp.shape[:2] + (4, 4), f32)
+    b2w[..., :3, :3] = rot
+    b2w[..., :3, 3] = interp[..., 6:]
+    b2w[..., 3, 3] = 1
+    return b2w, valid
+
+
+def pose_inverse(b2w):
+    """utils/poses.py:42-55 -> [...,3,4]"""
+    R = b2w[..., :3, :3]
+    t = b2w[..., :3, 3:]
+    Ri = np.swapaxes(R, -1, -2)
+    return np.concatenate([Ri, -(Ri @ t)], -1).astype(f32)
+
+
+def actor_hits(a: ActorParams, mean_pos, b2w, valid, w2b):
+    """_get_actor_indices (neurad_encoding.py:225-263) -> (ray_idx, sample_idx, actor_idx), duplicates kept, in the
+    reference's order (pair order, then sample)."""
+    eps = f32(1e-7)
+    bounds = a.bounds
+    radii = np.sqrt((bounds * bounds).sum(-1)).astype(f32)
+    p0 = mean_pos[:, 0, :]
+    ld = mean_pos[:, -1, :] - p0
+    ld = ld / (np.linalg.norm(ld, axis=-1, keepdims=True).astype(f32) + eps)
+    vec = b2w[..., :3, 3] - p0[:, None, :]
+    dist = np.linalg.norm(np.cross(vec, ld[:, None, :]), axis=-1).astype(f32)
+    close = (dist < radii[None, :]) & valid
+    ray_idx, actor_idx = np.nonzero(close)
+    sp = mean_pos[ray_idx]                                     # [P,S,3]
+    ap = b2w[ray_idx, actor_idx, :3, 3][:, None, :]
+    d2 = np.linalg.norm(sp - ap, axis=-1).astype(f32)
+    within = d2 < radii[actor_idx][:, None]
+    pi, si = np.nonzero(within)
+    r, s, k = ray_idx[pi], si, actor_idx[pi]
+    sel = mean_pos[r, s]
+    tr = w2b[r, k]
+    pib = (tr[:, :3, :3] @ sel[:, :, None])[:, :, 0] + tr[:, :3, 3]
+    inside = np.all(np.abs(pib) < bounds[k], axis=-1)
+    return r[inside], s[inside], k[inside]
+
+
+def encode_with_actors(grid: GridParams, static_scale, a: ActorParams, origins, directions, pixel_area, starts, ends,
+                       times):
+    """NeuRADHashEncoding.forward (neurad_encoding.py:150-187), eval mode (no flip), per-actor 3-D grids.
+    -> features [R*S, L*F], directions [R,S,3] (box frame + renormalised where a sample is inside an actor)."""
+    R, S = np.asarray(starts).shape
+    mean, std = fast_isotropic_gaussian(origins, directions, pixel_area, starts, ends)
+    feats = encode_static(grid, static_scale, origins, directions, pixel_area, starts, ends).reshape(R, S, -1).copy()
+    dirs = np.broadcast_to(np.asarray(directions, f32)[:, None, :], (R, S, 3)).copy()
+    if len(a.grids) == 0:
+        return feats.reshape(R * S, -1), dirs
+    b2w, valid = actor_boxes2world(a, times)
+    w2b = pose_inverse(b2w)
+    r, s, k = actor_hits(a, mean, b2w, valid, w2b)
+    if r.shape[0] == 0:
+        return feats.reshape(R * S, -1), dirs
+    tr = w2b[r, k]
+    pos = (tr[:, :3, :3] @ mean[r, s][:, :, None])[:, :, 0] + tr[:, :3, 3]
+    dd = (tr[:, :3, :3] @ dirs[r, s][:, :, None])[:, :, 0]
+    dd = dd / (np.linalg.norm(dd, axis=-1, keepdims=True).astype(f32) + f32(1e-7))
+    dirs[r, s] = dd  # last write wins (CPU index_put order), as for the features below
+    cpos, cstd = contract_gaussian(pos.astype(f32), std[r, s], a.actor_scale)
+    out_dim = feats.shape[-1]
+    for m in range(r.shape[0]):  # reference order: later triples overwrite earlier ones (neurad_encoding.py:184-185)
+        g = a.grids[k[m]]
+        f = hashgrid_fwd(cpos[m:m + 1], g.table, g.scalings, g.table_size)
+        f = rescale_grid_features(f, cstd[m:m + 1], g.scalings, g.n_feat)[0]
+        feats[r[m], s[m]] = np.pad(f, (0, out_dim - f.shape[0]))
+    return feats.reshape(R * S, -1), dirs
+
+
+def field_fwd_actors(p: FieldParams, a: ActorParams, origins, directions, pixel_area, starts, ends, times):
+    """NeuRADField.forward with dynamic actors (fields/neurad_field.py:128-152)."""
+    R, S = np.asarray(starts).shape
+    enc, dirs = encode_with_actors(p.grid, p.static_scale, a, origins, directions, pixel_area, starts, ends, times)
+    geo = mlp_fwd(enc, p.geo_w, p.geo_b)
+    geo_out, geo_emb = geo[:, :1], geo[:, 1:]
+    sh = sh_deg4(((dirs + f32(1)) / f32(2)).reshape(-1, 3))
+    feat = geo_emb + mlp_fwd(np.concatenate([geo_emb, sh], -1), p.feat_w, p.feat_b)
+    out = {"feature": feat.reshape(R, S, -1).astype(f32), "directions": dirs, "enc": enc}
+    if p.use_sdf:
+        beta = f32(abs(p.beta) + p.beta_min)
+        out["sdf"] = geo_out.reshape(R, S)
+        out["alpha"] = sigmoid(-geo_out.reshape(R, S) * beta)
+    else:
+        out["density"] = np.exp(geo_out.reshape(R, S)).astype(f32)
+    return out
