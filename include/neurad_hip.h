@@ -190,6 +190,42 @@ int nrhip_pdf_sample(const float* weights /*[R,S_prev]*/, const float* spacing_b
                      float* new_spacing_bins /*[R,S_new+1]*/, float* new_euclid_bins /*[R,S_new+1]*/,
                      void* stream);
 
+/* ---- H5: dynamic actors (NeuRADHashEncoding._split_static_vs_actors / _get_actor_indices /
+ *      _get_actor_features_slow, field_components/neurad_encoding.py:189-295; DynamicActors.get_boxes2world,
+ *      model_components/dynamic_actors.py:251-268; interpolate_trajectories_6d, utils/poses.py:90-150).
+ *      Torch-path semantics: one 3-D hash grid per actor; when boxes overlap the highest actor index wins
+ *      (the CPU index_put order of neurad_encoding.py:184-185); eval mode (no random flip).              */
+typedef struct {
+  int32_t n_actors;              /* A */
+  int32_t n_times;               /* Tn */
+  const float* timestamps;       /* [Tn]      unique_timestamps */
+  const float* positions;        /* [Tn,A,3]  actor_positions */
+  const float* rotations_6d;     /* [Tn,A,6]  actor_rotations_6d */
+  const uint8_t* present;        /* [Tn,A]    actor_present_at_time */
+  const float* bounds;           /* [A,3]     actor_sizes/2 + actor_padding (dynamic_actors.py:106-107) */
+  nrhip_grid grid;               /* geometry shared by all actor grids (ActorSettings) */
+  const void* const* tables;     /* DEVICE array of A table pointers, indexed by actor_to_id[actor] */
+  float actor_scale;             /* actor contraction scale, 10 m (neurad_encoding.py:52,100) */
+} nrhip_actors;
+
+#define NRHIP_MAX_ACTOR_CANDIDATES 8
+/* Per ray: interpolate every actor's pose at the ray's time, cull by distance to the ray's first->last sample line,
+ * and compact the survivors: cand_count [R] int32, cand_actor [R,K] int32, cand_w2b [R,K,12] (3x4 world->box),
+ * K = NRHIP_MAX_ACTOR_CANDIDATES.  overflow (device int32, caller zeroes) is set if a ray has more than K.   */
+int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const float* times /*[R]*/,
+                        int32_t* cand_count, int32_t* cand_actor, float* cand_w2b, int32_t* overflow, void* stream);
+/* Field features: for every sample inside an actor box, OVERWRITE its feature row [out_dim] with the actor grid's
+ * rescaled features zero-padded to out_dim, and write the per-sample direction (box frame, renormalised) -- ray
+ * direction elsewhere.  hit [N] uint8 marks the overwritten samples.                                         */
+int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
+                       const int32_t* cand_actor, const float* cand_w2b, int32_t out_dim, float* features /*[N,out_dim]*/,
+                       float* directions /*[N,3]*/, uint8_t* hit /*[N]*/, void* stream);
+/* Proposal density: density = exp(decoder . padded actor features) for samples inside an actor box
+ * (fields/neurad_field.py:208-213 with the actor branch of neurad_encoding.py:170-185).                      */
+int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
+                        const int32_t* cand_actor, const float* cand_w2b, const float* decoder_weight, int32_t n_dec,
+                        float* density /*[R,S] overwritten where hit*/, uint8_t* hit, void* stream);
+
 /* ---- S5+M1 fused: ProposalNetworkSampler as driven by NeuRADModel._get_ray_samples
  *      (ray_samplers.py:623-666, models/neurad.py:443-459).  One wave marches one ray through
  *      power bins -> (density -> weights -> pdf resample) x n_rounds, entirely on chip.

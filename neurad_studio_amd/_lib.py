@@ -48,6 +48,13 @@ class SamplerCfg(C.Structure):
                 ("histogram_padding", C.c_float), ("sky_distance", C.c_float)]
 
 
+class Actors(C.Structure):
+    _fields_ = [("n_actors", C.c_int32), ("n_times", C.c_int32), ("timestamps", C.c_void_p), ("positions", C.c_void_p),
+                ("rotations_6d", C.c_void_p), ("present", C.c_void_p), ("bounds", C.c_void_p), ("grid", Grid),
+                ("tables", C.c_void_p), ("actor_scale", C.c_float)]
+
+
+MAX_ACTOR_CANDIDATES = 8
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes : exactly the prototypes of include/neurad_hip.h (tests/test_abi.py cross-checks this
@@ -77,6 +84,9 @@ PROTOTYPES = {
     "nrhip_weights_from_density_bwd": [P, P, P, I64, I32, P, P],
     "nrhip_power_sampler": [P, P, I64, I32, F32, F32, P, P, P, P],
     "nrhip_pdf_sample": [P, P, P, P, I64, I32, I32, F32, F32, F32, P, I32, P, P, P],
+    "nrhip_actor_prepare": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P],
+    "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P],
+    "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P],
     "nrhip_proposal_sampler_fwd": [C.POINTER(SamplerCfg), C.POINTER(Proposal), P, P, P, P, P, I64, C.POINTER(P),
                                    C.POINTER(P), C.POINTER(P), P],
 }

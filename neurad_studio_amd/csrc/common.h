@@ -213,6 +213,36 @@ __device__ __forceinline__ float fast_cbrt(float x) {
   return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 3.0f));
 }
 
+// H2 alone: gaussian mean (world space) and std of a sample (cameras/rays.py:109-124, M=1)
+__device__ __forceinline__ SamplePos sample_gaussian(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                     float area, float t0, float t1) {
+#pragma clang fp contract(off)
+  const float dist = (t1 - t0) / 2.f;
+  const float t = t0 + 1.f * dist;
+  SamplePos p;
+  p.x = ox + dx * t, p.y = oy + dy * t, p.z = oz + dz * t;
+  p.std = fast_cbrt((area * (t * t)) * dist);
+  return p;
+}
+
+// H3 alone: ScaledSceneContraction(order=inf) of a gaussian -> [0,1]^3 (spatial_distortions.py:103-141)
+__device__ __forceinline__ SamplePos contract_gaussian(float mx, float my, float mz, float std, float scale) {
+#pragma clang fp contract(off)
+  mx /= scale, my /= scale, mz /= scale, std /= scale;
+  const float mag = fmaxf(fabsf(mx), fmaxf(fabsf(my), fabsf(mz)));
+  if (!(mag < 1.f)) {
+    const float cm = fmaxf(mag, 1.f);
+    const float k = 2.f - (1.f / cm);
+    mx = k * (mx / cm), my = k * (my / cm), mz = k * (mz / cm);
+    const float sc = fast_cbrt(2.f * cm - 1.f) / cm;
+    std = std * (sc * sc);
+  }
+  SamplePos p;
+  p.x = (mx + 2.f) / 4.f, p.y = (my + 2.f) / 4.f, p.z = (mz + 2.f) / 4.f;
+  p.std = std / 4.f;
+  return p;
+}
+
 __device__ __forceinline__ SamplePos sample_position(float ox, float oy, float oz, float dx, float dy, float dz,
                                                      float area, float t0, float t1, float inv_scale_dummy,
                                                      float scale) {

@@ -1,9 +1,11 @@
-"""NeuRADHashEncoding: static-world hash grid with ZipNeRF-style down-weighting
-(mirror of nerfstudio/field_components/neurad_encoding.py:34-304, static path).
+"""NeuRADHashEncoding: static-world hash grid + per-actor grids with ZipNeRF-style down-weighting
+(mirror of nerfstudio/field_components/neurad_encoding.py:34-304).
 
-The contraction (H3), gaussian (H2), lookup (H1) and rescale (H4) are ONE HIP kernel (nrhip_encode_fwd) that
-consumes per-ray origin/direction and per-sample [start,end]; nothing of shape [R,S,3] is materialised.
-Dynamic actors (H5) are the next row of SURVEY §8: a non-empty ``dynamic_actors`` raises."""
+Static path: contraction (H3), gaussian (H2), lookup (H1) and rescale (H4) are ONE HIP kernel (nrhip_encode_fwd)
+consuming per-ray origin/direction and per-sample [start,end]; nothing of shape [R,S,3] is materialised.
+Actor path (H5): nrhip_actor_prepare (pose interpolation + line cull per ray) then nrhip_actor_encode (in-box test,
+actor-grid lookup, overwrite) -- torch-path semantics (one 3-D grid per actor, use_4d_hashgrid=False); forward only:
+actor grids and trajectories receive no gradient yet (next row), the static table does (overwritten rows get none)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -12,7 +14,9 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from .. import _lib
 from .. import autograd as ag
+from .. import ops
 from .encodings import HashEncoding
 
 
@@ -48,21 +52,44 @@ class NeuRADHashEncodingConfig:  # neurad_encoding.py:69-82
         return NeuRADHashEncoding(self, **kwargs)
 
 
+class _MaskRowsFn(torch.autograd.Function):
+    """identity forward on the (already overwritten) feature rows; backward zeroes the gradient of the rows that
+    were replaced by actor features, i.e. the autograd of ``features[ray_idx, sample_idx] = ...`` w.r.t. the
+    static features (neurad_encoding.py:184-185)."""
+
+    @staticmethod
+    def forward(ctx, feats, hit):
+        ctx.save_for_backward(hit)
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        (hit,) = ctx.saved_tensors
+        return g.masked_fill(hit[:, None], 0.0), None
+
+
 class NeuRADHashEncoding(nn.Module):
     def __init__(self, config: NeuRADHashEncodingConfig, dynamic_actors=None, static_scale: float = 1.0,
                  implementation: str = "hip") -> None:
         super().__init__()
-        self.config, self.implementation, self.actors = config, implementation, dynamic_actors
-        n_actors = 0 if dynamic_actors is None else int(getattr(dynamic_actors, "n_actors", 0))
-        if n_actors > 0 and not config.disable_actors:
-            raise NotImplementedError("dynamic actors (SURVEY §8a-H5) are not part of this round's HIP path")
+        self.config, self.implementation = config, implementation
+        self.actors = dynamic_actors
         self.static_scale = float(static_scale)
-        s = config.static
+        s, a = config.static, config.actor
         self.static_grid = HashEncoding(num_levels=s.num_levels, min_res=s.base_res, max_res=s.max_res,
                                         log2_hashmap_size=s.log2_hashmap_size, features_per_level=s.hashgrid_dim,
                                         implementation=implementation)
-        self.actor_grids = nn.ModuleList([])
+        n_actors = 0 if dynamic_actors is None else int(getattr(dynamic_actors, "n_actors", 0))
+        if n_actors and a.use_4d_hashgrid:
+            raise NotImplementedError("use_4d_hashgrid=True exists only in tiny-cuda-nn; the torch path (and this one) "
+                                      "uses one 3-D grid per actor (neurad_encoding.py:110-131)")
+        self.actor_grids = nn.ModuleList([
+            HashEncoding(num_levels=a.num_levels, min_res=a.base_res, max_res=a.max_res,
+                         log2_hashmap_size=a.log2_hashmap_size, features_per_level=a.hashgrid_dim,
+                         implementation=implementation) for _ in range(n_actors)])
         self.scene_repr_dim = self.static_grid.get_out_dim()
+        if n_actors and a.num_levels * a.hashgrid_dim > self.scene_repr_dim:
+            raise ValueError("actor feature dim exceeds the static feature dim (F.pad would be negative)")
 
     def get_out_dim(self) -> int:
         return self.scene_repr_dim
@@ -70,15 +97,55 @@ class NeuRADHashEncoding(nn.Module):
     def get_param_groups(self, param_groups: Dict):
         param_groups["hashgrids"] += list(self.static_grid.parameters()) + list(self.actor_grids.parameters())
 
-    def forward_rays(self, origins, directions, pixel_area, starts, ends) -> Tensor:
-        """-> [R*S, L*F] rescaled static features (autograd: table gradient via scatter-add atomics)."""
+    def has_actors(self) -> bool:
+        return (not self.config.disable_actors) and self.actors is not None and int(self.actors.n_actors) > 0
+
+    def actor_spec(self) -> ops.ActorSpec:
+        act = self.actors
+        ids = act.actor_to_id.tolist()
+        g0 = self.actor_grids[0]
+        return ops.ActorSpec(act.unique_timestamps.float(), act.actor_positions.detach(),
+                             act.actor_rotations_6d.detach(), act.actor_present_at_time, act.actor_bounds(), g0.spec,
+                             [self.actor_grids[i].hash_table.detach() for i in ids], self.config.actor.actor_scale)
+
+    def prepare_actors(self, origins, directions, pixel_area, starts, ends, times):
+        """per-ray candidate lists (shared by every field evaluated on the same ray bundle)."""
+        spec = self.actor_spec()
+        cand = ops.actor_prepare(spec, origins, directions, pixel_area, starts, ends, times)
+        if int(cand[3].item()):
+            raise _lib.NeuradHipError(f"a ray passes more than {_lib.MAX_ACTOR_CANDIDATES} actors' bounding spheres")
+        return spec, cand
+
+    def forward_rays(self, origins, directions, pixel_area, starts, ends, times: Optional[Tensor] = None):
+        """-> (features [R*S, L*F], per-sample directions [R*S,3] or None when there are no actors)."""
         g = self.static_grid
-        return ag.EncodeFn.apply(g.hash_table, g.spec, self.static_scale, origins, directions, pixel_area, starts, ends)
+        feats = ag.EncodeFn.apply(g.hash_table, g.spec, self.static_scale, origins, directions, pixel_area, starts, ends)
+        if not self.has_actors():
+            return feats, None
+        if self.training and self.config.actor.flip_prob > 1e-7:
+            raise NotImplementedError("random actor flip (training, neurad_encoding.py:212-219) is not implemented; "
+                                      "set actor.flip_prob=0 or run in eval mode")
+        if times is None:
+            raise ValueError("dynamic actors need ray times")
+        with torch.no_grad():
+            spec, cand = self.prepare_actors(origins, directions, pixel_area, starts, ends, times)
+            merged = feats.detach().clone()
+            dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, merged)
+        if feats.requires_grad:
+            # value = merged rows; gradient flows to the static features of the non-overwritten rows only
+            feats = _MaskRowsFn.apply(feats + (merged - feats.detach()), hit)
+        else:
+            feats = merged
+        return feats, dirs
 
     def forward(self, ray_samples, times=None, directions: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """Reference signature is forward(GaussiansStd, times, directions); here the frustums are passed directly
         (the gaussian is computed inside the kernel).  Returns (features [N, L*F], directions)."""
         fr = ray_samples.frustums
         o, d, a = fr.per_ray()
-        feats = self.forward_rays(o, d, a, fr.starts[..., 0], fr.ends[..., 0])
+        t = times if times is not None else ray_samples.times
+        t = None if t is None else (t[:, 0] if t.dim() == 3 else t).reshape(-1)
+        feats, dirs = self.forward_rays(o, d, a, fr.starts[..., 0], fr.ends[..., 0], t)
+        if dirs is not None:
+            return feats, dirs.view(*fr.starts.shape[:-1], 3)
         return feats, directions

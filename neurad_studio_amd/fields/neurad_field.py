@@ -104,6 +104,8 @@ class NeuRADField(nn.Module):
     # ---- fused path -----------------------------------------------------------------------------
     def fused_supported(self) -> bool:
         c, g = self.config, self.hashgrid.static_grid
+        if self.hashgrid.has_actors():
+            return False  # the fused kernels cover the static scene; actor scenes take the operator-level path
         return (g.get_out_dim() == 32 and g.num_levels % 4 == 0 and c.geo_num_layers == 2 and c.nff_num_layers == 3
                 and c.geo_hidden_dim == c.nff_hidden_dim and c.geo_hidden_dim in (32, 64) and c.nff_out_dim == 32)
 
@@ -137,11 +139,15 @@ class NeuRADField(nn.Module):
             else:
                 out[FieldHeadNames.DENSITY] = head[..., None]
             return out
-        features = self.hashgrid.forward_rays(o, d, a, starts, ends)
+        times = None if ray_samples.times is None else ray_samples.times[:, 0].reshape(-1)
+        features, sample_dirs = self.hashgrid.forward_rays(o, d, a, starts, ends, times)
         geo = self.mlp_geo(features)
         geo_out, geo_embedding = geo[:, :1], geo[:, 1:]
-        sh = self.direction_encoding(get_normalized_directions(d))  # per ray; broadcast over the samples
-        sh = sh[:, None, :].expand(R, S, 16).reshape(-1, 16)
+        if sample_dirs is None:
+            sh = self.direction_encoding(get_normalized_directions(d))  # per ray; broadcast over the samples
+            sh = sh[:, None, :].expand(R, S, 16).reshape(-1, 16)
+        else:  # samples inside actors carry box-frame directions (neurad_encoding.py:203-208)
+            sh = self.direction_encoding(get_normalized_directions(sample_dirs))
         feature = geo_embedding + self.mlp_feature(torch.cat([geo_embedding, sh], dim=-1))
         out = {FieldHeadNames.FEATURE: feature.view(R, S, self.config.nff_out_dim)}
         geo_out = geo_out.reshape(R, S, 1)
@@ -188,8 +194,17 @@ class NeuRADProposalField(nn.Module):
         fr = ray_samples.frustums
         o, d, a = fr.per_ray()
         g = self.hashgrid.static_grid
+        starts, ends = fr.starts[..., 0], fr.ends[..., 0]
         dens = ag.ProposalDensityFn.apply(g.hash_table, self.density_decoder.weight, g.spec, self.hashgrid.static_scale,
-                                          o, d, a, fr.starts[..., 0], fr.ends[..., 0])
+                                          o, d, a, starts, ends)
+        if self.hashgrid.has_actors():  # actor branch runs without gradient (require_actor_grad=False, :177)
+            if ray_samples.times is None:
+                raise ValueError("dynamic actors need ray times")
+            with torch.no_grad():
+                spec, cand = self.hashgrid.prepare_actors(o, d, a, starts, ends, ray_samples.times[:, 0].reshape(-1))
+                merged = dens.detach().clone()
+                hit = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged)
+            dens = torch.where(hit, merged, dens)
         return dens[..., None], None
 
     def get_outputs(self, ray_samples, density_embedding=None) -> dict:

@@ -1,0 +1,78 @@
+"""DynamicActors: actor trajectories as parameters/buffers with the reference's names
+(mirror of nerfstudio/model_components/dynamic_actors.py:44-300, the part the hot path reads).
+
+Pose interpolation, box tests and actor-grid lookups run in the HIP kernels (csrc/actors.hip); this module only
+owns the state (so checkpoints and the trajectory optimiser's parameter group keep working)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import torch
+from torch import Tensor, nn
+
+
+@dataclass
+class DynamicActorsConfig:  # dynamic_actors.py:31-41
+    optimize_trajectories: bool = True
+    actor_bbox_padding: Tuple[float, float, float] = (0.25, 0.25, 0.1)
+
+    def setup(self, **kwargs):
+        return DynamicActors(self, **kwargs)
+
+
+def matrix_to_rotation_6d(matrix: Tensor) -> Tensor:  # cameras/camera_utils.py:446-464
+    return matrix[..., :2, :].clone().reshape(*matrix.shape[:-2], 6)
+
+
+class DynamicActors(nn.Module):
+    def __init__(self, config: DynamicActorsConfig, trajectories: List[dict]):
+        super().__init__()
+        self.config = config
+        self._populate_actors(trajectories)
+        self.requires_grad_(config.optimize_trajectories)
+
+    def actor_bounds(self) -> Tensor:
+        return self.actor_sizes / 2 + self.actor_padding
+
+    def _populate_actors(self, trajectories: List[dict]) -> None:  # dynamic_actors.py:109-170
+        uniq = torch.tensor(sorted({t.item() for traj in trajectories for t in traj["timestamps"]}), dtype=torch.float32)
+        self.n_actors, self.n_times = len(trajectories), len(uniq)
+        poses = torch.eye(4, dtype=torch.float32).view(1, 1, 4, 4).repeat(self.n_times, self.n_actors, 1, 1)
+        present = torch.zeros((self.n_times, self.n_actors), dtype=torch.bool)
+        sizes = torch.zeros((self.n_actors, 3), dtype=torch.float32)
+        symmetric = torch.zeros((self.n_actors,), dtype=torch.bool)
+        deformable = torch.zeros((self.n_actors,), dtype=torch.bool)
+        for ai, traj in enumerate(trajectories):
+            sizes[ai] = traj["dims"]
+            symmetric[ai] = traj["symmetric"]
+            deformable[ai] = traj["deformable"]
+            for ti, t in enumerate(uniq):
+                diff = (traj["timestamps"] - t).abs()
+                k = diff.argmin(dim=0)
+                if diff[k] < 1e-4:
+                    present[ti, ai] = True
+                poses[ti, ai] = traj["poses"][k]  # absent timestamps duplicate the closest pose (:143-149)
+        self.register_buffer("unique_timestamps", uniq)
+        self.register_buffer("actor_poses_at_time", poses)
+        self.register_buffer("actor_present_at_time", present)
+        self.register_buffer("actor_sizes", sizes)
+        self.register_buffer("actor_symmetric", symmetric)
+        self.register_buffer("actor_deformable", deformable)
+        self.register_buffer("actor_padding", torch.tensor(self.config.actor_bbox_padding))
+        self.register_buffer("actor_to_id", torch.arange(self.n_actors, dtype=torch.int64))
+        self.actor_positions = nn.Parameter(poses[..., :3, 3].clone())
+        self.actor_rotations_6d = nn.Parameter(matrix_to_rotation_6d(poses[..., :3, :3]))
+        self.register_buffer("initial_positions", self.actor_positions.detach().clone())
+        self.register_buffer("initial_rotations_6d", self.actor_rotations_6d.detach().clone())
+        self.actor_vel_linear = nn.Parameter(torch.zeros((self.n_times, self.n_actors, 3)))
+        self.actor_vel_angular = nn.Parameter(torch.zeros((self.n_times, self.n_actors, 3)))
+
+    def requires_grad_(self, requires: bool = True):
+        self.actor_positions.requires_grad_(requires)
+        self.actor_rotations_6d.requires_grad_(requires)
+        return self
+
+    def get_param_groups(self, param_groups: Dict):
+        if self.config.optimize_trajectories:
+            param_groups["trajectory_opt"] = param_groups.get("trajectory_opt", []) + list(self.parameters())

@@ -113,7 +113,7 @@ class NeuRADHotPath(nn.Module):
 
     def _get_ray_samples(self, ray_bundle: RayBundle):
         sky = self._prepare_bundle(ray_bundle)
-        if torch.is_grad_enabled() or self.training:
+        if torch.is_grad_enabled() or self.training or self.field.hashgrid.has_actors():
             ray_samples, prop_weights, prop_ray_samples = self.sampler(ray_bundle, self.density_fns, pass_ray_samples=True)
             # bins come out of the kernels as views of one [R,S+1] edge tensor: materialise before the in-place stretch
             fr = ray_samples.frustums

@@ -447,6 +447,80 @@ def proposal_sampler_fwd(props: Sequence[ProposalSpec], origins, directions, pix
     return ws, sps, eus
 
 
+@dataclass
+class ActorSpec:
+    """Device-side view of DynamicActors + the per-actor grids."""
+
+    timestamps: Tensor      # [Tn] fp32
+    positions: Tensor       # [Tn,A,3]
+    rotations_6d: Tensor    # [Tn,A,6]
+    present: Tensor         # [Tn,A] bool
+    bounds: Tensor          # [A,3]
+    grid: GridSpec
+    tables: List[Tensor]    # A tables [L*T, F] fp32, already ordered by actor_to_id
+    actor_scale: float = 10.0
+
+    def c_actors(self):
+        keep = [_chk(self.timestamps, "timestamps"), _chk(self.positions, "positions"),
+                _chk(self.rotations_6d, "rotations_6d"), self.present.to(torch.uint8).contiguous(),
+                _chk(self.bounds, "bounds")]
+        tabs = [_chk(t, "actor table") for t in self.tables]
+        ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=keep[0].device)
+        a = _lib.Actors()
+        a.n_times, a.n_actors = self.positions.shape[0], self.positions.shape[1]
+        a.timestamps, a.positions, a.rotations_6d = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+        a.present, a.bounds = keep[3].data_ptr(), keep[4].data_ptr()
+        a.grid = self.grid.c_grid(tabs[0])
+        a.tables = ptrs.data_ptr()
+        a.actor_scale = float(self.actor_scale)
+        return a, (keep, tabs, ptrs)
+
+
+def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times):
+    """-> (cand_count [R] i32, cand_actor [R,K] i32, cand_w2b [R,K,12]); raises if a ray has more than K candidates."""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    a, keep2 = spec.c_actors()
+    R, K, dev = r.n_rays, _lib.MAX_ACTOR_CANDIDATES, origins.device
+    t = _chk(times.reshape(-1), "times")
+    cnt = torch.zeros((R,), dtype=torch.int32, device=dev)
+    act = torch.zeros((R, K), dtype=torch.int32, device=dev)
+    w2b = torch.zeros((R, K, 12), dtype=torch.float32, device=dev)
+    ovf = torch.zeros((1,), dtype=torch.int32, device=dev)
+    call("nrhip_actor_prepare", C.byref(a), C.byref(r), _ptr(t), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(ovf), _stream())
+    return cnt, act, w2b, ovf
+
+
+def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, features: Tensor):
+    """Overwrites the rows of ``features`` [N,out_dim] whose sample lies inside an actor box (in place).
+    -> (directions [N,3], hit [N] bool)"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    a, keep2 = spec.c_actors()
+    cnt, act, w2b, _ = cand
+    n = r.n_rays * r.n_samples
+    feats = _chk(features, "features")
+    assert feats.data_ptr() == features.data_ptr(), "features must be contiguous (updated in place)"
+    dirs = torch.empty((n, 3), dtype=torch.float32, device=feats.device)
+    hit = torch.empty((n,), dtype=torch.uint8, device=feats.device)
+    call("nrhip_actor_encode", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), feats.shape[1], _ptr(feats),
+         _ptr(dirs), _ptr(hit), _stream())
+    return dirs, hit.bool()
+
+
+def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, decoder_weight: Tensor,
+                  density: Tensor):
+    """Overwrites density [R,S] (in place) where the sample lies inside an actor box.  -> hit [R,S] bool"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    a, keep2 = spec.c_actors()
+    cnt, act, w2b, _ = cand
+    dw = _chk(decoder_weight.reshape(-1), "decoder_weight")
+    dens = _chk(density, "density")
+    assert dens.data_ptr() == density.data_ptr(), "density must be contiguous (updated in place)"
+    hit = torch.empty((r.n_rays, r.n_samples), dtype=torch.uint8, device=dens.device)
+    call("nrhip_actor_density", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(dw), dw.numel(),
+         _ptr(dens), _ptr(hit), _stream())
+    return hit.bool()
+
+
 def device_info():
     cus, xcds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
     call("nrhip_device_info", C.byref(cus), C.byref(xcds), C.byref(hbm))
