@@ -219,12 +219,15 @@ int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const flo
  * direction elsewhere.  hit [N] uint8 marks the overwritten samples.                                         */
 int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                        const int32_t* cand_actor, const float* cand_w2b, int32_t out_dim, float* features /*[N,out_dim]*/,
-                       float* directions /*[N,3]*/, uint8_t* hit /*[N]*/, void* stream);
+                       float* directions /*[N,3]*/, uint8_t* hit /*[N]*/,
+                       const float* ray_flip /*[R] +-1 (training x-flip, neurad_encoding.py:212-219) or NULL*/,
+                       void* stream);
 /* Proposal density: density = exp(decoder . padded actor features) for samples inside an actor box
  * (fields/neurad_field.py:208-213 with the actor branch of neurad_encoding.py:170-185).                      */
 int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                         const int32_t* cand_actor, const float* cand_w2b, const float* decoder_weight, int32_t n_dec,
-                        float* density /*[R,S] overwritten where hit*/, uint8_t* hit, void* stream);
+                        float* density /*[R,S] overwritten where hit*/, uint8_t* hit, const float* ray_flip,
+                        void* stream);
 
 /* ---- S5+M1 fused: ProposalNetworkSampler as driven by NeuRADModel._get_ray_samples
  *      (ray_samplers.py:623-666, models/neurad.py:443-459).  One wave marches one ray through

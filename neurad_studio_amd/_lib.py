@@ -85,8 +85,8 @@ PROTOTYPES = {
     "nrhip_power_sampler": [P, P, I64, I32, F32, F32, P, P, P, P],
     "nrhip_pdf_sample": [P, P, P, P, I64, I32, I32, F32, F32, F32, P, I32, P, P, P],
     "nrhip_actor_prepare": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P],
-    "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P],
-    "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P],
+    "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P, P],
+    "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],
     "nrhip_proposal_sampler_fwd": [C.POINTER(SamplerCfg), C.POINTER(Proposal), P, P, P, P, P, I64, C.POINTER(P),
                                    C.POINTER(P), C.POINTER(P), P],
 }

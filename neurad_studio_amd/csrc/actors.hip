@@ -16,6 +16,7 @@ struct ActorsDev {
   GridDev grid;
   const void* const* tables;
   float scale;
+  const float* flip;  // [R] +-1 per ray (training-mode x flip, neurad_encoding.py:212-219) or NULL
 };
 
 constexpr int K = NRHIP_MAX_ACTOR_CANDIDATES;
@@ -144,6 +145,10 @@ __device__ __forceinline__ ActorHit find_hit(const ActorsDev& a, const RaysDev& 
     float ddz = wsel[8] * h.dx + wsel[9] * h.dy + wsel[10] * h.dz;
     const float nn = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) + 1e-7f;  // neurad_encoding.py:207
     h.dx = ddx / nn, h.dy = ddy / nn, h.dz = ddz / nn;
+    if (a.flip) {
+      const float f = a.flip[ray];
+      h.px *= f, h.dx *= f;
+    }
   }
   return h;
 }
@@ -208,6 +213,7 @@ static int to_dev(const nrhip_actors* a, ActorsDev& d) {
   d.grid = to_dev(a->grid);
   d.tables = a->tables;
   d.scale = a->actor_scale;
+  d.flip = nullptr;
   return NRHIP_OK;
 }
 
@@ -232,9 +238,10 @@ extern "C" int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays
 
 extern "C" int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                                   const int32_t* cand_actor, const float* cand_w2b, int32_t out_dim, float* features,
-                                  float* directions, uint8_t* hit, void* stream) {
+                                  float* directions, uint8_t* hit, const float* ray_flip, void* stream) {
   ActorsDev d;
   if (int e = to_dev(a, d)) return e;
+  d.flip = ray_flip;
   if (int e = validate_grid(&a->grid)) return e;
   if (int e = validate_rays(rays)) return e;
   const int64_t n = rays->n_rays * rays->n_samples;
@@ -258,9 +265,10 @@ extern "C" int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays,
 
 extern "C" int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                                    const int32_t* cand_actor, const float* cand_w2b, const float* decoder_weight,
-                                   int32_t n_dec, float* density, uint8_t* hit, void* stream) {
+                                   int32_t n_dec, float* density, uint8_t* hit, const float* ray_flip, void* stream) {
   ActorsDev d;
   if (int e = to_dev(a, d)) return e;
+  d.flip = ray_flip;
   if (int e = validate_grid(&a->grid)) return e;
   if (int e = validate_rays(rays)) return e;
   const int64_t n = rays->n_rays * rays->n_samples;

@@ -116,21 +116,26 @@ class NeuRADHashEncoding(nn.Module):
             raise _lib.NeuradHipError(f"a ray passes more than {_lib.MAX_ACTOR_CANDIDATES} actors' bounding spheres")
         return spec, cand
 
+    def sample_ray_flip(self, origins) -> Optional[Tensor]:
+        """-1 with prob flip_prob else +1, per ray, training only (neurad_encoding.py:212-215)."""
+        p = self.config.actor.flip_prob
+        if not (self.training and p > 1e-7):
+            return None
+        return torch.bernoulli(torch.full((origins.shape[0],), p, device=origins.device)) * -2 + 1
+
     def forward_rays(self, origins, directions, pixel_area, starts, ends, times: Optional[Tensor] = None):
         """-> (features [R*S, L*F], per-sample directions [R*S,3] or None when there are no actors)."""
         g = self.static_grid
         feats = ag.EncodeFn.apply(g.hash_table, g.spec, self.static_scale, origins, directions, pixel_area, starts, ends)
         if not self.has_actors():
             return feats, None
-        if self.training and self.config.actor.flip_prob > 1e-7:
-            raise NotImplementedError("random actor flip (training, neurad_encoding.py:212-219) is not implemented; "
-                                      "set actor.flip_prob=0 or run in eval mode")
         if times is None:
             raise ValueError("dynamic actors need ray times")
         with torch.no_grad():
             spec, cand = self.prepare_actors(origins, directions, pixel_area, starts, ends, times)
             merged = feats.detach().clone()
-            dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, merged)
+            dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, merged,
+                                         self.sample_ray_flip(origins))
         if feats.requires_grad:
             # value = merged rows; gradient flows to the static features of the non-overwritten rows only
             feats = _MaskRowsFn.apply(feats + (merged - feats.detach()), hit)

@@ -203,7 +203,8 @@ class NeuRADProposalField(nn.Module):
             with torch.no_grad():
                 spec, cand = self.hashgrid.prepare_actors(o, d, a, starts, ends, ray_samples.times[:, 0].reshape(-1))
                 merged = dens.detach().clone()
-                hit = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged)
+                hit = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged,
+                                        self.hashgrid.sample_ray_flip(o))
             dens = torch.where(hit, merged, dens)
         return dens[..., None], None
 

@@ -490,7 +490,8 @@ def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends
     return cnt, act, w2b, ovf
 
 
-def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, features: Tensor):
+def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, features: Tensor,
+                 ray_flip: Optional[Tensor] = None):
     """Overwrites the rows of ``features`` [N,out_dim] whose sample lies inside an actor box (in place).
     -> (directions [N,3], hit [N] bool)"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
@@ -502,12 +503,12 @@ def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts,
     dirs = torch.empty((n, 3), dtype=torch.float32, device=feats.device)
     hit = torch.empty((n,), dtype=torch.uint8, device=feats.device)
     call("nrhip_actor_encode", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), feats.shape[1], _ptr(feats),
-         _ptr(dirs), _ptr(hit), _stream())
+         _ptr(dirs), _ptr(hit), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), _stream())
     return dirs, hit.bool()
 
 
 def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, decoder_weight: Tensor,
-                  density: Tensor):
+                  density: Tensor, ray_flip: Optional[Tensor] = None):
     """Overwrites density [R,S] (in place) where the sample lies inside an actor box.  -> hit [R,S] bool"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
@@ -517,7 +518,7 @@ def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts
     assert dens.data_ptr() == density.data_ptr(), "density must be contiguous (updated in place)"
     hit = torch.empty((r.n_rays, r.n_samples), dtype=torch.uint8, device=dens.device)
     call("nrhip_actor_density", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(dw), dw.numel(),
-         _ptr(dens), _ptr(hit), _stream())
+         _ptr(dens), _ptr(hit), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), _stream())
     return hit.bool()
 
 

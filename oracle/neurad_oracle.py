@@ -614,7 +614,7 @@ def actor_hits(a: ActorParams, mean_pos, b2w, valid, w2b):
 
 
 def encode_with_actors(grid: GridParams, static_scale, a: ActorParams, origins, directions, pixel_area, starts, ends,
-                       times):
+                       times, ray_flip=None):
     """NeuRADHashEncoding.forward (neurad_encoding.py:150-187), eval mode (no flip), per-actor 3-D grids.
     -> features [R*S, L*F], directions [R,S,3] (box frame + renormalised where a sample is inside an actor)."""
     R, S = np.asarray(starts).shape
@@ -632,6 +632,10 @@ def encode_with_actors(grid: GridParams, static_scale, a: ActorParams, origins, 
     pos = (tr[:, :3, :3] @ mean[r, s][:, :, None])[:, :, 0] + tr[:, :3, 3]
     dd = (tr[:, :3, :3] @ dirs[r, s][:, :, None])[:, :, 0]
     dd = dd / (np.linalg.norm(dd, axis=-1, keepdims=True).astype(f32) + f32(1e-7))
+    if ray_flip is not None:  # training-mode per-ray x flip, injected (+-1 per ray), neurad_encoding.py:212-219
+        fl = np.asarray(ray_flip, f32)[r]
+        pos[:, 0] *= fl
+        dd[:, 0] *= fl
     dirs[r, s] = dd  # last write wins (CPU index_put order), as for the features below
     cpos, cstd = contract_gaussian(pos.astype(f32), std[r, s], a.actor_scale)
     out_dim = feats.shape[-1]

@@ -106,6 +106,26 @@ def test_field_with_actors_vs_reference_golden():
     assert fld.hashgrid.static_grid.hash_table.grad.abs().sum() > 0
 
 
+def test_actor_training_flip_injected():
+    """training-mode per-ray x flip (neurad_encoding.py:212-219) with injected +-1 per ray, vs the oracle"""
+    from neurad_studio_amd import ops
+
+    g = load_golden("field_actors")
+    fld = make_field()
+    R, S = g["starts"].shape
+    o, d, a = dev(g["o"]), dev(g["d"]), dev(g["area"])
+    spec, cand = fld.hashgrid.prepare_actors(o, d, a, dev(g["starts"]), dev(g["ends"]), dev(g["times"]))
+    flip = np.where(np.arange(R) % 3 == 0, -1.0, 1.0).astype(np.float32)
+    grid = O.GridParams(synth.hash_table(8 * 2**11, 4, seed=51, scale=0.5), 8, 32, 8192, 11)
+    ref, rdirs = O.encode_with_actors(grid, 100.0, actor_params(g), g["o"], g["d"], g["area"], g["starts"], g["ends"],
+                                      g["times"], ray_flip=flip)
+    feats = ops.encode_fwd(fld.hashgrid.static_grid.spec, fld.hashgrid.static_grid.hash_table.detach(), 100.0, o, d, a,
+                           dev(g["starts"]), dev(g["ends"]))
+    dirs, hit = ops.actor_encode(spec, cand, o, d, a, dev(g["starts"]), dev(g["ends"]), feats, dev(flip))
+    assert rel_l2(host(feats), ref) < TOL
+    assert rel_l2(host(dirs).reshape(R, S, 3), rdirs) < 1e-6
+
+
 def test_proposal_density_with_actors_vs_oracle():
     from neurad_studio_amd.cameras.rays import RayBundle
     from neurad_studio_amd.fields.neurad_field import NeuRADProposalField, NeuRADProposalFieldConfig
