@@ -229,6 +229,27 @@ int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int
                         float* density /*[R,S] overwritten where hit*/, uint8_t* hit, const float* ray_flip,
                         void* stream);
 
+/* ---- S6: occupancy-grid ray march (VolumetricSampler.forward -> nerfacc OccGridEstimator.sampling,
+ *      model_components/ray_samplers.py:483-566).  nerfacc is un-vendored and nothing in neurad-studio instantiates
+ *      VolumetricSampler: the marching rule is this library's own statement (csrc/occgrid.hip header), parity
+ *      unpinned.  Two passes: offsets == NULL -> per-ray counts; then, with the exclusive prefix sum of the counts as
+ *      offsets, the packed (ray_indices, t_starts, t_ends) are written.                                        */
+typedef struct {
+  float aabb[6];            /* min xyz, max xyz */
+  int32_t resolution;       /* res^3 cells, one level; cell index = (ix*res + iy)*res + iz */
+  const uint8_t* binaries;  /* [res,res,res] occupancy */
+} nrhip_occgrid;
+int nrhip_occgrid_march(const nrhip_occgrid* grid, const float* origins, const float* directions,
+                        const float* t_min /*[R] or NULL*/, const float* t_max /*[R] or NULL*/,
+                        const float* t_rand /*[R] stratified offset in [0,1) or NULL*/, int64_t r,
+                        float render_step_size, float near_plane, float far_plane, float cone_angle,
+                        int32_t max_candidates, int32_t* counts /*[R], counting pass*/,
+                        const int64_t* offsets /*[R], write pass*/, int64_t* ray_indices, float* t_starts,
+                        float* t_ends, void* stream);
+/* nerfacc render_visibility_from_alpha, packed: segments [R+1] delimit each ray's samples */
+int nrhip_packed_visibility_from_alpha(const float* alphas, const int64_t* segments, int64_t r, float early_stop_eps,
+                                       float alpha_thre, uint8_t* mask, void* stream);
+
 /* ---- S5+M1 fused: ProposalNetworkSampler as driven by NeuRADModel._get_ray_samples
  *      (ray_samplers.py:623-666, models/neurad.py:443-459).  One wave marches one ray through
  *      power bins -> (density -> weights -> pdf resample) x n_rounds, entirely on chip.

@@ -54,6 +54,10 @@ class Actors(C.Structure):
                 ("tables", C.c_void_p), ("actor_scale", C.c_float)]
 
 
+class OccGrid(C.Structure):
+    _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
+
+
 MAX_ACTOR_CANDIDATES = 8
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -87,6 +91,8 @@ PROTOTYPES = {
     "nrhip_actor_prepare": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P],
     "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P, P],
     "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],
+    "nrhip_occgrid_march": [C.POINTER(OccGrid), P, P, P, P, P, I64, F32, F32, F32, F32, I32, P, P, P, P, P, P],
+    "nrhip_packed_visibility_from_alpha": [P, P, I64, F32, F32, P, P],
     "nrhip_proposal_sampler_fwd": [C.POINTER(SamplerCfg), C.POINTER(Proposal), P, P, P, P, P, I64, C.POINTER(P),
                                    C.POINTER(P), C.POINTER(P), P],
 }

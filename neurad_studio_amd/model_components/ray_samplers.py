@@ -181,3 +181,57 @@ class ProposalNetworkSampler(Sampler):
                           fars.clamp_max(sky_distance), lam, scaling)
         rs_list = [_edges_to_samples(ray_bundle, sps[i], eus[i], fn) for i in range(len(ns))]
         return rs_list[-1], [w[..., None] for w in ws], rs_list[:-1]
+
+
+class VolumetricSampler(Sampler):
+    """ray_samplers.py:401-566: occupancy-grid march producing PACKED samples (ray_indices + [M] starts/ends).
+    ``occupancy_grid`` is anything with nerfacc's ``OccGridEstimator.sampling`` signature
+    (neurad_studio_amd.shims.nerfacc.OccGridEstimator runs the wavefront-compaction HIP kernel)."""
+
+    def __init__(self, occupancy_grid, density_fn: Optional[Callable] = None, alpha_fn: Optional[Callable] = None):
+        super().__init__()
+        assert occupancy_grid is not None
+        assert not (alpha_fn is not None and density_fn is not None), "density_fn and alpha_fn cannot be both set"
+        self.occupancy_grid, self.density_fn, self.alpha_fn = occupancy_grid, density_fn, alpha_fn
+
+    def _wrap(self, fn, origins, directions, times):
+        if fn is None or not self.training:
+            return None
+
+        def wrapped(t_starts, t_ends, ray_indices):
+            positions = origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
+            out = fn(positions) if times is None else fn(positions, times[ray_indices])
+            return out.squeeze(-1)
+
+        return wrapped
+
+    def generate_ray_samples(self):
+        raise RuntimeError("The VolumetricSampler fuses sample generation and density check together. "
+                           "Please call forward() directly.")
+
+    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,
+                far_plane: Optional[float] = None, alpha_thre: float = 0.01, cone_angle: float = 0.0):
+        from ..cameras.rays import Frustums
+
+        rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        t_min = t_max = None
+        if ray_bundle.nears is not None and ray_bundle.fars is not None:
+            t_min, t_max = ray_bundle.nears.contiguous().reshape(-1), ray_bundle.fars.contiguous().reshape(-1)
+        ray_indices, starts, ends = self.occupancy_grid.sampling(
+            rays_o=rays_o, rays_d=rays_d, t_min=t_min, t_max=t_max,
+            sigma_fn=self._wrap(self.density_fn, rays_o, rays_d, ray_bundle.times),
+            alpha_fn=self._wrap(self.alpha_fn, rays_o, rays_d, ray_bundle.times), render_step_size=render_step_size,
+            near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane, stratified=self.training,
+            cone_angle=cone_angle, alpha_thre=alpha_thre)
+        if starts.shape[0] == 0:  # single fake sample (ray_samplers.py:541-547)
+            ray_indices = torch.zeros((1,), dtype=torch.long, device=rays_o.device)
+            starts = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+            ends = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+        ray_samples = RaySamples(frustums=Frustums(origins=rays_o[ray_indices], directions=rays_d[ray_indices],
+                                                   starts=starts[..., None], ends=ends[..., None],
+                                                   pixel_area=ray_bundle.pixel_area[ray_indices]),
+                                 camera_indices=None if ray_bundle.camera_indices is None
+                                 else ray_bundle.camera_indices[ray_indices])
+        if ray_bundle.times is not None:
+            ray_samples.times = ray_bundle.times[ray_indices]
+        return ray_samples, ray_indices

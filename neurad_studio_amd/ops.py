@@ -522,6 +522,57 @@ def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts
     return hit.bool()
 
 
+@dataclass
+class OccGridSpec:
+    aabb: Tensor       # [6] min xyz, max xyz (any device; read on the host)
+    binaries: Tensor   # [res,res,res] bool / uint8 on the GPU
+
+    def c_grid(self):
+        b = self.binaries
+        if not b.is_cuda or b.dim() != 3 or b.shape[0] != b.shape[1] or b.shape[1] != b.shape[2]:
+            raise ValueError("binaries must be a cubic [res,res,res] GPU tensor")
+        b8 = b.to(torch.uint8).contiguous()
+        g = _lib.OccGrid()
+        for i, v in enumerate(self.aabb.reshape(-1).tolist()):
+            g.aabb[i] = v
+        g.resolution, g.binaries = b.shape[0], b8.data_ptr()
+        return g, b8
+
+
+def occgrid_march(grid: OccGridSpec, origins, directions, render_step_size, near_plane=0.0, far_plane=1e10,
+                  t_min=None, t_max=None, cone_angle=0.0, t_rand=None, max_candidates=1 << 16):
+    """Two-pass packed march: count -> exclusive prefix sum (one host sync for the allocation, like nerfacc) -> write.
+    -> (ray_indices int64 [M], t_starts [M], t_ends [M], segments int64 [R+1])"""
+    o, d = _chk(origins, "origins"), _chk(directions, "directions")
+    R, dev = o.shape[0], o.device
+    g, keep = grid.c_grid()
+    tmn = None if t_min is None else _chk(t_min.reshape(-1), "t_min")
+    tmx = None if t_max is None else _chk(t_max.reshape(-1), "t_max")
+    tr = None if t_rand is None else _chk(t_rand.reshape(-1), "t_rand")
+    counts = torch.zeros((R,), dtype=torch.int32, device=dev)
+    args = (C.byref(g), _ptr(o), _ptr(d), _ptr(tmn), _ptr(tmx), _ptr(tr), R, float(render_step_size), float(near_plane),
+            float(far_plane), float(cone_angle), int(max_candidates))
+    call("nrhip_occgrid_march", *args, _ptr(counts), _ptr(None), _ptr(None), _ptr(None), _ptr(None), _stream())
+    seg = torch.zeros((R + 1,), dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=seg[1:])
+    M = int(seg[-1].item()) if R else 0
+    ri = torch.empty((M,), dtype=torch.int64, device=dev)
+    ts = torch.empty((M,), dtype=torch.float32, device=dev)
+    te = torch.empty((M,), dtype=torch.float32, device=dev)
+    if M:
+        call("nrhip_occgrid_march", *args, _ptr(None), _ptr(seg), _ptr(ri), _ptr(ts), _ptr(te), _stream())
+    return ri, ts, te, seg
+
+
+def packed_visibility_from_alpha(alphas: Tensor, segments: Tensor, early_stop_eps: float, alpha_thre: float) -> Tensor:
+    a = _chk(alphas.reshape(-1), "alphas")
+    mask = torch.empty((a.shape[0],), dtype=torch.uint8, device=a.device)
+    if a.shape[0]:
+        call("nrhip_packed_visibility_from_alpha", _ptr(a), _ptr(segments), segments.shape[0] - 1, float(early_stop_eps),
+             float(alpha_thre), _ptr(mask), _stream())
+    return mask.bool()
+
+
 def device_info():
     cus, xcds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
     call("nrhip_device_info", C.byref(cus), C.byref(xcds), C.byref(hbm))
