@@ -108,6 +108,10 @@ int nrhip_hashgrid_fwd(const nrhip_grid* g, const void* table, const float* x /*
 int nrhip_hashgrid_bwd(const nrhip_grid* g, const float* x, const float* grad_out /*[N,L*F]*/, int64_t n,
                        float* grad_table, void* stream);
 
+/* dL/dx of the lookup (fp32 table): only actor-hit samples need it */
+int nrhip_hashgrid_bwd_input(const nrhip_grid* g, const void* table, const float* x, const float* grad_out, int64_t n,
+                             float* grad_x /*[N,3]*/, void* stream);
+
 /* ---- H2+H3+H1+H4: NeuRADHashEncoding static path (neurad_encoding.py:164-169,265-268,297-304;
  *      cameras/rays.py:109-124; spatial_distortions.py:103-141) --------------------------------- */
 int nrhip_encode_fwd(const nrhip_grid* g, const void* table, float static_scale, const nrhip_rays* rays,
@@ -216,17 +220,22 @@ int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const flo
                         int32_t* cand_count, int32_t* cand_actor, float* cand_w2b, int32_t* overflow, void* stream);
 /* Field features: for every sample inside an actor box, OVERWRITE its feature row [out_dim] with the actor grid's
  * rescaled features zero-padded to out_dim, and write the per-sample direction (box frame, renormalised) -- ray
- * direction elsewhere.  hit [N] uint8 marks the overwritten samples.                                         */
+ * direction elsewhere.  hit [N] int32 = index of the actor whose grid was used, -1 elsewhere.                                         */
 int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                        const int32_t* cand_actor, const float* cand_w2b, int32_t out_dim, float* features /*[N,out_dim]*/,
-                       float* directions /*[N,3]*/, uint8_t* hit /*[N]*/,
+                       float* directions /*[N,3]*/, int32_t* hit /*[N] actor index or -1*/,
                        const float* ray_flip /*[R] +-1 (training x-flip, neurad_encoding.py:212-219) or NULL*/,
                        void* stream);
+/* All containments: hits [N,K] = actor index of every candidate whose box contains the sample, else -1 (ascending
+ * actor order; the last non-negative entry is the one nrhip_actor_encode used).  The reference's index_put backward
+ * gives EVERY duplicate (ray, sample) row the upstream gradient, so training needs the whole list.            */
+int nrhip_actor_hits(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
+                     const int32_t* cand_actor, const float* cand_w2b, int32_t* hits /*[N,K]*/, void* stream);
 /* Proposal density: density = exp(decoder . padded actor features) for samples inside an actor box
  * (fields/neurad_field.py:208-213 with the actor branch of neurad_encoding.py:170-185).                      */
 int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                         const int32_t* cand_actor, const float* cand_w2b, const float* decoder_weight, int32_t n_dec,
-                        float* density /*[R,S] overwritten where hit*/, uint8_t* hit, const float* ray_flip,
+                        float* density /*[R,S] overwritten where hit*/, int32_t* hit /*actor index or -1*/, const float* ray_flip,
                         void* stream);
 
 /* ---- S6: occupancy-grid ray march (VolumetricSampler.forward -> nerfacc OccGridEstimator.sampling,

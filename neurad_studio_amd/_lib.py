@@ -68,6 +68,7 @@ PROTOTYPES = {
     "nrhip_device_info": [C.POINTER(I32), C.POINTER(I32), C.POINTER(I64)],
     "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
+    "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],
     "nrhip_encode_fwd": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P],
     "nrhip_encode_bwd": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P],
     "nrhip_sh4_fwd": [P, I64, P, P],
@@ -90,6 +91,7 @@ PROTOTYPES = {
     "nrhip_pdf_sample": [P, P, P, P, I64, I32, I32, F32, F32, F32, P, I32, P, P, P],
     "nrhip_actor_prepare": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P],
     "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P, P],
+    "nrhip_actor_hits": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],
     "nrhip_occgrid_march": [C.POINTER(OccGrid), P, P, P, P, P, I64, F32, F32, F32, F32, I32, P, P, P, P, P, P],
     "nrhip_packed_visibility_from_alpha": [P, P, I64, F32, F32, P, P],

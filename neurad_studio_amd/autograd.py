@@ -21,15 +21,17 @@ class HashGridFn(torch.autograd.Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, table, spec):
         ctx.spec = spec
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, table)
         return ops.hashgrid_fwd(spec, table, x)
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        gt = ops.hashgrid_bwd(ctx.spec, None, x, g.contiguous()) if ctx.needs_input_grad[1] else None
-        return None, gt, None
+        x, table = ctx.saved_tensors
+        g = g.contiguous()
+        gt = ops.hashgrid_bwd(ctx.spec, None, x, g) if ctx.needs_input_grad[1] else None
+        gx = ops.hashgrid_bwd_input(ctx.spec, table, x, g) if ctx.needs_input_grad[0] else None  # actor poses only
+        return gx, gt, None
 
 
 class EncodeFn(torch.autograd.Function):

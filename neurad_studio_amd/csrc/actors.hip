@@ -159,12 +159,12 @@ __global__ __launch_bounds__(256) void actor_encode_kernel(ActorsDev a, RaysDev 
                                                             const int32_t* __restrict__ cand_actor,
                                                             const float* __restrict__ cand_w2b, int out_dim,
                                                             float* __restrict__ feat, float* __restrict__ dirs,
-                                                            uint8_t* __restrict__ hit) {
+                                                            int32_t* __restrict__ hit) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= r.R * r.S) return;
   const ActorHit h = find_hit(a, r, i, cand_count, cand_actor, cand_w2b);
   if (dirs) dirs[3 * i] = h.dx, dirs[3 * i + 1] = h.dy, dirs[3 * i + 2] = h.dz;
-  if (hit) hit[i] = h.actor >= 0;
+  if (hit) hit[i] = h.actor;
   if (h.actor < 0) return;
   const SamplePos p = contract_gaussian(h.px, h.py, h.pz, h.std, a.scale);
   const void* table = a.tables[h.actor];
@@ -185,11 +185,11 @@ __global__ __launch_bounds__(256) void actor_density_kernel(ActorsDev a, RaysDev
                                                              const int32_t* __restrict__ cand_actor,
                                                              const float* __restrict__ cand_w2b,
                                                              const float* __restrict__ dec, int n_dec,
-                                                             float* __restrict__ dens, uint8_t* __restrict__ hit) {
+                                                             float* __restrict__ dens, int32_t* __restrict__ hit) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= r.R * r.S) return;
   const ActorHit h = find_hit(a, r, i, cand_count, cand_actor, cand_w2b);
-  if (hit) hit[i] = h.actor >= 0;
+  if (hit) hit[i] = h.actor;
   if (h.actor < 0) return;
   const SamplePos p = contract_gaussian(h.px, h.py, h.pz, h.std, a.scale);
   const void* table = a.tables[h.actor];
@@ -201,6 +201,35 @@ __global__ __launch_bounds__(256) void actor_density_kernel(ActorsDev a, RaysDev
     acc += (v[0] * rescale_weight(a.grid.scal[l], p.std)) * dec[l];
   }
   dens[i] = expf(acc);
+}
+
+// every (sample, candidate) containment, not only the winner: the reference's index_put backward hands the
+// upstream gradient to ALL duplicate (ray, sample) rows (neurad_encoding.py:184-185,256-263), so overlapping
+// actors all receive gradients -- the training path needs the full list to reproduce that.
+__global__ __launch_bounds__(256) void actor_hits_kernel(ActorsDev a, RaysDev r, const int32_t* __restrict__ cand_count,
+                                                          const int32_t* __restrict__ cand_actor,
+                                                          const float* __restrict__ cand_w2b,
+                                                          int32_t* __restrict__ hits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= r.R * r.S) return;
+  const int64_t ray = i / r.S;
+  const int s = (int)(i - ray * r.S);
+  const int n = cand_count[ray];
+#pragma unroll
+  for (int c = 0; c < K; ++c) hits[i * K + c] = -1;
+  if (n == 0) return;
+  const SamplePos g = sample_gaussian(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray], r.d[3 * ray + 1],
+                                      r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
+                                      r.ends[ray * r.stride + s]);
+  for (int c = 0; c < n; ++c) {
+    const float* w = cand_w2b + (ray * K + c) * 12;
+    const int act = cand_actor[ray * K + c];
+    const float bx = w[0] * g.x + w[1] * g.y + w[2] * g.z + w[3];
+    const float by = w[4] * g.x + w[5] * g.y + w[6] * g.z + w[7];
+    const float bz = w[8] * g.x + w[9] * g.y + w[10] * g.z + w[11];
+    if (fabsf(bx) < a.bounds[3 * act] && fabsf(by) < a.bounds[3 * act + 1] && fabsf(bz) < a.bounds[3 * act + 2])
+      hits[i * K + c] = act;
+  }
 }
 
 static int to_dev(const nrhip_actors* a, ActorsDev& d) {
@@ -238,7 +267,7 @@ extern "C" int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays
 
 extern "C" int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                                   const int32_t* cand_actor, const float* cand_w2b, int32_t out_dim, float* features,
-                                  float* directions, uint8_t* hit, const float* ray_flip, void* stream) {
+                                  float* directions, int32_t* hit, const float* ray_flip, void* stream) {
   ActorsDev d;
   if (int e = to_dev(a, d)) return e;
   d.flip = ray_flip;
@@ -263,9 +292,22 @@ extern "C" int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays,
   return check_launch("actor_encode");
 }
 
+extern "C" int nrhip_actor_hits(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
+                                const int32_t* cand_actor, const float* cand_w2b, int32_t* hits, void* stream) {
+  ActorsDev d;
+  if (int e = to_dev(a, d)) return e;
+  if (int e = validate_rays(rays)) return e;
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  NR_REQUIRE(cand_count && cand_actor && cand_w2b && hits, NRHIP_ERR_INVALID_ARG, "actor_hits: null pointer");
+  actor_hits_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(d, to_dev(*rays), cand_count, cand_actor,
+                                                                      cand_w2b, hits);
+  return check_launch("actor_hits");
+}
+
 extern "C" int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
                                    const int32_t* cand_actor, const float* cand_w2b, const float* decoder_weight,
-                                   int32_t n_dec, float* density, uint8_t* hit, const float* ray_flip, void* stream) {
+                                   int32_t n_dec, float* density, int32_t* hit, const float* ray_flip, void* stream) {
   ActorsDev d;
   if (int e = to_dev(a, d)) return e;
   d.flip = ray_flip;

@@ -4,8 +4,9 @@
 Static path: contraction (H3), gaussian (H2), lookup (H1) and rescale (H4) are ONE HIP kernel (nrhip_encode_fwd)
 consuming per-ray origin/direction and per-sample [start,end]; nothing of shape [R,S,3] is materialised.
 Actor path (H5): nrhip_actor_prepare (pose interpolation + line cull per ray) then nrhip_actor_encode (in-box test,
-actor-grid lookup, overwrite) -- torch-path semantics (one 3-D grid per actor, use_4d_hashgrid=False); forward only:
-actor grids and trajectories receive no gradient yet (next row), the static table does (overwritten rows get none)."""
+actor-grid lookup, overwrite) -- torch-path semantics (one 3-D grid per actor, use_4d_hashgrid=False).  Training:
+the hit rows are recomputed differentiably (``_actor_rows_with_grad``) so actor grids and trajectories get the
+reference's gradients; rows overwritten by actors give the static table no gradient."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -131,17 +132,69 @@ class NeuRADHashEncoding(nn.Module):
             return feats, None
         if times is None:
             raise ValueError("dynamic actors need ray times")
+        flip = self.sample_ray_flip(origins)
         with torch.no_grad():
             spec, cand = self.prepare_actors(origins, directions, pixel_area, starts, ends, times)
             merged = feats.detach().clone()
-            dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, merged,
-                                         self.sample_ray_flip(origins))
-        if feats.requires_grad:
+            dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, merged, flip)
+        want_actor_grad = torch.is_grad_enabled() and self.config.require_actor_grad and (
+            any(gr.hash_table.requires_grad for gr in self.actor_grids) or self.actors.actor_positions.requires_grad)
+        if want_actor_grad:
+            with torch.no_grad():
+                hits = ops.actor_hits(spec, cand, origins, directions, pixel_area, starts, ends)
+            feats = self._actor_rows_with_grad(feats, hit, hits, origins, directions, pixel_area, starts, ends, times,
+                                               flip)
+        elif feats.requires_grad:
             # value = merged rows; gradient flows to the static features of the non-overwritten rows only
-            feats = _MaskRowsFn.apply(feats + (merged - feats.detach()), hit)
+            feats = _MaskRowsFn.apply(feats + (merged - feats.detach()), hit >= 0)
         else:
             feats = merged
         return feats, dirs
+
+    def _actor_rows_with_grad(self, feats, hit, hits, origins, directions, pixel_area, starts, ends, times, flip):
+        """Training path of the actor rows (B1): the kernels found WHICH samples lie in WHICH actor; the few hit rows
+        are recomputed differentiably -- box-frame position through torch (gradient to the trajectories), the
+        actor grid through HashGridFn (table scatter-add + nrhip_hashgrid_bwd_input for dL/dx) -- and spliced in
+        with index_put, whose autograd zeroes the static-table gradient of the replaced rows."""
+        pair = (hits >= 0).nonzero()                  # every (sample, candidate slot) containment
+        if pair.shape[0] == 0:
+            return feats
+        idx, act = pair[:, 0], hits[pair[:, 0], pair[:, 1]].long()
+        winner = act == hit[idx].long()               # the row the forward actually used (highest actor index)
+        S = starts.shape[1]
+        ray, smp = idx // S, idx % S
+        t0, t1 = starts[ray, smp], ends[ray, smp]
+        dist = (t1 - t0) / 2
+        t = t0 + dist
+        mean = origins[ray] + directions[ray] * t[:, None]                       # cameras/rays.py:118-121
+        std = (pixel_area.reshape(-1)[ray] * t.pow(2) * dist).pow(1 / 3)
+        r_inv, t_inv = self.actors.world2box_pairs(times[ray], act)
+        pos = (r_inv @ mean[:, :, None])[..., 0] + t_inv                         # transform_points_pairwise
+        if flip is not None:
+            pos = torch.cat([pos[:, :1] * flip[ray, None], pos[:, 1:]], dim=-1)
+        scale = self.config.actor.actor_scale                                    # ScaledSceneContraction(inf)
+        m, s = pos / scale, std / scale
+        mag = m.abs().amax(dim=-1, keepdim=True)
+        cm = mag.clamp_min(1.0)
+        m = torch.where(mag < 1, m, (2 - 1 / cm) * (m / cm))
+        s = torch.where(mag[:, 0] < 1, s, s * (((2 * cm[:, 0] - 1).pow(1 / 3) / cm[:, 0]) ** 2))
+        x01, cstd = (m + 2.0) / 4.0, s / 4.0
+        ids = self.actors.actor_to_id[act]
+        rows = feats.new_zeros((idx.numel(), self.scene_repr_dim))
+        for gid in ids.unique().tolist():                                        # _get_actor_features_slow
+            sel = (ids == gid).nonzero()[:, 0]
+            grid = self.actor_grids[gid]
+            f = grid(x01[sel])
+            w = 1 / (grid.scalings[None, :] * 2 * cstd[sel, None]).clamp_min(1.0)
+            f = (f.view(-1, grid.num_levels, grid.features_per_level) * w[..., None]).flatten(1)
+            rows = rows.index_put((sel,), torch.nn.functional.pad(f, (0, self.scene_repr_dim - f.shape[1])))
+        out = feats.index_put((idx[winner],), rows[winner])
+        if not bool(winner.all()):
+            # overlapping actors: the reference's index_put backward hands the upstream gradient to EVERY duplicate
+            # (ray, sample) row (neurad_encoding.py:184-185) -> the shadowed actors get gradients too; zero in value
+            lose = ~winner
+            out = out.index_put((idx[lose],), rows[lose] - rows[lose].detach(), accumulate=True)
+        return out
 
     def forward(self, ray_samples, times=None, directions: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """Reference signature is forward(GaussiansStd, times, directions); here the frustums are passed directly

@@ -149,6 +149,14 @@ def hashgrid_bwd(spec: GridSpec, table_like: Tensor, x: Tensor, grad_out: Tensor
     return gt
 
 
+def hashgrid_bwd_input(spec: GridSpec, table: Tensor, x: Tensor, grad_out: Tensor) -> Tensor:
+    x, grad_out = _chk(x, "x"), _chk(grad_out, "grad_out")
+    gx = torch.empty_like(x)
+    g = spec.c_grid(table)
+    call("nrhip_hashgrid_bwd_input", C.byref(g), _ptr(table), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gx), _stream())
+    return gx
+
+
 def encode_fwd(spec: GridSpec, table: Tensor, static_scale: float, origins, directions, pixel_area, starts, ends):
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     out = torch.empty((r.n_rays * r.n_samples, spec.out_dim), device=origins.device, dtype=torch.float32)
@@ -493,7 +501,7 @@ def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends
 def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, features: Tensor,
                  ray_flip: Optional[Tensor] = None):
     """Overwrites the rows of ``features`` [N,out_dim] whose sample lies inside an actor box (in place).
-    -> (directions [N,3], hit [N] bool)"""
+    -> (directions [N,3], hit_actor [N] int32: actor index or -1)"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
     cnt, act, w2b, _ = cand
@@ -501,10 +509,20 @@ def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts,
     feats = _chk(features, "features")
     assert feats.data_ptr() == features.data_ptr(), "features must be contiguous (updated in place)"
     dirs = torch.empty((n, 3), dtype=torch.float32, device=feats.device)
-    hit = torch.empty((n,), dtype=torch.uint8, device=feats.device)
+    hit = torch.empty((n,), dtype=torch.int32, device=feats.device)
     call("nrhip_actor_encode", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), feats.shape[1], _ptr(feats),
          _ptr(dirs), _ptr(hit), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), _stream())
-    return dirs, hit.bool()
+    return dirs, hit  # int32: actor index or -1
+
+
+def actor_hits(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends) -> Tensor:
+    """-> hits [N,K] int32: every candidate actor whose box contains the sample (-1 = no)"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    a, keep2 = spec.c_actors()
+    cnt, act, w2b, _ = cand
+    hits = torch.empty((r.n_rays * r.n_samples, _lib.MAX_ACTOR_CANDIDATES), dtype=torch.int32, device=origins.device)
+    call("nrhip_actor_hits", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(hits), _stream())
+    return hits
 
 
 def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, decoder_weight: Tensor,
@@ -516,10 +534,10 @@ def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts
     dw = _chk(decoder_weight.reshape(-1), "decoder_weight")
     dens = _chk(density, "density")
     assert dens.data_ptr() == density.data_ptr(), "density must be contiguous (updated in place)"
-    hit = torch.empty((r.n_rays, r.n_samples), dtype=torch.uint8, device=dens.device)
+    hit = torch.empty((r.n_rays, r.n_samples), dtype=torch.int32, device=dens.device)
     call("nrhip_actor_density", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(dw), dw.numel(),
          _ptr(dens), _ptr(hit), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), _stream())
-    return hit.bool()
+    return hit >= 0
 
 
 @dataclass

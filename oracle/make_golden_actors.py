@@ -73,6 +73,28 @@ def main():
         b2w, valid = actors.get_boxes2world(rs.times[:, 0].squeeze(-1), flatten=False)
         idx, _, _ = fld.hashgrid._split_static_vs_actors(gauss, rs.times, rs.frustums.directions)
     print("actor-hit samples:", idx[0].shape[0], "of", R * S)
+    # B1 with actors: gradients w.r.t. static table, actor grids and actor trajectories (require_actor_grad=True)
+    out_g = fld(rs)
+    gf = T(synth.normal(tuple(out_g[FieldHeadNames.FEATURE].shape), seed=71))
+    ga = T(synth.normal(tuple(out_g[FieldHeadNames.ALPHA].shape), seed=72))
+    ((out_g[FieldHeadNames.FEATURE] * gf).sum() + (out_g[FieldHeadNames.ALPHA] * ga).sum()).backward()
+    tg = fld.hashgrid.static_grid.hash_table.grad
+    nz = tg.abs().sum(-1) > 0
+    grads = dict(g_feature=gf, g_alpha=ga[..., 0], tg_idx=nz.nonzero()[:, 0], tg_val=tg[nz],
+                 dpos=actors.actor_positions.grad, drot=actors.actor_rotations_6d.grad)
+    for i, g in enumerate(fld.hashgrid.actor_grids):
+        grads[f"ag{i}"] = g.hash_table.grad if g.hash_table.grad is not None else torch.zeros_like(g.hash_table)
+    # dL/dx of a plain HashEncoding (autograd of encodings.py:425-464 w.r.t. in_tensor)
+    from nerfstudio.field_components.encodings import HashEncoding
+    enc = HashEncoding(num_levels=4, min_res=64, max_res=1024, log2_hashmap_size=9, features_per_level=4,
+                       implementation="torch")
+    enc.hash_table.data = T(synth.hash_table(4 * 2**9, 4, seed=400, scale=0.7))
+    x = T(synth.uniform((200, 3), 0.0, 1.0, seed=3)).requires_grad_(True)
+    y = enc(x)
+    gy = T(synth.normal(tuple(y.shape), seed=5))
+    (y * gy).sum().backward()
+    grads.update(hx=x.detach(), hgy=gy, hdx=x.grad)
+    save("field_actors_grads", **grads)
     save("field_actors", o=o, d=d.astype(np.float32), area=np.full((R,), 2.43e-6, np.float32), times=times,
          starts=rs.frustums.starts[..., 0], ends=rs.frustums.ends[..., 0], feature=out[FieldHeadNames.FEATURE],
          sdf=out[FieldHeadNames.SDF][..., 0], alpha=out[FieldHeadNames.ALPHA][..., 0], enc=feats, directions=dirs,

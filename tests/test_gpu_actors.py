@@ -90,7 +90,7 @@ def test_field_with_actors_vs_reference_golden():
     dirs, hit = ops.actor_encode(spec, cand, o, d, a, dev(g["starts"]), dev(g["ends"]), feats)
     want = np.zeros(g["starts"].shape, bool)
     want[g["hit_ray"], g["hit_sample"]] = True
-    np.testing.assert_array_equal(host(hit).reshape(want.shape), want)
+    np.testing.assert_array_equal(host(hit).reshape(want.shape) >= 0, want)
     assert rel_l2(host(dirs).reshape(g["directions"].shape), g["directions"]) < 1e-6
     with torch.no_grad():
         out = fld(rs)
@@ -158,3 +158,39 @@ def test_proposal_density_with_actors_vs_oracle():
     enc, _ = O.encode_with_actors(grid, 100.0, ap, g["o"], g["d"], g["area"], g["starts"], g["ends"], g["times"])
     ref = np.exp(enc @ pp.decoder_w.T).reshape(g["starts"].shape)
     assert rel_l2(dens, ref) < TOL
+
+
+def test_hashgrid_dx_vs_reference_autograd():
+    from neurad_studio_amd import ops
+
+    g = load_golden("field_actors_grads")
+    spec = ops.GridSpec(4, 4, 9, 64, 1024)
+    table = dev(synth.hash_table(4 * 2**9, 4, seed=400, scale=0.7))
+    gx = ops.hashgrid_bwd_input(spec, table, dev(g["hx"]), dev(g["hgy"]))
+    assert rel_l2(host(gx), g["hdx"]) < TOL
+
+
+def test_actor_gradients_vs_reference_autograd():
+    """B1 with actors: static table, per-actor grids and the trajectory parameters get the reference's gradients."""
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.field_components.field_heads import FieldHeadNames
+
+    g, gg = load_golden("field_actors"), load_golden("field_actors_grads")
+    fld = make_field()
+    R = g["o"].shape[0]
+    rb = RayBundle(origins=dev(g["o"]), directions=dev(g["d"]), pixel_area=dev(g["area"])[:, None],
+                   times=dev(g["times"])[:, None], nears=torch.zeros(R, 1, device="cuda"),
+                   fars=torch.full((R, 1), 60.0, device="cuda"))
+    rs = rb.get_ray_samples(dev(g["starts"])[..., None], dev(g["ends"])[..., None])
+    out = fld(rs)
+    assert rel_l2(host(out[FieldHeadNames.FEATURE]), g["feature"]) < TOL
+    ((out[FieldHeadNames.FEATURE] * dev(gg["g_feature"])).sum()
+     + (out[FieldHeadNames.ALPHA][..., 0] * dev(gg["g_alpha"])).sum()).backward()
+    tg = np.zeros((8 * 2**11, 4), np.float32)
+    tg[gg["tg_idx"]] = gg["tg_val"]
+    assert rel_l2(host(fld.hashgrid.static_grid.hash_table.grad), tg) < TOL
+    for i, gr in enumerate(fld.hashgrid.actor_grids):
+        assert rel_l2(host(gr.hash_table.grad), gg[f"ag{i}"]) < TOL, i
+    act = fld.hashgrid.actors
+    assert rel_l2(host(act.actor_positions.grad), gg["dpos"]) < 1e-3
+    assert rel_l2(host(act.actor_rotations_6d.grad), gg["drot"]) < 1e-3
