@@ -244,12 +244,10 @@ __device__ __forceinline__ SamplePos contract_gaussian(float mx, float my, float
 }
 
 __device__ __forceinline__ SamplePos sample_position(float ox, float oy, float oz, float dx, float dy, float dz,
-                                                     float area, float t0, float t1, float inv_scale_dummy,
-                                                     float scale) {
+                                                     float area, float t0, float t1, float scale) {
   // Position arithmetic mirrors torch op for op (separately rounded mul/add/div, no fma): one ulp of the
   // contracted coordinate is 8192 * 6e-8 = 5e-4 of a cell at the finest level, so rounding-order matters.
 #pragma clang fp contract(off)
-  (void)inv_scale_dummy;
   const float dist = (t1 - t0) / 2.f;
   const float t = t0 + 1.f * dist;
   float mx = ox + dx * t, my = oy + dy * t, mz = oz + dz * t;

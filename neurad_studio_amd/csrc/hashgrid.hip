@@ -61,8 +61,7 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(GridDev g, const void* 
   const int l = (int)(t - i * g.L);
   const int64_t ray = i / r.S;
   const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
-                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], 0.f,
-                                      scale);
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
   const uint32_t mask = (1u << g.log2T) - 1u;
   float v[F];
   hash_level<F, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
@@ -82,8 +81,7 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(GridDev g, float scale,
   const int l = (int)(t - i * g.L);
   const int64_t ray = i / r.S;
   const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
-                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], 0.f,
-                                      scale);
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
   const uint32_t mask = (1u << g.log2T) - 1u;
   const Corners c = hash_corners(p.x, p.y, p.z, g.scal[l], mask);
   float w[8];
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void encode_bwd_runs_kernel(GridDev g, float s
   const int s = (int)(i - ray * r.S);
   const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
                                       r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
-                                      r.ends[ray * r.stride + s], 0.f, scale);
+                                      r.ends[ray * r.stride + s], scale);
   const uint32_t mask = (1u << g.log2T) - 1u;
   for (int l = 0; l < g.L; ++l) {
     const float sc = g.scal[l];
@@ -184,8 +182,7 @@ __global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, co
   if (i >= r.R * r.S) return;
   const int64_t ray = i / r.S;
   const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
-                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], 0.f,
-                                      scale);
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
   const uint32_t mask = (1u << g.log2T) - 1u;
   float acc = 0.f;
   for (int l = 0; l < g.L; ++l) {
@@ -212,8 +209,7 @@ __global__ __launch_bounds__(256) void proposal_density_bwd_kernel(GridDev g, co
   if (live) {
     const int64_t ray = i / r.S;
     const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
-                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)],
-                                        0.f, scale);
+                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
     const uint32_t mask = (1u << g.log2T) - 1u;
     const float xlog = logf(dens[i]);
     const float gx = gd[i] * expf(fminf(fmaxf(xlog, -15.f), 15.f));
@@ -254,9 +250,6 @@ __global__ __launch_bounds__(256) void proposal_density_bwd_kernel(GridDev g, co
 }
 
 // --------------------------------------------------------------------------------------------
-template <template <int, bool> class K>
-struct Dummy {};
-
 #define DISPATCH_F_HALF(F_, HALF_, CALL)                                   \
   do {                                                                     \
     const int f__ = (F_);                                                  \

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
       const bool live = s < S;
       const int64_t si = ray * rays.stride + (live ? s : S - 1);
       const float t0 = rays.starts[si], t1 = rays.ends[si];
-      const SamplePos p = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, 0.f, fd.scale);
+      const SamplePos p = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, fd.scale);
 
       // ---- gather: LPL levels x 8 corners, rescaled (H1 + H4) ------------------------------------
       float feat[8];

@@ -176,7 +176,7 @@ struct SamplerDev {
 template <bool HALF>
 __device__ __forceinline__ float prop_density(const PropDev& p, float ox, float oy, float oz, float dx, float dy,
                                               float dz, float area, float t0, float t1) {
-  const SamplePos q = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, 0.f, p.scale);
+  const SamplePos q = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, p.scale);
   const uint32_t mask = (1u << p.grid.log2T) - 1u;
   float acc = 0.f;
   for (int l = 0; l < p.grid.L; ++l) {

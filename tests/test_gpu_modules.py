@@ -215,3 +215,38 @@ def test_tinycudann_shaped_shim_matches_torch_path_oracle():
     sh = tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": 4}).cuda()
     d = synth.uniform((50, 3), 0, 1, 5)
     assert rel_l2(host(sh(dev(d))), O.sh_deg4(d)) < 1e-6
+
+
+def test_full_size_neurad_default_chain_properties():
+    """BASELINE config[2]/[3] shape at full size: default NeuRAD grids (static 8 x 2^22 x 4 = 537 MB, proposals
+    6 x 2^20), 8192 rays, sampler (128, 64) -> 32 + field + compositing.  Size-independent properties: fused eval path
+    == operator-level path, bins sorted inside [0, sky], accumulation in [0, 1], finite, ray-permutation covariance."""
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    torch.manual_seed(0)
+    m = NeuRADHotPath(NeuRADHotPathConfig(appearance_dim=0), static_scale=100.0).cuda().eval()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(300.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(1000.0)
+    R = 8192
+    o, d, area, _ = synth.rays(R, 21)
+    with torch.no_grad():
+        out = m.get_nff_outputs(bundle(o, d, area / 9))
+        rs, wl, rsl = m.sampler.generate_fused(bundle(o, d, area), [m.proposal_fields[1]] * 2)
+    assert all(torch.isfinite(v).all() for v in out.values())
+    acc = out["accumulation"]
+    assert float(acc.min()) >= -1e-6 and float(acc.max()) <= 1 + 1e-5
+    e = torch.cat([rs.frustums.starts[..., 0], rs.frustums.ends[:, -1:, 0]], -1)
+    assert bool((e[:, 1:] >= e[:, :-1]).all()) and float(e.min()) >= 0 and float(e.max()) <= 20000.0 + 1e-2
+    assert wl[0].shape == (R, 128, 1) and wl[1].shape == (R, 64, 1)
+    assert float(wl[0].sum(-2).max()) <= 1 + 1e-4  # proposal weights are a sub-probability along each ray
+    perm = torch.randperm(R, device="cuda").cpu().numpy()
+    with torch.no_grad():
+        outp = m.get_nff_outputs(bundle(o[perm], d[perm], area[perm] / 9))
+    assert torch.equal(outp["features"], out["features"][torch.from_numpy(perm).cuda()])
+    # operator-level path on a slice (grad-enabled call in eval mode -> no jitter) agrees with the fused kernels
+    sl = slice(0, 512)
+    out2 = m.get_nff_outputs(bundle(o[sl], d[sl], area[sl] / 9))
+    for k in ("features", "accumulation", "depth"):
+        assert rel_l2(host(out2[k]), host(out[k][sl])) < 5e-5, k
