@@ -15,7 +15,9 @@
 // Exact fp32 (f32-input MFMA == fmaf chain): the parity target is the reference's fp32 torch path.
 #include "common.h"
 
+
 namespace nrhip {
+
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -53,18 +55,17 @@ struct Lds {
   static constexpr int TOTAL = SCAL + NRHIP_MAX_LEVELS;
 };
 
-// stage W[row_off + 16mb + i][col(g,s)] into fragment order; CHAIN: col = 16*(s/4) + 4g + s%4 (input is a D
-// tile of the previous layer), else col = 8g + s (input is the gathered feature registers).
-template <bool CHAIN>
-__device__ void stage_frag(float* dst, const float* __restrict__ W, int ldw, int row_off, int nblk, int nstep) {
-  const int total = nblk * nstep * 64;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int s3 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;  // [mb][s4][lane][s3]
-    const int s4 = rest % (nstep / 4), mb = rest / (nstep / 4);
-    const int s = 4 * s4 + s3, i = lane & 15, g = lane >> 4;
-    const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
-    dst[e] = W[(size_t)(row_off + 16 * mb + i) * ldw + col];
-  }
+// Weight staging.  W[row_off + 16mb + i][col(g,s)] goes to fragment order [mb][s4][lane][s3]; CHAIN: col =
+// 16*(s/4) + 4g + s%4 (input is a D tile of the previous layer), else col = 8g + s (input is the gathered feature
+// registers).  Every thread first ISSUES all of its global loads (one register each, ~60 in flight), then stores:
+// one memory round trip for the whole 54 KB image instead of one per loop iteration.
+template <bool CHAIN, int NBLK, int NSTEP>
+__device__ __forceinline__ float frag_src(const float* __restrict__ W, int ldw, int row_off, int e) {
+  const int s3 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+  const int s4 = rest % (NSTEP / 4), mb = rest / (NSTEP / 4);
+  const int s = 4 * s4 + s3, i = lane & 15, g = lane >> 4;
+  const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
+  return W[(size_t)(row_off + 16 * mb + i) * ldw + col];
 }
 
 // one MFMA layer: acc[mb] += Σ_s A[mb][s] * B[s],  NS k-steps, NBLK output blocks, all statically unrolled.
@@ -112,25 +113,59 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
-  stage_frag<false>(lds + Ld::G0, fd.gw0, 32, 0, NB, 8);
-  stage_frag<true>(lds + Ld::G1, fd.gw1, H, 1, 2, H / 4);
-  stage_frag<true>(lds + Ld::F0, fd.fw0, 48, 0, NB, 8);
-  stage_frag<true>(lds + Ld::F1, fd.fw1, H, 0, NB, H / 4);
-  stage_frag<true>(lds + Ld::F2, fd.fw2, H, 0, 2, H / 4);
-  for (int e = threadIdx.x; e < 16 * H; e += blockDim.x) {  // SHW[c][n] = fw0[n][32+c]
-    const int c = e / H, n = e - c * H;
-    lds[Ld::SHW + e] = fd.fw0[(size_t)n * 48 + 32 + c];
-  }
-  for (int e = threadIdx.x; e < H; e += blockDim.x) {
-    lds[Ld::SDFW + e] = fd.gw1[e];
-    lds[Ld::BG0 + e] = fd.gb0 ? fd.gb0[e] : 0.f;
-    lds[Ld::BF0 + e] = fd.fb0 ? fd.fb0[e] : 0.f;
-    lds[Ld::BF1 + e] = fd.fb1 ? fd.fb1[e] : 0.f;
-  }
-  for (int e = threadIdx.x; e < 33; e += blockDim.x) lds[Ld::BG1 + e] = fd.gb1 ? fd.gb1[e] : 0.f;
-  for (int e = threadIdx.x; e < 32; e += blockDim.x) {
-    lds[Ld::BF2 + e] = fd.fb2 ? fd.fb2[e] : 0.f;
-    lds[Ld::SCAL + e] = fd.grid.scal[e];
+  {
+    constexpr int T = 256;  // == blockDim.x
+    constexpr int N_G0 = H * 32 / T, N_G1 = 32 * H / T, N_F0 = H * 32 / T, N_F1 = H * H / T, N_F2 = 32 * H / T,
+                  N_SH = 16 * H / T;
+    static_assert((H * 32) % T == 0 && (H * H) % T == 0 && (16 * H) % T == 0, "regions are whole passes of the block");
+    const int tid = threadIdx.x;
+    float vg0[N_G0], vg1[N_G1], vf0[N_F0], vf1[N_F1], vf2[N_F2], vsh[N_SH], vs[7];
+#pragma unroll
+    for (int it = 0; it < N_G0; ++it) vg0[it] = frag_src<false, NB, 8>(fd.gw0, 32, 0, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_G1; ++it) vg1[it] = frag_src<true, 2, H / 4>(fd.gw1, H, 1, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_F0; ++it) vf0[it] = frag_src<true, NB, 8>(fd.fw0, 48, 0, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_F1; ++it) vf1[it] = frag_src<true, NB, H / 4>(fd.fw1, H, 0, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_F2; ++it) vf2[it] = frag_src<true, 2, H / 4>(fd.fw2, H, 0, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_SH; ++it) {  // SHW[c][n] = fw0[n][32+c]
+      const int e = it * T + tid, c = e / H, n = e - c * H;
+      vsh[it] = fd.fw0[(size_t)n * 48 + 32 + c];
+    }
+    const int th = tid < H ? tid : 0, t33 = tid < 33 ? tid : 0, t32 = tid & 31;
+    vs[0] = fd.gw1[th];
+    vs[1] = fd.gb0 ? fd.gb0[th] : 0.f;
+    vs[2] = fd.fb0 ? fd.fb0[th] : 0.f;
+    vs[3] = fd.fb1 ? fd.fb1[th] : 0.f;
+    vs[4] = fd.gb1 ? fd.gb1[t33] : 0.f;
+    vs[5] = fd.fb2 ? fd.fb2[t32] : 0.f;
+    vs[6] = fd.grid.scal[t32];
+#pragma unroll
+    for (int it = 0; it < N_G0; ++it) lds[Ld::G0 + it * T + tid] = vg0[it];
+#pragma unroll
+    for (int it = 0; it < N_G1; ++it) lds[Ld::G1 + it * T + tid] = vg1[it];
+#pragma unroll
+    for (int it = 0; it < N_F0; ++it) lds[Ld::F0 + it * T + tid] = vf0[it];
+#pragma unroll
+    for (int it = 0; it < N_F1; ++it) lds[Ld::F1 + it * T + tid] = vf1[it];
+#pragma unroll
+    for (int it = 0; it < N_F2; ++it) lds[Ld::F2 + it * T + tid] = vf2[it];
+#pragma unroll
+    for (int it = 0; it < N_SH; ++it) lds[Ld::SHW + it * T + tid] = vsh[it];
+    if (tid < H) {
+      lds[Ld::SDFW + tid] = vs[0];
+      lds[Ld::BG0 + tid] = vs[1];
+      lds[Ld::BF0 + tid] = vs[2];
+      lds[Ld::BF1 + tid] = vs[3];
+    }
+    if (tid < 33) lds[Ld::BG1 + tid] = vs[4];
+    if (tid < 32) {
+      lds[Ld::BF2 + tid] = vs[5];
+      lds[Ld::SCAL + tid] = vs[6];
+    }
   }
   __syncthreads();
 

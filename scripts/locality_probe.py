@@ -33,3 +33,10 @@ for name, lg, oo, dd, half in [("C2 random rays T=2^19", 19, o, d, False), ("C2 
     do, ddv = dev(oo), dev(dd)
     us = timeit(lambda: ops.render_fwd(fs,do,ddv,da,ed[:,:-1],ed[:,1:]))
     print(f"{name:42s} {us:8.1f} us")
+
+# every sample of every ray at the same point: each gather instruction touches <= 4 lines (one per level group)
+fs = mk(16,2,19,64,16,1024)
+do, ddv = dev(np.repeat(o[:1],R,0)), dev(np.repeat(d[:1],R,0))
+st = torch.full((R,S), 5.0, device='cuda'); en = torch.full((R,S), 5.01, device='cuda')
+us = timeit(lambda: ops.render_fwd(fs,do,ddv,da,st,en))
+print(f"{'C2 all samples at ONE point':42s} {us:8.1f} us")
