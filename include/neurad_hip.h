@@ -118,6 +118,14 @@ int nrhip_encode_fwd(const nrhip_grid* g, const void* table, float static_scale,
                      float* out /*[N,L*F]*/, void* stream);
 int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
                      const float* grad_out /*[N,L*F]*/, float* grad_table, void* stream);
+/* Same result without memory-side atomics (every table entry gets one owning workgroup; see
+ * csrc/encode_bwd_binned.hip).  Needs scratch: ask _workspace for the size (0 = this grid can not be binned, use
+ * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  grad_table is
+ * ACCUMULATED into, as above. */
+int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_samples, int64_t* bytes);
+int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
+                            const float* grad_out /*[N,L*F]*/, float* grad_table, void* workspace,
+                            int64_t workspace_bytes, void* stream);
 
 /* ---- F3: SHEncoding(levels=4) (encodings.py:797-805 -> utils/math.py:31-94) -------------------- */
 int nrhip_sh4_fwd(const float* dirs /*[N,3]*/, int64_t n, float* out /*[N,16]*/, void* stream);

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],
     "nrhip_encode_fwd": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P],
     "nrhip_encode_bwd": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P],
+    "nrhip_encode_bwd_binned_workspace": [C.POINTER(Grid), I64, C.POINTER(I64)],
+    "nrhip_encode_bwd_binned": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P, I64, P],
     "nrhip_sh4_fwd": [P, I64, P, P],
     "nrhip_mlp_fwd": [C.POINTER(Mlp), P, I64, P, P, P],
     "nrhip_mlp_bwd": [C.POINTER(Mlp), P, P, P, I64, P, C.POINTER(P), C.POINTER(P), P, P],

@@ -1,0 +1,291 @@
+// B1 (table gradient) without device-scope atomics.
+//
+// On MI355X every fp32 global atomic is executed memory-side: rocprofv3 shows TCC_EA0_ATOMIC == TCC_ATOMIC for the
+// scatter-add kernel (hashgrid.hip), i.e. each of its ~55 M atomic requests is one fabric transaction, and the
+// fabric retires ~1.8e10 of them per second no matter where the line lives -> 3.1 ms for config 2, 44 % of a
+// training step.  The per-XCD L2s are not coherent with each other, so there is no cheaper scope to fall back to.
+//
+// This path gives every table entry exactly one owner instead:
+//   pass A (bin_scatter):  the table of a level is cut into LDS-sized slices of TS = 32768/F entries (128 KB of
+//       fp32).  A workgroup takes 1024 or 4096 consecutive samples, parks their contracted positions in LDS, and for
+//       each level bins the (entry, F gradient values) records of its samples by slice: LDS histogram -> one
+//       returning global atomic per non-empty slice to reserve a range of that slice's queue -> records written
+//       at (range base + LDS rank).  Runs of equal entries in neighbouring lanes (consecutive samples of a ray in
+//       the same coarse cell) are summed first, as in the atomic kernel.
+//   pass B (bin_reduce):   one 1024-thread workgroup per (level, slice) streams its queue, accumulates into the
+//       slice image in LDS with ds_add_f32, and adds the image to grad_table with plain 16-byte loads/stores.
+// A queue holds 2x the mean record count of its level; records beyond that (never seen in the tests) fall back to
+// the global atomic in pass A, which pass B's read-modify-write then picks up (stream order).
+#include "common.h"
+
+namespace nrhip {
+namespace {
+
+constexpr int kMaxSamplesPerBlock = 4096;  // pass A: 4 samples per thread, 256 or 1024 threads
+constexpr int kMaxSlices = 2048;        // per level (LDS histogram + base table = 16 KB)
+constexpr int kTileFloats = 32768;      // slice image in LDS (128 KB)
+
+struct BinPlan {
+  int log2TS;          // entries per slice
+  int nb;              // slices per level
+  uint32_t cap;        // records per queue
+  int spb;             // pass A: samples per workgroup (threads = spb / 4)
+  int lgroups;         // pass A: the levels are dealt round-robin to this many workgroups per sample chunk
+  size_t counter_bytes;
+  size_t total_bytes;
+};
+
+// Returns false when the grid can not be binned (too many slices per level).
+bool make_plan(const GridDev& g, int64_t n, BinPlan* p) {
+  int log2F = 0;
+  while ((1 << log2F) < g.F) ++log2F;
+  int log2TS = 15 - log2F;
+  if (log2TS > g.log2T) log2TS = g.log2T;
+  // small tables: shrink the slices until pass B has ~2 workgroups per CU (one workgroup owns one slice)
+  while (((int64_t)g.L << (g.log2T - log2TS)) < 512 && log2TS > 9) --log2TS;
+  const int64_t nb = (int64_t)1 << (g.log2T - log2TS);
+  if (nb > kMaxSlices) return false;
+  const int64_t mean = (n * 8 + nb - 1) / nb;
+  const int64_t cap = 2 * mean + 256;
+  if (cap > 0x7fffffff) return false;
+  p->log2TS = log2TS;
+  p->nb = (int)nb;
+  p->cap = (uint32_t)cap;
+  // few slices: small chunks already give long contiguous runs per (workgroup, slice); many slices: bigger chunks
+  // so that a reservation atomic still buys >= ~64 records.  Levels are split over workgroups until the grid has
+  // ~4 workgroups per CU.
+  p->spb = nb <= 128 ? 1024 : kMaxSamplesPerBlock;
+  const int64_t chunks = (n + p->spb - 1) / p->spb;
+  int lg = (int)((1024 + chunks - 1) / chunks);
+  p->lgroups = lg < 1 ? 1 : (lg > g.L ? g.L : lg);
+  p->counter_bytes = (((size_t)g.L * nb * sizeof(uint32_t)) + 255) & ~(size_t)255;
+  p->total_bytes = p->counter_bytes + (size_t)g.L * nb * cap * (g.F + 1) * sizeof(float);
+  return true;
+}
+
+template <int F>
+__global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, float scale, RaysDev r,
+                                                            const float* __restrict__ go, float* __restrict__ gt,
+                                                            uint32_t* __restrict__ qcount, float* __restrict__ qrec,
+                                                            int log2TS, int nb, uint32_t cap, int spb) {
+  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
+  uint32_t* hist = reinterpret_cast<uint32_t*>(pos + spb);
+  uint32_t* base = hist + nb;
+  const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
+  const int64_t n = r.R * r.S;
+  const int64_t i_blk = (int64_t)blockIdx.x * spb;
+  const int nit = (int)(((n - i_blk < spb ? n - i_blk : spb) + nt - 1) / nt);
+  for (int it = 0; it < nit; ++it) {
+    const int64_t i0 = i_blk + it * nt + tid;
+    const int64_t i = i0 < n ? i0 : n - 1;
+    const int64_t ray = i / r.S;
+    const int s = (int)(i - ray * r.S);
+    const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
+                                        r.ends[ray * r.stride + s], scale);
+    pos[it * nt + tid] = make_float4(p.x, p.y, p.z, p.std);
+  }
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  const uint32_t tsmask = (1u << log2TS) - 1u;
+  for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
+    const float sc = g.scal[l];
+    __syncthreads();  // pos[] written / previous level's ranks consumed
+    for (int b = tid; b < nb; b += nt) hist[b] = 0;
+    __syncthreads();
+    // ---- count: how many records does this block send to each slice -------------------------------
+    for (int it = 0; it < nit; ++it) {
+      const bool live = i_blk + it * nt + tid < n;
+      const float4 p = pos[it * nt + tid];
+      const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t key = c.idx[k];
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        if (live && (lane == 0 || prev != key)) atomicAdd(&hist[key >> log2TS], 1u);
+      }
+    }
+    __syncthreads();
+    // ---- reserve a range of every non-empty slice queue -------------------------------------------
+    for (int b = tid; b < nb; b += nt) {
+      const uint32_t cnt = hist[b];
+      base[b] = cnt ? atomicAdd(&qcount[l * nb + b], cnt) : 0u;
+      hist[b] = 0;
+    }
+    __syncthreads();
+    // ---- emit ---------------------------------------------------------------------------------------
+    float* gl = gt + ((size_t)l << g.log2T) * F;
+    for (int it = 0; it < nit; ++it) {
+      const int64_t i0 = i_blk + it * nt + tid;
+      const bool live = i0 < n;
+      const int64_t i = live ? i0 : n - 1;
+      const float4 p = pos[it * nt + tid];
+      const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
+      float w[8];
+      corner_weights(c, w);
+      const float rw = live ? rescale_weight(sc, p.w) : 0.f;
+      float gv[F];
+#pragma unroll
+      for (int k = 0; k < F; ++k) gv[k] = go[(i * g.L + l) * F + k] * rw;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t key = c.idx[k];
+        const uint32_t prev = __shfl_up(key, 1, 64);
+        const bool head = lane == 0 || prev != key;
+        const unsigned long long hm = __ballot(head);
+        float v[F];
+#pragma unroll
+        for (int j = 0; j < F; ++j) v[j] = w[k] * gv[j];
+        if (hm != ~0ull) {  // at least one run longer than 1 in this wave: segmented suffix sum onto the heads
+          const int run = __popcll(hm & ((2ull << lane) - 1ull));
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int orun = __shfl_down(run, off, 64);
+            const bool same = (lane + off < 64) && orun == run;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+              const float t = __shfl_down(v[j], off, 64);
+              if (same) v[j] += t;
+            }
+          }
+        }
+        if (head && live) {
+          const uint32_t b = key >> log2TS;
+          const uint32_t at = base[b] + atomicAdd(&hist[b], 1u);
+          if (at < cap) {
+            float* rec = qrec + ((size_t)(l * nb + b) * cap + at) * (F + 1);
+            rec[0] = __uint_as_float(key & tsmask);
+#pragma unroll
+            for (int j = 0; j < F; ++j) rec[1 + j] = v[j];
+          } else {  // queue full: fall back to the memory-side atomic (pass B adds on top of it)
+#pragma unroll
+            for (int j = 0; j < F; ++j) unsafeAtomicAdd(gl + (size_t)key * F + j, v[j]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ qcount,
+                                                           const float* __restrict__ qrec, float* __restrict__ gt,
+                                                           int log2T, int log2TS, int nb, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int lb = blockIdx.x;
+  const uint32_t filled = qcount[lb];
+  if (filled == 0) return;  // uniform: nothing was sent to this slice
+  const uint32_t cnt = filled < cap ? filled : cap;
+  const int nfl = F << log2TS;
+  for (int e = threadIdx.x * 4; e < nfl; e += 4096) *reinterpret_cast<float4*>(tile + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const float* rec = qrec + (size_t)lb * cap * (F + 1);
+  // 4 records per thread in flight: the loads are independent, only the LDS adds follow them
+  for (uint32_t e0 = 0; e0 < cnt; e0 += 4096) {
+    float q[4][F + 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t e = e0 + u * 1024 + threadIdx.x;
+      const float* src = rec + (size_t)(e < cnt ? e : cnt - 1) * (F + 1);
+#pragma unroll
+      for (int j = 0; j <= F; ++j) q[u][j] = src[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + u * 1024 + threadIdx.x < cnt) {
+        const uint32_t key = __float_as_uint(q[u][0]);
+#pragma unroll
+        for (int j = 0; j < F; ++j) unsafeAtomicAdd(tile + key * F + j, q[u][1 + j]);
+      }
+    }
+  }
+  __syncthreads();
+  const int l = lb / nb, b = lb - l * nb;
+  float* out = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+  if (nfl % 4 == 0) {
+    for (int e = threadIdx.x * 4; e < nfl; e += 4096) {
+      float4 o = *reinterpret_cast<const float4*>(out + e);
+      const float4 t = *reinterpret_cast<const float4*>(tile + e);
+      o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
+      *reinterpret_cast<float4*>(out + e) = o;
+    }
+  } else {
+    for (int e = threadIdx.x; e < nfl; e += 1024) out[e] += tile[e];
+  }
+}
+
+#define NR_DISPATCH_F(F_, CALL)      \
+  do {                               \
+    const int f__ = (F_);            \
+    if (f__ == 1) { CALL(1); }       \
+    else if (f__ == 2) { CALL(2); }  \
+    else if (f__ == 4) { CALL(4); }  \
+    else { CALL(8); }                \
+  } while (0)
+
+}  // namespace
+}  // namespace nrhip
+
+using namespace nrhip;
+
+extern "C" int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_samples, int64_t* bytes) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(bytes && n_samples >= 0, NRHIP_ERR_INVALID_ARG, "encode_bwd_binned_workspace: bad argument");
+  BinPlan p;
+  *bytes = (n_samples > 0 && make_plan(to_dev(*g), n_samples, &p)) ? (int64_t)p.total_bytes : 0;
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
+                                       const float* grad_out, float* grad_table, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(grad_out && grad_table && static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "encode_bwd_binned: bad argument");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  const GridDev gd = to_dev(*g);
+  BinPlan p;
+  NR_REQUIRE(make_plan(gd, n, &p), NRHIP_ERR_UNSUPPORTED,
+             "encode_bwd_binned: 2^%d entries x %d features need more than %d slices per level; use nrhip_encode_bwd",
+             gd.log2T, gd.F, kMaxSlices);
+  NR_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total_bytes, NRHIP_ERR_INVALID_ARG,
+             "encode_bwd_binned: workspace of %lld bytes, need %zu", (long long)workspace_bytes, p.total_bytes);
+  NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
+             NRHIP_ERR_INVALID_ARG, "encode_bwd_binned: workspace and grad_table must be 16-byte aligned");
+  const RaysDev rd = to_dev(*rays);
+  const hipStream_t st = (hipStream_t)stream;
+  uint32_t* qcount = static_cast<uint32_t*>(workspace);
+  float* qrec = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
+  if (hipMemsetAsync(qcount, 0, p.counter_bytes, st) != hipSuccess) return check_launch("encode_bwd_binned memset");
+  const dim3 grid_a((unsigned)((n + p.spb - 1) / p.spb), (unsigned)p.lgroups);
+  const int lds_a = p.spb * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
+  constexpr int lds_a_max = kMaxSamplesPerBlock * (int)sizeof(float4) + 2 * kMaxSlices * (int)sizeof(uint32_t);
+#define CALL(F)                                                                                                     \
+  do {                                                                                                              \
+    static thread_local bool configured = false;                                                                    \
+    if (!configured) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                lds_a_max);                                                                         \
+      configured = true;                                                                                            \
+    }                                                                                                               \
+    bin_scatter_kernel<F><<<grid_a, p.spb / 4, lds_a, st>>>(gd, static_scale, rd, grad_out, grad_table, qcount,     \
+                                                            qrec, p.log2TS, p.nb, p.cap, p.spb);                    \
+  } while (0)
+  NR_DISPATCH_F(gd.F, CALL);
+#undef CALL
+  if (int e = check_launch("encode_bwd_binned scatter")) return e;
+  const size_t lds = (size_t)(gd.F << p.log2TS) * sizeof(float);
+#define CALL(F)                                                                                                   \
+  do {                                                                                                            \
+    static thread_local bool configured = false;                                                                  \
+    if (!configured) {                                                                                            \
+      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                          kTileFloats * (int)sizeof(float));                                                      \
+      configured = true;                                                                                          \
+    }                                                                                                             \
+    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds, st>>>(qcount, qrec, grad_table, gd.log2T, p.log2TS, p.nb, p.cap); \
+  } while (0)
+  NR_DISPATCH_F(gd.F, CALL);
+#undef CALL
+  return check_launch("encode_bwd_binned reduce");
+}

@@ -7,6 +7,7 @@ loudly when given CPU tensors -- there is no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -157,6 +158,10 @@ def hashgrid_bwd_input(spec: GridSpec, table: Tensor, x: Tensor, grad_out: Tenso
     return gx
 
 
+# A/B switch for profiling and for the parity test of the atomic path
+_FORCE_ATOMIC_SCATTER = os.environ.get("NRHIP_ENCODE_BWD_ATOMIC") is not None
+
+
 def encode_fwd(spec: GridSpec, table: Tensor, static_scale: float, origins, directions, pixel_area, starts, ends):
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     out = torch.empty((r.n_rays * r.n_samples, spec.out_dim), device=origins.device, dtype=torch.float32)
@@ -170,7 +175,14 @@ def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_a
     grad_out = _chk(grad_out, "grad_out")
     gt = torch.zeros((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
     g = spec.c_grid(gt)
-    call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), _stream())
+    need = C.c_int64(0)
+    call("nrhip_encode_bwd_binned_workspace", C.byref(g), r.n_rays * r.n_samples, C.byref(need))
+    if need.value > 0 and not _FORCE_ATOMIC_SCATTER:
+        ws = torch.empty((need.value,), device=origins.device, dtype=torch.uint8)
+        call("nrhip_encode_bwd_binned", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt),
+             _ptr(ws), need.value, _stream())
+    else:  # tables too large to cut into LDS slices: memory-side atomics
+        call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), _stream())
     return gt
 
 

@@ -378,3 +378,29 @@ def test_full_size_properties_config2(ops):
     sl = slice(100, 116)
     ref = O.render_rays(p, o[sl], d[sl], area[sl], s[sl], e[sl])
     assert rel_l2(host(feats[sl]), ref["features"]) < TOL and rel_l2(host(acc[sl]), ref["accumulation"]) < TOL
+
+
+@pytest.mark.parametrize("cfg", [(16, 2, 19, 4096, 128), (8, 4, 16, 257, 33), (4, 8, 12, 64, 7), (6, 1, 20, 300, 48),
+                                 (2, 4, 9, 5, 3)])
+def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
+    """B1 table gradient: the owner-computes path (LDS slices, no memory-side atomics) against the atomic
+    scatter-add, from BASELINE config 2 at full size down to ragged batches and tables smaller than one slice.
+    Same terms, different summation order -> agreement to fp32 rounding; linearity in grad_out is exact-ish too."""
+    L, F, lg, R, S = cfg
+    spec = ops.GridSpec(L, F, lg, 16, 2048)
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=5)
+    do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
+    go = dev(synth.normal((R * S, L * F), 11))
+    st, en = edges[:, :-1], edges[:, 1:]
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    binned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    binned2 = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, 2 * go)
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+    atomic = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    assert torch.isfinite(binned).all()
+    assert rel_l2(host(binned), host(atomic)) < 2e-6
+    assert (binned - atomic).abs().max() <= 1e-5 * atomic.abs().max()
+    assert rel_l2(host(binned2), 2 * host(binned)) < 2e-6
+    # mass conservation: trilinear weights sum to 1, so each feature column's gradient mass is preserved
+    rw_go = host(binned).reshape(L, -1, F).sum(1)
+    assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
