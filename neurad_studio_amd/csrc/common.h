@@ -308,4 +308,29 @@ __device__ __forceinline__ float dpp_row_shr(float v, float fill) {
 
 inline int grid_for(int64_t threads, int block) { return (int)((threads + block - 1) / block); }
 
+// --------------------------------------------------------------------------------------------
+// fp32 MFMA building block shared by the fused render kernel and the chained MLP kernels.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// One MFMA layer on a 16-sample tile, weights as the A operand read from LDS in fragment order
+// [mb][s4][lane][s3] (one conflict-free ds_read_b128 per 4 k-steps), samples as the B operand in registers:
+// acc[mb] += Σ_s A[mb][s] * B[s],  NS k-steps, NBLK output blocks, all statically unrolled.
+template <int NBLK, int NS>
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ wf, int lane, const float (&b)[NS],
+                                           f32x4 (&acc)[NBLK]) {
+#pragma unroll
+  for (int s4 = 0; s4 < NS / 4; ++s4) {
+    f32x4 a[NBLK];
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb)
+      a[mb] = *reinterpret_cast<const f32x4*>(wf + ((mb * (NS / 4) + s4) * 64 + lane) * 4);
+#pragma unroll
+    for (int s3 = 0; s3 < 4; ++s3)
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][s3], b[4 * s4 + s3], acc[mb], 0, 0, 0);
+  }
+}
+
+
 }  // namespace nrhip

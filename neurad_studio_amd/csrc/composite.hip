@@ -273,6 +273,36 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void composite_bwd_kernel(
   for (int ch = lane; ch < C; ch += 64) qlast += gFr[ch] * fr[(int64_t)(S - 1) * C + ch];
   qlast = wave_sum(qlast);
   const float gacc = gA ? gA[ray] : 0.f, gdep = gD ? gD[ray] : 0.f;
+  // vector path: LP = C/4 lanes share a sample, each owns one float4 of the channel row -> every load/store of a
+  // wave is a run of full 16-byte pieces (a lane-per-sample loop walks 64 separate lines 4 bytes at a time)
+  const int LP = C >> 2;
+  if ((C & 3) == 0 && LP <= 64 && (LP & (LP - 1)) == 0 && ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(gF) |
+                                                            reinterpret_cast<uintptr_t>(gf)) & 15) == 0) {
+    const int sub = lane & (LP - 1), sl = lane / LP, spw = 64 / LP;
+    const float4 g4 = *reinterpret_cast<const float4*>(gFr + 4 * sub);
+    for (int s0 = 0; s0 < S; s0 += spw) {
+      const int s = s0 + sl;
+      const bool live = s < S;
+      const int sc = live ? s : S - 1;
+      const float4 f4 = *reinterpret_cast<const float4*>(fr + (int64_t)sc * C + 4 * sub);
+      float q = g4.x * f4.x;
+      q = fmaf(g4.y, f4.y, q);
+      q = fmaf(g4.z, f4.z, q);
+      q = fmaf(g4.w, f4.w, q);
+      for (int off = 1; off < LP; off <<= 1) q += __shfl_xor(q, off, 64);
+      if (live) {
+        const float w2 = wr[s] + (s == S - 1 ? resid : 0.f);
+        if (gf) *reinterpret_cast<float4*>(gf + (ray * S + s) * (int64_t)C + 4 * sub) =
+            make_float4(w2 * g4.x, w2 * g4.y, w2 * g4.z, w2 * g4.w);
+        if (sub == 0) {
+          float g = q - qlast + gacc;
+          if (s < S - 1) g += gdep * ((starts[ray * S + s] + ends[ray * S + s]) / 2.f);
+          gw[ray * S + s] = g;
+        }
+      }
+    }
+    return;
+  }
   for (int s = lane; s < S; s += 64) {
     float q = 0.f;
     const float w2 = wr[s] + (s == S - 1 ? resid : 0.f);

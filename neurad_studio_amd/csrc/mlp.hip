@@ -6,11 +6,12 @@
 // (Wf[(mb*nstep+s)*64 + lane] = W[16mb + (lane&15)][4s + (lane>>4)]) so an A fragment is one
 // conflict-free, lane-linear ds_read_b32; activations ping-pong through a small per-wave LDS tile.
 // fp32 MFMA is bit-for-bit an fmaf chain, so results match the reference's fp32 Linear to rounding order.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace nrhip {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // Wave-private LDS tiles: ds ops of one wave execute in order, so only the COMPILER must be kept from
 // moving a lane's reads above other lanes' writes.
@@ -237,21 +238,31 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const float* __restrict_
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t nquads = (n + 3) / 4;
-  for (int64_t q = (int64_t)blockIdx.x * 4 + wid; q < nquads; q += (int64_t)gridDim.x * 4) {
-    const int64_t row = q * 4 + g;
-    const bool live = row < n;
-    float a[4], b[4];
+  constexpr int U = 4;  // sample quads in flight per wave: 8*U independent loads before the first MFMA needs one
+  const int64_t qstep = (int64_t)gridDim.x * 4;
+  for (int64_t q0 = (int64_t)blockIdx.x * 4 + wid; q0 < nquads; q0 += qstep * U) {
+    float a[U][4], b[U][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int o = ob * 64 + 16 * k + i16, i = ib * 64 + 16 * k + i16;
-      a[k] = (live && o < out) ? dzp[row * dz_ld + o] : 0.f;
-      b[k] = (live && i < in) ? hp[row * h_ld + i] : 0.f;
-      bsum[k] += a[k];
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (q0 + u * qstep) * 4 + g;
+      const bool live = row < n;  // also false for quads past the end
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int o = ob * 64 + 16 * k + i16, i = ib * 64 + 16 * k + i16;
+        a[u][k] = (live && o < out) ? dzp[row * dz_ld + o] : 0.f;
+        b[u][k] = (live && i < in) ? hp[row * h_ld + i] : 0.f;
+      }
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+      for (int k = 0; k < 4; ++k) bsum[k] += a[u][k];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][x], b[u][y], acc[x][y], 0, 0, 0);
+    }
   }
   // merge the 4 waves of the workgroup in LDS, then one set of atomics per workgroup
   __shared__ float red[3][64][64];
@@ -295,6 +306,15 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const float* __restrict_
       if (g == 0 && o < out) unsafeAtomicAdd(db + o, v);
     }
   }
+}
+
+// mlp_chain.hip: register-chained kernels for NeuRAD's own MLP shapes; NRHIP_ERR_UNSUPPORTED = not covered
+int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float* hidden, void* stream);
+int mlp_chain_bwd(const nrhip_mlp* m, const float* hidden, const float* gy, int64_t n, float* gx, float* dz,
+                  void* stream);
+static bool use_chain() {
+  static const bool off = getenv("NRHIP_MLP_GENERIC") != nullptr;  // A/B switch (tests run both paths)
+  return !off;
 }
 
 int validate_mlp(const nrhip_mlp* m) {
@@ -350,6 +370,10 @@ extern "C" int nrhip_mlp_fwd(const nrhip_mlp* m, const float* x, int64_t n, floa
   NR_REQUIRE(n >= 0, NRHIP_ERR_INVALID_ARG, "mlp_fwd: negative n");
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(x && y, NRHIP_ERR_INVALID_ARG, "mlp_fwd: null pointer");
+  if (use_chain()) {
+    const int rc = mlp_chain_fwd(m, x, n, y, hidden, stream);
+    if (rc != NRHIP_ERR_UNSUPPORTED) return rc;
+  }
   const MlpDev d = to_dev(*m);
   const int waves = pick_waves<false>(d);
   NR_REQUIRE(waves > 0, NRHIP_ERR_UNSUPPORTED, "mlp_fwd: weights need %zu B of LDS (> 160 KiB)",
@@ -375,7 +399,12 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
              "mlp_bwd: hidden activations and workspace are required for num_layers > 1");
   const MlpDev d = to_dev(*m);
   const hipStream_t st = (hipStream_t)stream;
-  if (d.nl > 1 || grad_x) {
+  int chained = NRHIP_ERR_UNSUPPORTED;
+  if (use_chain() && d.nl > 1) {
+    chained = mlp_chain_bwd(m, hidden, grad_y, n, grad_x, workspace, stream);
+    if (chained != NRHIP_OK && chained != NRHIP_ERR_UNSUPPORTED) return chained;
+  }
+  if (chained == NRHIP_ERR_UNSUPPORTED && (d.nl > 1 || grad_x)) {
     const int waves = pick_waves<true>(d);
     NR_REQUIRE(waves > 0, NRHIP_ERR_UNSUPPORTED, "mlp_bwd: weights need %zu B of LDS (> 160 KiB)",
                lds_bytes<true>(d, 1));

@@ -19,7 +19,6 @@
 namespace nrhip {
 
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct FieldDev {
   GridDev grid;
@@ -66,24 +65,6 @@ __device__ __forceinline__ float frag_src(const float* __restrict__ W, int ldw, 
   const int s = 4 * s4 + s3, i = lane & 15, g = lane >> 4;
   const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
   return W[(size_t)(row_off + 16 * mb + i) * ldw + col];
-}
-
-// one MFMA layer: acc[mb] += Σ_s A[mb][s] * B[s],  NS k-steps, NBLK output blocks, all statically unrolled.
-template <int NBLK, int NS>
-__device__ __forceinline__ void mfma_layer(const float* __restrict__ wf, int lane, const float (&b)[NS],
-                                           f32x4 (&acc)[NBLK]) {
-#pragma unroll
-  for (int s4 = 0; s4 < NS / 4; ++s4) {
-    f32x4 a[NBLK];
-#pragma unroll
-    for (int mb = 0; mb < NBLK; ++mb)
-      a[mb] = *reinterpret_cast<const f32x4*>(wf + ((mb * (NS / 4) + s4) * 64 + lane) * 4);
-#pragma unroll
-    for (int s3 = 0; s3 < 4; ++s3)
-#pragma unroll
-      for (int mb = 0; mb < NBLK; ++mb)
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][s3], b[4 * s4 + s3], acc[mb], 0, 0, 0);
-  }
 }
 
 template <int N>

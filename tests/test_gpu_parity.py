@@ -404,3 +404,37 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     # mass conservation: trilinear weights sum to 1, so each feature column's gradient mass is preserved
     rw_go = host(binned).reshape(L, -1, F).sum(1)
     assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dims", [(32, 2, 64, 33), (32, 2, 32, 33), (48, 3, 64, 32), (48, 3, 32, 32), (64, 3, 64, 32),
+                                  (64, 3, 32, 32)])
+def test_mlp_register_chained_shapes_vs_oracle(ops, dims):
+    """F2 fast path (mlp_chain.hip): NeuRAD's own MLP shapes, forward + data/weight gradients against the oracle on
+    ragged batch sizes (partial 16-sample tiles, one tile, many workgroups), with and without biases."""
+    i, n, w, o = dims
+    dd = [i] + [w] * (n - 1) + [o]
+    for use_bias in (True, False):
+        ws, bs = [], []
+        for k in range(n):
+            wk, bk = synth.linear(dd[k + 1], dd[k], 900 + k)
+            ws.append(wk), bs.append(bk if use_bias else None)
+        dws, dbs = [dev(a) for a in ws], [None if b is None else dev(b) for b in bs]
+        for N in (1, 15, 16, 17, 1000, 70001):
+            x = synth.normal((N, i), seed=N)
+            go = synth.normal((N, o), seed=N + 1)
+            y, hidden = ops.mlp_fwd(dev(x), dws, dbs, save_hidden=True)
+            ref_y, acts = O.mlp_fwd(x, ws, bs, return_hidden=True)
+            assert rel_l2(host(y), ref_y) < TIGHT, (dims, N)
+            gx, gws, gbs = ops.mlp_bwd(dev(x), hidden, dev(go), dws, dbs)
+            # the ReLU masks come from the activations the device saved: with 9 M hidden units a pre-activation
+            # within one rounding of zero flips its mask between summation orders, which is not a backward error
+            hh = host(hidden)
+            for k in range(n - 1):
+                assert rel_l2(hh[:, k * w:(k + 1) * w], acts[k + 1]) < TIGHT, (dims, N, k)
+            acts_dev = [x] + [hh[:, k * w:(k + 1) * w] for k in range(n - 1)] + [host(y)]
+            rx, rws, rbs = O.mlp_bwd(acts_dev, ws, go)
+            assert rel_l2(host(gx), rx) < TIGHT, (dims, N)
+            for k in range(n):
+                assert rel_l2(host(gws[k]), rws[k]) < TIGHT, (dims, N, k)
+                if use_bias:
+                    assert rel_l2(host(gbs[k]), rbs[k]) < TIGHT, (dims, N, k)
