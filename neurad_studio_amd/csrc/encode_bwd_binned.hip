@@ -6,14 +6,19 @@
 // training step.  The per-XCD L2s are not coherent with each other, so there is no cheaper scope to fall back to.
 //
 // This path gives every table entry exactly one owner instead:
-//   pass A (bin_scatter):  the table of a level is cut into LDS-sized slices of TS = 32768/F entries (128 KB of
-//       fp32).  A workgroup takes 1024 or 4096 consecutive samples, parks their contracted positions in LDS, and for
+//   pass A (bin_scatter):  the table of a level is cut into LDS-sized slices of TS = 16384/F entries (128 KB of
+//       64-bit accumulators).  A workgroup takes 1024 or 4096 consecutive samples, parks their contracted positions in LDS, and for
 //       each level bins the (entry, F gradient values) records of its samples by slice: LDS histogram -> one
 //       returning global atomic per non-empty slice to reserve a range of that slice's queue -> records written
 //       at (range base + LDS rank).  Runs of equal entries in neighbouring lanes (consecutive samples of a ray in
 //       the same coarse cell) are summed first, as in the atomic kernel.
 //   pass B (bin_reduce):   one 1024-thread workgroup per (level, slice) streams its queue, accumulates into the
-//       slice image in LDS with ds_add_f32, and adds the image to grad_table with plain 16-byte loads/stores.
+//       slice image in LDS, and adds the image to grad_table with plain 16-byte loads/stores.  The image is 64-bit
+//       FIXED POINT: ds_add_f32 turned out ~10x slower than the integer LDS atomics on gfx950 (493 vs 147 us for
+//       this kernel), so values are scaled by a power of two chosen from the level's largest |value| (found by
+//       pass A) and the slice's record count so that the sum cannot overflow, and added with ds_add_u64.  The
+//       quantum is below 2^-40 of the level's largest term -- finer than the fp32 rounding of the atomic path for
+//       anything that matters -- and integer addition is associative: the result is bit-reproducible run to run.
 // A queue holds 2x the mean record count of its level; records beyond that (never seen in the tests) fall back to
 // the global atomic in pass A, which pass B's read-modify-write then picks up (stream order).
 #include "common.h"
@@ -23,7 +28,7 @@ namespace {
 
 constexpr int kMaxSamplesPerBlock = 4096;  // pass A: 4 samples per thread, 256 or 1024 threads
 constexpr int kMaxSlices = 2048;        // per level (LDS histogram + base table = 16 KB)
-constexpr int kTileFloats = 32768;      // slice image in LDS (128 KB)
+constexpr int kTileBytes = 128 * 1024;   // slice image in LDS
 
 struct BinPlan {
   int log2TS;          // entries per slice
@@ -31,6 +36,7 @@ struct BinPlan {
   uint32_t cap;        // records per queue
   int spb;             // pass A: samples per workgroup (threads = spb / 4)
   int lgroups;         // pass A: the levels are dealt round-robin to this many workgroups per sample chunk
+  int nmax;            // partial maxima per level (pass A waves)
   size_t counter_bytes;
   size_t total_bytes;
 };
@@ -39,7 +45,7 @@ struct BinPlan {
 bool make_plan(const GridDev& g, int64_t n, BinPlan* p) {
   int log2F = 0;
   while ((1 << log2F) < g.F) ++log2F;
-  int log2TS = 15 - log2F;
+  int log2TS = 14 - log2F;  // 8-byte accumulators: 16384 / F entries fill the 128 KB image
   if (log2TS > g.log2T) log2TS = g.log2T;
   // small tables: shrink the slices until pass B has ~2 workgroups per CU (one workgroup owns one slice)
   while (((int64_t)g.L << (g.log2T - log2TS)) < 512 && log2TS > 9) --log2TS;
@@ -58,7 +64,10 @@ bool make_plan(const GridDev& g, int64_t n, BinPlan* p) {
   const int64_t chunks = (n + p->spb - 1) / p->spb;
   int lg = (int)((1024 + chunks - 1) / chunks);
   p->lgroups = lg < 1 ? 1 : (lg > g.L ? g.L : lg);
-  p->counter_bytes = (((size_t)g.L * nb * sizeof(uint32_t)) + 255) & ~(size_t)255;
+  // header: [L * nb] queue fill counters, then [L][chunks * waves] partial maxima of |value| (plain stores, one
+  // slot per wave of pass A: a contended atomicMax on L words costs more than reading the slots back)
+  p->nmax = (int)(chunks * (p->spb / 4 / 64));
+  p->counter_bytes = (((size_t)g.L * (nb + p->nmax) * sizeof(uint32_t)) + 255) & ~(size_t)255;
   p->total_bytes = p->counter_bytes + (size_t)g.L * nb * cap * (g.F + 1) * sizeof(float);
   return true;
 }
@@ -114,6 +123,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, float scal
     __syncthreads();
     // ---- emit ---------------------------------------------------------------------------------------
     float* gl = gt + ((size_t)l << g.log2T) * F;
+    float vmax = 0.f;
     for (int it = 0; it < nit; ++it) {
       const int64_t i0 = i_blk + it * nt + tid;
       const bool live = i0 < n;
@@ -149,13 +159,20 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, float scal
           }
         }
         if (head && live) {
+          bool finite = true;
+#pragma unroll
+          for (int j = 0; j < F; ++j) finite = finite && fabsf(v[j]) <= 3.402823466e38f;
+          if (!finite) {  // Inf/NaN can not go through the fixed-point image: hand them to the atomic directly
+#pragma unroll
+            for (int j = 0; j < F; ++j) unsafeAtomicAdd(gl + (size_t)key * F + j, v[j]), v[j] = 0.f;
+          }
           const uint32_t b = key >> log2TS;
           const uint32_t at = base[b] + atomicAdd(&hist[b], 1u);
           if (at < cap) {
             float* rec = qrec + ((size_t)(l * nb + b) * cap + at) * (F + 1);
             rec[0] = __uint_as_float(key & tsmask);
 #pragma unroll
-            for (int j = 0; j < F; ++j) rec[1 + j] = v[j];
+            for (int j = 0; j < F; ++j) rec[1 + j] = v[j], vmax = fmaxf(vmax, fabsf(v[j]));
           } else {  // queue full: fall back to the memory-side atomic (pass B adds on top of it)
 #pragma unroll
             for (int j = 0; j < F; ++j) unsafeAtomicAdd(gl + (size_t)key * F + j, v[j]);
@@ -163,20 +180,45 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, float scal
         }
       }
     }
+    // level maximum of |value| (non-negative floats order like their bit patterns); NaN/Inf propagate as "huge"
+#pragma unroll
+    for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if (lane == 0) {
+      const int nwave = nt >> 6;
+      float* qmax = reinterpret_cast<float*>(qcount + (size_t)g.L * nb);
+      qmax[((size_t)l * gridDim.x + blockIdx.x) * nwave + (tid >> 6)] = vmax;
+    }
   }
 }
 
 template <int F>
 __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ qcount,
                                                            const float* __restrict__ qrec, float* __restrict__ gt,
-                                                           int log2T, int log2TS, int nb, uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
+                                                           int L, int log2T, int log2TS, int nb, uint32_t cap,
+                                                           int nmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];
+  __shared__ float smax[16];
   const int lb = blockIdx.x;
   const uint32_t filled = qcount[lb];
   if (filled == 0) return;  // uniform: nothing was sent to this slice
   const uint32_t cnt = filled < cap ? filled : cap;
-  const int nfl = F << log2TS;
-  for (int e = threadIdx.x * 4; e < nfl; e += 4096) *reinterpret_cast<float4*>(tile + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int l = lb / nb, b = lb - l * nb;
+  // |value| < 2^(e+1) for every record of the level; cnt < 2^hb records -> |value * 2^sh| < 2^(61-hb), sum < 2^61
+  const float* qmax = reinterpret_cast<const float*>(qcount + (size_t)L * nb) + (size_t)l * nmax;
+  float vmax = 0.f;
+  for (int i = threadIdx.x; i < nmax; i += 1024) vmax = fmaxf(vmax, qmax[i]);
+#pragma unroll
+  for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  vmax = smax[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) vmax = fmaxf(vmax, smax[i]);
+  const int e = (int)((__float_as_uint(vmax) >> 23) & 0xff) - 127;
+  const int hb = 32 - __clz(cnt);
+  const int sh = 61 - hb - (e + 1);
+  const int nacc = F << log2TS;
+  for (int i = threadIdx.x; i < nacc; i += 1024) tile[i] = 0ull;
   __syncthreads();
   const float* rec = qrec + (size_t)lb * cap * (F + 1);
   // 4 records per thread in flight: the loads are independent, only the LDS adds follow them
@@ -184,8 +226,8 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
     float q[4][F + 1];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t e = e0 + u * 1024 + threadIdx.x;
-      const float* src = rec + (size_t)(e < cnt ? e : cnt - 1) * (F + 1);
+      const uint32_t i = e0 + u * 1024 + threadIdx.x;
+      const float* src = rec + (size_t)(i < cnt ? i : cnt - 1) * (F + 1);
 #pragma unroll
       for (int j = 0; j <= F; ++j) q[u][j] = src[j];
     }
@@ -194,22 +236,26 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
       if (e0 + u * 1024 + threadIdx.x < cnt) {
         const uint32_t key = __float_as_uint(q[u][0]);
 #pragma unroll
-        for (int j = 0; j < F; ++j) unsafeAtomicAdd(tile + key * F + j, q[u][1 + j]);
+        for (int j = 0; j < F; ++j) {
+          const long long fx = __float2ll_rn(ldexpf(q[u][1 + j], sh));
+          atomicAdd(tile + key * F + j, (unsigned long long)fx);
+        }
       }
     }
   }
   __syncthreads();
-  const int l = lb / nb, b = lb - l * nb;
   float* out = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
-  if (nfl % 4 == 0) {
-    for (int e = threadIdx.x * 4; e < nfl; e += 4096) {
-      float4 o = *reinterpret_cast<const float4*>(out + e);
-      const float4 t = *reinterpret_cast<const float4*>(tile + e);
-      o.x += t.x, o.y += t.y, o.z += t.z, o.w += t.w;
-      *reinterpret_cast<float4*>(out + e) = o;
+  if (nacc % 4 == 0) {
+    for (int i = threadIdx.x * 4; i < nacc; i += 4096) {
+      float4 o = *reinterpret_cast<const float4*>(out + i);
+      o.x += (float)ldexp((double)(long long)tile[i], -sh);
+      o.y += (float)ldexp((double)(long long)tile[i + 1], -sh);
+      o.z += (float)ldexp((double)(long long)tile[i + 2], -sh);
+      o.w += (float)ldexp((double)(long long)tile[i + 3], -sh);
+      *reinterpret_cast<float4*>(out + i) = o;
     }
   } else {
-    for (int e = threadIdx.x; e < nfl; e += 1024) out[e] += tile[e];
+    for (int i = threadIdx.x; i < nacc; i += 1024) out[i] += (float)ldexp((double)(long long)tile[i], -sh);
   }
 }
 
@@ -274,16 +320,17 @@ extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, 
   NR_DISPATCH_F(gd.F, CALL);
 #undef CALL
   if (int e = check_launch("encode_bwd_binned scatter")) return e;
-  const size_t lds = (size_t)(gd.F << p.log2TS) * sizeof(float);
+  const size_t lds = (size_t)(gd.F << p.log2TS) * sizeof(unsigned long long);
 #define CALL(F)                                                                                                   \
   do {                                                                                                            \
     static thread_local bool configured = false;                                                                  \
     if (!configured) {                                                                                            \
       (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                          kTileFloats * (int)sizeof(float));                                                      \
+                          kTileBytes);                                                                            \
       configured = true;                                                                                          \
     }                                                                                                             \
-    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds, st>>>(qcount, qrec, grad_table, gd.log2T, p.log2TS, p.nb, p.cap); \
+    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds, st>>>(qcount, qrec, grad_table, gd.L, gd.log2T, p.log2TS, p.nb,  \
+                                                         p.cap, p.nmax);                                          \
   } while (0)
   NR_DISPATCH_F(gd.F, CALL);
 #undef CALL

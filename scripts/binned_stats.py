@@ -21,7 +21,7 @@ for (L, F, lg, mn, mx) in [(16, 2, 19, 16, 1024), (8, 4, 22, 32, 8192)]:
     ws = torch.empty((need.value,), device="cuda", dtype=torch.uint8)
     call("nrhip_encode_bwd_binned", C.byref(cg), 100.0, C.byref(r), ops._ptr(go), ops._ptr(gt), ops._ptr(ws), need.value, ops._stream())
     torch.cuda.synchronize()
-    log2ts = min(15 - (F.bit_length() - 1), lg)
+    log2ts = min(14 - (F.bit_length() - 1), lg)
     while (L << (lg - log2ts)) < 512 and log2ts > 9:
         log2ts -= 1
     nb = 1 << (lg - log2ts)

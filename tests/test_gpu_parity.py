@@ -395,12 +395,19 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
     binned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
     binned2 = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, 2 * go)
+    again = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    bad = go.clone()
+    bad[0, 0], bad[-1, -1] = float("inf"), float("nan")
+    poisoned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, bad)
     monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
     atomic = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
     assert torch.isfinite(binned).all()
     assert rel_l2(host(binned), host(atomic)) < 2e-6
     assert (binned - atomic).abs().max() <= 1e-5 * atomic.abs().max()
     assert rel_l2(host(binned2), 2 * host(binned)) < 2e-6
+    # bit-reproducible (integer accumulation is associative), and non-finite gradients still poison their entries
+    assert torch.equal(binned, again)
+    assert not torch.isfinite(poisoned).all() and torch.isfinite(poisoned).float().mean() > 0.5
     # mass conservation: trilinear weights sum to 1, so each feature column's gradient mass is preserved
     rw_go = host(binned).reshape(L, -1, F).sum(1)
     assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
