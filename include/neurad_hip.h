@@ -123,6 +123,11 @@ int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const nrhip_rays* 
  * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  grad_table is
  * ACCUMULATED into, as above. */
 int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_samples, int64_t* bytes);
+/* The same scratch size serves the two other table gradients below (it depends on the grid and the sample count
+ * only): nrhip_hashgrid_bwd_binned == nrhip_hashgrid_bwd, nrhip_proposal_density_bwd_binned ==
+ * nrhip_proposal_density_bwd, without memory-side atomics. */
+int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, const float* grad_out /*[N,L*F]*/, int64_t n,
+                              float* grad_table, void* workspace, int64_t workspace_bytes, void* stream);
 int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
                             const float* grad_out /*[N,L*F]*/, float* grad_table, void* workspace,
                             int64_t workspace_bytes, void* stream);
@@ -181,6 +186,9 @@ int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, 
 /* grad_table / grad_decoder are accumulated into */
 int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
                                const float* grad_density, float* grad_table, float* grad_decoder, void* stream);
+int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
+                                      const float* grad_density, float* grad_table, float* grad_decoder,
+                                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- S3: RaySamples.get_weights (cameras/rays.py:188-210) -------------------------------------- */
 int nrhip_weights_from_density(const float* deltas, const float* densities, int64_t r, int32_t s, float* weights,

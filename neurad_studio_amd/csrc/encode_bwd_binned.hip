@@ -72,27 +72,79 @@ bool make_plan(const GridDev& g, int64_t n, BinPlan* p) {
   return true;
 }
 
-template <int F>
-__global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, float scale, RaysDev r,
-                                                            const float* __restrict__ go, float* __restrict__ gt,
+// Where the samples and their feature gradients come from (pass A is otherwise identical):
+//   position(i) -> (x, y, z in [0,1]^3, aux);  grad(i, l, level scale, aux, gv[F]) -> dL/d(level-l features of sample i)
+struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray samples, gradient of the rescaled features
+  RaysDev r;
+  float scale;
+  const float* go;
+  int L;
+  __device__ int64_t count() const { return r.R * r.S; }
+  __device__ float4 position(int64_t i) const {
+    const int64_t ray = i / r.S;
+    const int s = (int)(i - ray * r.S);
+    const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
+                                        r.ends[ray * r.stride + s], scale);
+    return make_float4(p.x, p.y, p.z, p.std);
+  }
+  template <int F>
+  __device__ void grad(int64_t i, int l, float sc, float std, float (&gv)[F]) const {
+    const float rw = rescale_weight(sc, std);
+#pragma unroll
+    for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k] * rw;
+  }
+};
+struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
+  const float* x;
+  const float* go;
+  int64_t n;
+  int L;
+  __device__ int64_t count() const { return n; }
+  __device__ float4 position(int64_t i) const { return make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f); }
+  template <int F>
+  __device__ void grad(int64_t i, int l, float, float, float (&gv)[F]) const {
+#pragma unroll
+    for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k];
+  }
+};
+struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(decoder . rescaled features), F = 1
+  RaysDev r;
+  float scale;
+  const float* dec;
+  const float* dens;
+  const float* gd;
+  __device__ int64_t count() const { return r.R * r.S; }
+  __device__ float4 position(int64_t i) const {
+    const int64_t ray = i / r.S;
+    const int s = (int)(i - ray * r.S);
+    const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
+                                        r.ends[ray * r.stride + s], scale);
+    return make_float4(p.x, p.y, p.z, p.std);
+  }
+  template <int F>
+  __device__ void grad(int64_t i, int l, float sc, float std, float (&gv)[F]) const {
+    const float xlog = logf(dens[i]);  // activations.py:37-41: g * exp(clamp(x, -15, 15))
+    const float gx = gd[i] * expf(fminf(fmaxf(xlog, -15.f), 15.f));
+    gv[0] = gx * dec[l] * rescale_weight(sc, std);
+  }
+};
+
+template <int F, class Src>
+__global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, float* __restrict__ gt,
                                                             uint32_t* __restrict__ qcount, float* __restrict__ qrec,
                                                             int log2TS, int nb, uint32_t cap, int spb) {
   extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
   uint32_t* hist = reinterpret_cast<uint32_t*>(pos + spb);
   uint32_t* base = hist + nb;
   const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
-  const int64_t n = r.R * r.S;
+  const int64_t n = src.count();
   const int64_t i_blk = (int64_t)blockIdx.x * spb;
   const int nit = (int)(((n - i_blk < spb ? n - i_blk : spb) + nt - 1) / nt);
   for (int it = 0; it < nit; ++it) {
     const int64_t i0 = i_blk + it * nt + tid;
-    const int64_t i = i0 < n ? i0 : n - 1;
-    const int64_t ray = i / r.S;
-    const int s = (int)(i - ray * r.S);
-    const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
-                                        r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
-                                        r.ends[ray * r.stride + s], scale);
-    pos[it * nt + tid] = make_float4(p.x, p.y, p.z, p.std);
+    pos[it * nt + tid] = src.position(i0 < n ? i0 : n - 1);
   }
   const uint32_t mask = (1u << g.log2T) - 1u;
   const uint32_t tsmask = (1u << log2TS) - 1u;
@@ -132,10 +184,12 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, float scal
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
       float w[8];
       corner_weights(c, w);
-      const float rw = live ? rescale_weight(sc, p.w) : 0.f;
       float gv[F];
+      src.template grad<F>(i, l, sc, p.w, gv);
+      if (!live) {
 #pragma unroll
-      for (int k = 0; k < F; ++k) gv[k] = go[(i * g.L + l) * F + k] * rw;
+        for (int k = 0; k < F; ++k) gv[k] = 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t key = c.idx[k];
@@ -281,6 +335,59 @@ extern "C" int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_
   return NRHIP_OK;
 }
 
+namespace {
+
+// Both passes for one source of samples.  `what` names the entry point in error messages.
+template <class Src>
+int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, void* workspace,
+               int64_t workspace_bytes, hipStream_t st) {
+  BinPlan p;
+  NR_REQUIRE(make_plan(gd, n, &p), NRHIP_ERR_UNSUPPORTED,
+             "%s: 2^%d entries x %d features need more than %d slices per level; use the atomic entry point", what,
+             gd.log2T, gd.F, kMaxSlices);
+  NR_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total_bytes, NRHIP_ERR_INVALID_ARG,
+             "%s: workspace of %lld bytes, need %zu", what, (long long)workspace_bytes, p.total_bytes);
+  NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
+             NRHIP_ERR_INVALID_ARG, "%s: workspace and grad_table must be 16-byte aligned", what);
+  uint32_t* qcount = static_cast<uint32_t*>(workspace);
+  float* qrec = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
+  if (hipMemsetAsync(qcount, 0, p.counter_bytes, st) != hipSuccess) return check_launch(what);
+  const dim3 grid_a((unsigned)((n + p.spb - 1) / p.spb), (unsigned)p.lgroups);
+  const int lds_a = p.spb * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
+  constexpr int lds_a_max = kMaxSamplesPerBlock * (int)sizeof(float4) + 2 * kMaxSlices * (int)sizeof(uint32_t);
+#define CALL(F)                                                                                                     \
+  do {                                                                                                              \
+    static thread_local bool configured = false;                                                                    \
+    if (!configured) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<F, Src>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                lds_a_max);                                                                         \
+      configured = true;                                                                                            \
+    }                                                                                                               \
+    bin_scatter_kernel<F, Src><<<grid_a, p.spb / 4, lds_a, st>>>(gd, src, grad_table, qcount, qrec, p.log2TS, p.nb, \
+                                                                 p.cap, p.spb);                                     \
+  } while (0)
+  NR_DISPATCH_F(gd.F, CALL);
+#undef CALL
+  if (int e = check_launch(what)) return e;
+  const size_t lds = (size_t)(gd.F << p.log2TS) * sizeof(unsigned long long);
+#define CALL(F)                                                                                                    \
+  do {                                                                                                             \
+    static thread_local bool configured = false;                                                                   \
+    if (!configured) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                kTileBytes);                                                                       \
+      configured = true;                                                                                           \
+    }                                                                                                              \
+    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds, st>>>(qcount, qrec, grad_table, gd.L, gd.log2T, p.log2TS, p.nb,  \
+                                                         p.cap, p.nmax);                                           \
+  } while (0)
+  NR_DISPATCH_F(gd.F, CALL);
+#undef CALL
+  return check_launch(what);
+}
+
+}  // namespace
+
 extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
                                        const float* grad_out, float* grad_table, void* workspace,
                                        int64_t workspace_bytes, void* stream) {
@@ -290,49 +397,29 @@ extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, 
   const int64_t n = rays->n_rays * rays->n_samples;
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
-  BinPlan p;
-  NR_REQUIRE(make_plan(gd, n, &p), NRHIP_ERR_UNSUPPORTED,
-             "encode_bwd_binned: 2^%d entries x %d features need more than %d slices per level; use nrhip_encode_bwd",
-             gd.log2T, gd.F, kMaxSlices);
-  NR_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total_bytes, NRHIP_ERR_INVALID_ARG,
-             "encode_bwd_binned: workspace of %lld bytes, need %zu", (long long)workspace_bytes, p.total_bytes);
-  NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
-             NRHIP_ERR_INVALID_ARG, "encode_bwd_binned: workspace and grad_table must be 16-byte aligned");
-  const RaysDev rd = to_dev(*rays);
-  const hipStream_t st = (hipStream_t)stream;
-  uint32_t* qcount = static_cast<uint32_t*>(workspace);
-  float* qrec = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
-  if (hipMemsetAsync(qcount, 0, p.counter_bytes, st) != hipSuccess) return check_launch("encode_bwd_binned memset");
-  const dim3 grid_a((unsigned)((n + p.spb - 1) / p.spb), (unsigned)p.lgroups);
-  const int lds_a = p.spb * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
-  constexpr int lds_a_max = kMaxSamplesPerBlock * (int)sizeof(float4) + 2 * kMaxSlices * (int)sizeof(uint32_t);
-#define CALL(F)                                                                                                     \
-  do {                                                                                                              \
-    static thread_local bool configured = false;                                                                    \
-    if (!configured) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                lds_a_max);                                                                         \
-      configured = true;                                                                                            \
-    }                                                                                                               \
-    bin_scatter_kernel<F><<<grid_a, p.spb / 4, lds_a, st>>>(gd, static_scale, rd, grad_out, grad_table, qcount,     \
-                                                            qrec, p.log2TS, p.nb, p.cap, p.spb);                    \
-  } while (0)
-  NR_DISPATCH_F(gd.F, CALL);
-#undef CALL
-  if (int e = check_launch("encode_bwd_binned scatter")) return e;
-  const size_t lds = (size_t)(gd.F << p.log2TS) * sizeof(unsigned long long);
-#define CALL(F)                                                                                                   \
-  do {                                                                                                            \
-    static thread_local bool configured = false;                                                                  \
-    if (!configured) {                                                                                            \
-      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                          kTileBytes);                                                                            \
-      configured = true;                                                                                          \
-    }                                                                                                             \
-    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds, st>>>(qcount, qrec, grad_table, gd.L, gd.log2T, p.log2TS, p.nb,  \
-                                                         p.cap, p.nmax);                                          \
-  } while (0)
-  NR_DISPATCH_F(gd.F, CALL);
-#undef CALL
-  return check_launch("encode_bwd_binned reduce");
+  const EncodeSrc src{to_dev(*rays), static_scale, grad_out, gd.L};
+  return run_binned("encode_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, const float* grad_out, int64_t n,
+                                         float* grad_table, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(x && grad_out && grad_table && n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_binned: bad argument");
+  if (n == 0) return NRHIP_OK;
+  const GridDev gd = to_dev(*g);
+  const GridSrc src{x, grad_out, n, gd.L};
+  return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// grad_table part of nrhip_proposal_density_bwd (the decoder gradient stays with that entry point's kernel)
+namespace nrhip {
+int proposal_table_grad_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
+                               const float* grad_density, float* grad_table, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  const int64_t n = rays->n_rays * rays->n_samples;
+  const GridDev gd = to_dev(p->grid);
+  const ProposalSrc src{to_dev(*rays), p->static_scale, p->decoder_weight, density, grad_density};
+  return run_binned("proposal_density_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}
+}  // namespace nrhip

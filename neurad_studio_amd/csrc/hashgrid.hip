@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, co
 
 // backward of S2 through trunc_exp (activations.py:37-41: g * exp(clamp(x,-15,15))) into the decoder
 // weight and the table.  x = log(density) is recovered from the saved forward output.
+// TABLE=false: decoder gradient only (the table gradient is then produced by the binned path).
+template <bool TABLE>
 __global__ __launch_bounds__(256) void proposal_density_bwd_kernel(GridDev g, const void* __restrict__ table,
                                                                     float scale, const float* __restrict__ dec,
                                                                     RaysDev r, const float* __restrict__ dens,
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void proposal_density_bwd_kernel(GridDev g, co
           float v[1];
           Entry<1, false>::load(table, row0 + c.idx[k], v);
           f += w[k] * v[0];
-          unsafeAtomicAdd(gt + row0 + c.idx[k], w[k] * (gx * dec[l] * rw));
+          if constexpr (TABLE) unsafeAtomicAdd(gt + row0 + c.idx[k], w[k] * (gx * dec[l] * rw));
         }
         gl[l] = gx * f * rw;
       }
@@ -381,8 +383,34 @@ extern "C" int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_r
              NRHIP_ERR_INVALID_ARG, "proposal_density_bwd: null pointer");
   const int64_t n = rays->n_rays * rays->n_samples;
   if (n == 0) return NRHIP_OK;
-  proposal_density_bwd_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+  proposal_density_bwd_kernel<true><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
       to_dev(p->grid), p->table, p->static_scale, p->decoder_weight, to_dev(*rays), density, grad_density, grad_table,
       grad_decoder);
   return check_launch("proposal_density_bwd");
+}
+
+namespace nrhip {
+int proposal_table_grad_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
+                               const float* grad_density, float* grad_table, void* workspace, int64_t workspace_bytes,
+                               void* stream);  // encode_bwd_binned.hip
+}
+
+extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const nrhip_rays* rays,
+                                                 const float* density, const float* grad_density, float* grad_table,
+                                                 float* grad_decoder, void* workspace, int64_t workspace_bytes,
+                                                 void* stream) {
+  NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null descriptor");
+  if (int e = validate_grid(&p->grid)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(p->grid.n_features == 1 && p->grid.num_levels <= 8 && p->grid.param_dtype == 0, NRHIP_ERR_UNSUPPORTED,
+             "proposal_density_bwd_binned: needs F=1, L<=8, fp32 table");
+  NR_REQUIRE(p->table && p->decoder_weight && density && grad_density && grad_table && grad_decoder,
+             NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null pointer");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  if (n == 0) return NRHIP_OK;
+  proposal_density_bwd_kernel<false><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+      to_dev(p->grid), p->table, p->static_scale, p->decoder_weight, to_dev(*rays), density, grad_density, grad_table,
+      grad_decoder);
+  if (int e = check_launch("proposal_density_bwd_binned decoder")) return e;
+  return proposal_table_grad_binned(p, rays, density, grad_density, grad_table, workspace, workspace_bytes, stream);
 }

@@ -146,7 +146,12 @@ def hashgrid_bwd(spec: GridSpec, table_like: Tensor, x: Tensor, grad_out: Tensor
     x, grad_out = _chk(x, "x"), _chk(grad_out, "grad_out")
     gt = torch.zeros((spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
     g = spec.c_grid(gt)
-    call("nrhip_hashgrid_bwd", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), _stream())
+    ws = _table_grad_workspace(g, x.shape[0], x.device)
+    if ws is not None:
+        call("nrhip_hashgrid_bwd_binned", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), _ptr(ws),
+             ws.numel(), _stream())
+    else:
+        call("nrhip_hashgrid_bwd", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), _stream())
     return gt
 
 
@@ -162,6 +167,17 @@ def hashgrid_bwd_input(spec: GridSpec, table: Tensor, x: Tensor, grad_out: Tenso
 _FORCE_ATOMIC_SCATTER = os.environ.get("NRHIP_ENCODE_BWD_ATOMIC") is not None
 
 
+def _table_grad_workspace(c_grid, n_samples: int, device) -> Optional[Tensor]:
+    """Scratch for the atomics-free table gradients (csrc/encode_bwd_binned.hip); None -> use the atomic entry point."""
+    if _FORCE_ATOMIC_SCATTER or n_samples == 0:
+        return None
+    need = C.c_int64(0)
+    call("nrhip_encode_bwd_binned_workspace", C.byref(c_grid), int(n_samples), C.byref(need))
+    if need.value <= 0:
+        return None
+    return torch.empty((need.value,), device=device, dtype=torch.uint8)
+
+
 def encode_fwd(spec: GridSpec, table: Tensor, static_scale: float, origins, directions, pixel_area, starts, ends):
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     out = torch.empty((r.n_rays * r.n_samples, spec.out_dim), device=origins.device, dtype=torch.float32)
@@ -175,12 +191,10 @@ def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_a
     grad_out = _chk(grad_out, "grad_out")
     gt = torch.zeros((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
     g = spec.c_grid(gt)
-    need = C.c_int64(0)
-    call("nrhip_encode_bwd_binned_workspace", C.byref(g), r.n_rays * r.n_samples, C.byref(need))
-    if need.value > 0 and not _FORCE_ATOMIC_SCATTER:
-        ws = torch.empty((need.value,), device=origins.device, dtype=torch.uint8)
+    ws = _table_grad_workspace(g, r.n_rays * r.n_samples, origins.device)
+    if ws is not None:
         call("nrhip_encode_bwd_binned", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt),
-             _ptr(ws), need.value, _stream())
+             _ptr(ws), ws.numel(), _stream())
     else:  # tables too large to cut into LDS slices: memory-side atomics
         call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), _stream())
     return gt
@@ -383,8 +397,13 @@ def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, star
     p, keep2 = ps.c_prop()
     gt = torch.zeros((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
     gdec = torch.zeros((1, ps.grid.num_levels), device=origins.device, dtype=torch.float32)
-    call("nrhip_proposal_density_bwd", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
-         _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _stream())
+    ws = _table_grad_workspace(p.grid, r.n_rays * r.n_samples, origins.device)
+    if ws is not None:
+        call("nrhip_proposal_density_bwd_binned", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
+             _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _ptr(ws), ws.numel(), _stream())
+    else:
+        call("nrhip_proposal_density_bwd", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
+             _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _stream())
     return gt, gdec
 
 

@@ -71,8 +71,10 @@ def test_hash_indices_bit_exact(ops):
     np.testing.assert_array_equal(y.astype(np.int64), idx[:, lvl, 6] - lvl * 2**lg)
 
 
+@pytest.mark.parametrize("atomic", [False, True], ids=["binned", "atomic"])
 @pytest.mark.parametrize("tag", list(HASH_CFGS))
-def test_hashgrid_bwd(ops, tag):
+def test_hashgrid_bwd(ops, tag, atomic, monkeypatch):
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", atomic)
     g = load_golden(f"hashgrid_{tag}")
     L, mn, mx, lg, F = HASH_CFGS[tag]
     spec = ops.GridSpec(L, F, lg, mn, mx)
@@ -320,7 +322,9 @@ def test_fused_proposal_sampler_vs_reference_golden(ops):
     assert rel_l2(host(sps[2][:, :-1]), g["sps"]) < TOL and rel_l2(host(sps[2][:, 1:]), g["spe"]) < TOL
 
 
-def test_proposal_density_bwd(ops):
+@pytest.mark.parametrize("atomic", [False, True], ids=["binned", "atomic"])
+def test_proposal_density_bwd(ops, atomic, monkeypatch):
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", atomic)
     p = prop_params(95)
     ps = to_pspec(ops, p)
     R, S = 11, 40
