@@ -181,14 +181,16 @@ int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_fe
                      void* stream);
 
 /* ---- S2: NeuRADProposalField.get_density (neurad_field.py:208-213) ----------------------------- */
+/* level_features (may be NULL): [R*S, L] rescaled per-level features, saved for the decoder gradient */
 int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, float* density /*[R,S]*/,
-                               void* stream);
+                               float* level_features, void* stream);
 /* grad_table / grad_decoder are accumulated into */
 int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
                                const float* grad_density, float* grad_table, float* grad_decoder, void* stream);
+/* level_features: what the forward saved, or NULL (the interpolated features are then recomputed) */
 int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
-                                      const float* grad_density, float* grad_table, float* grad_decoder,
-                                      void* workspace, int64_t workspace_bytes, void* stream);
+                                      const float* level_features, const float* grad_density, float* grad_table,
+                                      float* grad_decoder, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- S3: RaySamples.get_weights (cameras/rays.py:188-210) -------------------------------------- */
 int nrhip_weights_from_density(const float* deltas, const float* densities, int64_t r, int32_t s, float* weights,

@@ -86,9 +86,9 @@ PROTOTYPES = {
     "nrhip_composite_fwd": [P, P, P, P, I64, I32, I32, P, P, P, P],
     "nrhip_composite_bwd": [P, P, P, P, P, P, P, I64, I32, I32, P, P, P],
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
-    "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P],
+    "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
-    "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I64, P],
+    "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, P, I64, P],
     "nrhip_weights_from_density": [P, P, I64, I32, P, P],
     "nrhip_weights_from_density_bwd": [P, P, P, I64, I32, P, P],
     "nrhip_power_sampler": [P, P, I64, I32, F32, F32, P, P, P, P],

@@ -181,14 +181,16 @@ class ProposalDensityFn(torch.autograd.Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, table, decoder_weight, spec, static_scale, origins, directions, pixel_area, starts, ends):
         ps = ops.ProposalSpec(spec, table, static_scale, decoder_weight)
-        dens = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends)
+        if not (table.requires_grad or decoder_weight.requires_grad):  # eval / frozen: nothing to save
+            return ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends)
+        dens, lf = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends, save_features=True)
         ctx.ps = ps
-        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, dens)
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, dens, lf)
         return dens
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        o, d, a, s, e, dens = ctx.saved_tensors
-        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g.contiguous())
+        o, d, a, s, e, dens, lf = ctx.saved_tensors
+        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g.contiguous(), level_features=lf)
         return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None, None

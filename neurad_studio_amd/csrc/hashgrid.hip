@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void sh4_kernel(const float* __restrict__ d, i
 template <bool HALF>
 __global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, const void* __restrict__ table,
                                                                     float scale, const float* __restrict__ dec,
-                                                                    RaysDev r, float* __restrict__ dens) {
+                                                                    RaysDev r, float* __restrict__ dens,
+                                                                    float* __restrict__ lf) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= r.R * r.S) return;
   const int64_t ray = i / r.S;
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, co
   for (int l = 0; l < g.L; ++l) {
     float v[1];
     hash_level<1, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
-    acc += (v[0] * rescale_weight(g.scal[l], p.std)) * dec[l];
+    const float f = v[0] * rescale_weight(g.scal[l], p.std);
+    if (lf) lf[i * g.L + l] = f;  // saved for the decoder gradient (training)
+    acc += f * dec[l];
   }
   dens[i] = expf(acc);
 }
@@ -349,7 +352,7 @@ extern "C" int nrhip_sh4_fwd(const float* dirs, int64_t n, float* out, void* str
   return check_launch("sh4_fwd");
 }
 
-extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, float* density,
+extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, float* density, float* level_features,
                                           void* stream) {
   NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_fwd: null descriptor");
   if (int e = validate_grid(&p->grid)) return e;
@@ -364,10 +367,10 @@ extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_r
   const RaysDev rd = to_dev(*rays);
   if (gd.dtype == 1)
     proposal_density_fwd_kernel<true><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
-        gd, p->table, p->static_scale, p->decoder_weight, rd, density);
+        gd, p->table, p->static_scale, p->decoder_weight, rd, density, level_features);
   else
     proposal_density_fwd_kernel<false><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
-        gd, p->table, p->static_scale, p->decoder_weight, rd, density);
+        gd, p->table, p->static_scale, p->decoder_weight, rd, density, level_features);
   return check_launch("proposal_density_fwd");
 }
 
@@ -390,15 +393,44 @@ extern "C" int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_r
 }
 
 namespace nrhip {
+// decoder gradient from the per-level features the forward saved: d dec[l] = sum_i g_i * exp(clamp(x_i)) * f_il
+__global__ __launch_bounds__(256) void proposal_decoder_grad_kernel(const float* __restrict__ lf,
+                                                                     const float* __restrict__ dens,
+                                                                     const float* __restrict__ gd, int64_t n, int L,
+                                                                     float* __restrict__ gdec) {
+  float gl[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) gl[l] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gx = gd[i] * expf(fminf(fmaxf(logf(dens[i]), -15.f), 15.f));
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < L) gl[l] = fmaf(gx, lf[i * L + l], gl[l]);
+  }
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    float v = gl[l];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wid][l] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < L) unsafeAtomicAdd(gdec + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                               red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+}  // namespace nrhip
+
+namespace nrhip {
 int proposal_table_grad_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
                                const float* grad_density, float* grad_table, void* workspace, int64_t workspace_bytes,
                                void* stream);  // encode_bwd_binned.hip
 }
 
 extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const nrhip_rays* rays,
-                                                 const float* density, const float* grad_density, float* grad_table,
-                                                 float* grad_decoder, void* workspace, int64_t workspace_bytes,
-                                                 void* stream) {
+                                                 const float* density, const float* level_features,
+                                                 const float* grad_density, float* grad_table, float* grad_decoder,
+                                                 void* workspace, int64_t workspace_bytes, void* stream) {
   NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null descriptor");
   if (int e = validate_grid(&p->grid)) return e;
   if (int e = validate_rays(rays)) return e;
@@ -408,9 +440,16 @@ extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const 
              NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null pointer");
   const int64_t n = rays->n_rays * rays->n_samples;
   if (n == 0) return NRHIP_OK;
-  proposal_density_bwd_kernel<false><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
-      to_dev(p->grid), p->table, p->static_scale, p->decoder_weight, to_dev(*rays), density, grad_density, grad_table,
-      grad_decoder);
+  if (level_features) {
+    int blocks = grid_for(n, 256);
+    if (blocks > 1024) blocks = 1024;
+    proposal_decoder_grad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(level_features, density, grad_density, n,
+                                                                        p->grid.num_levels, grad_decoder);
+  } else {  // forward did not save them: recompute the interpolated features
+    proposal_density_bwd_kernel<false><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+        to_dev(p->grid), p->table, p->static_scale, p->decoder_weight, to_dev(*rays), density, grad_density,
+        grad_table, grad_decoder);
+  }
   if (int e = check_launch("proposal_density_bwd_binned decoder")) return e;
   return proposal_table_grad_binned(p, rays, density, grad_density, grad_table, workspace, workspace_bytes, stream);
 }

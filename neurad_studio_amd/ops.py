@@ -384,15 +384,19 @@ class ProposalSpec:
         return p, dw
 
 
-def proposal_density_fwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends) -> Tensor:
+def proposal_density_fwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends, save_features: bool = False):
+    """density [R,S]; with save_features also the rescaled per-level features [R*S, L] the backward wants."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     p, keep2 = ps.c_prop()
     dens = torch.empty((r.n_rays, r.n_samples), device=origins.device, dtype=torch.float32)
-    call("nrhip_proposal_density_fwd", C.byref(p), C.byref(r), _ptr(dens), _stream())
-    return dens
+    lf = (torch.empty((r.n_rays * r.n_samples, ps.grid.num_levels), device=origins.device, dtype=torch.float32)
+          if save_features else None)
+    call("nrhip_proposal_density_fwd", C.byref(p), C.byref(r), _ptr(dens), _ptr(lf), _stream())
+    return (dens, lf) if save_features else dens
 
 
-def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends, density, grad_density):
+def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends, density, grad_density,
+                         level_features: Optional[Tensor] = None):
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     p, keep2 = ps.c_prop()
     gt = torch.zeros((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
@@ -400,7 +404,8 @@ def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, star
     ws = _table_grad_workspace(p.grid, r.n_rays * r.n_samples, origins.device)
     if ws is not None:
         call("nrhip_proposal_density_bwd_binned", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
-             _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _ptr(ws), ws.numel(), _stream())
+             _ptr(level_features), _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _ptr(ws),
+             ws.numel(), _stream())
     else:
         call("nrhip_proposal_density_bwd", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
              _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _stream())

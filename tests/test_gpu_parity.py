@@ -345,6 +345,12 @@ def test_proposal_density_bwd(ops, atomic, monkeypatch):
     g_enc = (gx * p.decoder_w.astype(np.float64)) * rw
     ref_t = O.hashgrid_bwd(pos.reshape(-1, 3), g_enc, sc, p.grid.table_size, 6 * p.grid.table_size, 1)
     assert rel_l2(host(gt), ref_t) < TOL
+    # training path: the forward saves the rescaled per-level features, the decoder gradient streams them back
+    dens2, lf = ops.proposal_density_fwd(ps, dev(o), dev(d), dev(area), dev(s), dev(e), save_features=True)
+    assert torch.equal(dens2, dens) and rel_l2(host(lf), enc) < TIGHT
+    gt2, gdec2 = ops.proposal_density_bwd(ps, dev(o), dev(d), dev(area), dev(s), dev(e), dens, dev(gd),
+                                          level_features=lf)
+    assert rel_l2(host(gdec2)[0], ref_dec) < TOL and rel_l2(host(gt2), ref_t) < TOL
 
 
 def test_empty_batches(ops):
