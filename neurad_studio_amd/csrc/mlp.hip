@@ -225,10 +225,34 @@ __global__ __launch_bounds__(256) void mlp_bwd_data_kernel(MlpDev m, const float
 // weight gradient: dW[o][i] += Σ_n dz[n][o] * h[n][i] ; db[o] += Σ_n dz[n][o].
 // MFMA with K = samples: A[o][n] = dz (lane: o = lane&15, n = lane>>4), B[n][i] = h.  One workgroup owns a
 // 64x64 sub-matrix (blockIdx.y) and a slice of the samples (blockIdx.x); fp32 atomics merge the slices.
-__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const float* __restrict__ dzp, int dz_ld, int out,
-                                                         const float* __restrict__ hp, int h_ld, int in, int64_t n,
-                                                         int nb_in, float* __restrict__ dW, float* __restrict__ db) {
-  const int ob = blockIdx.y / nb_in, ib = blockIdx.y % nb_in;  // 64-wide sub-matrix coordinates
+struct WgradLayer {
+  const float* dz;  // [N, dz_ld]: gradient w.r.t. the layer's pre-activation
+  const float* h;   // [N, h_ld]:  the layer's input
+  float* dW;        // [out][in], accumulated into
+  float* db;        // [out] or nullptr
+  int dz_ld, h_ld, out, in, nb_in;
+  int sub0;         // first blockIdx.y of this layer (64x64 sub-matrices are numbered layer by layer)
+};
+struct WgradArgs {
+  WgradLayer layer[NRHIP_MAX_LAYERS];
+  int nl;
+};
+
+// All layers of an MLP in ONE launch: a single layer's grid (<= 256 sample slices) is one wave per SIMD and runs at
+// memory latency; with the layers side by side the CU overlaps them.
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a, int64_t n) {
+  int li = 0;
+#pragma unroll
+  for (int l = 1; l < NRHIP_MAX_LAYERS; ++l)
+    if (l < a.nl && (int)blockIdx.y >= a.layer[l].sub0) li = l;
+  const WgradLayer& L = a.layer[li];
+  const float* __restrict__ dzp = L.dz;
+  const float* __restrict__ hp = L.h;
+  float* __restrict__ dW = L.dW;
+  float* __restrict__ db = L.db;
+  const int dz_ld = L.dz_ld, h_ld = L.h_ld, out = L.out, in = L.in, nb_in = L.nb_in;
+  const int sub = (int)blockIdx.y - L.sub0;
+  const int ob = sub / nb_in, ib = sub % nb_in;  // 64-wide sub-matrix coordinates
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   f32x4 acc[4][4];
@@ -418,19 +442,27 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
     if (int e = check_launch("mlp_bwd_data")) return e;
   }
   const int hid_ld = (d.nl - 1) * d.hidden;
+  WgradArgs wa{};
+  int nsub = 0;
   for (int l = 0; l < d.nl; ++l) {
     if (!grad_weight[l]) continue;
     const int in = layer_in(d, l), out = layer_out(d, l);
-    const float* dzp = (l == d.nl - 1) ? grad_y : workspace + (size_t)l * d.hidden;
-    const int dz_ld = (l == d.nl - 1) ? d.out_dim : hid_ld;
-    const float* hp = (l == 0) ? x : hidden + (size_t)(l - 1) * d.hidden;
-    const int h_ld = (l == 0) ? d.in_dim : hid_ld;
-    const int nb_out = (out + 63) / 64, nb_in = (in + 63) / 64;
+    WgradLayer& L = wa.layer[wa.nl++];
+    L.dz = (l == d.nl - 1) ? grad_y : workspace + (size_t)l * d.hidden;
+    L.dz_ld = (l == d.nl - 1) ? d.out_dim : hid_ld;
+    L.h = (l == 0) ? x : hidden + (size_t)(l - 1) * d.hidden;
+    L.h_ld = (l == 0) ? d.in_dim : hid_ld;
+    L.dW = grad_weight[l];
+    L.db = grad_bias ? grad_bias[l] : nullptr;
+    L.out = out, L.in = in, L.nb_in = (in + 63) / 64;
+    L.sub0 = nsub;
+    nsub += ((out + 63) / 64) * L.nb_in;
+  }
+  if (wa.nl > 0) {
     int64_t bx = ((n + 3) / 4 + 4 * 64 - 1) / (4 * 64);  // >= 64 sample-quads per wave
     if (bx > 256) bx = 256;  // every workgroup ends in out*in memory-side atomics: measured optimum on 524 288 samples
     if (bx < 1) bx = 1;
-    mlp_wgrad_kernel<<<dim3((unsigned)bx, (unsigned)(nb_out * nb_in)), 256, 0, st>>>(
-        dzp, dz_ld, out, hp, h_ld, in, n, nb_in, grad_weight[l], grad_bias ? grad_bias[l] : nullptr);
+    mlp_wgrad_kernel<<<dim3((unsigned)bx, (unsigned)nsub), 256, 0, st>>>(wa, n);
     if (int e = check_launch("mlp_wgrad")) return e;
   }
   return NRHIP_OK;
