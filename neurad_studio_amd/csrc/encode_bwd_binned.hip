@@ -29,6 +29,7 @@ namespace {
 constexpr int kMaxSamplesPerBlock = 4096;  // pass A: 4 samples per thread, 256 or 1024 threads
 constexpr int kMaxSlices = 2048;        // per level (LDS histogram + base table = 16 KB)
 constexpr int kTileBytes = 128 * 1024;   // slice image in LDS
+constexpr int64_t kChunkSamples = 1 << 20;  // samples per (pass A, pass B) round: bounds the scratch (3.2 GB on config 2)
 
 struct BinPlan {
   int log2TS;          // entries per slice
@@ -42,7 +43,8 @@ struct BinPlan {
 };
 
 // Returns false when the grid can not be binned (too many slices per level).
-bool make_plan(const GridDev& g, int64_t n, BinPlan* p) {
+bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
+  const int64_t n = n_total < kChunkSamples ? n_total : kChunkSamples;  // larger batches go through in rounds
   int log2F = 0;
   while ((1 << log2F) < g.F) ++log2F;
   int log2TS = 14 - log2F;  // 8-byte accumulators: 16384 / F entries fill the 128 KB image
@@ -134,17 +136,17 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
 template <int F, class Src>
 __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, float* __restrict__ gt,
                                                             uint32_t* __restrict__ qcount, float* __restrict__ qrec,
-                                                            int log2TS, int nb, uint32_t cap, int spb) {
+                                                            int log2TS, int nb, uint32_t cap, int spb,
+                                                            int64_t i_off, int64_t n, int nmax) {
   extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
   uint32_t* hist = reinterpret_cast<uint32_t*>(pos + spb);
   uint32_t* base = hist + nb;
   const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
-  const int64_t n = src.count();
-  const int64_t i_blk = (int64_t)blockIdx.x * spb;
+  const int64_t i_blk = (int64_t)blockIdx.x * spb;  // sample i of this round is sample i_off + i of the source
   const int nit = (int)(((n - i_blk < spb ? n - i_blk : spb) + nt - 1) / nt);
   for (int it = 0; it < nit; ++it) {
     const int64_t i0 = i_blk + it * nt + tid;
-    pos[it * nt + tid] = src.position(i0 < n ? i0 : n - 1);
+    pos[it * nt + tid] = src.position(i_off + (i0 < n ? i0 : n - 1));
   }
   const uint32_t mask = (1u << g.log2T) - 1u;
   const uint32_t tsmask = (1u << log2TS) - 1u;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
       float w[8];
       corner_weights(c, w);
       float gv[F];
-      src.template grad<F>(i, l, sc, p.w, gv);
+      src.template grad<F>(i_off + i, l, sc, p.w, gv);
       if (!live) {
 #pragma unroll
         for (int k = 0; k < F; ++k) gv[k] = 0.f;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
     if (lane == 0) {
       const int nwave = nt >> 6;
       float* qmax = reinterpret_cast<float*>(qcount + (size_t)g.L * nb);
-      qmax[((size_t)l * gridDim.x + blockIdx.x) * nwave + (tid >> 6)] = vmax;
+      qmax[(size_t)l * nmax + (size_t)blockIdx.x * nwave + (tid >> 6)] = vmax;
     }
   }
 }
@@ -351,10 +353,13 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
              NRHIP_ERR_INVALID_ARG, "%s: workspace and grad_table must be 16-byte aligned", what);
   uint32_t* qcount = static_cast<uint32_t*>(workspace);
   float* qrec = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
-  if (hipMemsetAsync(qcount, 0, p.counter_bytes, st) != hipSuccess) return check_launch(what);
-  const dim3 grid_a((unsigned)((n + p.spb - 1) / p.spb), (unsigned)p.lgroups);
   const int lds_a = p.spb * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
   constexpr int lds_a_max = kMaxSamplesPerBlock * (int)sizeof(float4) + 2 * kMaxSlices * (int)sizeof(uint32_t);
+  const size_t lds_b = (size_t)(gd.F << p.log2TS) * sizeof(unsigned long long);
+  for (int64_t i_off = 0; i_off < n; i_off += kChunkSamples) {
+    const int64_t cnt = n - i_off < kChunkSamples ? n - i_off : kChunkSamples;
+    if (hipMemsetAsync(qcount, 0, p.counter_bytes, st) != hipSuccess) return check_launch(what);
+    const dim3 grid_a((unsigned)((cnt + p.spb - 1) / p.spb), (unsigned)p.lgroups);
 #define CALL(F)                                                                                                     \
   do {                                                                                                              \
     static thread_local bool configured = false;                                                                    \
@@ -364,12 +369,11 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
       configured = true;                                                                                            \
     }                                                                                                               \
     bin_scatter_kernel<F, Src><<<grid_a, p.spb / 4, lds_a, st>>>(gd, src, grad_table, qcount, qrec, p.log2TS, p.nb, \
-                                                                 p.cap, p.spb);                                     \
+                                                                 p.cap, p.spb, i_off, cnt, p.nmax);                 \
   } while (0)
-  NR_DISPATCH_F(gd.F, CALL);
+    NR_DISPATCH_F(gd.F, CALL);
 #undef CALL
-  if (int e = check_launch(what)) return e;
-  const size_t lds = (size_t)(gd.F << p.log2TS) * sizeof(unsigned long long);
+    if (int e = check_launch(what)) return e;
 #define CALL(F)                                                                                                    \
   do {                                                                                                             \
     static thread_local bool configured = false;                                                                   \
@@ -378,12 +382,14 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
                                 kTileBytes);                                                                       \
       configured = true;                                                                                           \
     }                                                                                                              \
-    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds, st>>>(qcount, qrec, grad_table, gd.L, gd.log2T, p.log2TS, p.nb,  \
-                                                         p.cap, p.nmax);                                           \
+    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds_b, st>>>(qcount, qrec, grad_table, gd.L, gd.log2T, p.log2TS,      \
+                                                           p.nb, p.cap, p.nmax);                                   \
   } while (0)
-  NR_DISPATCH_F(gd.F, CALL);
+    NR_DISPATCH_F(gd.F, CALL);
 #undef CALL
-  return check_launch(what);
+    if (int e = check_launch(what)) return e;
+  }
+  return NRHIP_OK;
 }
 
 }  // namespace

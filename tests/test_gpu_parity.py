@@ -391,7 +391,7 @@ def test_full_size_properties_config2(ops):
 
 
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 4096, 128), (8, 4, 16, 257, 33), (4, 8, 12, 64, 7), (6, 1, 20, 300, 48),
-                                 (2, 4, 9, 5, 3)])
+                                 (2, 4, 9, 5, 3), (6, 1, 14, 9001, 128)])  # last: > 2^20 samples -> two rounds
 def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     """B1 table gradient: the owner-computes path (LDS slices, no memory-side atomics) against the atomic
     scatter-add, from BASELINE config 2 at full size down to ragged batches and tables smaller than one slice.
