@@ -163,13 +163,9 @@ __device__ __forceinline__ void hash_lerp(const float (&f)[8][F], float ox, floa
   }
 }
 
-template <int F, bool HALF>
-__device__ __forceinline__ void hash_level(const void* table, uint32_t level_row0, float x, float y, float z,
-                                           float scale, uint32_t mask, float (&out)[F]) {
-  const Corners c = hash_corners(x, y, z, scale, mask);
-  float f[8][F];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(table, level_row0 + c.idx[k], f[k]);
+// trilinear blend of the 8 corner entries, reference order of operations (encodings.py:446-464)
+template <int F>
+__device__ __forceinline__ void lerp_corners(const Corners& c, const float (&f)[8][F], float (&out)[F]) {
   const float ox = c.ox, oy = c.oy, oz = c.oz;
   const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
 #pragma unroll
@@ -183,6 +179,16 @@ __device__ __forceinline__ void hash_level(const void* table, uint32_t level_row
     const float f4756 = fmaf(f47, oy, f56 * my);
     out[i] = fmaf(f0312, oz, f4756 * mz);
   }
+}
+
+template <int F, bool HALF>
+__device__ __forceinline__ void hash_level(const void* table, uint32_t level_row0, float x, float y, float z,
+                                           float scale, uint32_t mask, float (&out)[F]) {
+  const Corners c = hash_corners(x, y, z, scale, mask);
+  float f[8][F];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(table, level_row0 + c.idx[k], f[k]);
+  lerp_corners<F>(c, f, out);
 }
 
 // Trilinear corner weights in the same corner order (for the scatter-add backward).

@@ -200,15 +200,28 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
       const SamplePos p = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, fd.scale);
 
       // ---- gather: LPL levels x 8 corners, rescaled (H1 + H4) ------------------------------------
+      // All 8*LPL gathers of the tile are issued before the first lerp: one memory round trip per tile
+      // instead of one per level (the loads of a level would otherwise wait for the previous level's blend).
       float feat[8];
+      {
+        Corners cs[LPL];
+        float fv[LPL][8][F];
 #pragma unroll
-      for (int q = 0; q < LPL; ++q) {
-        const int l = LPL * g + q;
-        float v[F];
-        hash_level<F, HALF>(fd.table, (uint32_t)l << fd.grid.log2T, p.x, p.y, p.z, scal_l[q], mask, v);
-        const float w = rescale_weight(scal_l[q], p.std);
+        for (int q = 0; q < LPL; ++q) cs[q] = hash_corners(p.x, p.y, p.z, scal_l[q], mask);
 #pragma unroll
-        for (int f = 0; f < F; ++f) feat[q * F + f] = v[f] * w;
+        for (int q = 0; q < LPL; ++q)
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            Entry<F, HALF>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs[q].idx[k], fv[q][k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < LPL; ++q) {
+          float v[F];
+          lerp_corners<F>(cs[q], fv[q], v);
+          const float w = rescale_weight(scal_l[q], p.std);
+#pragma unroll
+          for (int f = 0; f < F; ++f) feat[q * F + f] = v[f] * w;
+        }
       }
 
       // ---- geo MLP layer 0 (32 -> H, ReLU) ---------------------------------------------------------
