@@ -149,6 +149,13 @@ int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const
  * feature [R,S,C], sdf_or_raw [R,S] (sdf when use_sdf else the pre-exp geo output), alpha_or_density [R,S] */
 int nrhip_field_fwd(const nrhip_field* f, const nrhip_rays* rays, float* feature, float* sdf, float* alpha,
                     void* stream);
+/* Training forward: the same kernel, additionally storing what nrhip_mlp_bwd / nrhip_encode_bwd* need, in their
+ * layouts (N = R*S, H = hidden width, all 16-byte aligned):  save_enc [N,32] rescaled grid features (geometry MLP
+ * input), save_geo_hidden [N,H], save_feat_in [N,48] = geometry embedding | SH(direction) (feature MLP input),
+ * save_feat_hidden [N,2H] = layer 0 | layer 1.  Replaces encode_fwd + 2x mlp_fwd + sh4 + concat of the operator path. */
+int nrhip_field_fwd_train(const nrhip_field* f, const nrhip_rays* rays, float* feature, float* sdf, float* alpha,
+                          float* save_enc, float* save_geo_hidden, float* save_feat_in, float* save_feat_hidden,
+                          void* stream);
 
 /* ---- C1: nerfacc 0.5.2 dense-mode (call sites models/neurad.py:716-723,734; renderers.py:88,345) */
 int nrhip_render_weight_from_alpha(const float* alphas /*[R,S]*/, int64_t r, int32_t s, float* weights,

@@ -52,6 +52,39 @@ class EncodeFn(torch.autograd.Function):
         return gt, None, None, None, None, None, None, None
 
 
+class FieldTrainFn(torch.autograd.Function):
+    """NeuRADField.forward for the static scene in ONE kernel, with the hand-written backward chained behind it
+    (neurad_field.py:128-152).  Forward = the fused field kernel storing its activations; backward = feature-MLP
+    gradients -> residual -> geometry-MLP gradients -> table gradient.  Replaces EncodeFn + 2x MLPFn + SH + concat.
+
+    args: table, spec, static_scale, use_sdf, beta, o, d, area, starts, ends, gw0, gb0, gw1, gb1, fw0, fb0, fw1, fb1, fw2, fb2
+    returns feature [N,32], geo_out [N,1] (sdf, or the pre-exp density logit)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, table, spec, static_scale, use_sdf, beta, origins, directions, pixel_area, starts, ends, *params):
+        gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
+        fs = ops.FieldSpec(spec, table, static_scale, gw, gb, fw, fb, use_sdf=use_sdf, beta=beta)
+        (feature, geo_out, _head), (enc, hg, xf, hf) = ops.field_fwd_train(fs, origins, directions, pixel_area, starts, ends)
+        ctx.spec, ctx.scale = spec, static_scale
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, enc, hg, xf, hf, *params)
+        return feature, geo_out[:, None]
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_feature, g_geo_out):
+        o, d, a, s, e, enc, hg, xf, hf, *params = ctx.saved_tensors
+        gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
+        g_feature = g_feature.contiguous()
+        # feature = embedding + mlp_feature([embedding | sh])
+        gxf, gfw, gfb = ops.mlp_bwd(xf, hf, g_feature, fw, fb)
+        g_geo = torch.cat([g_geo_out.reshape(-1, 1), g_feature + gxf[:, :32]], dim=1)
+        genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
+        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc) if ctx.needs_input_grad[0] else None
+        grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
+        return (gt, None, None, None, None, None, None, None, None, None, *grads)
+
+
 class MLPFn(torch.autograd.Function):
     """MLP.pytorch_fwd (mlp.py:159-178).  args: x, n_layers, w0, b0, w1, b1, ... (b may be None)."""
 

@@ -35,6 +35,15 @@ struct FieldDev {
 
 // LDS carve (floats), H = hidden width.  Fragment-ordered weights use [mb][s/4][lane][s%4] so that one
 // ds_read_b128 fetches the A fragments of 4 consecutive k-steps.
+// Training forward (nrhip_field_fwd_train): what the hand-written backward needs, written in the layouts the
+// operator-level kernels read ([N, width] row-major).  All null for inference.
+struct SaveDev {
+  float* enc;  // [N, 32]   rescaled grid features = input of the geometry MLP
+  float* hg;   // [N, H]    geometry MLP hidden activations (post-ReLU)
+  float* xf;   // [N, 48]   feature MLP input: geometry embedding (32) | SH of the ray direction (16)
+  float* hf;   // [N, 2H]   feature MLP hidden activations, layer 0 | layer 1
+};
+
 template <int H>
 struct Lds {
   static constexpr int NB = H / 16;        // 16-neuron blocks of a hidden layer
@@ -85,7 +94,7 @@ template <int L, int F, int H, bool HALF, bool COMPOSITE>
 __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev rays, float* __restrict__ out_feat,
                                                         float* __restrict__ out_depth, float* __restrict__ out_acc,
                                                         float* __restrict__ out_w, float* __restrict__ out_sdf,
-                                                        float* __restrict__ out_alpha) {
+                                                        float* __restrict__ out_alpha, SaveDev sv) {
   static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
   using Ld = Lds<H>;
@@ -167,9 +176,15 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
 
     // per-ray part of feat layer 0:  rb[n] = fb0[n] + Σ_c fw0[n][32+c] * SH_c((d+1)/2)   (neurad_field.py:140-141)
     f32x4 rb[NB];
+    f32x4 shq = f32x4{0.f, 0.f, 0.f, 0.f};  // SH coefficients 4g..4g+3 (only read when saving for the backward)
     {
       float sh[16];
       sh4((dx + 1.f) / 2.f, (dy + 1.f) / 2.f, (dz + 1.f) / 2.f, sh);
+      if constexpr (!COMPOSITE) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if ((c >> 2) == g) shq[c & 3] = sh[c];
+      }
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) rb[mb] = *reinterpret_cast<const f32x4*>(lds + Ld::BF0 + 16 * mb + 4 * g);
 #pragma unroll
@@ -224,6 +239,18 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
         }
       }
 
+      bool saving = false;
+      int64_t srow = 0;
+      if constexpr (!COMPOSITE) {
+        saving = sv.enc != nullptr && live;
+        srow = ray * S + s;
+        if (saving) {
+          float* ep = sv.enc + srow * 32 + 8 * g;
+          *reinterpret_cast<f32x4*>(ep) = f32x4{feat[0], feat[1], feat[2], feat[3]};
+          *reinterpret_cast<f32x4*>(ep + 4) = f32x4{feat[4], feat[5], feat[6], feat[7]};
+        }
+      }
+
       // ---- geo MLP layer 0 (32 -> H, ReLU) ---------------------------------------------------------
       f32x4 h[NB];
 #pragma unroll
@@ -234,6 +261,15 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
       for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+
+      if constexpr (!COMPOSITE) {
+        if (saving) {
+#pragma unroll
+          for (int mb = 0; mb < NB; ++mb)
+            *reinterpret_cast<f32x4*>(sv.hg + srow * H + 16 * mb + 4 * g) =
+                f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
+        }
+      }
 
       // ---- geo MLP layer 1 (H -> 1 + 32): row 0 (sdf / raw density) on the VALU, rows 1..32 on MFMA --
       float sdf = 0.f;
@@ -258,6 +294,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
       for (int k = 0; k < 8; ++k) eb[k] = e[k >> 2][k & 3];
 
       // ---- feature MLP (32 [+16 SH folded into rb] -> H -> H -> 32), residual add -------------------
+      if constexpr (!COMPOSITE) {
+        if (saving) {
+          float* xp = sv.xf + srow * 48;
+          *reinterpret_cast<f32x4*>(xp + 4 * g) = e[0];
+          *reinterpret_cast<f32x4*>(xp + 16 + 4 * g) = e[1];
+          *reinterpret_cast<f32x4*>(xp + 32 + 4 * g) = shq;
+        }
+      }
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) h[mb] = rb[mb];
       mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
@@ -265,6 +309,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
       for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+      if constexpr (!COMPOSITE) {
+        if (saving) {
+#pragma unroll
+          for (int mb = 0; mb < NB; ++mb)
+            *reinterpret_cast<f32x4*>(sv.hf + srow * (2 * H) + 16 * mb + 4 * g) =
+                f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
+        }
+      }
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF1 + 16 * mb + 4 * g);
       mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
@@ -272,6 +324,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
       for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+      if constexpr (!COMPOSITE) {
+        if (saving) {
+#pragma unroll
+          for (int mb = 0; mb < NB; ++mb)
+            *reinterpret_cast<f32x4*>(sv.hf + srow * (2 * H) + H + 16 * mb + 4 * g) =
+                f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
+        }
+      }
       f32x4 o[2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) o[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF2 + 16 * mb + 4 * g);
@@ -394,7 +454,7 @@ static FieldDev to_dev(const nrhip_field& f) {
 
 template <int L, int F, int H, bool HALF, bool COMPOSITE>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
-                         float* oal, hipStream_t st) {
+                         float* oal, const SaveDev& sv, hipStream_t st) {
   constexpr size_t lds = Lds<H>::TOTAL * sizeof(float);
   auto kern = render_kernel<L, F, H, HALF, COMPOSITE>;
   static bool configured = false;
@@ -424,13 +484,13 @@ static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float
   }
   const int64_t cap = (int64_t)n_cu * per_cu;
   if (blocks > cap) blocks = cap;
-  kern<<<(int)blocks, 256, lds, st>>>(fd, rd, of, od, oa, ow, os, oal);
+  kern<<<(int)blocks, 256, lds, st>>>(fd, rd, of, od, oa, ow, os, oal, sv);
   return check_launch("render/field fused kernel");
 }
 
 template <bool COMPOSITE>
 static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
-                           float* os, float* oal, void* stream) {
+                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{}) {
   const FieldDev fd = to_dev(*f);
   const RaysDev rd = to_dev(*rays);
   const hipStream_t st = (hipStream_t)stream;
@@ -438,8 +498,8 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   const bool half = f->grid.param_dtype == 1;
 #define CASE(L_, F_, H_)                                                                                   \
   if (L == L_ && F == F_ && H == H_) {                                                                     \
-    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, st)          \
-                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, st);        \
+    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, st)      \
+                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, st);    \
   }
   CASE(16, 2, 64)
   CASE(16, 2, 32)
@@ -463,6 +523,21 @@ extern "C" int nrhip_field_fwd(const nrhip_field* f, const nrhip_rays* rays, flo
   if (rays->n_rays == 0 || rays->n_samples == 0) return NRHIP_OK;
   NR_REQUIRE(feature && sdf && alpha, NRHIP_ERR_INVALID_ARG, "field_fwd: NULL output");
   return dispatch_render<false>(f, rays, feature, nullptr, nullptr, nullptr, sdf, alpha, stream);
+}
+
+extern "C" int nrhip_field_fwd_train(const nrhip_field* f, const nrhip_rays* rays, float* feature, float* sdf,
+                                     float* alpha, float* save_enc, float* save_geo_hidden, float* save_feat_in,
+                                     float* save_feat_hidden, void* stream) {
+  if (int e = validate_field(f)) return e;
+  if (int e = validate_rays(rays)) return e;
+  if (rays->n_rays == 0 || rays->n_samples == 0) return NRHIP_OK;
+  NR_REQUIRE(feature && sdf && alpha && save_enc && save_geo_hidden && save_feat_in && save_feat_hidden,
+             NRHIP_ERR_INVALID_ARG, "field_fwd_train: NULL output");
+  NR_REQUIRE(((reinterpret_cast<uintptr_t>(save_enc) | reinterpret_cast<uintptr_t>(save_geo_hidden) |
+               reinterpret_cast<uintptr_t>(save_feat_in) | reinterpret_cast<uintptr_t>(save_feat_hidden)) & 15) == 0,
+             NRHIP_ERR_INVALID_ARG, "field_fwd_train: save buffers must be 16-byte aligned");
+  const SaveDev sv{save_enc, save_geo_hidden, save_feat_in, save_feat_hidden};
+  return dispatch_render<false>(f, rays, feature, nullptr, nullptr, nullptr, sdf, alpha, stream, sv);
 }
 
 extern "C" int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,

@@ -84,6 +84,9 @@ class NeuRADField(nn.Module):
         if config.num_multisamples != 1:
             raise NotImplementedError("num_multisamples != 1 is not used by any NeuRAD config (neurad_field.py:67)")
         self.config, self.implementation = config, implementation
+        self.fused_training = True
+        """Training forward through the fused field kernel + hand-chained backward (autograd.FieldTrainFn); False
+        runs the reference orchestration over operator-level autograd functions (same numbers, 2x the launches)."""
         self.hashgrid: NeuRADHashEncoding = config.grid.setup(dynamic_actors=actors, static_scale=static_scale,
                                                               implementation=implementation)
         self.geo_feat_dim = config.nff_out_dim
@@ -139,6 +142,15 @@ class NeuRADField(nn.Module):
             else:
                 out[FieldHeadNames.DENSITY] = head[..., None]
             return out
+        if self.fused_training and self.fused_supported() and self._fused_train_ok():
+            g = self.hashgrid.static_grid
+            # beta only shapes the kernel's own alpha output, which training does not use (the torch head below owns
+            # the learnable beta) -- reading it here would be a device->host sync per step
+            feature, geo_out = ag.FieldTrainFn.apply(
+                g.hash_table, g.spec, self.hashgrid.static_scale, self.config.use_sdf, 1.0, o, d, a, starts, ends,
+                *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
+                *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])
+            return self._heads(feature.view(R, S, self.config.nff_out_dim), geo_out.view(R, S, 1))
         times = None if ray_samples.times is None else ray_samples.times[:, 0].reshape(-1)
         features, sample_dirs = self.hashgrid.forward_rays(o, d, a, starts, ends, times)
         geo = self.mlp_geo(features)
@@ -149,14 +161,22 @@ class NeuRADField(nn.Module):
         else:  # samples inside actors carry box-frame directions (neurad_encoding.py:203-208)
             sh = self.direction_encoding(get_normalized_directions(sample_dirs))
         feature = geo_embedding + self.mlp_feature(torch.cat([geo_embedding, sh], dim=-1))
-        out = {FieldHeadNames.FEATURE: feature.view(R, S, self.config.nff_out_dim)}
-        geo_out = geo_out.reshape(R, S, 1)
+        return self._heads(feature.view(R, S, self.config.nff_out_dim), geo_out.reshape(R, S, 1))
+
+    def _heads(self, feature: Tensor, geo_out: Tensor) -> Dict[FieldHeadNames, Tensor]:
+        out = {FieldHeadNames.FEATURE: feature}
         if self.config.use_sdf:
             out[FieldHeadNames.SDF] = geo_out
-            out[FieldHeadNames.ALPHA] = self.sdf_to_density(geo_out)
+            out[FieldHeadNames.ALPHA] = self.sdf_to_density(geo_out)  # torch: beta may be learnable
         else:
             out[FieldHeadNames.DENSITY] = trunc_exp(geo_out)
         return out
+
+    def _fused_train_ok(self) -> bool:
+        """The fused training forward needs an fp32 table, biases on every layer and fp32 parameters."""
+        if self.hashgrid.static_grid.hash_table.dtype != torch.float32:
+            return False
+        return all(l.bias is not None for l in list(self.mlp_geo.layers) + list(self.mlp_feature.layers))
 
 
 @dataclass

@@ -276,6 +276,22 @@ def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends):
     return feature, sdf, alpha
 
 
+def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends):
+    """field_fwd + the activations the backward needs: -> (feature [N,32], geo_out [N], head [N]),
+    (enc [N,32], geo_hidden [N,H], feat_in [N,48], feat_hidden [N,2H])"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    f, keep2 = fs.c_field()
+    n, dev = r.n_rays * r.n_samples, origins.device
+    H = fs.geo_w[0].shape[0]
+    mk = lambda c: torch.empty((n, c), device=dev, dtype=torch.float32)  # noqa: E731
+    feature, enc, hg, xf, hf = mk(32), mk(32), mk(H), mk(48), mk(2 * H)
+    sdf = torch.empty((n,), device=dev, dtype=torch.float32)
+    head = torch.empty((n,), device=dev, dtype=torch.float32)
+    call("nrhip_field_fwd_train", C.byref(f), C.byref(r), _ptr(feature), _ptr(sdf), _ptr(head), _ptr(enc), _ptr(hg),
+         _ptr(xf), _ptr(hf), _stream())
+    return (feature, sdf, head), (enc, hg, xf, hf)
+
+
 def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, return_weights: bool = False,
                out: Optional[Tuple[Tensor, Tensor, Tensor]] = None):
     """The fused headline kernel.  -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S])"""

@@ -46,22 +46,25 @@ def bundle(o, d, area, fars=None):
                      fars=torch.full((R, 1), 20000.0, device="cuda") if fars is None else dev(fars)[:, None])
 
 
+@pytest.mark.parametrize("fused_training", [True, False], ids=["fused-train", "operator-train"])
 @pytest.mark.parametrize("tag", ["sdf", "density"])
-def test_field_forward_backward_vs_reference_autograd(tag):
+def test_field_forward_backward_vs_reference_autograd(tag, fused_training):
     """Same parameters, inputs and upstream gradients as oracle/make_golden.py::golden_field; the golden gradients
-    come from the reference's own autograd (B1)."""
+    come from the reference's own autograd (B1).  Both training paths: the fused field kernel that saves its
+    activations + hand-chained backward (FieldTrainFn), and the reference orchestration over operator autograd."""
     from neurad_studio_amd.field_components.field_heads import FieldHeadNames
     from neurad_studio_amd.model_components.ray_samplers import PowerSampler
 
     g = load_golden(f"field_{tag}")
     fld = make_field(tag == "sdf").eval()
+    fld.fused_training = fused_training
     rb = bundle(g["o"], g["d"], g["area"])
     rs = PowerSampler(num_samples=12, lambda_=-1.0, scaling=0.1).eval()(rb)
     assert rel_l2(host(rs.frustums.starts[..., 0]), g["starts"]) < 1e-5
     key = FieldHeadNames.ALPHA if tag == "sdf" else FieldHeadNames.DENSITY
     with torch.no_grad():  # fused kernel
         out_f = fld(rs)
-    out = fld(rs)  # operator-level autograd path
+    out = fld(rs)  # training path (parameters require grad)
     assert rel_l2(host(out[FieldHeadNames.FEATURE]), g["feature"]) < TOL
     assert rel_l2(host(out_f[FieldHeadNames.FEATURE]), g["feature"]) < TOL
     assert rel_l2(host(out[key][..., 0]), g["alpha" if tag == "sdf" else "density"]) < TOL
