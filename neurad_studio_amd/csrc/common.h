@@ -312,6 +312,22 @@ __device__ __forceinline__ float dpp_row_shr(float v, float fill) {
                                          0xf, false));
 }
 
+// row_shl:n = 0x100+n : lane i reads lane i+n of its row; lanes whose source is outside the row get `fill`.
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v, float fill) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x100 + N, 0xf,
+                                         0xf, false));
+}
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shl(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x100 + N, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + N, 0xf, 0xf, false);
+}
+
 inline int grid_for(int64_t threads, int block) { return (int)((threads + block - 1) / block); }
 
 // --------------------------------------------------------------------------------------------

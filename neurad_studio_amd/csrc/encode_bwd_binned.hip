@@ -10,8 +10,8 @@
 //       64-bit accumulators).  A workgroup takes 1024 or 4096 consecutive samples, parks their contracted positions in LDS, and for
 //       each level bins the (entry, F gradient values) records of its samples by slice: LDS histogram -> one
 //       returning global atomic per non-empty slice to reserve a range of that slice's queue -> records written
-//       at (range base + LDS rank).  Runs of equal entries in neighbouring lanes (consecutive samples of a ray in
-//       the same coarse cell) are summed first, as in the atomic kernel.
+//       at (range base + LDS rank).  Runs of equal entries in neighbouring lanes of a 16-lane row (consecutive
+//       samples of a ray in the same coarse cell) are summed first.
 //   pass B (bin_reduce):   one 1024-thread workgroup per (level, slice) streams its queue, accumulates into the
 //       slice image in LDS, and adds the image to grad_table with plain 16-byte loads/stores.  The image is 64-bit
 //       FIXED POINT: ds_add_f32 turned out ~10x slower than the integer LDS atomics on gfx950 (493 vs 147 us for
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t key = c.idx[k];
-        const uint32_t prev = __shfl_up(key, 1, 64);
-        if (live && (lane == 0 || prev != key)) atomicAdd(&hist[key >> log2TS], 1u);
+        const uint32_t prev = dpp_row_shr<1>(key, ~key);  // first lane of a 16-lane row always heads a run
+        if (live && prev != key) atomicAdd(&hist[key >> log2TS], 1u);
       }
     }
     __syncthreads();
@@ -195,24 +195,29 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t key = c.idx[k];
-        const uint32_t prev = __shfl_up(key, 1, 64);
-        const bool head = lane == 0 || prev != key;
+        const uint32_t prev = dpp_row_shr<1>(key, ~key);
+        const bool head = prev != key;
         const unsigned long long hm = __ballot(head);
         float v[F];
 #pragma unroll
         for (int j = 0; j < F; ++j) v[j] = w[k] * gv[j];
-        if (hm != ~0ull) {  // at least one run longer than 1 in this wave: segmented suffix sum onto the heads
-          const int run = __popcll(hm & ((2ull << lane) - 1ull));
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const int orun = __shfl_down(run, off, 64);
-            const bool same = (lane + off < 64) && orun == run;
-#pragma unroll
-            for (int j = 0; j < F; ++j) {
-              const float t = __shfl_down(v[j], off, 64);
-              if (same) v[j] += t;
-            }
-          }
+        if (hm != ~0ull) {
+          // some run is longer than 1: segmented suffix sum onto the run heads, inside each 16-lane row, on DPP
+          // row shifts (VALU rate; the 64-lane __shfl version went through the LDS crossbar 18x per corner)
+          const uint32_t run = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull));
+#define NR_SEG_STEP(OFF)                                                   \
+  {                                                                        \
+    const bool same = dpp_row_shl<OFF>(run, 0xffffffffu) == run;           \
+    _Pragma("unroll") for (int j = 0; j < F; ++j) {                        \
+      const float t = dpp_row_shl<OFF>(v[j], 0.f);                         \
+      if (same) v[j] += t;                                                 \
+    }                                                                      \
+  }
+          NR_SEG_STEP(1)
+          NR_SEG_STEP(2)
+          NR_SEG_STEP(4)
+          NR_SEG_STEP(8)
+#undef NR_SEG_STEP
         }
         if (head && live) {
           bool finite = true;
