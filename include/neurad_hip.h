@@ -140,10 +140,13 @@ int nrhip_sh4_fwd(const float* dirs /*[N,3]*/, int64_t n, float* out /*[N,16]*/,
 int nrhip_mlp_fwd(const nrhip_mlp* m, const float* x /*[N,in]*/, int64_t n, float* y /*[N,out]*/,
                   float* hidden, void* stream);
 /* Backward.  grad_x may be NULL.  grad_weight[k] ([out_k][in_k]) and grad_bias[k] (may be NULL) are
- * ACCUMULATED into.  workspace: [N, (num_layers-1)*hidden_dim] floats of scratch (same shape as hidden). */
+ * ACCUMULATED into.  workspace: at least N*(num_layers-1)*hidden_dim floats (dZ of the hidden layers); with the
+ * nrhip_mlp_bwd_workspace() amount NeuRAD's own MLP shapes get their weight gradients from the same pass as the
+ * data gradient (no second read of the activations, no atomics). */
+int nrhip_mlp_bwd_workspace(const nrhip_mlp* m, int64_t n, int64_t* floats);
 int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_y, int64_t n,
                   float* grad_x, float* const* grad_weight /*host array*/, float* const* grad_bias /*host array*/,
-                  float* workspace, void* stream);
+                  float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- F1+F4: NeuRADField.forward, per-sample outputs (neurad_field.py:128-152) ------------------
  * feature [R,S,C], sdf_or_raw [R,S] (sdf when use_sdf else the pre-exp geo output), alpha_or_density [R,S] */

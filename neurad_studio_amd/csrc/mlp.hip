@@ -334,8 +334,10 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a, int64_t n) 
 
 // mlp_chain.hip: register-chained kernels for NeuRAD's own MLP shapes; NRHIP_ERR_UNSUPPORTED = not covered
 int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float* hidden, void* stream);
-int mlp_chain_bwd(const nrhip_mlp* m, const float* hidden, const float* gy, int64_t n, float* gx, float* dz,
+int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, int64_t n, float* gx,
+                  float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, bool* did_wgrad,
                   void* stream);
+int64_t mlp_chain_part_floats(const nrhip_mlp* m);
 static bool use_chain() {
   static const bool off = getenv("NRHIP_MLP_GENERIC") != nullptr;  // A/B switch (tests run both paths)
   return !off;
@@ -412,21 +414,40 @@ extern "C" int nrhip_mlp_fwd(const nrhip_mlp* m, const float* x, int64_t n, floa
   return check_launch("mlp_fwd");
 }
 
+namespace {
+int64_t dz_floats(const nrhip_mlp* m, int64_t n) { return n * (int64_t)(m->num_layers - 1) * m->hidden_dim; }
+}  // namespace
+
+extern "C" int nrhip_mlp_bwd_workspace(const nrhip_mlp* m, int64_t n, int64_t* floats) {
+  if (int e = validate_mlp(m)) return e;
+  NR_REQUIRE(floats && n >= 0, NRHIP_ERR_INVALID_ARG, "mlp_bwd_workspace: bad argument");
+  *floats = ((dz_floats(m, n) + 3) & ~(int64_t)3) + mlp_chain_part_floats(m);
+  return NRHIP_OK;
+}
+
 extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_y, int64_t n,
                              float* grad_x, float* const* grad_weight, float* const* grad_bias, float* workspace,
-                             void* stream) {
+                             int64_t workspace_floats, void* stream) {
   if (int e = validate_mlp(m)) return e;
   NR_REQUIRE(n >= 0 && grad_weight, NRHIP_ERR_INVALID_ARG, "mlp_bwd: bad argument");
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(x && grad_y, NRHIP_ERR_INVALID_ARG, "mlp_bwd: null pointer");
-  NR_REQUIRE(m->num_layers == 1 || (hidden && workspace), NRHIP_ERR_INVALID_ARG,
-             "mlp_bwd: hidden activations and workspace are required for num_layers > 1");
+  NR_REQUIRE(m->num_layers == 1 || (hidden && workspace && workspace_floats >= dz_floats(m, n)),
+             NRHIP_ERR_INVALID_ARG,
+             "mlp_bwd: hidden activations and a workspace of >= N*(num_layers-1)*hidden_dim floats are required");
   const MlpDev d = to_dev(*m);
   const hipStream_t st = (hipStream_t)stream;
   int chained = NRHIP_ERR_UNSUPPORTED;
   if (use_chain() && d.nl > 1) {
-    chained = mlp_chain_bwd(m, hidden, grad_y, n, grad_x, workspace, stream);
+    // room behind the dZ block (nrhip_mlp_bwd_workspace) lets the chained kernel produce the weight gradients too
+    const int64_t part_off = (dz_floats(m, n) + 3) & ~(int64_t)3;
+    static const bool no_fused_wgrad = getenv("NRHIP_MLP_SPLIT_WGRAD") != nullptr;  // A/B switch
+    const int64_t part_floats = no_fused_wgrad ? 0 : workspace_floats - part_off;
+    bool did_wgrad = false;
+    chained = mlp_chain_bwd(m, x, hidden, grad_y, n, grad_x, workspace, part_floats > 0 ? workspace + part_off : nullptr,
+                            part_floats > 0 ? part_floats : 0, grad_weight, grad_bias, &did_wgrad, stream);
     if (chained != NRHIP_OK && chained != NRHIP_ERR_UNSUPPORTED) return chained;
+    if (did_wgrad) return NRHIP_OK;
   }
   if (chained == NRHIP_ERR_UNSUPPORTED && (d.nl > 1 || grad_x)) {
     const int waves = pick_waves<true>(d);

@@ -212,6 +212,294 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(ChainArgs a, const f
   }
 }
 
+// ---- data gradient + weight gradient in one pass ---------------------------------------------------------------
+// The weight gradient dW_l[o][i] = sum_n dZ_l[n][o] * a_{l-1}[n][i] is an MFMA with the SAMPLES on the K axis.  The
+// separate kernel (mlp.hip) re-reads dZ and the activations of every layer from HBM (1.1 GB per step on config 2)
+// and runs at memory latency; here the tile is already in flight: dZ_l goes through a wave-private LDS tile to
+// turn its [neuron 4g+r][sample j] register layout into the A operand's (row = neuron, k = sample), the B operand
+// (k = sample, col = input) comes straight from the rows the wave has just touched (L1/L2 hits), and the products
+// accumulate in registers over the wave's whole tile loop.  Each workgroup parks ONE partial (all layers) in the
+// caller's workspace; wgrad_merge_kernel sums them into dW/db -- no atomics.
+template <int IN, int H, int OUT, int NL>
+struct WgShape {
+  using S = Shape<IN, H, OUT, NL>;
+  static constexpr int NB = S::NB, IB = S::IB, OB = S::OB, KS = S::KP / 4;
+  static constexpr int A0 = 0;                            // layer 0  [H x IN]   NB x IB blocks
+  static constexpr int A1 = A0 + NB * IB;                 // layer 1  [H x H]    NB x NB blocks (NL == 3)
+  static constexpr int AL = A1 + (NL == 3 ? NB * NB : 0); // last     [OUT x H]  OB x NB blocks
+  static constexpr int NACC = AL + OB * NB;               // f32x4 accumulators per lane
+  // bias partial sums, per lane: hidden layers in D layout (NB f32x4 each), last layer as the KS grad_y columns
+  static constexpr int B0 = NACC * 4;                     // float slots
+  static constexpr int B1 = B0 + NB * 4;
+  static constexpr int BL = B1 + (NL == 3 ? NB * 4 : 0);
+  static constexpr int NSLOT = BL + KS;                   // float slots per lane
+  static constexpr int PART_FLOATS = NSLOT * 64;          // one workgroup's partial
+  static constexpr int LD = H + 16;                       // dZ tile row stride: rows 4s+k land in distinct banks
+  static constexpr int TILE = 16 * LD;
+};
+
+template <int IN, int H, int OUT, int NL>
+__global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, const float* __restrict__ x,
+                                                                const float* __restrict__ hidden,
+                                                                const float* __restrict__ gy, int64_t n,
+                                                                float* __restrict__ gx, float* __restrict__ dz,
+                                                                float* __restrict__ part) {
+  using S = Shape<IN, H, OUT, NL>;
+  using W = WgShape<IN, H, OUT, NL>;
+  constexpr int NB = S::NB, IB = S::IB, OB = S::OB, KP = S::KP, KS = W::KS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_matrix<false, true, NB, KP / 4>(lds + S::B_TL, a.w[NL - 1], H, H, OUT);
+  if constexpr (NL == 3) stage_matrix<true, true, NB, H / 4>(lds + S::B_T1, a.w[1], H, H, H);
+  if (gx) stage_matrix<true, true, IB, H / 4>(lds + S::B_T0, a.w[0], IN, IN, H);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t ntiles = (n + 15) / 16;
+  constexpr int HID_LD = (NL - 1) * H;
+  float* tz = lds + S::B_TOTAL + wid * W::TILE;  // wave-private dZ tile [16 samples][LD]
+
+  f32x4 acc[W::NACC];
+#pragma unroll
+  for (int q = 0; q < W::NACC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bs0[NB], bs1[NL == 3 ? NB : 1];
+  float bsl[KS];
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) bs0[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mb = 0; mb < (NL == 3 ? NB : 1); ++mb) bs1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < KS; ++q) bsl[q] = 0.f;
+
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const float* lw = lds + opaque;
+    const int64_t row0 = tile * 16;
+    const int64_t row = row0 + j;
+    const bool live = row < n;
+    const int64_t rc = live ? row : n - 1;
+    // rows of the four k-steps of a weight-gradient MFMA: sample 4s + g, for the lane's operand column j
+    int64_t rk[4];
+    bool lk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t rr = row0 + 4 * q + g;
+      lk[q] = rr < n;
+      rk[q] = lk[q] ? rr : n - 1;
+    }
+    float gb[KP / 4];
+    const float* gp = gy + rc * OUT;
+#pragma unroll
+    for (int q = 0; q < KP / 4; ++q) {
+      const int c = (KP / 4) * g + q;
+      gb[q] = (c < OUT && live) ? gp[c] : 0.f;  // dead rows contribute nothing (data path never stores them)
+      bsl[q] += gb[q];
+    }
+    // ---- last layer: dW_L[o][i] += gy[n][o] * h_{NL-2}[n][i], both operands straight from global ------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float av[OB], bv[NB];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) av[ob] = (lk[q] && 16 * ob + j < OUT) ? gy[rk[q] * OUT + 16 * ob + j] : 0.f;
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib) bv[ib] = hidden[rk[q] * HID_LD + (NL - 2) * H + 16 * ib + j];
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib)
+          acc[W::AL + ob * NB + ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ob], bv[ib], acc[W::AL + ob * NB + ib], 0, 0, 0);
+    }
+    f32x4 d[NB];
+    float db[H / 4];
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mfma_layer<NB, KP / 4>(lw + S::B_TL, lane, gb, d);
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hidden + rc * HID_LD + (NL - 2) * H + 16 * mb + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) db[4 * mb + r] = d[mb][r] = hv[r] > 0.f ? d[mb][r] : 0.f;
+      if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + (NL - 2) * H + 16 * mb + 4 * g) = d[mb];
+      *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];  // zero for dead rows (gb was zeroed)
+      if constexpr (NL == 3) bs1[mb] += d[mb]; else bs0[mb] += d[mb];
+    }
+    // ---- layer NL-2: dW[o][i] += dZ[n][o] * (NL == 3 ? h_0 : x)[n][i] ------------------------------------------
+    {
+      constexpr int NI = NL == 3 ? NB : IB;
+      constexpr int ABASE = NL == 3 ? W::A1 : W::A0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float av[NB], bv[NI];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) av[ob] = tz[(4 * q + g) * W::LD + 16 * ob + j];
+#pragma unroll
+        for (int ib = 0; ib < NI; ++ib)
+          bv[ib] = NL == 3 ? hidden[rk[q] * HID_LD + 16 * ib + j] : x[rk[q] * IN + 16 * ib + j];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+          for (int ib = 0; ib < NI; ++ib)
+            acc[ABASE + ob * NI + ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ob], bv[ib], acc[ABASE + ob * NI + ib], 0, 0, 0);
+      }
+    }
+    if constexpr (NL == 3) {
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mfma_layer<NB, H / 4>(lw + S::B_T1, lane, db, d);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hidden + rc * HID_LD + 16 * mb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db[4 * mb + r] = d[mb][r] = hv[r] > 0.f ? d[mb][r] : 0.f;
+        if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + 16 * mb + 4 * g) = d[mb];
+        *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];
+        bs0[mb] += d[mb];
+      }
+      // ---- layer 0: dW_0[o][i] += dZ_0[n][o] * x[n][i] ---------------------------------------------------------
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float av[NB], bv[IB];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) av[ob] = tz[(4 * q + g) * W::LD + 16 * ob + j];
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) bv[ib] = x[rk[q] * IN + 16 * ib + j];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+          for (int ib = 0; ib < IB; ++ib)
+            acc[W::A0 + ob * IB + ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ob], bv[ib], acc[W::A0 + ob * IB + ib], 0, 0, 0);
+      }
+    }
+    if (gx) {
+      f32x4 dx[IB];
+#pragma unroll
+      for (int mb = 0; mb < IB; ++mb) dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mfma_layer<IB, H / 4>(lw + S::B_T0, lane, db, dx);
+      if (live) {
+#pragma unroll
+        for (int mb = 0; mb < IB; ++mb) *reinterpret_cast<f32x4*>(gx + row * IN + 16 * mb + 4 * g) = dx[mb];
+      }
+    }
+  }
+
+  // ---- merge the four waves (through LDS, one wave at a time), then park the workgroup's partial ---------------
+  __syncthreads();  // all waves are done with the weight image: reuse it
+  float* red = lds;
+  for (int w = 1; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int q = 0; q < W::NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(q * 4 + r) * 64 + lane] = acc[q][r];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[(W::B0 + mb * 4 + r) * 64 + lane] = bs0[mb][r];
+          if constexpr (NL == 3) red[(W::B1 + mb * 4 + r) * 64 + lane] = bs1[mb][r];
+        }
+#pragma unroll
+      for (int q = 0; q < KS; ++q) red[(W::BL + q) * 64 + lane] = bsl[q];
+    }
+    __syncthreads();
+    if (wid == 0) {
+#pragma unroll
+      for (int q = 0; q < W::NACC; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] += red[(q * 4 + r) * 64 + lane];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bs0[mb][r] += red[(W::B0 + mb * 4 + r) * 64 + lane];
+          if constexpr (NL == 3) bs1[mb][r] += red[(W::B1 + mb * 4 + r) * 64 + lane];
+        }
+#pragma unroll
+      for (int q = 0; q < KS; ++q) bsl[q] += red[(W::BL + q) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wid == 0) {
+    float* pp = part + (size_t)blockIdx.x * W::PART_FLOATS;
+#pragma unroll
+    for (int q = 0; q < W::NACC; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[(q * 4 + r) * 64 + lane] = acc[q][r];
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pp[(W::B0 + mb * 4 + r) * 64 + lane] = bs0[mb][r];
+        if constexpr (NL == 3) pp[(W::B1 + mb * 4 + r) * 64 + lane] = bs1[mb][r];
+      }
+#pragma unroll
+    for (int q = 0; q < KS; ++q) pp[(W::BL + q) * 64 + lane] = bsl[q];
+  }
+}
+
+// Second stage.  A 256-thread workgroup owns 64 consecutive float slots of the partial (one (block,r) row of an
+// accumulator, or one bias slot); its four waves split the parked partials, an LDS step joins them, and lane
+// arithmetic maps the slot back to (o, i).  dW/db are ACCUMULATED into (plain read-modify-write: one owner each).
+struct MergeLayer {
+  float* dW;
+  float* db;
+  int out, in, nbi;  // nbi = 16-wide input blocks of this layer
+  int acc0;          // first accumulator of the layer
+  int bias0, bias_kind, bias_n;  // float-slot base; 0 = D layout (o = 16mb + 4g + r), 1 = column layout (o = n*g + s)
+};
+struct MergeArgs {
+  MergeLayer layer[3];
+  int nl, nacc, nslot;
+};
+
+__global__ __launch_bounds__(256) void wgrad_merge_kernel(MergeArgs m, const float* __restrict__ part, int nparts,
+                                                           int part_floats) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int slot = blockIdx.x;  // float slot (64 lanes wide)
+  const float* pp = part + (size_t)slot * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = wid;
+  for (; b + 12 < nparts; b += 16) {
+    s0 += pp[(size_t)b * part_floats];
+    s1 += pp[(size_t)(b + 4) * part_floats];
+    s2 += pp[(size_t)(b + 8) * part_floats];
+    s3 += pp[(size_t)(b + 12) * part_floats];
+  }
+  for (; b < nparts; b += 4) s0 += pp[(size_t)b * part_floats];
+  red[wid][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wid != 0) return;
+  float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  const int j = lane & 15, g = lane >> 4;
+  if (slot < m.nacc * 4) {  // accumulator row: slot = acc * 4 + r; D[o = 16ob + 4g + r][i = 16ib + j]
+    const int q = slot >> 2, r = slot & 3;
+    int li = 0;
+    for (int l = 1; l < m.nl; ++l)
+      if (q >= m.layer[l].acc0) li = l;
+    const MergeLayer& L = m.layer[li];
+    const int rel = q - L.acc0, ob = rel / L.nbi, ib = rel % L.nbi;
+    const int o = 16 * ob + 4 * g + r, i = 16 * ib + j;
+    if (o < L.out && i < L.in) L.dW[(size_t)o * L.in + i] += v;
+    return;
+  }
+  // bias slot: the 16 lanes of a row hold the same neuron for 16 different samples
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  for (int l = 0; l < m.nl; ++l) {
+    const MergeLayer& L = m.layer[l];
+    const int cnt = L.bias_kind == 0 ? L.bias_n * 4 : L.bias_n;
+    if (slot >= L.bias0 && slot < L.bias0 + cnt && L.db) {
+      const int e = slot - L.bias0;
+      const int o = L.bias_kind == 0 ? 16 * (e >> 2) + 4 * g + (e & 3) : L.bias_n * g + e;
+      if (j == 0 && o < L.out) L.db[o] += v;
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int grid_blocks(int64_t n) {
@@ -265,7 +553,7 @@ int launch_bwd(const ChainArgs& a, const float* hidden, const float* gy, int64_t
 
 }  // namespace
 
-// Both return NRHIP_ERR_UNSUPPORTED (without setting the error string) when the shape or the pointer alignment
+// Returns NRHIP_ERR_UNSUPPORTED (without setting the error string) when the shape or the pointer alignment
 // is not covered; the caller then runs the generic kernels.
 int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float* hidden, void* stream) {
   if (!aligned16(x) || !aligned16(hidden) || (m->out_dim % 4 == 0 && !aligned16(y))) return NRHIP_ERR_UNSUPPORTED;
@@ -279,11 +567,78 @@ int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float
   return NRHIP_ERR_UNSUPPORTED;
 }
 
-int mlp_chain_bwd(const nrhip_mlp* m, const float* hidden, const float* gy, int64_t n, float* gx, float* dz,
+namespace {
+
+template <int IN, int H, int OUT, int NL>
+int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const float* hidden, const float* gy,
+                  int64_t n, float* gx, float* dz, float* part, int64_t part_floats, float* const* gw,
+                  float* const* gbias, hipStream_t st) {
+  using S = Shape<IN, H, OUT, NL>;
+  using W = WgShape<IN, H, OUT, NL>;
+  // 36 accumulator tiles (48|64 -> 64 -> 64 -> 32) leave one wave per SIMD and measure slower than the separate
+  // weight-gradient kernel (0.44 vs 0.43 ms per call); up to 20 tiles it wins (geometry MLP: 0.29 -> 0.21 ms)
+  if (W::NACC > 24) return NRHIP_ERR_UNSUPPORTED;
+  const int64_t fit = part_floats / W::PART_FLOATS;
+  if (fit < 1) return NRHIP_ERR_UNSUPPORTED;
+  auto kern = mlp_chain_bwd_wg_kernel<IN, H, OUT, NL>;
+  constexpr int lds = (S::B_TOTAL + 4 * W::TILE > W::PART_FLOATS ? S::B_TOTAL + 4 * W::TILE : W::PART_FLOATS) *
+                      (int)sizeof(float);
+  static thread_local int resident = 0;  // workgroups per CU the accumulators + LDS admit: one partial per resident one
+  if (!resident) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    resident = nb > 4 ? 4 : nb;
+  }
+  int blocks = grid_blocks(n);  // <= 4 per CU
+  if (blocks > (grid_blocks(INT64_MAX / 2) / 4) * resident) blocks = (grid_blocks(INT64_MAX / 2) / 4) * resident;
+  if (blocks > fit) blocks = (int)fit;
+  kern<<<blocks, 256, lds, st>>>(a, x, hidden, gy, n, gx, dz, part);
+  if (int e = check_launch("mlp_chain_bwd_wg")) return e;
+  MergeArgs ma{};
+  ma.nl = NL, ma.nacc = W::NACC, ma.nslot = W::NSLOT;
+  ma.layer[0] = MergeLayer{gw[0], gbias ? gbias[0] : nullptr, H, IN, W::IB, W::A0, W::B0, 0, W::NB};
+  if (NL == 3) ma.layer[1] = MergeLayer{gw[1], gbias ? gbias[1] : nullptr, H, H, W::NB, W::A1, W::B1, 0, W::NB};
+  ma.layer[NL - 1] = MergeLayer{gw[NL - 1], gbias ? gbias[NL - 1] : nullptr, OUT, H, W::NB, W::AL, W::BL, 1, W::KS};
+  wgrad_merge_kernel<<<W::NSLOT, 256, 0, st>>>(ma, part, blocks, W::PART_FLOATS);
+  return check_launch("mlp_wgrad_merge");
+}
+
+}  // namespace
+
+// floats of scratch the fused weight gradient wants for this MLP (0: shape not covered)
+int64_t mlp_chain_part_floats(const nrhip_mlp* m) {
+#define X(IN_, H_, OUT_, NL_)                                                                  \
+  if (m->in_dim == IN_ && m->hidden_dim == H_ && m->out_dim == OUT_ && m->num_layers == NL_)    \
+    return (int64_t)WgShape<IN_, H_, OUT_, NL_>::PART_FLOATS * 1024;
+  NR_CHAIN_SHAPES(X)
+#undef X
+  return 0;
+}
+
+// Data gradient (+ weight gradients when `part` has room and every layer wants one: *did_wgrad is set then).
+int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, int64_t n, float* gx,
+                  float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, bool* did_wgrad,
                   void* stream) {
+  *did_wgrad = false;
   if (!aligned16(hidden) || !aligned16(dz) || !aligned16(gx)) return NRHIP_ERR_UNSUPPORTED;
   ChainArgs a{};
   for (int l = 0; l < m->num_layers && l < 3; ++l) a.w[l] = m->weight[l], a.b[l] = m->bias[l];
+  bool all_w = part != nullptr && gw != nullptr;
+  for (int l = 0; all_w && l < m->num_layers; ++l) all_w = gw[l] != nullptr;
+  if (all_w) {
+#define X(IN_, H_, OUT_, NL_)                                                                      \
+  if (m->in_dim == IN_ && m->hidden_dim == H_ && m->out_dim == OUT_ && m->num_layers == NL_) {       \
+    const int rc = launch_bwd_wg<IN_, H_, OUT_, NL_>(m, a, x, hidden, gy, n, gx, dz, part, part_floats, gw, gbias, \
+                                                     (hipStream_t)stream);                          \
+    if (rc != NRHIP_ERR_UNSUPPORTED) {                                                              \
+      *did_wgrad = rc == NRHIP_OK;                                                                  \
+      return rc;                                                                                    \
+    }                                                                                               \
+  }
+    NR_CHAIN_SHAPES(X)
+#undef X
+  }
 #define X(IN_, H_, OUT_, NL_)                                                                       \
   if (m->in_dim == IN_ && m->hidden_dim == H_ && m->out_dim == OUT_ && m->num_layers == NL_)         \
     return launch_bwd<IN_, H_, OUT_, NL_>(a, hidden, gy, n, gx, dz, (hipStream_t)stream);

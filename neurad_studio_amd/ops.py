@@ -228,11 +228,13 @@ def mlp_bwd(x: Tensor, hidden: Optional[Tensor], grad_y: Tensor, weights, biases
     gx = torch.empty_like(x) if need_grad_x else None
     gws = [torch.zeros_like(w, dtype=torch.float32) for w in weights]
     gbs = [None if b is None else torch.zeros_like(b, dtype=torch.float32) for b in biases]
-    ws = torch.empty_like(hidden) if hidden is not None else None
+    need = C.c_int64(0)
+    call("nrhip_mlp_bwd_workspace", C.byref(m), n, C.byref(need))
+    ws = torch.empty((max(need.value, 1),), device=x.device, dtype=torch.float32)
     pw = (C.c_void_p * _lib.MAX_LAYERS)(*[g.data_ptr() for g in gws])
     pb = (C.c_void_p * _lib.MAX_LAYERS)(*[(0 if g is None else g.data_ptr()) for g in gbs])
     call("nrhip_mlp_bwd", C.byref(m), _ptr(x), _ptr(hidden), _ptr(grad_y), n, _ptr(gx),
-         C.cast(pw, C.POINTER(C.c_void_p)), C.cast(pb, C.POINTER(C.c_void_p)), _ptr(ws), _stream())
+         C.cast(pw, C.POINTER(C.c_void_p)), C.cast(pb, C.POINTER(C.c_void_p)), _ptr(ws), need.value, _stream())
     return gx, gws, gbs
 
 
