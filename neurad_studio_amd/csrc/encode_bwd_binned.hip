@@ -81,7 +81,6 @@ struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray sample
   float scale;
   const float* go;
   int L;
-  __device__ int64_t count() const { return r.R * r.S; }
   __device__ float4 position(int64_t i) const {
     const int64_t ray = i / r.S;
     const int s = (int)(i - ray * r.S);
@@ -100,9 +99,7 @@ struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray sample
 struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   const float* x;
   const float* go;
-  int64_t n;
   int L;
-  __device__ int64_t count() const { return n; }
   __device__ float4 position(int64_t i) const { return make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f); }
   template <int F>
   __device__ void grad(int64_t i, int l, float, float, float (&gv)[F]) const {
@@ -116,7 +113,6 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
   const float* dec;
   const float* dens;
   const float* gd;
-  __device__ int64_t count() const { return r.R * r.S; }
   __device__ float4 position(int64_t i) const {
     const int64_t ray = i / r.S;
     const int s = (int)(i - ray * r.S);
@@ -418,7 +414,7 @@ extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, co
   NR_REQUIRE(x && grad_out && grad_table && n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_binned: bad argument");
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
-  const GridSrc src{x, grad_out, n, gd.L};
+  const GridSrc src{x, grad_out, gd.L};
   return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -71,34 +71,6 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(GridDev g, const void* 
   for (int k = 0; k < F; ++k) o[k] = v[k] * w;
 }
 
-template <int F>
-__global__ __launch_bounds__(256) void encode_bwd_kernel(GridDev g, float scale, RaysDev r,
-                                                          const float* __restrict__ go, float* __restrict__ gt) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n = r.R * r.S;
-  if (t >= n * g.L) return;
-  const int64_t i = t / g.L;
-  const int l = (int)(t - i * g.L);
-  const int64_t ray = i / r.S;
-  const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
-                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
-  const uint32_t mask = (1u << g.log2T) - 1u;
-  const Corners c = hash_corners(p.x, p.y, p.z, g.scal[l], mask);
-  float w[8];
-  corner_weights(c, w);
-  const float rw = rescale_weight(g.scal[l], p.std);
-  float gv[F];
-#pragma unroll
-  for (int k = 0; k < F; ++k) gv[k] = go[t * F + k] * rw;
-  float* base = gt + ((size_t)l << g.log2T) * F;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float* q = base + (size_t)c.idx[k] * F;
-#pragma unroll
-    for (int j = 0; j < F; ++j) unsafeAtomicAdd(q + j, w[k] * gv[j]);
-  }
-}
-
 // Scatter-add with wave-level run combining.  One lane = one sample, a wave = 64 CONSECUTIVE samples of a
 // ray, looping over the levels.  Neighbouring samples of a ray fall into the same cell at the coarse levels, so
 // equal corner indices come in runs of adjacent lanes: a segmented suffix sum (6 shuffle steps) collapses each
@@ -330,18 +302,10 @@ extern "C" int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const n
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
   const RaysDev rd = to_dev(*rays);
-  static const bool naive = getenv("NRHIP_ENCODE_BWD_NAIVE") != nullptr;  // A/B switch for profiling only
-  if (naive) {
-    const int blocks = grid_for(n * gd.L, 256);
-#define CALL(F) encode_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, static_scale, rd, grad_out, grad_table)
-    DISPATCH_F(gd.F, CALL);
-#undef CALL
-  } else {
-    const int blocks = grid_for(n, 256);
+  const int blocks = grid_for(n, 256);
 #define CALL(F) encode_bwd_runs_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, static_scale, rd, grad_out, grad_table)
-    DISPATCH_F(gd.F, CALL);
+  DISPATCH_F(gd.F, CALL);
 #undef CALL
-  }
   return check_launch("encode_bwd");
 }
 

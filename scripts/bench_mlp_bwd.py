@@ -1,3 +1,4 @@
+"""nrhip_mlp_bwd on 524 288 samples for NeuRAD's two MLP shapes (A/B: NRHIP_MLP_SPLIT_WGRAD=1, NRHIP_MLP_GENERIC=1)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0,'tests')
 import torch, numpy as np, synth
@@ -11,4 +12,5 @@ for dims in [(32,2,64,33),(48,3,64,32)]:
     for _ in range(3): ops.mlp_bwd(x,h,go,ws,bs)
     torch.cuda.synchronize(); t0=time.perf_counter()
     for _ in range(10): ops.mlp_bwd(x,h,go,ws,bs)
-    torch.cuda.synchronize(); print(dims, f"mlp_bwd total {(time.perf_counter()-t0)/10*1e3:.3f} ms", os.environ.get("NRHIP_WGRAD_BX"))
+    torch.cuda.synchronize(); print(dims, f"mlp_bwd (data + weight gradients) {(time.perf_counter()-t0)/10*1e3:.3f} ms",
+          "split wgrad" if os.environ.get("NRHIP_MLP_SPLIT_WGRAD") else "fused wgrad where it pays")
