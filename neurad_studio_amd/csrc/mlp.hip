@@ -407,7 +407,7 @@ extern "C" int nrhip_mlp_fwd(const nrhip_mlp* m, const float* x, int64_t n, floa
   const size_t lds = lds_bytes<false>(d, waves);
   static thread_local size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = lds;
   }
   mlp_fwd_kernel<<<blocks_for_tiles(n, waves), 64 * waves, lds, (hipStream_t)stream>>>(d, x, n, y, hidden);
@@ -456,7 +456,7 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
     const size_t lds = lds_bytes<true>(d, waves);
     static thread_local size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
-      hipFuncSetAttribute((const void*)mlp_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)mlp_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       configured = lds;
     }
     mlp_bwd_data_kernel<<<blocks_for_tiles(n, waves), 64 * waves, lds, st>>>(d, hidden, grad_y, n, grad_x, workspace);
