@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a, int64_t n) 
 // mlp_chain.hip: register-chained kernels for NeuRAD's own MLP shapes; NRHIP_ERR_UNSUPPORTED = not covered
 int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float* hidden, void* stream);
 int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, int64_t n, float* gx,
-                  float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, bool* did_wgrad,
+                  float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, int* done_mask,
                   void* stream);
 int64_t mlp_chain_part_floats(const nrhip_mlp* m);
 static bool use_chain() {
@@ -438,16 +438,15 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
   const MlpDev d = to_dev(*m);
   const hipStream_t st = (hipStream_t)stream;
   int chained = NRHIP_ERR_UNSUPPORTED;
+  int wgrad_done = 0;  // bit l: layer l's weight gradient came out of the chained kernel
   if (use_chain() && d.nl > 1) {
     // room behind the dZ block (nrhip_mlp_bwd_workspace) lets the chained kernel produce the weight gradients too
     const int64_t part_off = (dz_floats(m, n) + 3) & ~(int64_t)3;
     static const bool no_fused_wgrad = getenv("NRHIP_MLP_SPLIT_WGRAD") != nullptr;  // A/B switch
     const int64_t part_floats = no_fused_wgrad ? 0 : workspace_floats - part_off;
-    bool did_wgrad = false;
     chained = mlp_chain_bwd(m, x, hidden, grad_y, n, grad_x, workspace, part_floats > 0 ? workspace + part_off : nullptr,
-                            part_floats > 0 ? part_floats : 0, grad_weight, grad_bias, &did_wgrad, stream);
+                            part_floats > 0 ? part_floats : 0, grad_weight, grad_bias, &wgrad_done, stream);
     if (chained != NRHIP_OK && chained != NRHIP_ERR_UNSUPPORTED) return chained;
-    if (did_wgrad) return NRHIP_OK;
   }
   if (chained == NRHIP_ERR_UNSUPPORTED && (d.nl > 1 || grad_x)) {
     const int waves = pick_waves<true>(d);
@@ -466,7 +465,7 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
   WgradArgs wa{};
   int nsub = 0;
   for (int l = 0; l < d.nl; ++l) {
-    if (!grad_weight[l]) continue;
+    if (!grad_weight[l] || ((wgrad_done >> l) & 1)) continue;
     const int in = layer_in(d, l), out = layer_out(d, l);
     WgradLayer& L = wa.layer[wa.nl++];
     L.dz = (l == d.nl - 1) ? grad_y : workspace + (size_t)l * d.hidden;

@@ -220,19 +220,32 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(ChainArgs a, const f
 // (k = sample, col = input) comes straight from the rows the wave has just touched (L1/L2 hits), and the products
 // accumulate in registers over the wave's whole tile loop.  Each workgroup parks ONE partial (all layers) in the
 // caller's workspace; wgrad_merge_kernel sums them into dW/db -- no atomics.
+// Which layers accumulate in registers: all of them when that is <= 24 accumulator tiles (96 VGPRs); the 64-wide
+// feature MLP (12 + 16 + 8 tiles) keeps layers 1 and 2 and leaves layer 0 to the separate kernel in mlp.hip.
+template <int IN, int H, int OUT, int NL>
+constexpr int wg_mask() {
+  constexpr int nb = H / 16, ib = IN / 16, ob = (OUT + 15) / 16;
+  constexpr int t0 = nb * ib, t1 = NL == 3 ? nb * nb : 0, tl = ob * nb;
+  if (t0 + t1 + tl <= 24) return (1 << NL) - 1;
+  if (t1 + tl <= 24) return ((1 << NL) - 1) & ~1;
+  return 0;
+}
+
 template <int IN, int H, int OUT, int NL>
 struct WgShape {
   using S = Shape<IN, H, OUT, NL>;
+  static constexpr int MASK = wg_mask<IN, H, OUT, NL>();
+  static constexpr bool L0 = (MASK & 1) != 0, L1 = NL == 3 && (MASK & 2) != 0, LL = (MASK >> (NL - 1)) & 1;
   static constexpr int NB = S::NB, IB = S::IB, OB = S::OB, KS = S::KP / 4;
   static constexpr int A0 = 0;                            // layer 0  [H x IN]   NB x IB blocks
-  static constexpr int A1 = A0 + NB * IB;                 // layer 1  [H x H]    NB x NB blocks (NL == 3)
-  static constexpr int AL = A1 + (NL == 3 ? NB * NB : 0); // last     [OUT x H]  OB x NB blocks
-  static constexpr int NACC = AL + OB * NB;               // f32x4 accumulators per lane
+  static constexpr int A1 = A0 + (L0 ? NB * IB : 0);      // layer 1  [H x H]    NB x NB blocks (NL == 3)
+  static constexpr int AL = A1 + (L1 ? NB * NB : 0);      // last     [OUT x H]  OB x NB blocks
+  static constexpr int NACC = AL + (LL ? OB * NB : 0);    // f32x4 accumulators per lane
   // bias partial sums, per lane: hidden layers in D layout (NB f32x4 each), last layer as the KS grad_y columns
   static constexpr int B0 = NACC * 4;                     // float slots
-  static constexpr int B1 = B0 + NB * 4;
-  static constexpr int BL = B1 + (NL == 3 ? NB * 4 : 0);
-  static constexpr int NSLOT = BL + KS;                   // float slots per lane
+  static constexpr int B1 = B0 + (L0 ? NB * 4 : 0);
+  static constexpr int BL = B1 + (L1 ? NB * 4 : 0);
+  static constexpr int NSLOT = BL + (LL ? KS : 0);        // float slots per lane
   static constexpr int PART_FLOATS = NSLOT * 64;          // one workgroup's partial
   static constexpr int LD = H + 16;                       // dZ tile row stride: rows 4s+k land in distinct banks
   static constexpr int TILE = 16 * LD;
@@ -259,6 +272,9 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
   constexpr int HID_LD = (NL - 1) * H;
   float* tz = lds + S::B_TOTAL + wid * W::TILE;  // wave-private dZ tile [16 samples][LD]
 
+  constexpr bool WL0 = W::L0, WL1 = W::L1, WLL = W::LL;
+  // the weight gradient of the layer whose dZ is produced first / second in the chain (layer NL-2 / layer 0 of 3)
+  constexpr bool WFIRST = NL == 3 ? WL1 : WL0;
   f32x4 acc[W::NACC];
 #pragma unroll
   for (int q = 0; q < W::NACC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -294,9 +310,10 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
     for (int q = 0; q < KP / 4; ++q) {
       const int c = (KP / 4) * g + q;
       gb[q] = (c < OUT && live) ? gp[c] : 0.f;  // dead rows contribute nothing (data path never stores them)
-      bsl[q] += gb[q];
+      if constexpr (WLL) bsl[q] += gb[q];
     }
     // ---- last layer: dW_L[o][i] += gy[n][o] * h_{NL-2}[n][i], both operands straight from global ------------
+    if constexpr (WLL)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float av[OB], bv[NB];
@@ -321,11 +338,13 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) db[4 * mb + r] = d[mb][r] = hv[r] > 0.f ? d[mb][r] : 0.f;
       if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + (NL - 2) * H + 16 * mb + 4 * g) = d[mb];
-      *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];  // zero for dead rows (gb was zeroed)
-      if constexpr (NL == 3) bs1[mb] += d[mb]; else bs0[mb] += d[mb];
+      if constexpr (WFIRST) {
+        *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];  // zero for dead rows (gb was zeroed)
+        if constexpr (NL == 3) bs1[mb] += d[mb]; else bs0[mb] += d[mb];
+      }
     }
     // ---- layer NL-2: dW[o][i] += dZ[n][o] * (NL == 3 ? h_0 : x)[n][i] ------------------------------------------
-    {
+    if constexpr (WFIRST) {
       constexpr int NI = NL == 3 ? NB : IB;
       constexpr int ABASE = NL == 3 ? W::A1 : W::A0;
 #pragma unroll
@@ -353,10 +372,13 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) db[4 * mb + r] = d[mb][r] = hv[r] > 0.f ? d[mb][r] : 0.f;
         if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + 16 * mb + 4 * g) = d[mb];
-        *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];
-        bs0[mb] += d[mb];
+        if constexpr (WL0) {
+          *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];
+          bs0[mb] += d[mb];
+        }
       }
       // ---- layer 0: dW_0[o][i] += dZ_0[n][o] * x[n][i] ---------------------------------------------------------
+      if constexpr (WL0)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float av[NB], bv[IB];
@@ -396,11 +418,12 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
       for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          red[(W::B0 + mb * 4 + r) * 64 + lane] = bs0[mb][r];
-          if constexpr (NL == 3) red[(W::B1 + mb * 4 + r) * 64 + lane] = bs1[mb][r];
+          if constexpr (WL0) red[(W::B0 + mb * 4 + r) * 64 + lane] = bs0[mb][r];
+          if constexpr (WL1) red[(W::B1 + mb * 4 + r) * 64 + lane] = bs1[mb][r];
         }
+      if constexpr (WLL)
 #pragma unroll
-      for (int q = 0; q < KS; ++q) red[(W::BL + q) * 64 + lane] = bsl[q];
+        for (int q = 0; q < KS; ++q) red[(W::BL + q) * 64 + lane] = bsl[q];
     }
     __syncthreads();
     if (wid == 0) {
@@ -412,11 +435,12 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
       for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          bs0[mb][r] += red[(W::B0 + mb * 4 + r) * 64 + lane];
-          if constexpr (NL == 3) bs1[mb][r] += red[(W::B1 + mb * 4 + r) * 64 + lane];
+          if constexpr (WL0) bs0[mb][r] += red[(W::B0 + mb * 4 + r) * 64 + lane];
+          if constexpr (WL1) bs1[mb][r] += red[(W::B1 + mb * 4 + r) * 64 + lane];
         }
+      if constexpr (WLL)
 #pragma unroll
-      for (int q = 0; q < KS; ++q) bsl[q] += red[(W::BL + q) * 64 + lane];
+        for (int q = 0; q < KS; ++q) bsl[q] += red[(W::BL + q) * 64 + lane];
     }
     __syncthreads();
   }
@@ -430,11 +454,12 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
     for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pp[(W::B0 + mb * 4 + r) * 64 + lane] = bs0[mb][r];
-        if constexpr (NL == 3) pp[(W::B1 + mb * 4 + r) * 64 + lane] = bs1[mb][r];
+        if constexpr (WL0) pp[(W::B0 + mb * 4 + r) * 64 + lane] = bs0[mb][r];
+        if constexpr (WL1) pp[(W::B1 + mb * 4 + r) * 64 + lane] = bs1[mb][r];
       }
+    if constexpr (WLL)
 #pragma unroll
-    for (int q = 0; q < KS; ++q) pp[(W::BL + q) * 64 + lane] = bsl[q];
+      for (int q = 0; q < KS; ++q) pp[(W::BL + q) * 64 + lane] = bsl[q];
   }
 }
 
@@ -572,12 +597,12 @@ namespace {
 template <int IN, int H, int OUT, int NL>
 int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const float* hidden, const float* gy,
                   int64_t n, float* gx, float* dz, float* part, int64_t part_floats, float* const* gw,
-                  float* const* gbias, hipStream_t st) {
+                  float* const* gbias, int* done_mask, hipStream_t st) {
   using S = Shape<IN, H, OUT, NL>;
   using W = WgShape<IN, H, OUT, NL>;
-  // 36 accumulator tiles (48|64 -> 64 -> 64 -> 32) leave one wave per SIMD and measure slower than the separate
-  // weight-gradient kernel (0.44 vs 0.43 ms per call); up to 20 tiles it wins (geometry MLP: 0.29 -> 0.21 ms)
-  if (W::NACC > 24) return NRHIP_ERR_UNSUPPORTED;
+  // (all 36 accumulator tiles of 48|64 -> 64 -> 64 -> 32 in registers leave one wave per SIMD and measured slower
+  // than the separate weight-gradient kernel, 0.44 vs 0.43 ms per call: hence wg_mask())
+  if (W::MASK == 0) return NRHIP_ERR_UNSUPPORTED;
   const int64_t fit = part_floats / W::PART_FLOATS;
   if (fit < 1) return NRHIP_ERR_UNSUPPORTED;
   auto kern = mlp_chain_bwd_wg_kernel<IN, H, OUT, NL>;
@@ -596,12 +621,15 @@ int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const 
   kern<<<blocks, 256, lds, st>>>(a, x, hidden, gy, n, gx, dz, part);
   if (int e = check_launch("mlp_chain_bwd_wg")) return e;
   MergeArgs ma{};
-  ma.nl = NL, ma.nacc = W::NACC, ma.nslot = W::NSLOT;
-  ma.layer[0] = MergeLayer{gw[0], gbias ? gbias[0] : nullptr, H, IN, W::IB, W::A0, W::B0, 0, W::NB};
-  if (NL == 3) ma.layer[1] = MergeLayer{gw[1], gbias ? gbias[1] : nullptr, H, H, W::NB, W::A1, W::B1, 0, W::NB};
-  ma.layer[NL - 1] = MergeLayer{gw[NL - 1], gbias ? gbias[NL - 1] : nullptr, OUT, H, W::NB, W::AL, W::BL, 1, W::KS};
+  ma.nacc = W::NACC, ma.nslot = W::NSLOT;
+  if (W::L0) ma.layer[ma.nl++] = MergeLayer{gw[0], gbias ? gbias[0] : nullptr, H, IN, W::IB, W::A0, W::B0, 0, W::NB};
+  if (W::L1) ma.layer[ma.nl++] = MergeLayer{gw[1], gbias ? gbias[1] : nullptr, H, H, W::NB, W::A1, W::B1, 0, W::NB};
+  if (W::LL)
+    ma.layer[ma.nl++] = MergeLayer{gw[NL - 1], gbias ? gbias[NL - 1] : nullptr, OUT, H, W::NB, W::AL, W::BL, 1, W::KS};
   wgrad_merge_kernel<<<W::NSLOT, 256, 0, st>>>(ma, part, blocks, W::PART_FLOATS);
-  return check_launch("mlp_wgrad_merge");
+  if (int e = check_launch("mlp_wgrad_merge")) return e;
+  *done_mask = W::MASK;
+  return NRHIP_OK;
 }
 
 }  // namespace
@@ -616,11 +644,12 @@ int64_t mlp_chain_part_floats(const nrhip_mlp* m) {
   return 0;
 }
 
-// Data gradient (+ weight gradients when `part` has room and every layer wants one: *did_wgrad is set then).
+// Data gradient; when `part` has room and every layer wants a weight gradient, also the weight gradients of the
+// layers in *done_mask (bit l = layer l); the caller runs the separate kernel for the others.
 int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, int64_t n, float* gx,
-                  float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, bool* did_wgrad,
+                  float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, int* done_mask,
                   void* stream) {
-  *did_wgrad = false;
+  *done_mask = 0;
   if (!aligned16(hidden) || !aligned16(dz) || !aligned16(gx)) return NRHIP_ERR_UNSUPPORTED;
   ChainArgs a{};
   for (int l = 0; l < m->num_layers && l < 3; ++l) a.w[l] = m->weight[l], a.b[l] = m->bias[l];
@@ -630,11 +659,8 @@ int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const
 #define X(IN_, H_, OUT_, NL_)                                                                      \
   if (m->in_dim == IN_ && m->hidden_dim == H_ && m->out_dim == OUT_ && m->num_layers == NL_) {       \
     const int rc = launch_bwd_wg<IN_, H_, OUT_, NL_>(m, a, x, hidden, gy, n, gx, dz, part, part_floats, gw, gbias, \
-                                                     (hipStream_t)stream);                          \
-    if (rc != NRHIP_ERR_UNSUPPORTED) {                                                              \
-      *did_wgrad = rc == NRHIP_OK;                                                                  \
-      return rc;                                                                                    \
-    }                                                                                               \
+                                                     done_mask, (hipStream_t)stream);               \
+    if (rc != NRHIP_ERR_UNSUPPORTED) return rc;                                                     \
   }
     NR_CHAIN_SHAPES(X)
 #undef X
