@@ -67,9 +67,10 @@ def make_workload(device, seed):
 
 
 def train_section(device, rank, world, steps, warmup):
-    """train iters/sec on the same config-2 workload: PowerSampler bins -> NeuRADField (operator-level HIP autograd:
-    encode, MFMA MLPs, SH, head) -> C1/C2 compositing -> loss -> backward (slice-owner table gradient without memory-side atomics, MFMA dgrad/wgrad)
-    -> gradient exchange (RCCL reduce-scatter/all-gather on the flat table gradient) -> Adam step."""
+    """train iters/sec on the same config-2 workload: PowerSampler bins -> NeuRADField in training mode (fused field
+    kernel that stores its activations, torch head) -> C1/C2 compositing -> loss -> backward (MFMA data + weight
+    gradients, slice-owner table gradient without memory-side atomics) -> gradient exchange (RCCL reduce-scatter /
+    all-gather on the flat table gradient) -> Adam step."""
     import torch.distributed as dist
 
     from neurad_studio_amd.cameras.rays import RayBundle

@@ -7,8 +7,12 @@ Same constructor arguments, ``forward(ray_samples) -> Dict[FieldHeadNames, Tenso
 Two execution paths, both pure HIP:
   * no-grad (eval / render): ONE fused kernel -- nrhip_field_fwd per-sample, or nrhip_render_fwd when the
     caller wants composited rays (``render``);
-  * grad-enabled (training): operator-level autograd chain encode -> MLP(MFMA) -> SH -> MLP -> head, each op
-    with its hand-written backward (hash scatter-add atomics, MFMA data/weight gradients).
+  * grad-enabled (training), static scene: the same fused field kernel storing its activations, with the
+    hand-written backward chained behind it in one autograd node (autograd.FieldTrainFn: feature-MLP and
+    geometry-MLP data + weight gradients on the matrix cores, table gradient without memory-side atomics);
+    the head (learnable-beta sigmoid / trunc_exp) stays a torch module;
+  * grad-enabled with actors, or ``fused_training = False``: the reference's orchestration over operator-level
+    autograd functions encode -> MLP -> SH -> MLP -> head.
 """
 from __future__ import annotations
 
