@@ -5,72 +5,70 @@
 // fabric retires ~1.8e10 of them per second no matter where the line lives -> 3.1 ms for config 2, 44 % of a
 // training step.  The per-XCD L2s are not coherent with each other, so there is no cheaper scope to fall back to.
 //
-// This path gives every table entry exactly one owner instead:
-//   pass A (bin_scatter):  the table of a level is cut into LDS-sized slices of TS = 16384/F entries (128 KB of
-//       64-bit accumulators).  A workgroup takes 1024 or 4096 consecutive samples, parks their contracted positions in LDS, and for
-//       each level bins the (entry, F gradient values) records of its samples by slice: LDS histogram -> one
-//       returning global atomic per non-empty slice to reserve a range of that slice's queue -> records written
-//       at (range base + LDS rank).  Runs of equal entries in neighbouring lanes of a 16-lane row (consecutive
-//       samples of a ray in the same coarse cell) are summed first.
-//   pass B (bin_reduce):   one 1024-thread workgroup per (level, slice) streams its queue, accumulates into the
-//       slice image in LDS, and adds the image to grad_table with plain 16-byte loads/stores.  The image is 64-bit
-//       FIXED POINT: ds_add_f32 turned out ~10x slower than the integer LDS atomics on gfx950 (493 vs 147 us for
-//       this kernel), so values are scaled by a power of two chosen from the level's largest |value| (found by
-//       pass A) and the slice's record count so that the sum cannot overflow, and added with ds_add_u64.  The
-//       quantum is below 2^-40 of the level's largest term -- finer than the fp32 rounding of the atomic path for
-//       anything that matters -- and integer addition is associative: the result is bit-reproducible run to run.
-// A queue holds 2x the mean record count of its level; records beyond that (never seen in the tests) fall back to
-// the global atomic in pass A, which pass B's read-modify-write then picks up (stream order).
+// This path gives every table entry exactly one owner instead -- a radix partition by table slice:
+//   count   : the table of a level is cut into slices of TS = 16384/F entries (128 KB of 64-bit accumulators).
+//             A workgroup takes 4096 consecutive samples, parks their contracted positions in LDS (and in the
+//             scratch, for `emit`), and for each of its levels histograms, in LDS, the records its samples send to
+//             every slice.  Runs of equal entries in neighbouring lanes of a 16-lane row (consecutive samples of a
+//             ray in the same coarse cell) count once: they are summed before they are emitted.
+//   scan    : exclusive prefix sums over the workgroups (per slice) and over the slices -> every workgroup's write
+//             position in every slice queue, exactly; queues are as long as their slice needs, whatever the sample
+//             distribution (real scenes put most samples into a thin slab of the volume: a fixed per-slice capacity
+//             overflowed there, and the overflow went to the memory-side atomics this path exists to avoid).
+//   emit    : same walk as `count`; each record (entry, F values) goes to base + LDS rank.  No global atomics.
+//   reduce  : one 1024-thread workgroup per (level, slice) streams its queue, accumulates into the slice image in
+//             LDS, and adds the image to grad_table with plain 16-byte loads/stores.  The image is 64-bit FIXED
+//             POINT: ds_add_f32 turned out ~10x slower than the integer LDS atomics on gfx950 (493 vs 147 us for
+//             this pass), so values are scaled by a power of two chosen from the level's largest |value| (found by
+//             `emit`) and the slice's record count so that the sum cannot overflow, and added with ds_add_u64.  The
+//             quantum is below 2^-40 of the level's largest term -- finer than the fp32 rounding of the atomic path
+//             for anything that matters -- and integer addition is associative: the result is bit-reproducible.
+//             Inf/NaN values poison their entry (NaN out), as an atomic add of them would.
 #include "common.h"
 
 namespace nrhip {
 namespace {
 
-constexpr int kMaxSamplesPerBlock = 4096;  // pass A: 4 samples per thread, 256 or 1024 threads
-constexpr int kMaxSlices = 2048;        // per level (LDS histogram + base table = 16 KB)
-constexpr int kTileBytes = 128 * 1024;   // slice image in LDS
-constexpr int64_t kChunkSamples = 1 << 20;  // samples per (pass A, pass B) round: bounds the scratch (3.2 GB on config 2)
+constexpr int kSamplesPerBlock = 4096;      // count/emit: 1024 threads x 4 samples
+constexpr int kMaxSlices = 2048;            // per level (LDS histogram + base table = 16 KB)
+constexpr int kTileBytes = 128 * 1024;      // slice image in LDS
+constexpr int64_t kRoundSamples = 1 << 20;  // samples per count/scan/emit/reduce round: bounds the scratch
 
 struct BinPlan {
-  int log2TS;          // entries per slice
-  int nb;              // slices per level
-  uint32_t cap;        // records per queue
-  int spb;             // pass A: samples per workgroup (threads = spb / 4)
-  int lgroups;         // pass A: the levels are dealt round-robin to this many workgroups per sample chunk
-  int nmax;            // partial maxima per level (pass A waves)
-  size_t counter_bytes;
-  size_t total_bytes;
+  int log2TS, nb;        // entries per slice (log2), slices per level
+  int chunks, lgroups;   // count/emit grid: sample chunks x level groups (levels dealt round-robin)
+  int nmax;              // per-level partial maxima (one per emit wave)
+  size_t off_counts, off_totals, off_offsets, off_qmax, off_pos, off_rec, total_bytes;
 };
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Returns false when the grid can not be binned (too many slices per level).
 bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
-  const int64_t n = n_total < kChunkSamples ? n_total : kChunkSamples;  // larger batches go through in rounds
+  const int64_t n = n_total < kRoundSamples ? n_total : kRoundSamples;  // larger batches go through in rounds
   int log2F = 0;
   while ((1 << log2F) < g.F) ++log2F;
   int log2TS = 14 - log2F;  // 8-byte accumulators: 16384 / F entries fill the 128 KB image
   if (log2TS > g.log2T) log2TS = g.log2T;
-  // small tables: shrink the slices until pass B has ~2 workgroups per CU (one workgroup owns one slice)
+  // small tables: shrink the slices until `reduce` has ~2 workgroups per CU (one workgroup owns one slice)
   while (((int64_t)g.L << (g.log2T - log2TS)) < 512 && log2TS > 9) --log2TS;
   const int64_t nb = (int64_t)1 << (g.log2T - log2TS);
   if (nb > kMaxSlices) return false;
-  const int64_t mean = (n * 8 + nb - 1) / nb;
-  const int64_t cap = 2 * mean + 256;
-  if (cap > 0x7fffffff) return false;
   p->log2TS = log2TS;
   p->nb = (int)nb;
-  p->cap = (uint32_t)cap;
-  // few slices: small chunks already give long contiguous runs per (workgroup, slice); many slices: bigger chunks
-  // so that a reservation atomic still buys >= ~64 records.  Levels are split over workgroups until the grid has
-  // ~4 workgroups per CU.
-  p->spb = nb <= 128 ? 1024 : kMaxSamplesPerBlock;
-  const int64_t chunks = (n + p->spb - 1) / p->spb;
-  int lg = (int)((1024 + chunks - 1) / chunks);
+  p->chunks = (int)((n + kSamplesPerBlock - 1) / kSamplesPerBlock);
+  int lg = (1024 + p->chunks - 1) / p->chunks;  // ~4 workgroups of 1024 threads per CU
   p->lgroups = lg < 1 ? 1 : (lg > g.L ? g.L : lg);
-  // header: [L * nb] queue fill counters, then [L][chunks * waves] partial maxima of |value| (plain stores, one
-  // slot per wave of pass A: a contended atomicMax on L words costs more than reading the slots back)
-  p->nmax = (int)(chunks * (p->spb / 4 / 64));
-  p->counter_bytes = (((size_t)g.L * (nb + p->nmax) * sizeof(uint32_t)) + 255) & ~(size_t)255;
-  p->total_bytes = p->counter_bytes + (size_t)g.L * nb * cap * (g.F + 1) * sizeof(float);
+  p->nmax = p->chunks * (kSamplesPerBlock / 4 / 64);
+  const size_t cols = (size_t)g.L * nb;
+  size_t o = 0;
+  p->off_counts = o, o += align256((size_t)p->chunks * cols * sizeof(uint32_t));
+  p->off_totals = o, o += align256(cols * sizeof(uint32_t));
+  p->off_offsets = o, o += align256((cols + 1) * sizeof(uint32_t));
+  p->off_qmax = o, o += align256((size_t)g.L * p->nmax * sizeof(float));
+  p->off_pos = o, o += align256((size_t)p->chunks * kSamplesPerBlock * sizeof(float4));
+  p->off_rec = o, o += (size_t)n * 8 * g.L * (g.F + 1) * sizeof(float);  // every corner term its own record: worst case
+  p->total_bytes = o;
   return true;
 }
 
@@ -129,29 +127,29 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
   }
 };
 
-template <int F, class Src>
-__global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, float* __restrict__ gt,
-                                                            uint32_t* __restrict__ qcount, float* __restrict__ qrec,
-                                                            int log2TS, int nb, uint32_t cap, int spb,
-                                                            int64_t i_off, int64_t n, int nmax) {
+// ---- count ---------------------------------------------------------------------------------------------------
+template <class Src>
+__global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
+                                                          uint32_t* __restrict__ counts, float4* __restrict__ gpos) {
   extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
-  uint32_t* hist = reinterpret_cast<uint32_t*>(pos + spb);
-  uint32_t* base = hist + nb;
-  const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
-  const int64_t i_blk = (int64_t)blockIdx.x * spb;  // sample i of this round is sample i_off + i of the source
-  const int nit = (int)(((n - i_blk < spb ? n - i_blk : spb) + nt - 1) / nt);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
+  const int tid = threadIdx.x;
+  constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
+  const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;  // sample i of this round = sample i_off + i of the source
+#pragma unroll
   for (int it = 0; it < nit; ++it) {
     const int64_t i0 = i_blk + it * nt + tid;
-    pos[it * nt + tid] = src.position(i_off + (i0 < n ? i0 : n - 1));
+    const float4 p = src.position(i_off + (i0 < n ? i0 : n - 1));
+    pos[it * nt + tid] = p;
+    if (blockIdx.y == 0) gpos[i_blk + it * nt + tid] = p;
   }
   const uint32_t mask = (1u << g.log2T) - 1u;
-  const uint32_t tsmask = (1u << log2TS) - 1u;
   for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
     const float sc = g.scal[l];
-    __syncthreads();  // pos[] written / previous level's ranks consumed
+    __syncthreads();  // pos[] written / previous level's histogram stored
     for (int b = tid; b < nb; b += nt) hist[b] = 0;
     __syncthreads();
-    // ---- count: how many records does this block send to each slice -------------------------------
+#pragma unroll
     for (int it = 0; it < nit; ++it) {
       const bool live = i_blk + it * nt + tid < n;
       const float4 p = pos[it * nt + tid];
@@ -164,16 +162,90 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
       }
     }
     __syncthreads();
-    // ---- reserve a range of every non-empty slice queue -------------------------------------------
+    uint32_t* row = counts + ((size_t)blockIdx.x * g.L + l) * nb;
+    for (int b = tid; b < nb; b += nt) row[b] = hist[b];
+  }
+}
+
+// ---- scan ----------------------------------------------------------------------------------------------------
+// counts[chunk][col] -> exclusive prefix over the chunks (in place), totals[col] = column sum.  The loads of a
+// column do not depend on the running sum, so they are issued 8 at a time.
+__global__ __launch_bounds__(256) void bin_scan_chunks_kernel(uint32_t* __restrict__ counts, int chunks, int cols,
+                                                               uint32_t* __restrict__ totals) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  uint32_t run = 0;
+  int k = 0;
+  for (; k + 8 <= chunks; k += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = counts[(size_t)(k + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      counts[(size_t)(k + u) * cols + c] = run;
+      run += v[u];
+    }
+  }
+  for (; k < chunks; ++k) {
+    const uint32_t v = counts[(size_t)k * cols + c];
+    counts[(size_t)k * cols + c] = run;
+    run += v;
+  }
+  totals[c] = run;
+}
+
+// offsets[0..cols] = exclusive prefix of totals (one workgroup; cols <= 32 * 2048)
+__global__ __launch_bounds__(1024) void bin_scan_totals_kernel(const uint32_t* __restrict__ totals, int cols,
+                                                                uint32_t* __restrict__ offsets) {
+  __shared__ uint32_t part[1024];
+  const int per = (cols + 1023) / 1024, c0 = threadIdx.x * per;
+  uint32_t s = 0;
+  for (int k = 0; k < per; ++k)
+    if (c0 + k < cols) s += totals[c0 + k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele over the 1024 partial sums
+    const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;  // exclusive
+  for (int k = 0; k < per; ++k)
+    if (c0 + k < cols) {
+      offsets[c0 + k] = run;
+      run += totals[c0 + k];
+    }
+  if (threadIdx.x == 1023) offsets[cols] = part[1023];
+}
+
+// ---- emit ----------------------------------------------------------------------------------------------------
+template <int F, class Src>
+__global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
+                                                         const uint32_t* __restrict__ bases,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const float4* __restrict__ gpos, float* __restrict__ qrec,
+                                                         float* __restrict__ qmax, int nmax) {
+  extern __shared__ __attribute__((aligned(16))) float4 pos[];
+  uint32_t* rank = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
+  uint32_t* base = rank + nb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
+  const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
+#pragma unroll
+  for (int it = 0; it < nit; ++it) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  const uint32_t tsmask = (1u << log2TS) - 1u;
+  for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
+    const float sc = g.scal[l];
+    __syncthreads();  // pos[] loaded / previous level's ranks consumed
     for (int b = tid; b < nb; b += nt) {
-      const uint32_t cnt = hist[b];
-      base[b] = cnt ? atomicAdd(&qcount[l * nb + b], cnt) : 0u;
-      hist[b] = 0;
+      rank[b] = 0;
+      base[b] = offsets[l * nb + b] + bases[((size_t)blockIdx.x * g.L + l) * nb + b];
     }
     __syncthreads();
-    // ---- emit ---------------------------------------------------------------------------------------
-    float* gl = gt + ((size_t)l << g.log2T) * F;
     float vmax = 0.f;
+#pragma unroll
     for (int it = 0; it < nit; ++it) {
       const int64_t i0 = i_blk + it * nt + tid;
       const bool live = i0 < n;
@@ -199,7 +271,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
         for (int j = 0; j < F; ++j) v[j] = w[k] * gv[j];
         if (hm != ~0ull) {
           // some run is longer than 1: segmented suffix sum onto the run heads, inside each 16-lane row, on DPP
-          // row shifts (VALU rate; the 64-lane __shfl version went through the LDS crossbar 18x per corner)
+          // row shifts (VALU rate; a 64-lane __shfl version goes through the LDS crossbar 18x per corner)
           const uint32_t run = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull));
 #define NR_SEG_STEP(OFF)                                                   \
   {                                                                        \
@@ -216,57 +288,51 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(GridDev g, Src src, f
 #undef NR_SEG_STEP
         }
         if (head && live) {
-          bool finite = true;
-#pragma unroll
-          for (int j = 0; j < F; ++j) finite = finite && fabsf(v[j]) <= 3.402823466e38f;
-          if (!finite) {  // Inf/NaN can not go through the fixed-point image: hand them to the atomic directly
-#pragma unroll
-            for (int j = 0; j < F; ++j) unsafeAtomicAdd(gl + (size_t)key * F + j, v[j]), v[j] = 0.f;
-          }
           const uint32_t b = key >> log2TS;
-          const uint32_t at = base[b] + atomicAdd(&hist[b], 1u);
-          if (at < cap) {
-            float* rec = qrec + ((size_t)(l * nb + b) * cap + at) * (F + 1);
-            rec[0] = __uint_as_float(key & tsmask);
+          const uint32_t at = base[b] + atomicAdd(&rank[b], 1u);
+          float* rec = qrec + (size_t)at * (F + 1);
+          rec[0] = __uint_as_float(key & tsmask);
 #pragma unroll
-            for (int j = 0; j < F; ++j) rec[1 + j] = v[j], vmax = fmaxf(vmax, fabsf(v[j]));
-          } else {  // queue full: fall back to the memory-side atomic (pass B adds on top of it)
-#pragma unroll
-            for (int j = 0; j < F; ++j) unsafeAtomicAdd(gl + (size_t)key * F + j, v[j]);
+          for (int j = 0; j < F; ++j) {
+            rec[1 + j] = v[j];
+            const float av = fabsf(v[j]);
+            if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);  // Inf/NaN do not set the scale; they poison in `reduce`
           }
         }
       }
     }
-    // level maximum of |value| (non-negative floats order like their bit patterns); NaN/Inf propagate as "huge"
+    // level maximum of |value|: one slot per wave, read back by `reduce`
 #pragma unroll
     for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-    if (lane == 0) {
-      const int nwave = nt >> 6;
-      float* qmax = reinterpret_cast<float*>(qcount + (size_t)g.L * nb);
-      qmax[(size_t)l * nmax + (size_t)blockIdx.x * nwave + (tid >> 6)] = vmax;
-    }
+    if (lane == 0) qmax[(size_t)l * nmax + (size_t)blockIdx.x * (nt >> 6) + (tid >> 6)] = vmax;
   }
 }
 
+// ---- reduce --------------------------------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ qcount,
-                                                           const float* __restrict__ qrec, float* __restrict__ gt,
-                                                           int L, int log2T, int log2TS, int nb, uint32_t cap,
-                                                           int nmax) {
+__global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ offsets,
+                                                           const float* __restrict__ qrec,
+                                                           const float* __restrict__ qmax_all, float* __restrict__ gt,
+                                                           int log2T, int log2TS, int nb, int nmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];
   __shared__ float smax[16];
+  __shared__ uint32_t poisoned;
   const int lb = blockIdx.x;
-  const uint32_t filled = qcount[lb];
-  if (filled == 0) return;  // uniform: nothing was sent to this slice
-  const uint32_t cnt = filled < cap ? filled : cap;
+  const uint32_t first = offsets[lb], cnt = offsets[lb + 1] - first;
+  if (cnt == 0) return;  // uniform: nothing was sent to this slice
   const int l = lb / nb, b = lb - l * nb;
-  // |value| < 2^(e+1) for every record of the level; cnt < 2^hb records -> |value * 2^sh| < 2^(61-hb), sum < 2^61
-  const float* qmax = reinterpret_cast<const float*>(qcount + (size_t)L * nb) + (size_t)l * nmax;
+  // |value| < 2^(e+1) for every finite record of the level; cnt < 2^hb records -> |value * 2^sh| < 2^(61-hb), sum < 2^61
+  const float* qmax = qmax_all + (size_t)l * nmax;
   float vmax = 0.f;
   for (int i = threadIdx.x; i < nmax; i += 1024) vmax = fmaxf(vmax, qmax[i]);
 #pragma unroll
   for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
   if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = vmax;
+  if (threadIdx.x == 0) poisoned = 0;
+  const int nacc = F << log2TS;
+  uint32_t* pbits = reinterpret_cast<uint32_t*>(tile + nacc);  // one poison bit per accumulator
+  for (int i = threadIdx.x; i < nacc; i += 1024) tile[i] = 0ull;
+  for (int i = threadIdx.x; i < (nacc + 31) / 32; i += 1024) pbits[i] = 0u;
   __syncthreads();
   vmax = smax[0];
 #pragma unroll
@@ -274,10 +340,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
   const int e = (int)((__float_as_uint(vmax) >> 23) & 0xff) - 127;
   const int hb = 32 - __clz(cnt);
   const int sh = 61 - hb - (e + 1);
-  const int nacc = F << log2TS;
-  for (int i = threadIdx.x; i < nacc; i += 1024) tile[i] = 0ull;
-  __syncthreads();
-  const float* rec = qrec + (size_t)lb * cap * (F + 1);
+  const float* rec = qrec + (size_t)first * (F + 1);
   // 4 records per thread in flight: the loads are independent, only the LDS adds follow them
   for (uint32_t e0 = 0; e0 < cnt; e0 += 4096) {
     float q[4][F + 1];
@@ -294,14 +357,21 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
         const uint32_t key = __float_as_uint(q[u][0]);
 #pragma unroll
         for (int j = 0; j < F; ++j) {
-          const long long fx = __float2ll_rn(ldexpf(q[u][1 + j], sh));
-          atomicAdd(tile + key * F + j, (unsigned long long)fx);
+          const float v = q[u][1 + j];
+          if (fabsf(v) <= 3.402823466e38f) {
+            atomicAdd(tile + key * F + j, (unsigned long long)__float2ll_rn(ldexpf(v, sh)));
+          } else {
+            atomicOr(&pbits[(key * F + j) >> 5], 1u << ((key * F + j) & 31));
+            poisoned = 1;
+          }
         }
       }
     }
   }
   __syncthreads();
   float* out = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+  const bool any_poison = poisoned != 0;
+  const float nan = __uint_as_float(0x7fc00000u);
   if (nacc % 4 == 0) {
     for (int i = threadIdx.x * 4; i < nacc; i += 4096) {
       float4 o = *reinterpret_cast<const float4*>(out + i);
@@ -309,10 +379,21 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
       o.y += (float)ldexp((double)(long long)tile[i + 1], -sh);
       o.z += (float)ldexp((double)(long long)tile[i + 2], -sh);
       o.w += (float)ldexp((double)(long long)tile[i + 3], -sh);
+      if (any_poison) {
+        const uint32_t pw = pbits[i >> 5] >> (i & 31);
+        if (pw & 1) o.x = nan;
+        if (pw & 2) o.y = nan;
+        if (pw & 4) o.z = nan;
+        if (pw & 8) o.w = nan;
+      }
       *reinterpret_cast<float4*>(out + i) = o;
     }
   } else {
-    for (int i = threadIdx.x; i < nacc; i += 1024) out[i] += (float)ldexp((double)(long long)tile[i], -sh);
+    for (int i = threadIdx.x; i < nacc; i += 1024) {
+      float o = out[i] + (float)ldexp((double)(long long)tile[i], -sh);
+      if (any_poison && ((pbits[i >> 5] >> (i & 31)) & 1)) o = nan;
+      out[i] = o;
+    }
   }
 }
 
@@ -340,7 +421,7 @@ extern "C" int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_
 
 namespace {
 
-// Both passes for one source of samples.  `what` names the entry point in error messages.
+// All four passes for one source of samples, in rounds of kRoundSamples.  `what` names the entry point in errors.
 template <class Src>
 int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, void* workspace,
                int64_t workspace_bytes, hipStream_t st) {
@@ -352,39 +433,48 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
              "%s: workspace of %lld bytes, need %zu", what, (long long)workspace_bytes, p.total_bytes);
   NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
              NRHIP_ERR_INVALID_ARG, "%s: workspace and grad_table must be 16-byte aligned", what);
-  uint32_t* qcount = static_cast<uint32_t*>(workspace);
-  float* qrec = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.counter_bytes);
-  const int lds_a = p.spb * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
-  constexpr int lds_a_max = kMaxSamplesPerBlock * (int)sizeof(float4) + 2 * kMaxSlices * (int)sizeof(uint32_t);
-  const size_t lds_b = (size_t)(gd.F << p.log2TS) * sizeof(unsigned long long);
-  for (int64_t i_off = 0; i_off < n; i_off += kChunkSamples) {
-    const int64_t cnt = n - i_off < kChunkSamples ? n - i_off : kChunkSamples;
-    if (hipMemsetAsync(qcount, 0, p.counter_bytes, st) != hipSuccess) return check_launch(what);
-    const dim3 grid_a((unsigned)((cnt + p.spb - 1) / p.spb), (unsigned)p.lgroups);
+  char* ws = static_cast<char*>(workspace);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(ws + p.off_counts);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(ws + p.off_totals);
+  uint32_t* offsets = reinterpret_cast<uint32_t*>(ws + p.off_offsets);
+  float* qmax = reinterpret_cast<float*>(ws + p.off_qmax);
+  float4* gpos = reinterpret_cast<float4*>(ws + p.off_pos);
+  float* qrec = reinterpret_cast<float*>(ws + p.off_rec);
+  const int cols = gd.L * p.nb;
+  const int lds_a = kSamplesPerBlock * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
+  constexpr int lds_a_max = kSamplesPerBlock * (int)sizeof(float4) + 2 * kMaxSlices * (int)sizeof(uint32_t);
+  const int nacc = gd.F << p.log2TS;
+  const size_t lds_b = (size_t)nacc * sizeof(unsigned long long) + (size_t)((nacc + 31) / 32) * sizeof(uint32_t);
+  static thread_local bool count_configured = false;
+  if (!count_configured) {
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    count_configured = true;
+  }
+  for (int64_t i_off = 0; i_off < n; i_off += kRoundSamples) {
+    const int64_t cnt = n - i_off < kRoundSamples ? n - i_off : kRoundSamples;
+    const int chunks = (int)((cnt + kSamplesPerBlock - 1) / kSamplesPerBlock);
+    const dim3 grid_a((unsigned)chunks, (unsigned)p.lgroups);
+    // qmax slots of chunks this round does not have stay from an earlier round otherwise
+    if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
+    bin_count_kernel<Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts, gpos);
+    if (int e = check_launch(what)) return e;
+    bin_scan_chunks_kernel<<<(cols + 255) / 256, 256, 0, st>>>(counts, chunks, cols, totals);
+    bin_scan_totals_kernel<<<1, 1024, 0, st>>>(totals, cols, offsets);
+    if (int e = check_launch(what)) return e;
 #define CALL(F)                                                                                                     \
   do {                                                                                                              \
     static thread_local bool configured = false;                                                                    \
     if (!configured) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)bin_scatter_kernel<F, Src>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)bin_emit_kernel<F, Src>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 lds_a_max);                                                                         \
+      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                kTileBytes + 4096);                                                                 \
       configured = true;                                                                                            \
     }                                                                                                               \
-    bin_scatter_kernel<F, Src><<<grid_a, p.spb / 4, lds_a, st>>>(gd, src, grad_table, qcount, qrec, p.log2TS, p.nb, \
-                                                                 p.cap, p.spb, i_off, cnt, p.nmax);                 \
-  } while (0)
-    NR_DISPATCH_F(gd.F, CALL);
-#undef CALL
-    if (int e = check_launch(what)) return e;
-#define CALL(F)                                                                                                    \
-  do {                                                                                                             \
-    static thread_local bool configured = false;                                                                   \
-    if (!configured) {                                                                                             \
-      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                kTileBytes);                                                                       \
-      configured = true;                                                                                           \
-    }                                                                                                              \
-    bin_reduce_kernel<F><<<gd.L * p.nb, 1024, lds_b, st>>>(qcount, qrec, grad_table, gd.L, gd.log2T, p.log2TS,      \
-                                                           p.nb, p.cap, p.nmax);                                   \
+    bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts, offsets, gpos, \
+                                                         qrec, qmax, p.nmax);                                       \
+    bin_reduce_kernel<F><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,      \
+                                                    p.nmax);                                                        \
   } while (0)
     NR_DISPATCH_F(gd.F, CALL);
 #undef CALL

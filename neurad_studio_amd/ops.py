@@ -165,12 +165,13 @@ def hashgrid_bwd_input(spec: GridSpec, table: Tensor, x: Tensor, grad_out: Tenso
 
 # A/B switch for profiling and for the parity test of the atomic path
 _FORCE_ATOMIC_SCATTER = os.environ.get("NRHIP_ENCODE_BWD_ATOMIC") is not None
+_BINNED_MIN_SAMPLES = 1 << 15
 
 
 def _table_grad_workspace(c_grid, n_samples: int, device) -> Optional[Tensor]:
     """Scratch for the atomics-free table gradients (csrc/encode_bwd_binned.hip); None -> use the atomic entry point."""
-    if _FORCE_ATOMIC_SCATTER or n_samples == 0:
-        return None
+    if _FORCE_ATOMIC_SCATTER or n_samples < _BINNED_MIN_SAMPLES:
+        return None  # small batches (one actor's hits): four launches + scratch cost more than the few atomics
     need = C.c_int64(0)
     call("nrhip_encode_bwd_binned_workspace", C.byref(c_grid), int(n_samples), C.byref(need))
     if need.value <= 0:

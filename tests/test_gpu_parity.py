@@ -75,6 +75,7 @@ def test_hash_indices_bit_exact(ops):
 @pytest.mark.parametrize("tag", list(HASH_CFGS))
 def test_hashgrid_bwd(ops, tag, atomic, monkeypatch):
     monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", atomic)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)  # the goldens are small batches
     g = load_golden(f"hashgrid_{tag}")
     L, mn, mx, lg, F = HASH_CFGS[tag]
     spec = ops.GridSpec(L, F, lg, mn, mx)
@@ -325,6 +326,7 @@ def test_fused_proposal_sampler_vs_reference_golden(ops):
 @pytest.mark.parametrize("atomic", [False, True], ids=["binned", "atomic"])
 def test_proposal_density_bwd(ops, atomic, monkeypatch):
     monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", atomic)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
     p = prop_params(95)
     ps = to_pspec(ops, p)
     R, S = 11, 40
@@ -403,6 +405,7 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     go = dev(synth.normal((R * S, L * F), 11))
     st, en = edges[:, :-1], edges[:, 1:]
     monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
     binned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
     binned2 = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, 2 * go)
     again = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
