@@ -112,6 +112,18 @@ int nrhip_hashgrid_bwd(const nrhip_grid* g, const float* x, const float* grad_ou
 int nrhip_hashgrid_bwd_input(const nrhip_grid* g, const void* table, const float* x, const float* grad_out, int64_t n,
                              float* grad_x /*[N,3]*/, void* stream);
 
+/* Several grids of one shape in one launch -- the per-actor grids of NeuRADHashEncoding (the reference loops over
+ * actor ids, `_get_actor_features_slow`, neurad_encoding.py:270-295).  tables / grad_tables: DEVICE arrays of n_grids
+ * pointers to [L*T,F] fp32 tables; grid_id [N] int32 selects the grid of each sample.  grad_tables are ACCUMULATED
+ * into. */
+int nrhip_hashgrid_multi_fwd(const nrhip_grid* g, const void* const* tables, int32_t n_grids, const int32_t* grid_id,
+                             const float* x /*[N,3]*/, int64_t n, float* out /*[N,L*F]*/, void* stream);
+int nrhip_hashgrid_multi_bwd(const nrhip_grid* g, int32_t n_grids, const int32_t* grid_id, const float* x,
+                             const float* grad_out, int64_t n, float* const* grad_tables, void* stream);
+int nrhip_hashgrid_multi_bwd_input(const nrhip_grid* g, const void* const* tables, int32_t n_grids,
+                                   const int32_t* grid_id, const float* x, const float* grad_out, int64_t n,
+                                   float* grad_x /*[N,3]*/, void* stream);
+
 /* ---- H2+H3+H1+H4: NeuRADHashEncoding static path (neurad_encoding.py:164-169,265-268,297-304;
  *      cameras/rays.py:109-124; spatial_distortions.py:103-141) --------------------------------- */
 int nrhip_encode_fwd(const nrhip_grid* g, const void* table, float static_scale, const nrhip_rays* rays,

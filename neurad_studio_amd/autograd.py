@@ -34,6 +34,30 @@ class HashGridFn(torch.autograd.Function):
         return gx, gt, None
 
 
+class MultiHashGridFn(torch.autograd.Function):
+    """HashEncoding.pytorch_fwd over several grids of one shape: row i looks into tables[grid_id[i]] -- the per-actor
+    grids of NeuRADHashEncoding in one launch (`_get_actor_features_slow` loops over actor ids,
+    neurad_encoding.py:270-295).  args: x [N,3], grid_id [N], spec, *tables."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, grid_id, spec, *tables):
+        ctx.spec = spec
+        grid_id = grid_id.to(torch.int32)
+        ctx.save_for_backward(x, grid_id, *tables)
+        return ops.hashgrid_multi_fwd(spec, tables, grid_id, x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, grid_id, *tables = ctx.saved_tensors
+        g = g.contiguous()
+        gts = ops.hashgrid_multi_bwd(ctx.spec, len(tables), grid_id, x, g) if any(ctx.needs_input_grad[3:]) else \
+            [None] * len(tables)
+        gx = ops.hashgrid_multi_bwd_input(ctx.spec, tables, grid_id, x, g) if ctx.needs_input_grad[0] else None
+        return (gx, None, None, *gts)
+
+
 class EncodeFn(torch.autograd.Function):
     """NeuRADHashEncoding static path, fused H2->H3->H1->H4 (neurad_encoding.py:164-169,265-268,297-304)."""
 

@@ -49,6 +49,46 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(GridDev g, const floa
   }
 }
 
+// several grids of one shape (the per-actor grids, neurad_encoding.py:270-295): sample i looks into
+// tables[grid_id[i]] -- one launch instead of one lookup per actor id.
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_multi_fwd_kernel(GridDev g, const void* const* __restrict__ tables,
+                                                                  const int32_t* __restrict__ grid_id,
+                                                                  const float* __restrict__ x, int64_t n,
+                                                                  float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * g.L) return;
+  const int64_t i = t / g.L;
+  const int l = (int)(t - i * g.L);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  float v[F];
+  hash_level<F, false>(tables[grid_id[i]], (uint32_t)l << g.log2T, x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask,
+                       v);
+  float* o = out + t * F;
+#pragma unroll
+  for (int k = 0; k < F; ++k) o[k] = v[k];
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_multi_bwd_kernel(GridDev g, const int32_t* __restrict__ grid_id,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ go, int64_t n,
+                                                                  float* const* __restrict__ gts) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * g.L) return;
+  const int64_t i = t / g.L;
+  const int l = (int)(t - i * g.L);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  const Corners c = hash_corners(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask);
+  float w[8];
+  corner_weights(c, w);
+  float* base = gts[grid_id[i]] + ((size_t)l << g.log2T) * F;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < F; ++j) unsafeAtomicAdd(base + (size_t)c.idx[k] * F + j, w[k] * go[t * F + j]);
+}
+
 // --------------------------------------------------------------------------------------------
 // encode: H2 -> H3 -> H1 -> H4, thread per (sample, level)
 template <int F, bool HALF>
@@ -416,4 +456,33 @@ extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const 
   }
   if (int e = check_launch("proposal_density_bwd_binned decoder")) return e;
   return proposal_table_grad_binned(p, rays, density, grad_density, grad_table, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nrhip_hashgrid_multi_fwd(const nrhip_grid* g, const void* const* tables, int32_t n_grids,
+                                        const int32_t* grid_id, const float* x, int64_t n, float* out, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(n >= 0 && n_grids >= 1, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_fwd: bad argument");
+  if (n == 0) return NRHIP_OK;
+  NR_REQUIRE(tables && grid_id && x && out, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_fwd: null pointer");
+  NR_REQUIRE(g->param_dtype == 0, NRHIP_ERR_UNSUPPORTED, "hashgrid_multi_fwd: fp32 tables only");
+  const GridDev gd = to_dev(*g);
+  const int blocks = grid_for(n * gd.L, 256);
+#define CALL(F) hashgrid_multi_fwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, tables, grid_id, x, n, out)
+  DISPATCH_F(gd.F, CALL);
+#undef CALL
+  return check_launch("hashgrid_multi_fwd");
+}
+
+extern "C" int nrhip_hashgrid_multi_bwd(const nrhip_grid* g, int32_t n_grids, const int32_t* grid_id, const float* x,
+                                        const float* grad_out, int64_t n, float* const* grad_tables, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(n >= 0 && n_grids >= 1, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd: bad argument");
+  if (n == 0) return NRHIP_OK;
+  NR_REQUIRE(grid_id && x && grad_out && grad_tables, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd: null pointer");
+  const GridDev gd = to_dev(*g);
+  const int blocks = grid_for(n * gd.L, 256);
+#define CALL(F) hashgrid_multi_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables)
+  DISPATCH_F(gd.F, CALL);
+#undef CALL
+  return check_launch("hashgrid_multi_bwd");
 }

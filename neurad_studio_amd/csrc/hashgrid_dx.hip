@@ -7,12 +7,9 @@
 namespace nrhip {
 
 template <int F>
-__global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(GridDev g, const void* __restrict__ table,
-                                                                  const float* __restrict__ x,
-                                                                  const float* __restrict__ go, int64_t n,
-                                                                  float* __restrict__ gx) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void dx_of_sample(const GridDev& g, const void* __restrict__ table,
+                                             const float* __restrict__ x, const float* __restrict__ go, int64_t i,
+                                             float* __restrict__ gx) {
   const uint32_t mask = (1u << g.log2T) - 1u;
   const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
   float ax = 0.f, ay = 0.f, az = 0.f;
@@ -40,6 +37,26 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(GridDev g, cons
   gx[3 * i] = ax, gx[3 * i + 1] = ay, gx[3 * i + 2] = az;
 }
 
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(GridDev g, const void* __restrict__ table,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ go, int64_t n,
+                                                                  float* __restrict__ gx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx_of_sample<F>(g, table, x, go, i, gx);
+}
+
+// several grids of one shape (the per-actor grids): sample i looks into tables[grid_id[i]]
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_multi_bwd_input_kernel(GridDev g, const void* const* __restrict__ tables,
+                                                                        const int32_t* __restrict__ grid_id,
+                                                                        const float* __restrict__ x,
+                                                                        const float* __restrict__ go, int64_t n,
+                                                                        float* __restrict__ gx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx_of_sample<F>(g, tables[grid_id[i]], x, go, i, gx);
+}
+
 }  // namespace nrhip
 
 using namespace nrhip;
@@ -61,4 +78,24 @@ extern "C" int nrhip_hashgrid_bwd_input(const nrhip_grid* g, const void* table, 
     default: hashgrid_bwd_input_kernel<8><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x); break;
   }
   return check_launch("hashgrid_bwd_input");
+}
+
+extern "C" int nrhip_hashgrid_multi_bwd_input(const nrhip_grid* g, const void* const* tables, int32_t n_grids,
+                                              const int32_t* grid_id, const float* x, const float* grad_out, int64_t n,
+                                              float* grad_x, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(n >= 0 && n_grids >= 1, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd_input: bad argument");
+  if (n == 0) return NRHIP_OK;
+  NR_REQUIRE(tables && grid_id && x && grad_out && grad_x, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd_input: null pointer");
+  NR_REQUIRE(g->param_dtype == 0, NRHIP_ERR_UNSUPPORTED, "hashgrid_multi_bwd_input: fp32 tables only");
+  const GridDev gd = to_dev(*g);
+  const int blocks = grid_for(n, 256);
+  const hipStream_t st = (hipStream_t)stream;
+  switch (gd.F) {
+    case 1: hashgrid_multi_bwd_input_kernel<1><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
+    case 2: hashgrid_multi_bwd_input_kernel<2><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
+    case 4: hashgrid_multi_bwd_input_kernel<4><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
+    default: hashgrid_multi_bwd_input_kernel<8><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
+  }
+  return check_launch("hashgrid_multi_bwd_input");
 }

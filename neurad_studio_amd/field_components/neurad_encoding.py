@@ -180,14 +180,13 @@ class NeuRADHashEncoding(nn.Module):
         s = torch.where(mag[:, 0] < 1, s, s * (((2 * cm[:, 0] - 1).pow(1 / 3) / cm[:, 0]) ** 2))
         x01, cstd = (m + 2.0) / 4.0, s / 4.0
         ids = self.actors.actor_to_id[act]
-        rows = feats.new_zeros((idx.numel(), self.scene_repr_dim))
-        for gid in ids.unique().tolist():                                        # _get_actor_features_slow
-            sel = (ids == gid).nonzero()[:, 0]
-            grid = self.actor_grids[gid]
-            f = grid(x01[sel])
-            w = 1 / (grid.scalings[None, :] * 2 * cstd[sel, None]).clamp_min(1.0)
-            f = (f.view(-1, grid.num_levels, grid.features_per_level) * w[..., None]).flatten(1)
-            rows = rows.index_put((sel,), torch.nn.functional.pad(f, (0, self.scene_repr_dim - f.shape[1])))
+        # _get_actor_features_slow loops over the actor ids; all actor grids share one shape, so one multi-grid
+        # lookup (row i -> actor_grids[ids[i]]) does the same without the per-id launches and host syncs
+        grid = self.actor_grids[0]
+        f = ag.MultiHashGridFn.apply(x01, ids, grid.spec, *[g.hash_table for g in self.actor_grids])
+        w = 1 / (grid.scalings[None, :] * 2 * cstd[:, None]).clamp_min(1.0)
+        f = (f.view(-1, grid.num_levels, grid.features_per_level) * w[..., None]).flatten(1)
+        rows = torch.nn.functional.pad(f, (0, self.scene_repr_dim - f.shape[1]))
         out = feats.index_put((idx[winner],), rows[winner])
         if not bool(winner.all()):
             # overlapping actors: the reference's index_put backward hands the upstream gradient to EVERY duplicate

@@ -155,6 +155,50 @@ def hashgrid_bwd(spec: GridSpec, table_like: Tensor, x: Tensor, grad_out: Tensor
     return gt
 
 
+def _ptr_array(tensors: Sequence[Tensor]) -> Tensor:
+    """device array of data pointers (the multi-grid entry points take `void* const*` in device memory)"""
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=tensors[0].device)
+
+
+def hashgrid_multi_fwd(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor, x: Tensor) -> Tensor:
+    """sample i -> tables[grid_id[i]]: all actor grids in one launch"""
+    x, grid_id = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32)
+    tables = [_chk(t, "table") for t in tables]
+    out = torch.empty((x.shape[0], spec.out_dim), device=x.device, dtype=torch.float32)
+    g = spec.c_grid(tables[0])
+    ptrs = _ptr_array(tables)
+    call("nrhip_hashgrid_multi_fwd", C.byref(g), _ptr(ptrs), len(tables), _ptr(grid_id), _ptr(x), x.shape[0], _ptr(out),
+         _stream())
+    return out
+
+
+def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, grad_out: Tensor):
+    """-> one gradient per grid, None for grids no sample refers to (like the reference's per-id loop, which never
+    touches them: their optimizer state must not decay)."""
+    x, grid_id, grad_out = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32), _chk(grad_out, "grad_out")
+    present = torch.bincount(grid_id, minlength=n_grids).gt(0).tolist()  # one small device->host read per backward
+    gts = [torch.zeros((spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32) if p else None
+           for p in present]
+    if not any(present):
+        return gts
+    g = spec.c_grid(next(t for t in gts if t is not None))
+    ptrs = torch.tensor([0 if t is None else t.data_ptr() for t in gts], dtype=torch.int64, device=x.device)
+    call("nrhip_hashgrid_multi_bwd", C.byref(g), n_grids, _ptr(grid_id), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(ptrs),
+         _stream())
+    return gts
+
+
+def hashgrid_multi_bwd_input(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor, x: Tensor, grad_out: Tensor):
+    x, grid_id, grad_out = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32), _chk(grad_out, "grad_out")
+    tables = [_chk(t, "table") for t in tables]
+    gx = torch.empty_like(x)
+    g = spec.c_grid(tables[0])
+    ptrs = _ptr_array(tables)
+    call("nrhip_hashgrid_multi_bwd_input", C.byref(g), _ptr(ptrs), len(tables), _ptr(grid_id), _ptr(x), _ptr(grad_out),
+         x.shape[0], _ptr(gx), _stream())
+    return gx
+
+
 def hashgrid_bwd_input(spec: GridSpec, table: Tensor, x: Tensor, grad_out: Tensor) -> Tensor:
     x, grad_out = _chk(x, "x"), _chk(grad_out, "grad_out")
     gx = torch.empty_like(x)
