@@ -458,3 +458,23 @@ def test_mlp_register_chained_shapes_vs_oracle(ops, dims):
                 assert rel_l2(host(gws[k]), rws[k]) < TIGHT, (dims, N, k)
                 if use_bias:
                     assert rel_l2(host(gbs[k]), rbs[k]) < TIGHT, (dims, N, k)
+
+
+def test_encode_bwd_binned_degenerate_distribution(ops, monkeypatch):
+    """Every ray identical (one line of cells), half of the samples at one point: a handful of table entries receive
+    almost all records.  The radix partition sizes its queues exactly, so this is slow-ish but exact."""
+    L, F, lg, R, S = 8, 4, 18, 2048, 64
+    spec = ops.GridSpec(L, F, lg, 32, 4096)
+    o, d, area, s, e, eu = _sample_rays(1, S, seed=9)
+    do, dd, da = dev(np.repeat(o, R, 0)), dev(np.repeat(d, R, 0)), dev(np.repeat(area, R, 0))
+    edges = dev(np.repeat(eu, R, 0)).clone()
+    edges[: R // 2] = torch.linspace(5.0, 5.0001, S + 1, device="cuda")  # half of the rays: all samples in one cell
+    go = dev(synth.normal((R * S, L * F), 3))
+    st, en = edges[:, :-1], edges[:, 1:]
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    binned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+    atomic = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    assert torch.isfinite(binned).all() and (binned != 0).sum() < 20000
+    assert rel_l2(host(binned), host(atomic)) < 1e-5  # the fp32 atomics lose bits summing 1e5 terms into one entry
