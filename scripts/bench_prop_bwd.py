@@ -1,8 +1,7 @@
 """proposal-field table gradient (S2 backward) on a NeuRAD-sized proposal batch: binned vs memory-side atomics"""
 import os, sys, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+sys.path.insert(0, os.getcwd())
 import numpy as np, torch
-import synth
 from neurad_studio_amd import ops
 R, S = 16384, 128
 spec = ops.GridSpec(6, 1, 20, 128, 4096)

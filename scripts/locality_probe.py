@@ -1,8 +1,8 @@
 """How much of render_kernel's time is the gather?  Same kernel, same work, different memory behaviour."""
 import sys, os
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle')
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests')
 import numpy as np, torch
-import synth, neurad_oracle as O
+import synth
 from neurad_studio_amd import ops
 dev = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to('cuda', dt)
 def lin(o,i,s):
@@ -24,7 +24,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1)/n*1e3
 R,S = 4096,128
 o,d,area,_ = synth.rays(R,1)
-_,eu,_ = O.power_sampler(np.zeros(R), np.full(R,20000.0,np.float32), S)
+eu = ops.power_sampler(None, torch.full((R,), 20000.0, device='cuda'), S)[1].cpu().numpy()
 ed = dev(eu); da = dev(area)
 for name, lg, oo, dd, half in [("C2 random rays T=2^19", 19, o, d, False), ("C2 identical rays T=2^19", 19, np.repeat(o[:1],R,0), np.repeat(d[:1],R,0), False),
                          ("C2 random rays T=2^12 (L2 resident)", 12, o, d, False), ("C2 random rays T=2^19 fp16 table", 19, o, d, True),

@@ -1,7 +1,7 @@
 import sys, os, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle')
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tests')
 import numpy as np, torch
-import synth, neurad_oracle as O
+import synth
 from neurad_studio_amd import ops
 dev = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to('cuda', dt)
 def lin(o,i,s):
@@ -15,7 +15,7 @@ def mk(L,F,lg,H,mn,mx):
 for name,(L,F,lg,H,mn,mx,R,S) in {'C2':(16,2,19,64,16,1024,4096,128),'neurad':(8,4,22,32,32,8192,16384,32)}.items():
     fs = mk(L,F,lg,H,mn,mx)
     o,d,area,_ = synth.rays(R,1)
-    _,eu,_ = O.power_sampler(np.zeros(R), np.full(R,20000.0,np.float32), S)
+    eu = ops.power_sampler(None, torch.full((R,), 20000.0, device='cuda'), S)[1].cpu().numpy()
     do,dd,da,ed = dev(o),dev(d),dev(area),dev(eu)
     for fn,label in ((lambda: ops.render_fwd(fs,do,dd,da,ed[:,:-1],ed[:,1:]),'render_fused'),
                      (lambda: ops.field_fwd(fs,do,dd,da,ed[:,:-1],ed[:,1:]),'field_fused'),
