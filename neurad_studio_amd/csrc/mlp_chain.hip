@@ -527,19 +527,23 @@ __global__ __launch_bounds__(256) void wgrad_merge_kernel(MergeArgs m, const flo
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int grid_blocks(int64_t n) {
-  int n_cu = 256;
-  hipDeviceProp_t prop;
-  int dev = 0;
-  static thread_local int cached_cu = 0;
-  if (!cached_cu) {
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cached_cu = prop.multiProcessorCount;
-    else
-      cached_cu = n_cu;
+int cu_count() {
+  static thread_local int cached = 0;
+  if (!cached) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    cached = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                 ? prop.multiProcessorCount
+                 : 256;
   }
+  return cached;
+}
+
+// persistent grid (the weight image is staged once per workgroup): one wave per 16-sample tile, at most per_cu
+// workgroups per CU
+int grid_blocks(int64_t n, int per_cu = 4) {
   const int64_t want = ((n + 15) / 16 + 3) / 4;
-  const int64_t cap = (int64_t)cached_cu * 4;  // persistent: the weight image is staged once per workgroup
+  const int64_t cap = (int64_t)cu_count() * per_cu;
   return (int)(want < cap ? (want < 1 ? 1 : want) : cap);
 }
 
@@ -615,8 +619,7 @@ int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const 
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
     resident = nb > 4 ? 4 : nb;
   }
-  int blocks = grid_blocks(n);  // <= 4 per CU
-  if (blocks > (grid_blocks(INT64_MAX / 2) / 4) * resident) blocks = (grid_blocks(INT64_MAX / 2) / 4) * resident;
+  int blocks = grid_blocks(n, resident);
   if (blocks > fit) blocks = (int)fit;
   kern<<<blocks, 256, lds, st>>>(a, x, hidden, gy, n, gx, dz, part);
   if (int e = check_launch("mlp_chain_bwd_wg")) return e;
