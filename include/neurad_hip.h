@@ -132,16 +132,18 @@ int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const nrhip_rays* 
                      const float* grad_out /*[N,L*F]*/, float* grad_table, void* stream);
 /* Same result without memory-side atomics (every table entry gets one owning workgroup; see
  * csrc/encode_bwd_binned.hip).  Needs scratch: ask _workspace for the size (0 = this grid can not be binned, use
- * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  grad_table is
- * ACCUMULATED into, as above. */
+ * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  overwrite = 0: grad_table
+ * is ACCUMULATED into, as above; overwrite = 1: every element of grad_table is WRITTEN (no zero-fill needed before,
+ * and the pass over the table is a store instead of a read-modify-write). */
 int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_samples, int64_t* bytes);
 /* The same scratch size serves the two other table gradients below (it depends on the grid and the sample count
  * only): nrhip_hashgrid_bwd_binned == nrhip_hashgrid_bwd, nrhip_proposal_density_bwd_binned ==
  * nrhip_proposal_density_bwd, without memory-side atomics. */
 int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, const float* grad_out /*[N,L*F]*/, int64_t n,
-                              float* grad_table, void* workspace, int64_t workspace_bytes, void* stream);
+                              float* grad_table, int32_t overwrite, void* workspace, int64_t workspace_bytes,
+                              void* stream);
 int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
-                            const float* grad_out /*[N,L*F]*/, float* grad_table, void* workspace,
+                            const float* grad_out /*[N,L*F]*/, float* grad_table, int32_t overwrite, void* workspace,
                             int64_t workspace_bytes, void* stream);
 
 /* ---- F3: SHEncoding(levels=4) (encodings.py:797-805 -> utils/math.py:31-94) -------------------- */
@@ -212,7 +214,8 @@ int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_rays* rays, 
 /* level_features: what the forward saved, or NULL (the interpolated features are then recomputed) */
 int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
                                       const float* level_features, const float* grad_density, float* grad_table,
-                                      float* grad_decoder, void* workspace, int64_t workspace_bytes, void* stream);
+                                      float* grad_decoder, int32_t overwrite /*grad_table only*/, void* workspace,
+                                      int64_t workspace_bytes, void* stream);
 
 /* ---- S3: RaySamples.get_weights (cameras/rays.py:188-210) -------------------------------------- */
 int nrhip_weights_from_density(const float* deltas, const float* densities, int64_t r, int32_t s, float* weights,

@@ -75,8 +75,8 @@ PROTOTYPES = {
     "nrhip_encode_fwd": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P],
     "nrhip_encode_bwd": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P],
     "nrhip_encode_bwd_binned_workspace": [C.POINTER(Grid), I64, C.POINTER(I64)],
-    "nrhip_encode_bwd_binned": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P, I64, P],
-    "nrhip_hashgrid_bwd_binned": [C.POINTER(Grid), P, P, I64, P, P, I64, P],
+    "nrhip_encode_bwd_binned": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, I32, P, I64, P],
+    "nrhip_hashgrid_bwd_binned": [C.POINTER(Grid), P, P, I64, P, I32, P, I64, P],
     "nrhip_sh4_fwd": [P, I64, P, P],
     "nrhip_mlp_fwd": [C.POINTER(Mlp), P, I64, P, P, P],
     "nrhip_mlp_bwd_workspace": [C.POINTER(Mlp), I64, C.POINTER(I64)],
@@ -93,7 +93,7 @@ PROTOTYPES = {
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
-    "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, P, I64, P],
+    "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],
     "nrhip_weights_from_density": [P, P, I64, I32, P, P],
     "nrhip_weights_from_density_bwd": [P, P, P, I64, I32, P, P],
     "nrhip_power_sampler": [P, P, I64, I32, F32, F32, P, P, P, P],

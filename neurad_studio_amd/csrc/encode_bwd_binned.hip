@@ -313,14 +313,24 @@ template <int F>
 __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ offsets,
                                                            const float* __restrict__ qrec,
                                                            const float* __restrict__ qmax_all, float* __restrict__ gt,
-                                                           int log2T, int log2TS, int nb, int nmax) {
+                                                           int log2T, int log2TS, int nb, int nmax, int overwrite) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];
   __shared__ float smax[16];
   __shared__ uint32_t poisoned;
   const int lb = blockIdx.x;
   const uint32_t first = offsets[lb], cnt = offsets[lb + 1] - first;
-  if (cnt == 0) return;  // uniform: nothing was sent to this slice
   const int l = lb / nb, b = lb - l * nb;
+  if (cnt == 0) {  // uniform: nothing was sent to this slice
+    if (overwrite) {  // the caller did not zero grad_table: this slice's part of it is ours to define
+      float* z = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+      const int nz = F << log2TS;
+      if (nz % 4 == 0)
+        for (int i = threadIdx.x * 4; i < nz; i += 4096) *reinterpret_cast<float4*>(z + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      else
+        for (int i = threadIdx.x; i < nz; i += 1024) z[i] = 0.f;
+    }
+    return;
+  }
   // |value| < 2^(e+1) for every finite record of the level; cnt < 2^hb records -> |value * 2^sh| < 2^(61-hb), sum < 2^61
   const float* qmax = qmax_all + (size_t)l * nmax;
   float vmax = 0.f;
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
   const float nan = __uint_as_float(0x7fc00000u);
   if (nacc % 4 == 0) {
     for (int i = threadIdx.x * 4; i < nacc; i += 4096) {
-      float4 o = *reinterpret_cast<const float4*>(out + i);
+      float4 o = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(out + i);
       o.x += (float)ldexp((double)(long long)tile[i], -sh);
       o.y += (float)ldexp((double)(long long)tile[i + 1], -sh);
       o.z += (float)ldexp((double)(long long)tile[i + 2], -sh);
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
     }
   } else {
     for (int i = threadIdx.x; i < nacc; i += 1024) {
-      float o = out[i] + (float)ldexp((double)(long long)tile[i], -sh);
+      float o = (overwrite ? 0.f : out[i]) + (float)ldexp((double)(long long)tile[i], -sh);
       if (any_poison && ((pbits[i >> 5] >> (i & 31)) & 1)) o = nan;
       out[i] = o;
     }
@@ -423,8 +433,8 @@ namespace {
 
 // All four passes for one source of samples, in rounds of kRoundSamples.  `what` names the entry point in errors.
 template <class Src>
-int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, void* workspace,
-               int64_t workspace_bytes, hipStream_t st) {
+int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, bool overwrite,
+               void* workspace, int64_t workspace_bytes, hipStream_t st) {
   BinPlan p;
   NR_REQUIRE(make_plan(gd, n, &p), NRHIP_ERR_UNSUPPORTED,
              "%s: 2^%d entries x %d features need more than %d slices per level; use the atomic entry point", what,
@@ -474,7 +484,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts, offsets, gpos, \
                                                          qrec, qmax, p.nmax);                                       \
     bin_reduce_kernel<F><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,      \
-                                                    p.nmax);                                                        \
+                                                    p.nmax, (overwrite && i_off == 0) ? 1 : 0);                     \
   } while (0)
     NR_DISPATCH_F(gd.F, CALL);
 #undef CALL
@@ -486,7 +496,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
 }  // namespace
 
 extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
-                                       const float* grad_out, float* grad_table, void* workspace,
+                                       const float* grad_out, float* grad_table, int32_t overwrite, void* workspace,
                                        int64_t workspace_bytes, void* stream) {
   if (int e = validate_grid(g)) return e;
   if (int e = validate_rays(rays)) return e;
@@ -495,28 +505,31 @@ extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, 
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
   const EncodeSrc src{to_dev(*rays), static_scale, grad_out, gd.L};
-  return run_binned("encode_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes, (hipStream_t)stream);
+  return run_binned("encode_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
+                    (hipStream_t)stream);
 }
 
 extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, const float* grad_out, int64_t n,
-                                         float* grad_table, void* workspace, int64_t workspace_bytes, void* stream) {
+                                         float* grad_table, int32_t overwrite, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
   if (int e = validate_grid(g)) return e;
   NR_REQUIRE(x && grad_out && grad_table && n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_binned: bad argument");
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
   const GridSrc src{x, grad_out, gd.L};
-  return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes, (hipStream_t)stream);
+  return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
+                    (hipStream_t)stream);
 }
 
 // grad_table part of nrhip_proposal_density_bwd (the decoder gradient stays with that entry point's kernel)
 namespace nrhip {
 int proposal_table_grad_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
-                               const float* grad_density, float* grad_table, void* workspace, int64_t workspace_bytes,
-                               void* stream) {
+                               const float* grad_density, float* grad_table, bool overwrite, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
   const int64_t n = rays->n_rays * rays->n_samples;
   const GridDev gd = to_dev(p->grid);
   const ProposalSrc src{to_dev(*rays), p->static_scale, p->decoder_weight, density, grad_density};
-  return run_binned("proposal_density_bwd_binned", gd, src, n, grad_table, workspace, workspace_bytes,
+  return run_binned("proposal_density_bwd_binned", gd, src, n, grad_table, overwrite, workspace, workspace_bytes,
                     (hipStream_t)stream);
 }
 }  // namespace nrhip

@@ -427,14 +427,15 @@ __global__ __launch_bounds__(256) void proposal_decoder_grad_kernel(const float*
 
 namespace nrhip {
 int proposal_table_grad_binned(const nrhip_proposal* p, const nrhip_rays* rays, const float* density,
-                               const float* grad_density, float* grad_table, void* workspace, int64_t workspace_bytes,
-                               void* stream);  // encode_bwd_binned.hip
+                               const float* grad_density, float* grad_table, bool overwrite, void* workspace,
+                               int64_t workspace_bytes, void* stream);  // encode_bwd_binned.hip
 }
 
 extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const nrhip_rays* rays,
                                                  const float* density, const float* level_features,
                                                  const float* grad_density, float* grad_table, float* grad_decoder,
-                                                 void* workspace, int64_t workspace_bytes, void* stream) {
+                                                 int32_t overwrite, void* workspace, int64_t workspace_bytes,
+                                                 void* stream) {
   NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null descriptor");
   if (int e = validate_grid(&p->grid)) return e;
   if (int e = validate_rays(rays)) return e;
@@ -455,7 +456,8 @@ extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const 
         grad_table, grad_decoder);
   }
   if (int e = check_launch("proposal_density_bwd_binned decoder")) return e;
-  return proposal_table_grad_binned(p, rays, density, grad_density, grad_table, workspace, workspace_bytes, stream);
+  return proposal_table_grad_binned(p, rays, density, grad_density, grad_table, overwrite != 0, workspace,
+                                    workspace_bytes, stream);
 }
 
 extern "C" int nrhip_hashgrid_multi_fwd(const nrhip_grid* g, const void* const* tables, int32_t n_grids,

@@ -144,14 +144,14 @@ def hashgrid_fwd(spec: GridSpec, table: Tensor, x: Tensor) -> Tensor:
 
 def hashgrid_bwd(spec: GridSpec, table_like: Tensor, x: Tensor, grad_out: Tensor) -> Tensor:
     x, grad_out = _chk(x, "x"), _chk(grad_out, "grad_out")
-    gt = torch.zeros((spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
+    gt = torch.empty((spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
     g = spec.c_grid(gt)
     ws = _table_grad_workspace(g, x.shape[0], x.device)
-    if ws is not None:
-        call("nrhip_hashgrid_bwd_binned", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), _ptr(ws),
+    if ws is not None:  # overwrite = 1: the partition writes every element of the gradient, no zero-fill
+        call("nrhip_hashgrid_bwd_binned", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), 1, _ptr(ws),
              ws.numel(), _stream())
     else:
-        call("nrhip_hashgrid_bwd", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt), _stream())
+        call("nrhip_hashgrid_bwd", C.byref(g), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(gt.zero_()), _stream())
     return gt
 
 
@@ -234,14 +234,15 @@ def encode_fwd(spec: GridSpec, table: Tensor, static_scale: float, origins, dire
 def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_area, starts, ends, grad_out):
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     grad_out = _chk(grad_out, "grad_out")
-    gt = torch.zeros((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
+    gt = torch.empty((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
     g = spec.c_grid(gt)
     ws = _table_grad_workspace(g, r.n_rays * r.n_samples, origins.device)
-    if ws is not None:
-        call("nrhip_encode_bwd_binned", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt),
+    if ws is not None:  # overwrite = 1: the partition writes every element of the gradient, no zero-fill
+        call("nrhip_encode_bwd_binned", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), 1,
              _ptr(ws), ws.numel(), _stream())
-    else:  # tables too large to cut into LDS slices: memory-side atomics
-        call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), _stream())
+    else:  # tables too large to cut into LDS slices, or a tiny batch: memory-side atomics
+        call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt.zero_()),
+             _stream())
     return gt
 
 
@@ -462,14 +463,15 @@ def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, star
                          level_features: Optional[Tensor] = None):
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     p, keep2 = ps.c_prop()
-    gt = torch.zeros((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
     gdec = torch.zeros((1, ps.grid.num_levels), device=origins.device, dtype=torch.float32)
     ws = _table_grad_workspace(p.grid, r.n_rays * r.n_samples, origins.device)
     if ws is not None:
+        gt = torch.empty((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
         call("nrhip_proposal_density_bwd_binned", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
-             _ptr(level_features), _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _ptr(ws),
+             _ptr(level_features), _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), 1, _ptr(ws),
              ws.numel(), _stream())
     else:
+        gt = torch.zeros((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
         call("nrhip_proposal_density_bwd", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
              _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _stream())
     return gt, gdec
