@@ -77,3 +77,56 @@ def test_product_path_refuses_cpu_tensors():
     spec = ops.GridSpec(4, 2, 8, 16, 128)
     with pytest.raises(_lib.NeuradHipError):
         ops.hashgrid_fwd(spec, torch.zeros(4 * 256, 2), torch.rand(5, 3))
+
+
+def _grid(L, F, lg):
+    from neurad_studio_amd import _lib
+
+    g = _lib.Grid()
+    g.num_levels, g.n_features, g.log2_table_size, g.param_dtype = L, F, lg, 0
+    for i in range(L):
+        g.scalings[i] = 16.0 * (i + 1)
+    return g
+
+
+def test_table_gradient_workspace_query_is_host_logic(lib):
+    """nrhip_encode_bwd_binned_workspace needs no GPU: one record slot per corner term + bookkeeping, flat beyond 2^20
+    samples (larger batches go through in rounds), 0 for grids with more than 2048 slices per level."""
+    fn = lib.nrhip_encode_bwd_binned_workspace
+    fn.restype = ctypes.c_int
+
+    def need(L, F, lg, n):
+        out = ctypes.c_int64(-1)
+        assert fn(ctypes.byref(_grid(L, F, lg)), ctypes.c_int64(n), ctypes.byref(out)) == 0
+        return out.value
+
+    assert need(16, 2, 19, 0) == 0
+    records = lambda L, F, n: n * 8 * L * (F + 1) * 4  # noqa: E731
+    for L, F, lg in [(16, 2, 19), (8, 4, 22), (6, 1, 20), (4, 4, 17)]:
+        a, b = need(L, F, lg, 4096 * 128), need(L, F, lg, 2 * 4096 * 128)
+        assert records(L, F, 4096 * 128) <= a <= records(L, F, 4096 * 128) + (64 << 20)
+        assert a < b and need(L, F, lg, 1 << 20) == need(L, F, lg, 1 << 24)
+    assert need(8, 8, 24, 4096) == 0  # 2^24 entries x 8 features: 8192 slices per level -> atomic entry point
+    bad = ctypes.c_int64(0)
+    assert fn(ctypes.byref(_grid(0, 2, 19)), ctypes.c_int64(16), ctypes.byref(bad)) != 0  # invalid grid is an error
+
+
+def test_mlp_backward_workspace_query(lib):
+    from neurad_studio_amd import _lib
+
+    fn = lib.nrhip_mlp_bwd_workspace
+    fn.restype = ctypes.c_int
+
+    def need(i, h, o, nl, n):
+        m = _lib.Mlp()
+        m.in_dim, m.hidden_dim, m.out_dim, m.num_layers = i, h, o, nl
+        for k in range(nl):
+            m.weight[k] = 1  # never dereferenced by the query
+        out = ctypes.c_int64(-1)
+        assert fn(ctypes.byref(m), ctypes.c_int64(n), ctypes.byref(out)) == 0
+        return out.value
+
+    n = 1000
+    assert need(13, 24, 3, 4, n) == (n * 3 * 24 + 3) // 4 * 4           # generic shape: dZ of the hidden layers only
+    assert need(32, 64, 33, 2, n) > n * 64                              # NeuRAD's geometry MLP: + weight-gradient partials
+    assert need(48, 64, 32, 3, n) > n * 128
