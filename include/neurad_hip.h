@@ -324,6 +324,19 @@ int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposa
                                float* const* round_euclid  /*host array[n_rounds+1] of [R,S_i+1]*/,
                                void* stream);
 
+/* ---- losses on the sampler outputs (model_components/losses.py) ---------------
+ * One wavefront per ray; spacing-space bin edges c [R,S+1] in [0,1], weights [R,S].
+ * zipnerf_interlevel_loss (losses.py:645-705), ONE proposal level per call: c/w = the fine (field) histogram
+ * (detached in the reference), cp/wp = the proposal level, pulse_width = 0.03 / 0.003 for level 0 / 1.
+ * loss_per_ray [R] = sum_s relu(w_s - wp)^2 / (wp + 1e-5); grad_wp [R,n_prop] (may be NULL) = d loss_per_ray / d wp.
+ * The reference's value is the mean over rays, summed over levels. */
+int nrhip_interlevel_loss(const float* c, const float* w, int32_t n_fine, const float* cp, const float* wp,
+                          int32_t n_prop, float pulse_width, int64_t r, float* loss_per_ray, float* grad_wp,
+                          void* stream);
+/* distortion_loss / lossfun_distortion (losses.py:137-156): loss_per_ray [R], grad_w [R,S] (may be NULL) */
+int nrhip_distortion_loss(const float* c, const float* w, int32_t n_samples, int64_t r, float* loss_per_ray,
+                          float* grad_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,3 +251,40 @@ class ProposalDensityFn(torch.autograd.Function):
         o, d, a, s, e, dens, lf = ctx.saved_tensors
         gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g.contiguous(), level_features=lf)
         return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None, None
+
+
+class InterlevelLossFn(torch.autograd.Function):
+    """One proposal level of zipnerf_interlevel_loss (model_components/losses.py:672-705), mean over rays.
+    Gradient to the proposal weights only: the fine histogram is detached in the reference (losses.py:678-679)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, c, w, cp, wp, pulse_width):
+        loss, g = ops.interlevel_loss_level(c, w, cp, wp, pulse_width, need_grad=True)
+        ctx.save_for_backward(g)
+        ctx.n_rays = wp.shape[0]
+        return loss.mean()
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return None, None, None, g * (go / ctx.n_rays), None
+
+
+class DistortionLossFn(torch.autograd.Function):
+    """distortion_loss (model_components/losses.py:137-156): mean over rays of lossfun_distortion(c, w)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, c, w):
+        loss, g = ops.distortion_loss_rays(c, w, need_grad=True)
+        ctx.save_for_backward(g)
+        ctx.n_rays = w.shape[0]
+        return loss.mean()
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return None, g * (go / ctx.n_rays)

@@ -696,3 +696,30 @@ def device_info():
     cus, xcds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
     call("nrhip_device_info", C.byref(cus), C.byref(xcds), C.byref(hbm))
     return {"cus": cus.value, "xcds": xcds.value, "hbm_bytes": hbm.value}
+
+
+# ------------------------------------------------------------------------------------------------
+# losses on the sampler outputs
+def interlevel_loss_level(c: Tensor, w: Tensor, cp: Tensor, wp: Tensor, pulse_width: float, need_grad: bool = True):
+    """one proposal level of zipnerf_interlevel_loss: -> loss_per_ray [R], d loss_per_ray / d wp [R,Sp] (or None)"""
+    c, w, cp, wp = _chk(c, "c"), _chk(w, "w"), _chk(cp, "cp"), _chk(wp, "wp")
+    R, sf, sp = w.shape[0], w.shape[1], wp.shape[1]
+    if c.shape != (R, sf + 1) or cp.shape != (R, sp + 1) or wp.shape[0] != R:
+        raise ValueError(f"interlevel_loss: shapes c {tuple(c.shape)} w {tuple(w.shape)} cp {tuple(cp.shape)} wp {tuple(wp.shape)}")
+    loss = torch.empty((R,), device=w.device, dtype=torch.float32)
+    g = torch.empty_like(wp) if need_grad else None
+    call("nrhip_interlevel_loss", _ptr(c), _ptr(w), sf, _ptr(cp), _ptr(wp), sp, float(pulse_width), R, _ptr(loss), _ptr(g),
+         _stream())
+    return loss, g
+
+
+def distortion_loss_rays(c: Tensor, w: Tensor, need_grad: bool = True):
+    """lossfun_distortion per ray: -> loss_per_ray [R], d loss_per_ray / d w [R,S] (or None)"""
+    c, w = _chk(c, "c"), _chk(w, "w")
+    R, s = w.shape
+    if c.shape != (R, s + 1):
+        raise ValueError(f"distortion_loss: c {tuple(c.shape)} does not match w {tuple(w.shape)}")
+    loss = torch.empty((R,), device=w.device, dtype=torch.float32)
+    g = torch.empty_like(w) if need_grad else None
+    call("nrhip_distortion_loss", _ptr(c), _ptr(w), s, R, _ptr(loss), _ptr(g), _stream())
+    return loss, g

@@ -663,3 +663,68 @@ def field_fwd_actors(p: FieldParams, a: ActorParams, origins, directions, pixel_
     else:
         out["density"] = np.exp(geo_out.reshape(R, S)).astype(f32)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# losses on the sampler outputs (model_components/losses.py)
+def blur_stepfun(x: np.ndarray, y: np.ndarray, r: float):
+    """losses.py:645-653 for one ray: x [n+1] edges, y [n] step heights -> (xr [2n+2], yr [2n+2])."""
+    xr_all = np.concatenate([x - f32(r), x + f32(r)]).astype(f32)
+    idx = np.argsort(xr_all, kind="stable")
+    xr = xr_all[idx]
+    y1 = ((np.concatenate([y, [f32(0)]]) - np.concatenate([[f32(0)], y])) / f32(2 * r)).astype(f32)
+    y2 = np.concatenate([y1, -y1])[idx[:-1]]
+    # torch's CPU cumsum accumulates float32 inputs in double (at::acc_type) and rounds every prefix to float32
+    inner = np.cumsum(y2, dtype=np.float64).astype(f32)
+    yr = np.maximum(np.cumsum(((xr[1:] - xr[:-1]) * inner).astype(f32), dtype=np.float64).astype(f32), f32(0))
+    return xr, np.concatenate([[f32(0)], yr]).astype(f32)
+
+
+def sorted_interp_quad(x, xp, fpdf, fcdf):
+    """losses.py:656-669 for one ray."""
+    right = np.searchsorted(xp, x, side="left")
+    left = np.maximum(right - 1, 0)
+    right = np.minimum(right, xp.shape[-1] - 1)
+    xp0, xp1, f0, f1, c0 = xp[left], xp[right], fpdf[left], fpdf[right], fcdf[left]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        off = (x - xp0) / (xp1 - xp0)
+    off = np.clip(np.nan_to_num(off, nan=0.0), 0, 1).astype(f32)
+    return (c0 + (x - xp0) * (f0 + f1 * off + f0 * (1 - off)) * f32(0.5)).astype(f32)
+
+
+def interlevel_loss_level(c, w, cp, wp, pulse_width):
+    """One proposal level of zipnerf_interlevel_loss (losses.py:672-705).  c [R,Sf+1], w [R,Sf] fine spacing edges /
+    weights, cp [R,Sp+1], wp [R,Sp] proposal ones.  -> per-ray loss [R], w_s [R,Sp], d loss_ray / d wp [R,Sp]."""
+    c, w, cp, wp = (np.asarray(a, f32) for a in (c, w, cp, wp))
+    R = c.shape[0]
+    loss, ws_all, g_all = np.zeros(R, f32), np.zeros_like(wp), np.zeros_like(wp)
+    for i in range(R):
+        wi = w[i].copy()
+        wi[-1] = wi[-1] + (f32(1) - wi.sum(dtype=f32))
+        wn = (wi / (c[i, 1:] - c[i, :-1])).astype(f32)
+        c_, w_ = blur_stepfun(c[i], wn, pulse_width)
+        area = (f32(0.5) * (w_[1:] + w_[:-1]) * (c_[1:] - c_[:-1])).astype(f32)
+        cdf = np.concatenate([[f32(0)], np.cumsum(area, dtype=np.float64).astype(f32)])
+        c_ = np.concatenate([[f32(0)], c_, [f32(1)]]).astype(f32)
+        w_ = np.concatenate([[f32(0)], w_, [f32(0)]]).astype(f32)
+        cdf = np.concatenate([[f32(0)], cdf, [f32(1)]]).astype(f32)
+        ci = sorted_interp_quad(cp[i], c_, w_, cdf)
+        ws = np.diff(ci).astype(f32)
+        d = np.maximum(ws - wp[i], f32(0))
+        den = wp[i] + f32(1e-5)
+        loss[i] = (d * d / den).sum(dtype=f32)
+        ws_all[i] = ws
+        g_all[i] = -(f32(2) * d / den + d * d / (den * den))
+    return loss, ws_all, g_all
+
+
+def distortion_loss_rays(c, w):
+    """lossfun_distortion (losses.py:137-148) per ray: c [R,S+1], w [R,S] -> loss [R], d loss / d w [R,S]."""
+    c, w = np.asarray(c, f32), np.asarray(w, f32)
+    ut = ((c[:, 1:] + c[:, :-1]) / f32(2)).astype(f32)
+    dut = np.abs(ut[:, :, None] - ut[:, None, :]).astype(f32)
+    inner = (w[:, None, :] * dut).sum(-1, dtype=f32)
+    delta = (c[:, 1:] - c[:, :-1]).astype(f32)
+    loss = (w * inner).sum(-1, dtype=f32) + (w * w * delta).sum(-1, dtype=f32) / f32(3)
+    grad = f32(2) * inner + f32(2) / f32(3) * w * delta
+    return loss.astype(f32), grad.astype(f32)

@@ -1,6 +1,7 @@
 """Whole NeuRAD hot-path training step at the reference's default sizes (models/neurad.py defaults: static grid L=8,
 F=4, T=2^22; proposal grids L=6, F=1, T=2^20; 128+64 proposal samples, 32 field samples; 32-wide MLPs):
-get_nff_outputs (training mode, jitter) -> stand-in losses on features/depth/proposal weights -> backward -> Adam.
+get_nff_outputs (training mode, jitter) -> feature/depth stand-ins + the reference's sampler losses (zipnerf interlevel,
+distortion, with NeuRAD's multipliers, models/neurad.py:83-85) -> backward -> Adam.
 Prints ms/step; run under rocprofv3 --kernel-trace --stats for the per-kernel split.
 
   python scripts/bench_full_train.py [n_rays] [steps]
@@ -13,6 +14,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 
 from neurad_studio_amd.cameras.rays import RayBundle
+from neurad_studio_amd.model_components.losses import distortion_loss, zipnerf_interlevel_loss
 from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
@@ -43,7 +45,8 @@ def step():
                    nears=torch.zeros((R, 1), device=dev), fars=torch.full((R, 1), 20000.0, device=dev))
     out = m.get_nff_outputs(rb)
     loss = (out["features"] - target).square().mean() + 1e-3 * out["depth"].abs().mean()
-    loss = loss + 1e-2 * sum(w.square().sum(-2).mean() for w in out["weights_list"][:2])  # stand-in for interlevel loss
+    loss = loss + 0.001 * zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
+    loss = loss + 0.002 * distortion_loss(out["weights_list"], out["ray_samples_list"])
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()

@@ -478,3 +478,59 @@ def test_encode_bwd_binned_degenerate_distribution(ops, monkeypatch):
     atomic = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
     assert torch.isfinite(binned).all() and (binned != 0).sum() < 20000
     assert rel_l2(host(binned), host(atomic)) < 1e-5  # the fp32 atomics lose bits summing 1e5 terms into one entry
+
+
+def test_sampler_losses_vs_reference_autograd(ops):
+    """zipnerf_interlevel_loss / distortion_loss -- one wavefront per ray against the reference's
+    own values and autograd gradients (tests/golden/losses.npz), the oracle on ragged sizes, and autograd plumbing."""
+    from types import SimpleNamespace
+
+    from neurad_studio_amd.model_components import losses as hl
+
+    g = load_golden("losses")
+    R = g["w0"].shape[0]
+    total = 0.0
+    for cp, wp, gw, r in [(g["sd0"], g["w0"], g["g_w0"], 0.03), (g["sd1"], g["w1"], g["g_w1"], 0.003)]:
+        loss, grad = ops.interlevel_loss_level(dev(g["sdf"]), dev(g["wf"]), dev(cp), dev(wp), r)
+        ref_loss, _, ref_grad = O.interlevel_loss_level(g["sdf"], g["wf"], cp, wp, r)
+        assert rel_l2(host(loss), ref_loss) < TIGHT
+        assert rel_l2(host(grad) / R, gw) < TOL and rel_l2(host(grad), ref_grad) < TIGHT
+        total += host(loss).mean()
+    assert abs(total - g["interlevel"]) / g["interlevel"] < TIGHT
+    dl, dg = ops.distortion_loss_rays(dev(g["sdf"]), dev(g["wf"]))
+    assert abs(host(dl).mean() - g["distortion"]) / g["distortion"] < TIGHT and rel_l2(host(dg) / R, g["g_wf"]) < TIGHT
+
+    # the reference-shaped functions, through autograd
+    def samples(sd):
+        t = dev(sd)
+        return SimpleNamespace(spacing_starts=t[:, :-1, None], spacing_ends=t[:, 1:, None])
+
+    w0, w1, wf = (dev(g[k]).requires_grad_(True) for k in ("w0", "w1", "wf"))
+    rsl = [samples(g["sd0"]), samples(g["sd1"]), samples(g["sdf"])]
+    wl = [w0[..., None], w1[..., None], wf[..., None]]
+    il = hl.zipnerf_interlevel_loss(wl, rsl)
+    (il * 0.5).backward()
+    assert abs(il.item() - g["interlevel"]) / g["interlevel"] < TIGHT
+    assert rel_l2(host(w0.grad), 0.5 * g["g_w0"]) < TOL and rel_l2(host(w1.grad), 0.5 * g["g_w1"]) < TOL and wf.grad is None
+    dist = hl.distortion_loss(wl, rsl)
+    dist.backward()
+    assert abs(dist.item() - g["distortion"]) / g["distortion"] < TIGHT and rel_l2(host(wf.grad), g["g_wf"]) < TIGHT
+
+    # ragged sizes / degenerate bins against the oracle: zero-width bins, zero weights, one fine sample
+    for (R2, sf, sp) in [(3, 1, 5), (5, 7, 130), (2, 128, 512), (4, 33, 64)]:
+        c = np.sort(synth.uniform((R2, sf + 1), 0.0, 1.0, seed=sf), -1).astype(np.float32)
+        c[:, 0], c[:, -1] = 0.0, 1.0
+        cp = np.sort(synth.uniform((R2, sp + 1), 0.0, 1.0, seed=sp), -1).astype(np.float32)
+        cp[:, 0], cp[:, -1] = 0.0, 1.0
+        if sp > 8:
+            cp[:, 3] = cp[:, 4]  # a zero-width proposal bin
+        w = synth.uniform((R2, sf), 0.0, 1.0, seed=7).astype(np.float32)
+        w = w / w.sum(-1, keepdims=True) * 0.8
+        wp = synth.uniform((R2, sp), 0.0, 2.0 / sp, seed=8).astype(np.float32)
+        wp[:, 0] = 0.0
+        loss, grad = ops.interlevel_loss_level(dev(c), dev(w), dev(cp), dev(wp), 0.03)
+        rl, _, rg = O.interlevel_loss_level(c, w, cp, wp, 0.03)
+        assert rel_l2(host(loss), rl) < TOL and rel_l2(host(grad), rg) < TOL, (R2, sf, sp)
+        dl, dg = ops.distortion_loss_rays(dev(cp), dev(wp))
+        rdl, rdg = O.distortion_loss_rays(cp, wp)
+        assert rel_l2(host(dl), rdl) < TIGHT and rel_l2(host(dg), rdg) < TIGHT

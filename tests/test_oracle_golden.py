@@ -175,3 +175,18 @@ def test_compositing_restatement_consistency():
     f, d, a = O.composite(wa, feats, np.zeros_like(wa), np.ones_like(wa))
     np.testing.assert_allclose(a[:, 0], acc, atol=1e-6)
     np.testing.assert_allclose(f, (wa[..., None] * feats).sum(1) + (1 - acc)[:, None] * feats[:, -1], atol=2e-6)
+
+
+def test_sampler_losses_vs_reference_autograd():
+    """zipnerf_interlevel_loss and distortion_loss (model_components/losses.py:137-156,645-705),
+    values and gradients from the reference's own autograd (oracle/make_golden_losses.py)."""
+    g = load_golden("losses")
+    R = g["w0"].shape[0]
+    total = 0.0
+    for cp, wp, gw, r in [(g["sd0"], g["w0"], g["g_w0"], 0.03), (g["sd1"], g["w1"], g["g_w1"], 0.003)]:
+        loss, _, grad = O.interlevel_loss_level(g["sdf"], g["wf"], cp, wp, r)
+        total += loss.mean()
+        assert rel_l2(grad / R, gw) < 1e-5
+    assert abs(total - g["interlevel"]) / g["interlevel"] < 1e-5
+    loss, grad = O.distortion_loss_rays(g["sdf"], g["wf"])
+    assert abs(loss.mean() - g["distortion"]) / g["distortion"] < 1e-5 and rel_l2(grad / R, g["g_wf"]) < 1e-5
