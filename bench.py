@@ -204,8 +204,8 @@ def main():
     state = {}
 
     def step(ev=None):
-        sp, eu = ops.power_sampler(None, fars, S, lam=-1.0, scaling=0.1)
-        eu[:, -1] = 20000.0  # M1 sky stretch (models/neurad.py:451-455); no-op here since far == sky_distance
+        # M1 sky stretch (models/neurad.py:451-455) folded into the sampler launch; far == sky_distance here anyway
+        sp, eu = ops.power_sampler(None, fars, S, lam=-1.0, scaling=0.1, last_edge=20000.0)
         if ev is not None:
             ev[0].record()
         ops.render_fwd(fs, origins, dirs, area, eu[:, :-1], eu[:, 1:], out=(feats, depth, acc))

@@ -224,9 +224,11 @@ int nrhip_weights_from_density_bwd(const float* deltas, const float* densities, 
                                    int32_t s, float* grad_densities, void* stream);
 
 /* ---- S1: PowerSampler / SpacedSampler (ray_samplers.py:80-132,838-852; utils/math.py:541-579) ---
- * t_rand [R,S+1] = injected stratified jitter (training) or NULL (eval).  Outputs are bin EDGES.     */
+ * t_rand [R,S+1] = injected stratified jitter (training) or NULL (eval).  Outputs are bin EDGES.
+ * last_edge > 0: the last euclidean edge is set to it -- the model's sky stretch (models/neurad.py:451-455) when
+ * the PowerSampler bins go straight to the field; <= 0: off.                                          */
 int nrhip_power_sampler(const float* nears /*[R]*/, const float* fars /*[R]*/, int64_t r, int32_t s, float lam,
-                        float scaling, const float* t_rand, float* spacing_bins /*[R,S+1]*/,
+                        float scaling, const float* t_rand, float last_edge, float* spacing_bins /*[R,S+1]*/,
                         float* euclid_bins /*[R,S+1]*/, void* stream);
 
 /* ---- S4: PDFSampler (ray_samplers.py:280-376), include_original=False -------------------------

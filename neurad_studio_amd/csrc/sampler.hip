@@ -54,7 +54,7 @@ __device__ __forceinline__ float power_bin(int k, int S, const float* t_rand_row
 __global__ __launch_bounds__(256) void power_sampler_kernel(const float* __restrict__ nears,
                                                              const float* __restrict__ fars, int64_t R, int S,
                                                              float lam, float scaling,
-                                                             const float* __restrict__ t_rand,
+                                                             const float* __restrict__ t_rand, float last_edge,
                                                              float* __restrict__ sp, float* __restrict__ eu) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= R * (S + 1)) return;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void power_sampler_kernel(const float* __restr
   const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
   const float b = power_bin(k, S, t_rand ? t_rand + ray * (S + 1) : nullptr);
   sp[t] = b;
-  eu[t] = spc.to_euclid(b);
+  // last_edge > 0: the model's sky stretch (models/neurad.py:451-455, frustums.ends[:, -1] = sky_distance) folded in
+  eu[t] = (k == S && last_edge > 0.f) ? last_edge : spc.to_euclid(b);
 }
 
 __device__ __forceinline__ float wsum(float v) {
@@ -263,14 +264,13 @@ __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, co
 using namespace nrhip;
 
 extern "C" int nrhip_power_sampler(const float* nears, const float* fars, int64_t r, int32_t s, float lam,
-                                   float scaling, const float* t_rand, float* spacing_bins, float* euclid_bins,
-                                   void* stream) {
+                                   float scaling, const float* t_rand, float last_edge, float* spacing_bins,
+                                   float* euclid_bins, void* stream) {
   NR_REQUIRE(fars && spacing_bins && euclid_bins && r >= 0 && s >= 1, NRHIP_ERR_INVALID_ARG,
              "power_sampler: bad argument");
-  NR_REQUIRE(lam != 0.f || true, NRHIP_ERR_INVALID_ARG, "unreachable");
   if (r == 0) return NRHIP_OK;
-  power_sampler_kernel<<<grid_for(r * (s + 1), 256), 256, 0, (hipStream_t)stream>>>(nears, fars, r, s, lam, scaling,
-                                                                                    t_rand, spacing_bins, euclid_bins);
+  power_sampler_kernel<<<grid_for(r * (s + 1), 256), 256, 0, (hipStream_t)stream>>>(
+      nears, fars, r, s, lam, scaling, t_rand, last_edge, spacing_bins, euclid_bins);
   return check_launch("power_sampler");
 }
 

@@ -492,15 +492,16 @@ def weights_from_density_bwd(deltas, densities, grad_w) -> Tensor:
 
 
 def power_sampler(nears: Optional[Tensor], fars: Tensor, num_samples: int, lam: float = -1.0, scaling: float = 0.1,
-                  t_rand: Optional[Tensor] = None):
+                  t_rand: Optional[Tensor] = None, last_edge: float = 0.0):
+    """-> spacing bins, euclidean bins [R,S+1]; last_edge > 0 sets the last euclidean edge (the model's sky stretch)"""
     f = _chk(fars.reshape(-1), "fars")
     n = None if nears is None else _chk(nears.reshape(-1), "nears")
     R = f.shape[0]
     tr = None if t_rand is None else _chk(t_rand, "t_rand")
     sp = torch.empty((R, num_samples + 1), device=f.device, dtype=torch.float32)
     eu = torch.empty_like(sp)
-    call("nrhip_power_sampler", _ptr(n), _ptr(f), R, num_samples, float(lam), float(scaling), _ptr(tr), _ptr(sp),
-         _ptr(eu), _stream())
+    call("nrhip_power_sampler", _ptr(n), _ptr(f), R, num_samples, float(lam), float(scaling), _ptr(tr),
+         float(last_edge), _ptr(sp), _ptr(eu), _stream())
     return sp, eu
 
 

@@ -534,3 +534,12 @@ def test_sampler_losses_vs_reference_autograd(ops):
         dl, dg = ops.distortion_loss_rays(dev(cp), dev(wp))
         rdl, rdg = O.distortion_loss_rays(cp, wp)
         assert rel_l2(host(dl), rdl) < TIGHT and rel_l2(host(dg), rdg) < TIGHT
+
+
+def test_power_sampler_sky_stretch_folded(ops):
+    """last_edge > 0 == the model's `frustums.ends[:, -1] = sky_distance` applied to the sampler's euclidean bins."""
+    fars = dev(synth.uniform((33,), 10.0, 20000.0, seed=4))
+    sp0, eu0 = ops.power_sampler(None, fars, 37)
+    sp1, eu1 = ops.power_sampler(None, fars, 37, last_edge=20000.0)
+    eu0[:, -1] = 20000.0
+    assert torch.equal(sp0, sp1) and torch.equal(eu0, eu1)
