@@ -102,7 +102,9 @@ class FieldTrainFn(torch.autograd.Function):
         g_feature = g_feature.contiguous()
         # feature = embedding + mlp_feature([embedding | sh])
         gxf, gfw, gfb = ops.mlp_bwd(xf, hf, g_feature, fw, fb)
-        g_geo = torch.cat([g_geo_out.reshape(-1, 1), g_feature + gxf[:, :32]], dim=1)
+        g_geo = torch.empty((g_feature.shape[0], 33), device=g_feature.device, dtype=torch.float32)
+        g_geo[:, 0] = g_geo_out.reshape(-1)
+        torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
         genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
         gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc) if ctx.needs_input_grad[0] else None
         grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
