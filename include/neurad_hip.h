@@ -205,7 +205,8 @@ int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_fe
                      void* stream);
 
 /* ---- S2: NeuRADProposalField.get_density (neurad_field.py:208-213) ----------------------------- */
-/* level_features (may be NULL): [R*S, L] rescaled per-level features, saved for the decoder gradient */
+/* level_features (may be NULL): LEVEL-MAJOR [L, R*S] rescaled per-level features, saved for the decoder gradient;
+ * when requested (training) the lookups run level-partitioned over the XCDs (csrc/hashgrid.hip) */
 int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_rays* rays, float* density /*[R,S]*/,
                                float* level_features, void* stream);
 /* grad_table / grad_decoder are accumulated into */

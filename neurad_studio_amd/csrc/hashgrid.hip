@@ -202,9 +202,47 @@ __global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, co
     float v[1];
     hash_level<1, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
     const float f = v[0] * rescale_weight(g.scal[l], p.std);
-    if (lf) lf[i * g.L + l] = f;  // saved for the decoder gradient (training)
+    if (lf) lf[(size_t)l * (r.R * r.S) + i] = f;  // level-major [L][N], as the level-partitioned path writes them
     acc += f * dec[l];
   }
+  dens[i] = expf(acc);
+}
+
+// Training forward of S2, level-partitioned.  A proposal level (2^20 entries x 4 B) is exactly one XCD L2; a kernel
+// in which every thread walks all levels keeps 6 x 4 MB in flight per XCD and misses most of the time.  Here the
+// work is cut into (level, sample-quarter) units dealt round-robin to the XCDs in the dispatcher's observed block ->
+// XCD order (block b on XCD b % 8; a wrong guess costs speed, not correctness): each XCD works through its units one
+// after the other, so its L2 holds one level at a time.  Output: the rescaled per-level features, LEVEL-MAJOR [L][N]
+// (coalesced), which the backward wants anyway; proposal_density_from_levels_kernel turns them into densities.
+template <bool HALF>
+__global__ __launch_bounds__(256) void proposal_levels_lp_kernel(GridDev g, const void* __restrict__ table, float scale,
+                                                                  RaysDev r, float* __restrict__ lf, int64_t n,
+                                                                  int64_t per_quarter, int64_t blocks_per_unit) {
+  constexpr int kQuarters = 4;
+  const int xcd = blockIdx.x & 7;
+  const int64_t q = blockIdx.x >> 3;
+  const int unit = xcd + 8 * (int)(q / blocks_per_unit);
+  if (unit >= g.L * kQuarters) return;
+  const int l = unit / kQuarters, quarter = unit - l * kQuarters;
+  const int64_t i = quarter * per_quarter + (q % blocks_per_unit) * 256 + threadIdx.x;
+  const int64_t hi = (quarter + 1) * per_quarter < n ? (quarter + 1) * per_quarter : n;
+  if (i >= hi) return;
+  const int64_t ray = i / r.S;
+  const SamplePos p = sample_position(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray],
+                                      r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  float v[1];
+  hash_level<1, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
+  lf[(size_t)l * n + i] = v[0] * rescale_weight(g.scal[l], p.std);
+}
+
+__global__ __launch_bounds__(256) void proposal_density_from_levels_kernel(const float* __restrict__ lf,
+                                                                            const float* __restrict__ dec, int64_t n,
+                                                                            int L, float* __restrict__ dens) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) acc += lf[(size_t)l * n + i] * dec[l];  // same order of operations as the fused kernel
   dens[i] = expf(acc);
 }
 
@@ -369,6 +407,23 @@ extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_r
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(p->grid);
   const RaysDev rd = to_dev(*rays);
+  if (level_features) {  // training: level-partitioned lookups + a streaming pass for the densities
+    constexpr int kQuarters = 4;
+    const int64_t per_quarter = ((n + kQuarters - 1) / kQuarters + 255) / 256 * 256;
+    const int64_t blocks_per_unit = per_quarter / 256;
+    const int units = gd.L * kQuarters;
+    const int64_t nblk = 8 * ((units + 7) / 8) * blocks_per_unit;
+    if (gd.dtype == 1)
+      proposal_levels_lp_kernel<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(
+          gd, p->table, p->static_scale, rd, level_features, n, per_quarter, blocks_per_unit);
+    else
+      proposal_levels_lp_kernel<false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(
+          gd, p->table, p->static_scale, rd, level_features, n, per_quarter, blocks_per_unit);
+    if (int e = check_launch("proposal_density_fwd levels")) return e;
+    proposal_density_from_levels_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+        level_features, p->decoder_weight, n, gd.L, density);
+    return check_launch("proposal_density_fwd");
+  }
   if (gd.dtype == 1)
     proposal_density_fwd_kernel<true><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
         gd, p->table, p->static_scale, p->decoder_weight, rd, density, level_features);
@@ -409,7 +464,7 @@ __global__ __launch_bounds__(256) void proposal_decoder_grad_kernel(const float*
     const float gx = gd[i] * expf(fminf(fmaxf(logf(dens[i]), -15.f), 15.f));
 #pragma unroll
     for (int l = 0; l < 8; ++l)
-      if (l < L) gl[l] = fmaf(gx, lf[i * L + l], gl[l]);
+      if (l < L) gl[l] = fmaf(gx, lf[(size_t)l * n + i], gl[l]);  // level-major [L][N]
   }
   __shared__ float red[4][8];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

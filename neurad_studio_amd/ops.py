@@ -449,11 +449,11 @@ class ProposalSpec:
 
 
 def proposal_density_fwd(ps: ProposalSpec, origins, directions, pixel_area, starts, ends, save_features: bool = False):
-    """density [R,S]; with save_features also the rescaled per-level features [R*S, L] the backward wants."""
+    """density [R,S]; with save_features also the rescaled per-level features, level-major [L, R*S], for the backward"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     p, keep2 = ps.c_prop()
     dens = torch.empty((r.n_rays, r.n_samples), device=origins.device, dtype=torch.float32)
-    lf = (torch.empty((r.n_rays * r.n_samples, ps.grid.num_levels), device=origins.device, dtype=torch.float32)
+    lf = (torch.empty((ps.grid.num_levels, r.n_rays * r.n_samples), device=origins.device, dtype=torch.float32)
           if save_features else None)
     call("nrhip_proposal_density_fwd", C.byref(p), C.byref(r), _ptr(dens), _ptr(lf), _stream())
     return (dens, lf) if save_features else dens
