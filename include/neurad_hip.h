@@ -203,6 +203,13 @@ int nrhip_composite_bwd(const float* weights, const float* features, const float
 int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features /*[R,C]*/,
                      float* out_depth /*[R]*/, float* out_acc /*[R]*/, float* out_weights /*[R,S] or NULL*/,
                      void* stream);
+/* The same with options.  early_stop_eps > 0 (eval only; 0 = exact): a ray stops marching once its transmittance has
+ * fallen below it -- the remaining samples carry less than early_stop_eps of weight in total and are skipped
+ * (wave-uniform test between 16-sample tiles; weights of skipped samples are written as 0).  variant: 0 = default,
+ * 1 = tile-serial kernel, 2 = software-pipelined gathers, 3 = pipelined + last feature layer applied once per ray
+ * (A/B and profiling; all variants are parity-tested). */
+int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
+                        float* out_acc, float* out_weights, float early_stop_eps, int32_t variant, void* stream);
 
 /* ---- S2: NeuRADProposalField.get_density (neurad_field.py:208-213) ----------------------------- */
 /* level_features (may be NULL): LEVEL-MAJOR [L, R*S] rescaled per-level features, saved for the decoder gradient;

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "nrhip_composite_fwd": [P, P, P, P, I64, I32, I32, P, P, P, P],
     "nrhip_composite_bwd": [P, P, P, P, P, P, P, I64, I32, I32, P, P, P],
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
+    "nrhip_render_fwd_ex": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, F32, I32, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],

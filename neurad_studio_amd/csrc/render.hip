@@ -13,81 +13,14 @@
 //     with row_shr DPP ops; the four rows (g) carry identical copies, each accumulates w*feature for its
 //     own 8 feature channels.
 // Exact fp32 (f32-input MFMA == fmaf chain): the parity target is the reference's fp32 torch path.
-#include "common.h"
+#include <stdlib.h>
+
+#include "render_common.h"
 
 
 namespace nrhip {
 
 
-
-struct FieldDev {
-  GridDev grid;
-  const void* table;
-  float scale;
-  const float* gw0; const float* gb0;   // geo layer 0: [H][32], [H]
-  const float* gw1; const float* gb1;   // geo layer 1: [33][H], [33]
-  const float* fw0; const float* fb0;   // feat layer 0: [H][48]
-  const float* fw1; const float* fb1;   // feat layer 1: [H][H]
-  const float* fw2; const float* fb2;   // feat layer 2: [32][H]
-  int use_sdf;
-  float beta;
-};
-
-// LDS carve (floats), H = hidden width.  Fragment-ordered weights use [mb][s/4][lane][s%4] so that one
-// ds_read_b128 fetches the A fragments of 4 consecutive k-steps.
-// Training forward (nrhip_field_fwd_train): what the hand-written backward needs, written in the layouts the
-// operator-level kernels read ([N, width] row-major).  All null for inference.
-struct SaveDev {
-  float* enc;  // [N, 32]   rescaled grid features = input of the geometry MLP
-  float* hg;   // [N, H]    geometry MLP hidden activations (post-ReLU)
-  float* xf;   // [N, 48]   feature MLP input: geometry embedding (32) | SH of the ray direction (16)
-  float* hf;   // [N, 2H]   feature MLP hidden activations, layer 0 | layer 1
-};
-
-template <int H>
-struct Lds {
-  static constexpr int NB = H / 16;        // 16-neuron blocks of a hidden layer
-  static constexpr int G0 = 0;             // geo L0 : NB blocks x 8 steps
-  static constexpr int G1 = G0 + H * 32;   // geo L1 (rows 1..32): 2 blocks x H/4 steps
-  static constexpr int F0 = G1 + 32 * H;   // feat L0 (geo part): NB blocks x 8 steps
-  static constexpr int F1 = F0 + H * 32;   // feat L1: NB blocks x H/4 steps
-  static constexpr int F2 = F1 + H * H;    // feat L2: 2 blocks x H/4 steps
-  static constexpr int SHW = F2 + 32 * H;  // feat L0 SH part: [16 c][NB][4 g][4 r]
-  static constexpr int SDFW = SHW + 16 * H;  // geo L1 row 0: [NB][4 g][4 r]
-  static constexpr int BG0 = SDFW + H;     // biases, [blk][g][r] == natural order
-  static constexpr int BG1 = BG0 + H;      // 33 -> [0] = sdf bias, [1..32]
-  static constexpr int BF0 = BG1 + 36;
-  static constexpr int BF1 = BF0 + H;
-  static constexpr int BF2 = BF1 + H;
-  static constexpr int SCAL = BF2 + 32;    // per-level scalings
-  static constexpr int TOTAL = SCAL + NRHIP_MAX_LEVELS;
-};
-
-// Weight staging.  W[row_off + 16mb + i][col(g,s)] goes to fragment order [mb][s4][lane][s3]; CHAIN: col =
-// 16*(s/4) + 4g + s%4 (input is a D tile of the previous layer), else col = 8g + s (input is the gathered feature
-// registers).  Every thread first ISSUES all of its global loads (one register each, ~60 in flight), then stores:
-// one memory round trip for the whole 54 KB image instead of one per loop iteration.
-template <bool CHAIN, int NBLK, int NSTEP>
-__device__ __forceinline__ float frag_src(const float* __restrict__ W, int ldw, int row_off, int e) {
-  const int s3 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
-  const int s4 = rest % (NSTEP / 4), mb = rest / (NSTEP / 4);
-  const int s = 4 * s4 + s3, i = lane & 15, g = lane >> 4;
-  const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
-  return W[(size_t)(row_off + 16 * mb + i) * ldw + col];
-}
-
-template <int N>
-__device__ __forceinline__ float row_shr(float v, float fill) {
-  return dpp_row_shr<N>(v, fill);
-}
-// sum over the 16 lanes of a DPP row (result valid in every lane of the row)
-__device__ __forceinline__ float row_sum16(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
-}
 
 // L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2.
 template <int L, int F, int H, bool HALF, bool COMPOSITE>
@@ -103,60 +36,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
-  {
-    constexpr int T = 256;  // == blockDim.x
-    constexpr int N_G0 = H * 32 / T, N_G1 = 32 * H / T, N_F0 = H * 32 / T, N_F1 = H * H / T, N_F2 = 32 * H / T,
-                  N_SH = 16 * H / T;
-    static_assert((H * 32) % T == 0 && (H * H) % T == 0 && (16 * H) % T == 0, "regions are whole passes of the block");
-    const int tid = threadIdx.x;
-    float vg0[N_G0], vg1[N_G1], vf0[N_F0], vf1[N_F1], vf2[N_F2], vsh[N_SH], vs[7];
-#pragma unroll
-    for (int it = 0; it < N_G0; ++it) vg0[it] = frag_src<false, NB, 8>(fd.gw0, 32, 0, it * T + tid);
-#pragma unroll
-    for (int it = 0; it < N_G1; ++it) vg1[it] = frag_src<true, 2, H / 4>(fd.gw1, H, 1, it * T + tid);
-#pragma unroll
-    for (int it = 0; it < N_F0; ++it) vf0[it] = frag_src<true, NB, 8>(fd.fw0, 48, 0, it * T + tid);
-#pragma unroll
-    for (int it = 0; it < N_F1; ++it) vf1[it] = frag_src<true, NB, H / 4>(fd.fw1, H, 0, it * T + tid);
-#pragma unroll
-    for (int it = 0; it < N_F2; ++it) vf2[it] = frag_src<true, 2, H / 4>(fd.fw2, H, 0, it * T + tid);
-#pragma unroll
-    for (int it = 0; it < N_SH; ++it) {  // SHW[c][n] = fw0[n][32+c]
-      const int e = it * T + tid, c = e / H, n = e - c * H;
-      vsh[it] = fd.fw0[(size_t)n * 48 + 32 + c];
-    }
-    const int th = tid < H ? tid : 0, t33 = tid < 33 ? tid : 0, t32 = tid & 31;
-    vs[0] = fd.gw1[th];
-    vs[1] = fd.gb0 ? fd.gb0[th] : 0.f;
-    vs[2] = fd.fb0 ? fd.fb0[th] : 0.f;
-    vs[3] = fd.fb1 ? fd.fb1[th] : 0.f;
-    vs[4] = fd.gb1 ? fd.gb1[t33] : 0.f;
-    vs[5] = fd.fb2 ? fd.fb2[t32] : 0.f;
-    vs[6] = fd.grid.scal[t32];
-#pragma unroll
-    for (int it = 0; it < N_G0; ++it) lds[Ld::G0 + it * T + tid] = vg0[it];
-#pragma unroll
-    for (int it = 0; it < N_G1; ++it) lds[Ld::G1 + it * T + tid] = vg1[it];
-#pragma unroll
-    for (int it = 0; it < N_F0; ++it) lds[Ld::F0 + it * T + tid] = vf0[it];
-#pragma unroll
-    for (int it = 0; it < N_F1; ++it) lds[Ld::F1 + it * T + tid] = vf1[it];
-#pragma unroll
-    for (int it = 0; it < N_F2; ++it) lds[Ld::F2 + it * T + tid] = vf2[it];
-#pragma unroll
-    for (int it = 0; it < N_SH; ++it) lds[Ld::SHW + it * T + tid] = vsh[it];
-    if (tid < H) {
-      lds[Ld::SDFW + tid] = vs[0];
-      lds[Ld::BG0 + tid] = vs[1];
-      lds[Ld::BF0 + tid] = vs[2];
-      lds[Ld::BF1 + tid] = vs[3];
-    }
-    if (tid < 33) lds[Ld::BG1 + tid] = vs[4];
-    if (tid < 32) {
-      lds[Ld::BF2 + tid] = vs[5];
-      lds[Ld::SCAL + tid] = vs[6];
-    }
-  }
+  stage_field_weights<H>(fd, lds);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -416,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
   }
 }
 
-static int validate_field(const nrhip_field* f) {
+int validate_field(const nrhip_field* f) {
   NR_REQUIRE(f, NRHIP_ERR_INVALID_ARG, "field descriptor is NULL");
   if (int e = validate_grid(&f->grid)) return e;
   NR_REQUIRE(f->table && f->static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "field: NULL table or non-positive scale");
@@ -437,7 +317,7 @@ static int validate_field(const nrhip_field* f) {
   return NRHIP_OK;
 }
 
-static FieldDev to_dev(const nrhip_field& f) {
+FieldDev to_dev(const nrhip_field& f) {
   FieldDev d;
   d.grid = to_dev(f.grid);
   d.table = f.table;
@@ -452,6 +332,21 @@ static FieldDev to_dev(const nrhip_field& f) {
   return d;
 }
 
+int persistent_blocks(const void* kernel, size_t lds_bytes, int64_t n_rays, int max_per_cu) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount
+                                                                                              : 256;
+  }
+  int nb = 0;  // persistent grid: as many workgroups per CU as registers + LDS admit
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, lds_bytes) != hipSuccess || nb < 1) nb = 2;
+  if (nb > max_per_cu) nb = max_per_cu;
+  const int64_t cap = (int64_t)n_cu * nb, blocks = (n_rays + 3) / 4;
+  return (int)(blocks < cap ? blocks : cap);
+}
+
 template <int L, int F, int H, bool HALF, bool COMPOSITE>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
                          float* oal, const SaveDev& sv, hipStream_t st) {
@@ -462,35 +357,17 @@ static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  int n_cu = 256;
-  {
-    static int cached = 0;
-    if (!cached) {
-      int dev = 0;
-      hipDeviceProp_t p;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-        cached = p.multiProcessorCount;
-      else
-        cached = 256;
-    }
-    n_cu = cached;
-  }
-  int64_t blocks = (rd.R + 3) / 4;
-  static int per_cu = 0;  // persistent grid: as many workgroups per CU as registers + LDS admit
-  if (!per_cu) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
-    per_cu = nb > 4 ? 4 : nb;
-  }
-  const int64_t cap = (int64_t)n_cu * per_cu;
-  if (blocks > cap) blocks = cap;
-  kern<<<(int)blocks, 256, lds, st>>>(fd, rd, of, od, oa, ow, os, oal, sv);
+  static int per_cu_blocks = 0;  // occupancy query once per instantiation
+  if (!per_cu_blocks) per_cu_blocks = persistent_blocks((const void*)kern, lds, INT64_C(1) << 40, 4);
+  const int64_t want = (rd.R + 3) / 4;
+  const int blocks = (int)(want < per_cu_blocks ? want : per_cu_blocks);
+  kern<<<blocks, 256, lds, st>>>(fd, rd, of, od, oa, ow, os, oal, sv);
   return check_launch("render/field fused kernel");
 }
 
 template <bool COMPOSITE>
-static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
-                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{}) {
+static int dispatch_render_serial(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa,
+                                  float* ow, float* os, float* oal, void* stream, const SaveDev& sv) {
   const FieldDev fd = to_dev(*f);
   const RaysDev rd = to_dev(*rays);
   const hipStream_t st = (hipStream_t)stream;
@@ -510,6 +387,31 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
 #undef CASE
   set_error("fused field kernel: no instantiation for L=%d F=%d H=%d", L, F, H);
   return NRHIP_ERR_UNSUPPORTED;
+}
+
+// A/B switch (read once per process): NRHIP_RENDER_VARIANT = 1 tile-serial, 2 pipelined, 3 pipelined + deferred
+// last feature layer.  Unset / 0 = the default chosen from measurements.
+static int env_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NRHIP_RENDER_VARIANT");
+    v = e ? atoi(e) : 0;
+    if (v < 0 || v > 3) v = 0;
+  }
+  return v;
+}
+
+template <bool COMPOSITE>
+static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
+                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{},
+                           RenderOpts opts = RenderOpts{0.f, 0}) {
+  if (opts.variant == 0) opts.variant = env_variant();
+  if (opts.variant == 0) opts.variant = COMPOSITE ? 3 : 2;
+  if (opts.variant == 1) {
+    NR_REQUIRE(opts.stop_eps == 0.f, NRHIP_ERR_UNSUPPORTED, "early ray termination needs the pipelined kernel");
+    return dispatch_render_serial<COMPOSITE>(f, rays, of, od, oa, ow, os, oal, stream, sv);
+  }
+  return dispatch_render_pipelined<COMPOSITE>(f, rays, of, od, oa, ow, os, oal, stream, sv, opts);
 }
 
 }  // namespace nrhip
@@ -540,12 +442,29 @@ extern "C" int nrhip_field_fwd_train(const nrhip_field* f, const nrhip_rays* ray
   return dispatch_render<false>(f, rays, feature, nullptr, nullptr, nullptr, sdf, alpha, stream, sv);
 }
 
-extern "C" int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
-                                float* out_acc, float* out_weights, void* stream) {
+static int render_fwd_impl(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
+                           float* out_acc, float* out_weights, const RenderOpts& opts, void* stream) {
   if (int e = validate_field(f)) return e;
   if (int e = validate_rays(rays)) return e;
   if (rays->n_rays == 0) return NRHIP_OK;
   NR_REQUIRE(out_features && out_depth && out_acc, NRHIP_ERR_INVALID_ARG, "render_fwd: NULL output");
   NR_REQUIRE(rays->n_samples >= 1, NRHIP_ERR_INVALID_ARG, "render_fwd: needs >= 1 sample per ray");
-  return dispatch_render<true>(f, rays, out_features, out_depth, out_acc, out_weights, nullptr, nullptr, stream);
+  NR_REQUIRE(opts.stop_eps >= 0.f && opts.stop_eps < 1.f, NRHIP_ERR_INVALID_ARG, "render_fwd: early_stop_eps %g not in [0,1)",
+             (double)opts.stop_eps);
+  NR_REQUIRE(opts.variant >= 0 && opts.variant <= 3, NRHIP_ERR_INVALID_ARG, "render_fwd: unknown kernel variant %d",
+             opts.variant);
+  return dispatch_render<true>(f, rays, out_features, out_depth, out_acc, out_weights, nullptr, nullptr, stream,
+                               SaveDev{}, opts);
+}
+
+extern "C" int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
+                                float* out_acc, float* out_weights, void* stream) {
+  return render_fwd_impl(f, rays, out_features, out_depth, out_acc, out_weights, RenderOpts{0.f, 0}, stream);
+}
+
+extern "C" int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
+                                   float* out_acc, float* out_weights, float early_stop_eps, int32_t variant,
+                                   void* stream) {
+  return render_fwd_impl(f, rays, out_features, out_depth, out_acc, out_weights, RenderOpts{early_stop_eps, variant},
+                         stream);
 }

@@ -341,8 +341,10 @@ def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends
 
 
 def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, return_weights: bool = False,
-               out: Optional[Tuple[Tensor, Tensor, Tensor]] = None):
-    """The fused headline kernel.  -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S])"""
+               out: Optional[Tuple[Tensor, Tensor, Tensor]] = None, early_stop_eps: float = 0.0, variant: int = 0):
+    """The fused headline kernel.  -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S]).
+    early_stop_eps > 0 (eval option, default exact): rays stop once their transmittance is below it.
+    variant: 0 default, 1 tile-serial, 2 pipelined gathers, 3 pipelined + deferred last feature layer (A/B)."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     f, keep2 = fs.c_field()
     R, S = r.n_rays, r.n_samples
@@ -354,7 +356,8 @@ def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, ret
     else:
         feats, depth, acc = out
     w = torch.empty((R, S), device=dev, dtype=torch.float32) if return_weights else None
-    call("nrhip_render_fwd", C.byref(f), C.byref(r), _ptr(feats), _ptr(depth), _ptr(acc), _ptr(w), _stream())
+    call("nrhip_render_fwd_ex", C.byref(f), C.byref(r), _ptr(feats), _ptr(depth), _ptr(acc), _ptr(w),
+         float(early_stop_eps), int(variant), _stream())
     return (feats, depth, acc, w) if return_weights else (feats, depth, acc)
 
 
