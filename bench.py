@@ -206,9 +206,11 @@ def main():
     def step(ev=None):
         # M1 sky stretch (models/neurad.py:451-455) folded into the sampler launch; far == sky_distance here anyway
         sp, eu = ops.power_sampler(None, fars, S, lam=-1.0, scaling=0.1, last_edge=20000.0)
+        # processing order of this batch (cache-locality hint, csrc/rayorder.hip): part of the step, computed every time
+        order = ops.ray_order(origins, dirs, STATIC_SCALE)
         if ev is not None:
             ev[0].record()
-        ops.render_fwd(fs, origins, dirs, area, eu[:, :-1], eu[:, 1:], out=(feats, depth, acc))
+        ops.render_fwd(fs, origins, dirs, area, eu[:, :-1], eu[:, 1:], out=(feats, depth, acc), order=order)
         if ev is not None:
             ev[1].record()
         state["edges"] = eu
@@ -253,12 +255,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: NeuRAD hash-grid (16 levels, T=2^19, F=2, fp32) + 64-wide MLPs, "
-                                   "4096 rays x 128 samples per GPU, PowerSampler bins + fused field + compositing "
-                                   "(forward / render path)",
+                                   "4096 rays x 128 samples per GPU, PowerSampler bins + ray ordering pass + fused field + "
+                                   "compositing (forward / render path)",
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S, "parallelism": f"rays sharded x{world}, no collective"},
             "per_gpu_value": n_samples * args.steps / elapsed,
             "target_per_gpu": 2e7,
-            "roofline": {"kernel": "nrhip::render_kernel<16,2,64,fp32,composite>", "bound": "hbm",
+            "roofline": {"kernel": "nrhip::render_kernel<16,2,64,fp32,composite> (software-pipelined gathers, XCD-coherent "
+                                   "ray ranges over the nrhip_ray_order permutation)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": n_samples * bytes_per,
                          "kernel_ms": kernel_ms},

@@ -71,6 +71,10 @@ typedef struct {
   const float* ends;        /* [R,S] euclidean bin ends   */
   int32_t sample_stride;    /* row stride (floats) of starts/ends; 0 = S.  With bin EDGES e[R,S+1] pass
                                starts = e, ends = e + 1, sample_stride = S + 1 (no copies).            */
+  const int32_t* order;     /* optional [R] permutation (NULL = batch order): the ORDER in which the fused kernels
+                               (nrhip_field_fwd*, nrhip_render_fwd*) walk the rays -- a cache-locality hint from
+                               nrhip_ray_order; every output stays indexed by the ray's own position in the batch,
+                               results do not depend on it.  Other entry points ignore it.                      */
 } nrhip_rays;
 
 /* NeuRADField (nerfstudio/fields/neurad_field.py:78-152), static scene part.
@@ -203,13 +207,20 @@ int nrhip_composite_bwd(const float* weights, const float* features, const float
 int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features /*[R,C]*/,
                      float* out_depth /*[R]*/, float* out_acc /*[R]*/, float* out_weights /*[R,S] or NULL*/,
                      void* stream);
-/* The same with options.  early_stop_eps > 0 (eval only; 0 = exact): a ray stops marching once its transmittance has
- * fallen below it -- the remaining samples carry less than early_stop_eps of weight in total and are skipped
- * (wave-uniform test between 16-sample tiles; weights of skipped samples are written as 0).  variant: 0 = default,
- * 1 = tile-serial kernel, 2 = software-pipelined gathers, 3 = pipelined + last feature layer applied once per ray
- * (A/B and profiling; all variants are parity-tested). */
+/* The same with options.  early_stop_eps > 0 (eval only; 0 = exact): a ray stops marching once the transmittance
+ * entering a 16-sample tile has fallen below it -- the samples behind that tile carry less than early_stop_eps of
+ * weight in total and are skipped (wave-uniform test; weights of skipped samples are written as 0). */
 int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
-                        float* out_acc, float* out_weights, float early_stop_eps, int32_t variant, void* stream);
+                        float* out_acc, float* out_weights, float early_stop_eps, void* stream);
+
+/* Processing order for cache locality (fills nrhip_rays.order): a permutation that groups rays looking at the same
+ * region -- counting sort by the Morton code of the contracted position (ScaledSceneContraction, static_scale as in
+ * nrhip_field) of the point origin + direction * t_ref, t_ref = a representative sample distance (the sampler's
+ * median).  The reference has no counterpart: its rays arrive in data-loader order (camera patches + random lidar
+ * points, data/datamanagers/image_lidar_datamanager.py:150-169).  order [R] int32 device buffer. */
+int nrhip_ray_order(const float* origins /*[R,3]*/, const float* directions /*[R,3]*/, int64_t n_rays, float t_ref,
+                    float static_scale, int32_t key_bits /* per axis: 0 = default (4), 3..5 */, int32_t* order,
+                    void* stream);
 
 /* ---- S2: NeuRADProposalField.get_density (neurad_field.py:208-213) ----------------------------- */
 /* level_features (may be NULL): LEVEL-MAJOR [L, R*S] rescaled per-level features, saved for the decoder gradient;

@@ -31,7 +31,7 @@ class Mlp(C.Structure):
 class Rays(C.Structure):
     _fields_ = [("n_rays", C.c_int64), ("n_samples", C.c_int32), ("origins", C.c_void_p),
                 ("directions", C.c_void_p), ("pixel_area", C.c_void_p), ("starts", C.c_void_p),
-                ("ends", C.c_void_p), ("sample_stride", C.c_int32)]
+                ("ends", C.c_void_p), ("sample_stride", C.c_int32), ("order", C.c_void_p)]
 
 
 class Field(C.Structure):
@@ -91,7 +91,8 @@ PROTOTYPES = {
     "nrhip_composite_fwd": [P, P, P, P, I64, I32, I32, P, P, P, P],
     "nrhip_composite_bwd": [P, P, P, P, P, P, P, I64, I32, I32, P, P, P],
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
-    "nrhip_render_fwd_ex": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, F32, I32, P],
+    "nrhip_render_fwd_ex": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, F32, P],
+    "nrhip_ray_order": [P, P, I64, F32, F32, I32, P, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],

@@ -53,7 +53,7 @@ int validate_rays(const nrhip_rays* r) {
 }  // namespace nrhip
 
 extern "C" const char* nrhip_last_error(void) { return nrhip::g_err; }
-extern "C" int nrhip_version(void) { return 100; }
+extern "C" int nrhip_version(void) { return 200; }  // 200: nrhip_rays.order, render_fwd_ex, ray_order
 
 extern "C" int nrhip_device_info(int32_t* n_cus, int32_t* n_xcds, int64_t* hbm_bytes) {
   int dev = 0;

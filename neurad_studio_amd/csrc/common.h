@@ -49,10 +49,11 @@ struct RaysDev {
   const float* area;
   const float* starts;
   const float* ends;
+  const int32_t* order;  // optional processing order (permutation of the rays), honoured by the fused kernels
 };
 inline RaysDev to_dev(const nrhip_rays& r) {
   return RaysDev{r.n_rays, r.n_samples, r.sample_stride > 0 ? r.sample_stride : r.n_samples, r.origins, r.directions,
-                 r.pixel_area, r.starts, r.ends};
+                 r.pixel_area, r.starts, r.ends, r.order};
 }
 int validate_rays(const nrhip_rays* r);
 

@@ -10,54 +10,310 @@
 //     i.e. lane (j,g) again holds 4 activations of ITS sample per 16-neuron block -> they feed the next layer's
 //     B operand directly.  No cross-lane traffic, no LDS round trip between the five layers.
 //   * compositing: the 16 samples of a tile live in one DPP row (16 lanes) -> exclusive transmittance scan
-//     with row_shr DPP ops; the four rows (g) carry identical copies, each accumulates w*feature for its
-//     own 8 feature channels.
+//     with row_shr DPP ops; the four rows (g) carry identical copies, each accumulates for its own channels.
 // Exact fp32 (f32-input MFMA == fmaf chain): the parity target is the reference's fp32 torch path.
-#include <stdlib.h>
-
-#include "render_common.h"
-
+//
+// What bounds this kernel on MI355X is the chip's random-line miss rate (every fine-level corner is a new 128-byte
+// line for 8-16 useful bytes), with the fp32 MFMA chain behind it.  Hence:
+//   * SOFTWARE PIPELINE.  A wave's (ray, tile) sequence is flattened; the 8*L/4 corner gathers of the NEXT tile (the
+//     next tile of this ray or the first tile of the wave's next ray) are issued right after the current tile's blend,
+//     BEFORE its ~170 MFMAs, and stay in flight in VGPRs during the MLP (2 waves / SIMD, ~220 VGPRs); the tile after
+//     that already has its sample interval and ray constants requested.  A wave therefore keeps requests in the
+//     memory system all the time instead of idling on memory for the ~2 us of its MFMA phase.  Ray constants are
+//     read at wave-uniform addresses from `const __restrict__` arguments -> scalar loads, no VGPRs, no vmcnt.
+//   * DEFERRED LAST LAYER (composited output).  The last feature layer (H -> 32, no activation) is linear and followed
+//     only by sum_s w_s * (.), so the kernel accumulates sum_s w_s*h2_s (H channels) and sum_s w_s*e_s per ray and
+//     applies fw2 / fb2 ONCE per ray:  sum_s w_s (fw2 h2_s + fb2 + e_s) = fw2 (sum w h2) + fb2 sum w + sum w e.
+//     -32 of 192 MFMAs per tile at H=64; reassociation only (~1e-7 relative).
+//   * XCD-COHERENT RAY RANGES.  Workgroup b runs on XCD b % 8 (dispatch order; a wrong guess costs speed only), so the
+//     processing order is cut into 8 contiguous ranges and XCD x walks range x with its own workgroups: rays that are
+//     neighbours in the order (a 32x32 camera patch; any batch after nrhip_ray_order) share ONE L2 instead of leaving
+//     copies of their lines in all eight.  `rays.order` (optional permutation) supplies that order without moving data.
+//   * EARLY RAY TERMINATION (eval option, off by default = exact): a ray stops once the transmittance entering a tile
+//     is below `stop_eps`; what is skipped weighs less than stop_eps in total.
+// The sky residual (models/neurad.py:381: w_{S-1} += 1 - sum w) is folded into the last tile -- the accumulated weight is
+// complete there, so no copy of the last sample's features has to be kept.
+#include "common.h"
 
 namespace nrhip {
 
+struct FieldDev {
+  GridDev grid;
+  const void* table;
+  float scale;
+  const float* gw0; const float* gb0;   // geo layer 0: [H][32], [H]
+  const float* gw1; const float* gb1;   // geo layer 1: [33][H], [33]
+  const float* fw0; const float* fb0;   // feat layer 0: [H][48]
+  const float* fw1; const float* fb1;   // feat layer 1: [H][H]
+  const float* fw2; const float* fb2;   // feat layer 2: [32][H]
+  int use_sdf;
+  float beta;
+};
 
+// Training forward (nrhip_field_fwd_train): what the hand-written backward needs, written in the layouts the
+// operator-level kernels read ([N, width] row-major).  All null for inference.
+struct SaveDev {
+  float* enc;  // [N, 32]   rescaled grid features = input of the geometry MLP
+  float* hg;   // [N, H]    geometry MLP hidden activations (post-ReLU)
+  float* xf;   // [N, 48]   feature MLP input: geometry embedding (32) | SH of the ray direction (16)
+  float* hf;   // [N, 2H]   feature MLP hidden activations, layer 0 | layer 1
+};
+
+// LDS carve (floats), H = hidden width.  Fragment-ordered weights use [mb][s/4][lane][s%4] so that one
+// ds_read_b128 fetches the A fragments of 4 consecutive k-steps.
+template <int H>
+struct Lds {
+  static constexpr int NB = H / 16;        // 16-neuron blocks of a hidden layer
+  static constexpr int G0 = 0;             // geo L0 : NB blocks x 8 steps
+  static constexpr int G1 = G0 + H * 32;   // geo L1 (rows 1..32): 2 blocks x H/4 steps
+  static constexpr int F0 = G1 + 32 * H;   // feat L0 (geo part): NB blocks x 8 steps
+  static constexpr int F1 = F0 + H * 32;   // feat L1: NB blocks x H/4 steps
+  static constexpr int F2 = F1 + H * H;    // feat L2: 2 blocks x H/4 steps
+  static constexpr int SHW = F2 + 32 * H;  // feat L0 SH part: [16 c][NB][4 g][4 r]
+  static constexpr int SDFW = SHW + 16 * H;  // geo L1 row 0: [NB][4 g][4 r]
+  static constexpr int BG0 = SDFW + H;     // biases, [blk][g][r] == natural order
+  static constexpr int BG1 = BG0 + H;      // 33 -> [0] = sdf bias, [1..32]
+  static constexpr int BF0 = BG1 + 36;
+  static constexpr int BF1 = BF0 + H;
+  static constexpr int BF2 = BF1 + H;
+  static constexpr int SCAL = BF2 + 32;    // per-level scalings
+  static constexpr int RB = SCAL + NRHIP_MAX_LEVELS;  // per wave: this ray's bias of feat L0 (fb0 + SH part), 4 x H
+  static constexpr int TOTAL = RB + 4 * H;
+};
+
+// Weight staging.  W[row_off + 16mb + i][col(g,s)] goes to fragment order [mb][s4][lane][s3]; CHAIN: col =
+// 16*(s/4) + 4g + s%4 (input is a D tile of the previous layer), else col = 8g + s (input is the gathered feature
+// registers).
+template <bool CHAIN, int NBLK, int NSTEP>
+__device__ __forceinline__ float frag_src(const float* __restrict__ W, int ldw, int row_off, int e) {
+  const int s3 = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+  const int s4 = rest % (NSTEP / 4), mb = rest / (NSTEP / 4);
+  const int s = 4 * s4 + s3, i = lane & 15, g = lane >> 4;
+  const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
+  return W[(size_t)(row_off + 16 * mb + i) * ldw + col];
+}
+
+// Stage all weights of the field into LDS (256-thread workgroup; caller barriers afterwards).  Every thread first
+// ISSUES all of its global loads (one register each, ~60 in flight), then stores: one memory round trip for the whole
+// 54 KB image instead of one per loop iteration.
+template <int H>
+__device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* __restrict__ lds) {
+  using Ld = Lds<H>;
+  constexpr int NB = H / 16;
+  constexpr int T = 256;  // == blockDim.x
+  constexpr int N_G0 = H * 32 / T, N_G1 = 32 * H / T, N_F0 = H * 32 / T, N_F1 = H * H / T, N_F2 = 32 * H / T,
+                N_SH = 16 * H / T;
+  static_assert((H * 32) % T == 0 && (H * H) % T == 0 && (16 * H) % T == 0, "regions are whole passes of the block");
+  const int tid = threadIdx.x;
+  float vg0[N_G0], vg1[N_G1], vf0[N_F0], vf1[N_F1], vf2[N_F2], vsh[N_SH], vs[7];
+#pragma unroll
+  for (int it = 0; it < N_G0; ++it) vg0[it] = frag_src<false, NB, 8>(fd.gw0, 32, 0, it * T + tid);
+#pragma unroll
+  for (int it = 0; it < N_G1; ++it) vg1[it] = frag_src<true, 2, H / 4>(fd.gw1, H, 1, it * T + tid);
+#pragma unroll
+  for (int it = 0; it < N_F0; ++it) vf0[it] = frag_src<true, NB, 8>(fd.fw0, 48, 0, it * T + tid);
+#pragma unroll
+  for (int it = 0; it < N_F1; ++it) vf1[it] = frag_src<true, NB, H / 4>(fd.fw1, H, 0, it * T + tid);
+#pragma unroll
+  for (int it = 0; it < N_F2; ++it) vf2[it] = frag_src<true, 2, H / 4>(fd.fw2, H, 0, it * T + tid);
+#pragma unroll
+  for (int it = 0; it < N_SH; ++it) {  // SHW[c][n] = fw0[n][32+c]
+    const int e = it * T + tid, c = e / H, n = e - c * H;
+    vsh[it] = fd.fw0[(size_t)n * 48 + 32 + c];
+  }
+  const int th = tid < H ? tid : 0, t33 = tid < 33 ? tid : 0, t32 = tid & 31;
+  vs[0] = fd.gw1[th];
+  vs[1] = fd.gb0 ? fd.gb0[th] : 0.f;
+  vs[2] = fd.fb0 ? fd.fb0[th] : 0.f;
+  vs[3] = fd.fb1 ? fd.fb1[th] : 0.f;
+  vs[4] = fd.gb1 ? fd.gb1[t33] : 0.f;
+  vs[5] = fd.fb2 ? fd.fb2[t32] : 0.f;
+  vs[6] = fd.grid.scal[t32];
+#pragma unroll
+  for (int it = 0; it < N_G0; ++it) lds[Ld::G0 + it * T + tid] = vg0[it];
+#pragma unroll
+  for (int it = 0; it < N_G1; ++it) lds[Ld::G1 + it * T + tid] = vg1[it];
+#pragma unroll
+  for (int it = 0; it < N_F0; ++it) lds[Ld::F0 + it * T + tid] = vf0[it];
+#pragma unroll
+  for (int it = 0; it < N_F1; ++it) lds[Ld::F1 + it * T + tid] = vf1[it];
+#pragma unroll
+  for (int it = 0; it < N_F2; ++it) lds[Ld::F2 + it * T + tid] = vf2[it];
+#pragma unroll
+  for (int it = 0; it < N_SH; ++it) lds[Ld::SHW + it * T + tid] = vsh[it];
+  if (tid < H) {
+    lds[Ld::SDFW + tid] = vs[0];
+    lds[Ld::BG0 + tid] = vs[1];
+    lds[Ld::BF0 + tid] = vs[2];
+    lds[Ld::BF1 + tid] = vs[3];
+  }
+  if (tid < 33) lds[Ld::BG1 + tid] = vs[4];
+  if (tid < 32) {
+    lds[Ld::BF2 + tid] = vs[5];
+    lds[Ld::SCAL + tid] = vs[6];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float fill) {
+  return dpp_row_shr<N>(v, fill);
+}
+// sum over the 16 lanes of a DPP row (result valid in every lane of the row)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// ---- the three pipeline stages' state ------------------------------------------------------------------------------
+template <int LPL, int F>
+struct TileFetch {
+  float fv[LPL][8][F];  // corner entries, in flight until the blend
+  float x, y, z, std;   // contracted sample position / std: the trilinear offsets and the H4 weights are re-derived from
+                        // them at blend time (3 VALU per level and axis) instead of holding 4*LPL more registers
+  float t0, t1;
+};
+
+// Range of the processing order one wave walks.  The ray-side pointers are separate `const __restrict__` kernel
+// arguments: the per-ray constants are read at wave-uniform addresses, and only noalias/readonly arguments let the
+// compiler turn those reads into scalar loads inside a loop that also stores.
+struct RayRange {
+  int64_t end;  // one past the last position of this wave's range
+  int S, stride;
+};
+
+// The tile that will be issued NEXT iteration: its sample interval (vector loads, per lane) and ray constants (scalar
+// loads) are requested one iteration ahead, so issuing its gathers never waits on a memory round trip.
+struct PendingTile {
+  int64_t pos;  // position in the processing order
+  int64_t ray;  // ray index = order[pos] (or pos)
+  int t;
+  bool valid;
+  float t0, t1;
+  float ox, oy, oz, dx, dy, dz, area;
+};
+
+__device__ __forceinline__ void load_pending(PendingTile& p, int64_t pos, int t, const RayRange& rr, int j,
+                                             const int32_t* __restrict__ order, const float* __restrict__ ro,
+                                             const float* __restrict__ rd, const float* __restrict__ rarea,
+                                             const float* __restrict__ rstarts, const float* __restrict__ rends) {
+  // Past the end of this wave's range the loads still go out (clamped to the last position, tile 0) and their gathers
+  // are issued and dropped: an `if (valid)` around them makes every fetched register a phi at the join, and the copies
+  // the compiler puts there wait for ALL gathers before the MFMA phase -- exactly the stall the pipeline removes.
+  p.pos = pos, p.t = t, p.valid = pos < rr.end;
+  const int64_t pc = p.valid ? pos : rr.end - 1;
+  const int64_t ray = order ? (int64_t)order[pc] : pc;
+  p.ray = ray;
+  const int s = p.valid ? 16 * t + j : j;
+  const int64_t si = ray * rr.stride + (s < rr.S ? s : rr.S - 1);
+  p.t0 = rstarts[si];
+  p.t1 = rends[si];
+  p.ox = ro[3 * ray], p.oy = ro[3 * ray + 1], p.oz = ro[3 * ray + 2];
+  p.dx = rd[3 * ray], p.dy = rd[3 * ray + 1], p.dz = rd[3 * ray + 2];
+  p.area = rarea[ray];
+}
+
+// H2 + H3 + the hash of H1 for one pending tile, then all gathers issued back to back (no waits in here beyond the
+// pending tile's own small loads, which were issued a whole tile earlier).
+template <int L, int F, bool HALF>
+__device__ __forceinline__ void issue_tile(const FieldDev& fd, const PendingTile& pt, int g, uint32_t mask,
+                                           const float* scal_lds, TileFetch<L / 4, F>& tf) {
+  constexpr int LPL = L / 4;
+  tf.t0 = pt.t0;
+  tf.t1 = pt.t1;
+  const SamplePos p = sample_position(pt.ox, pt.oy, pt.oz, pt.dx, pt.dy, pt.dz, pt.area, pt.t0, pt.t1, fd.scale);
+  tf.x = p.x, tf.y = p.y, tf.z = p.z, tf.std = p.std;
+#pragma unroll
+  for (int q = 0; q < LPL; ++q) {
+    const Corners cs = hash_corners(p.x, p.y, p.z, scal_lds[q], mask);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      Entry<F, HALF>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs.idx[k], tf.fv[q][k]);
+  }
+}
+
+template <int LPL, int F>
+__device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const float* scal_lds, float (&feat)[8]) {
+  static_assert(LPL * F == 8, "8 features per lane");
+#pragma unroll
+  for (int q = 0; q < LPL; ++q) {
+    const float sc = scal_lds[q];
+    Corners c;  // offsets rounded exactly as hash_corners does (encodings.py:431-446)
+    const float sx = __fmul_rn(tf.x, sc), sy = __fmul_rn(tf.y, sc), sz = __fmul_rn(tf.z, sc);
+    c.ox = __fsub_rn(sx, floorf(sx)), c.oy = __fsub_rn(sy, floorf(sy)), c.oz = __fsub_rn(sz, floorf(sz));
+    float v[F];
+    lerp_corners<F>(c, tf.fv[q], v);
+    const float rw = rescale_weight(sc, tf.std);
+#pragma unroll
+    for (int f = 0; f < F; ++f) feat[q * F + f] = v[f] * rw;
+  }
+}
 
 // L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2.
 template <int L, int F, int H, bool HALF, bool COMPOSITE>
-__global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev rays, float* __restrict__ out_feat,
-                                                        float* __restrict__ out_depth, float* __restrict__ out_acc,
-                                                        float* __restrict__ out_w, float* __restrict__ out_sdf,
-                                                        float* __restrict__ out_alpha, SaveDev sv) {
+__global__ __launch_bounds__(256, 2) void render_kernel(
+    FieldDev fd, int64_t n_rays, int S, int stride, const int32_t* __restrict__ order, const float* __restrict__ ro,
+    const float* __restrict__ rd, const float* __restrict__ rarea, const float* __restrict__ rstarts,
+    const float* __restrict__ rends, float* __restrict__ out_feat, float* __restrict__ out_depth,
+    float* __restrict__ out_acc, float* __restrict__ out_w, float* __restrict__ out_sdf, float* __restrict__ out_alpha,
+    SaveDev sv, float stop_eps) {
   static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
   using Ld = Lds<H>;
   constexpr int NB = H / 16;
-  constexpr int LPL = L / 4;  // levels per lane
+  constexpr int LPL = L / 4;         // levels per lane
+  constexpr bool DEFER = COMPOSITE;  // last feature layer applied once per ray
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
   stage_field_weights<H>(fd, lds);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
   const uint32_t mask = (1u << fd.grid.log2T) - 1u;
-  const int S = rays.S;
   const int ntile = (S + 15) >> 4;
 
-  float scal_l[LPL];
-#pragma unroll
-  for (int q = 0; q < LPL; ++q) scal_l[q] = lds[Ld::SCAL + LPL * g + q];
+  // XCD-coherent ranges of the processing order (see the header)
+  const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = (int)blockIdx.x % nx, lb = (int)blockIdx.x / nx;
+  const int nblk = ((int)gridDim.x - xcd + nx - 1) / nx;  // workgroups that share this range
+  const int64_t lo = n_rays * xcd / nx;
+  const RayRange rr{n_rays * (xcd + 1) / nx, S, stride};
+  const int64_t pos_step = (int64_t)nblk * 4;
 
-  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < rays.R; ray += (int64_t)gridDim.x * 4) {
-    const float ox = rays.o[3 * ray], oy = rays.o[3 * ray + 1], oz = rays.o[3 * ray + 2];
-    const float dx = rays.d[3 * ray], dy = rays.d[3 * ray + 1], dz = rays.d[3 * ray + 2];
-    const float area = rays.area[ray];
+  const float* scal_l = lds + Ld::SCAL + LPL * g;  // this lane's levels (re-read per tile: 1 ds_read, no VGPRs held)
+  float* rbw = lds + Ld::RB + wid * H;              // this wave's per-ray bias row
+  int64_t pos = lo + (int64_t)lb * 4 + wid;
+  if (pos >= rr.end) return;
+  int t = 0;
+  // three-stage pipeline over this wave's flattened (ray, tile) sequence:
+  //   tf = gathered corners of the CURRENT tile | q = next tile (interval + ray constants loaded, gathers not yet
+  //   issued) | the tile after q has its small loads requested at the end of the issue step
+  TileFetch<LPL, F> tf;
+  PendingTile q;
+  load_pending(q, pos, 0, rr, j, order, ro, rd, rarea, rstarts, rends);
+  int64_t ray = q.ray;
+  issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
+  {
+    const bool wrap = ntile == 1;
+    load_pending(q, wrap ? pos + pos_step : pos, wrap ? 0 : 1, rr, j, order, ro, rd, rarea, rstarts, rends);
+  }
 
-    // per-ray part of feat layer 0:  rb[n] = fb0[n] + Σ_c fw0[n][32+c] * SH_c((d+1)/2)   (neurad_field.py:140-141)
-    f32x4 rb[NB];
-    f32x4 shq = f32x4{0.f, 0.f, 0.f, 0.f};  // SH coefficients 4g..4g+3 (only read when saving for the backward)
-    {
+  // per-ray state
+  f32x4 shq = f32x4{0.f, 0.f, 0.f, 0.f};
+  float carry = 0.f, acc_w = 0.f, acc_d = 0.f;
+  constexpr int NHA = DEFER ? H / 4 : 1;
+  float ha[NHA];  // DEFER: sum_s w_s * h2_s (this lane's sample column)
+  f32x4 fa[2];    // DEFER: sum_s w_s * geo_embedding_s
+
+  while (true) {
+    if (t == 0) {
+      // per-ray part of feat layer 0:  rb[n] = fb0[n] + sum_c fw0[n][32+c] * SH_c((d+1)/2)   (neurad_field.py:140-141)
+      const float dx = rd[3 * ray], dy = rd[3 * ray + 1], dz = rd[3 * ray + 2];
       float sh[16];
       sh4((dx + 1.f) / 2.f, (dy + 1.f) / 2.f, (dz + 1.f) / 2.f, sh);
       if constexpr (!COMPOSITE) {
@@ -65,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
         for (int c = 0; c < 16; ++c)
           if ((c >> 2) == g) shq[c & 3] = sh[c];
       }
+      f32x4 rb[NB];
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) rb[mb] = *reinterpret_cast<const f32x4*>(lds + Ld::BF0 + 16 * mb + 4 * g);
 #pragma unroll
@@ -75,228 +332,249 @@ __global__ __launch_bounds__(256, 2) void render_kernel(FieldDev fd, RaysDev ray
 #pragma unroll
           for (int r = 0; r < 4; ++r) rb[mb][r] = fmaf(w[r], sh[c], rb[mb][r]);
         }
+      // parked in this wave's LDS row (the 16 lanes of a DPP row hold identical copies; every lane stores its own ->
+      // same value to the same address) and re-read as the accumulator init of feat layer 0 in every tile
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) *reinterpret_cast<f32x4*>(rbw + 16 * mb + 4 * g) = rb[mb];
+      carry = COMPOSITE ? (fd.use_sdf ? 1.f : 0.f) : 0.f;  // running transmittance (product) / optical depth (sum)
+      acc_w = 0.f, acc_d = 0.f;
+      fa[0] = fa[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NHA; ++k) ha[k] = 0.f;
     }
 
-    float carry = COMPOSITE ? (fd.use_sdf ? 1.f : 0.f) : 0.f;  // running transmittance (product) / optical depth (sum)
-    float acc_w = 0.f, acc_d = 0.f;
-    f32x4 fa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 flast[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // The weights in LDS are loop invariant: without this opaque offset the compiler hoists ~200 LDS
+    // loads out of the tile loop and spills them.  `lw` re-derives the LDS base once per tile.
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const float* lw = lds + opaque;
+    const int s = 16 * t + j;
+    const bool live = s < S;
+    const float t0 = tf.t0, t1 = tf.t1;
 
-    for (int t = 0; t < ntile; ++t) {
-      // The weights in LDS are loop invariant: without this opaque offset the compiler hoists ~200 LDS
-      // loads out of the tile loop and spills them.  `lw` re-derives the LDS base once per tile.
-      int opaque = 0;
-      asm volatile("" : "+v"(opaque));
-      const float* lw = lds + opaque;
-      const int s = 16 * t + j;
-      const bool live = s < S;
-      const int64_t si = ray * rays.stride + (live ? s : S - 1);
-      const float t0 = rays.starts[si], t1 = rays.ends[si];
-      const SamplePos p = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, fd.scale);
+    // ---- blend the fetched corners (H1 + H4): the only wait on the gathers ---------------------------
+    float feat[8];
+    blend_tile<LPL, F>(tf, scal_l, feat);
+    __builtin_amdgcn_sched_barrier(0);
 
-      // ---- gather: LPL levels x 8 corners, rescaled (H1 + H4) ------------------------------------
-      // All 8*LPL gathers of the tile are issued before the first lerp: one memory round trip per tile
-      // instead of one per level (the loads of a level would otherwise wait for the previous level's blend).
-      float feat[8];
-      {
-        Corners cs[LPL];
-        float fv[LPL][8][F];
-#pragma unroll
-        for (int q = 0; q < LPL; ++q) cs[q] = hash_corners(p.x, p.y, p.z, scal_l[q], mask);
-#pragma unroll
-        for (int q = 0; q < LPL; ++q)
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            Entry<F, HALF>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs[q].idx[k], fv[q][k]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < LPL; ++q) {
-          float v[F];
-          lerp_corners<F>(cs[q], fv[q], v);
-          const float w = rescale_weight(scal_l[q], p.std);
-#pragma unroll
-          for (int f = 0; f < F; ++f) feat[q * F + f] = v[f] * w;
-        }
+    // ---- early ray termination (eval option): the transmittance ENTERING this tile is already below stop_eps, so
+    // everything behind it weighs less than stop_eps in total -> this (already fetched) tile is the ray's last.
+    // The test lags one tile behind the carry so that the fetch below never has to be re-issued.
+    bool stop_here = false;
+    if constexpr (COMPOSITE) {
+      if (stop_eps > 0.f) {
+        const float c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, carry)));
+        stop_here = fd.use_sdf ? (c < stop_eps) : (c > -__logf(stop_eps));  // wave-uniform -> scalar branch
       }
+    }
+    const bool last_tile = t == ntile - 1;
+    const bool ray_done = last_tile || stop_here;
 
-      bool saving = false;
-      int64_t srow = 0;
-      if constexpr (!COMPOSITE) {
-        saving = sv.enc != nullptr && live;
-        srow = ray * S + s;
-        if (saving) {
-          float* ep = sv.enc + srow * 32 + 8 * g;
-          *reinterpret_cast<f32x4*>(ep) = f32x4{feat[0], feat[1], feat[2], feat[3]};
-          *reinterpret_cast<f32x4*>(ep + 4) = f32x4{feat[4], feat[5], feat[6], feat[7]};
-        }
-      }
+    // ---- issue the next tile's gathers: they fly while this tile runs through the MLPs ---------------
+    if (ray_done && q.valid && q.pos == pos)  // terminated early: q still points into this ray -> skip to the next ray
+      load_pending(q, pos + pos_step, 0, rr, j, order, ro, rd, rarea, rstarts, rends);  // (one exposed round trip)
+    const bool have_next = q.valid;
+    const int64_t npos = q.pos, nray = q.ray;
+    const int nt = q.t;
+    issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);  // unconditional (see load_pending)
+    {
+      const bool wrap = nt + 1 == ntile;  // request the small loads of the tile after it
+      load_pending(q, wrap ? npos + pos_step : npos, wrap ? 0 : nt + 1, rr, j, order, ro, rd, rarea, rstarts, rends);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-      // ---- geo MLP layer 0 (32 -> H, ReLU) ---------------------------------------------------------
-      f32x4 h[NB];
-#pragma unroll
-      for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BG0 + 16 * mb + 4 * g);
-      mfma_layer<NB, 8>(lw + Ld::G0, lane, feat, h);
-      float hb[H / 4];
-#pragma unroll
-      for (int mb = 0; mb < NB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+    bool saving = false;
+    int64_t srow = 0;
+    if constexpr (!COMPOSITE) {
+      saving = sv.enc != nullptr && live;
+      srow = ray * S + s;
+      if (saving) {
+        float* ep = sv.enc + srow * 32 + 8 * g;
+        *reinterpret_cast<f32x4*>(ep) = f32x4{feat[0], feat[1], feat[2], feat[3]};
+        *reinterpret_cast<f32x4*>(ep + 4) = f32x4{feat[4], feat[5], feat[6], feat[7]};
+      }
+    }
 
-      if constexpr (!COMPOSITE) {
-        if (saving) {
+    // ---- geo MLP layer 0 (32 -> H, ReLU) ---------------------------------------------------------
+    f32x4 h[NB];
 #pragma unroll
-          for (int mb = 0; mb < NB; ++mb)
-            *reinterpret_cast<f32x4*>(sv.hg + srow * H + 16 * mb + 4 * g) =
-                f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
-        }
-      }
+    for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BG0 + 16 * mb + 4 * g);
+    mfma_layer<NB, 8>(lw + Ld::G0, lane, feat, h);
+    float hb[H / 4];
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
 
-      // ---- geo MLP layer 1 (H -> 1 + 32): row 0 (sdf / raw density) on the VALU, rows 1..32 on MFMA --
-      float sdf = 0.f;
+    if constexpr (!COMPOSITE) {
+      if (saving) {
 #pragma unroll
-      for (int mb = 0; mb < NB; ++mb) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(lw + Ld::SDFW + 16 * mb + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sdf = fmaf(w[r], hb[4 * mb + r], sdf);
+        for (int mb = 0; mb < NB; ++mb)
+          *reinterpret_cast<f32x4*>(sv.hg + srow * H + 16 * mb + 4 * g) =
+              f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
       }
-      sdf += __shfl_xor(sdf, 16, 64);
-      sdf += __shfl_xor(sdf, 32, 64);
-      sdf += lw[Ld::BG1];
-      f32x4 e[2];
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const float* bp = lw + Ld::BG1 + 1 + 16 * mb + 4 * g;
-        e[mb] = f32x4{bp[0], bp[1], bp[2], bp[3]};
-      }
-      mfma_layer<2, H / 4>(lw + Ld::G1, lane, hb, e);
-      float eb[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) eb[k] = e[k >> 2][k & 3];
+    }
 
-      // ---- feature MLP (32 [+16 SH folded into rb] -> H -> H -> 32), residual add -------------------
-      if constexpr (!COMPOSITE) {
-        if (saving) {
-          float* xp = sv.xf + srow * 48;
-          *reinterpret_cast<f32x4*>(xp + 4 * g) = e[0];
-          *reinterpret_cast<f32x4*>(xp + 16 + 4 * g) = e[1];
-          *reinterpret_cast<f32x4*>(xp + 32 + 4 * g) = shq;
-        }
+    // ---- geo MLP layer 1 (H -> 1 + 32): row 0 (sdf / raw density) on the VALU, rows 1..32 on MFMA --
+    float sdf = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(lw + Ld::SDFW + 16 * mb + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sdf = fmaf(w[r], hb[4 * mb + r], sdf);
+    }
+    sdf += __shfl_xor(sdf, 16, 64);
+    sdf += __shfl_xor(sdf, 32, 64);
+    sdf += lw[Ld::BG1];
+    f32x4 e[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const float* bp = lw + Ld::BG1 + 1 + 16 * mb + 4 * g;
+      e[mb] = f32x4{bp[0], bp[1], bp[2], bp[3]};
+    }
+    mfma_layer<2, H / 4>(lw + Ld::G1, lane, hb, e);
+    float eb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) eb[k] = e[k >> 2][k & 3];
+
+    // ---- feature MLP (32 [+16 SH folded into the per-ray bias] -> H -> H -> 32), residual add ------
+    if constexpr (!COMPOSITE) {
+      if (saving) {
+        float* xp = sv.xf + srow * 48;
+        *reinterpret_cast<f32x4*>(xp + 4 * g) = e[0];
+        *reinterpret_cast<f32x4*>(xp + 16 + 4 * g) = e[1];
+        *reinterpret_cast<f32x4*>(xp + 32 + 4 * g) = shq;
       }
+    }
 #pragma unroll
-      for (int mb = 0; mb < NB; ++mb) h[mb] = rb[mb];
-      mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
+    for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::RB + wid * H + 16 * mb + 4 * g);
+    mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
 #pragma unroll
-      for (int mb = 0; mb < NB; ++mb)
+    for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
-      if constexpr (!COMPOSITE) {
-        if (saving) {
+      for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+    if constexpr (!COMPOSITE) {
+      if (saving) {
 #pragma unroll
-          for (int mb = 0; mb < NB; ++mb)
-            *reinterpret_cast<f32x4*>(sv.hf + srow * (2 * H) + 16 * mb + 4 * g) =
-                f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
-        }
+        for (int mb = 0; mb < NB; ++mb)
+          *reinterpret_cast<f32x4*>(sv.hf + srow * (2 * H) + 16 * mb + 4 * g) =
+              f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
       }
+    }
 #pragma unroll
-      for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF1 + 16 * mb + 4 * g);
-      mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
+    for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF1 + 16 * mb + 4 * g);
+    mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
 #pragma unroll
-      for (int mb = 0; mb < NB; ++mb)
+    for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
-      if constexpr (!COMPOSITE) {
-        if (saving) {
+      for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
+    if constexpr (!COMPOSITE) {
+      if (saving) {
 #pragma unroll
-          for (int mb = 0; mb < NB; ++mb)
-            *reinterpret_cast<f32x4*>(sv.hf + srow * (2 * H) + H + 16 * mb + 4 * g) =
-                f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
-        }
+        for (int mb = 0; mb < NB; ++mb)
+          *reinterpret_cast<f32x4*>(sv.hf + srow * (2 * H) + H + 16 * mb + 4 * g) =
+              f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]};
       }
+    }
+
+    // ---- head (F4 / trunc_exp) -------------------------------------------------------------------
+    float a_or_d;  // alpha (sdf mode) or density
+    if (fd.use_sdf) a_or_d = __builtin_amdgcn_rcpf(1.f + __expf(sdf * fd.beta));  // sigmoid(-sdf*beta)
+    else a_or_d = expf(sdf);
+
+    if constexpr (!COMPOSITE) {
+      // per-sample output: feature = geo_embedding + mlp_feature(...)   (neurad_field.py:141)
       f32x4 o[2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) o[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF2 + 16 * mb + 4 * g);
       mfma_layer<2, H / 4>(lw + Ld::F2, lane, hb, o);
       o[0] += e[0];
-      o[1] += e[1];  // feature = geo_embedding + mlp_feature(...)   (neurad_field.py:141)
+      o[1] += e[1];
+      if (live) {
+        float* fp = out_feat + (ray * S + s) * 32;
+        *reinterpret_cast<f32x4*>(fp + 4 * g) = o[0];
+        *reinterpret_cast<f32x4*>(fp + 16 + 4 * g) = o[1];
+        if (g == 0) {
+          out_sdf[ray * S + s] = sdf;
+          out_alpha[ray * S + s] = a_or_d;
+        }
+      }
+    } else {
+      // ---- C1: transmittance scan over the 16 samples of the DPP row, carried across tiles -------
+      float w, T;
+      if (fd.use_sdf) {
+        const float alpha = live ? a_or_d : 0.f;
+        float incl = 1.f - alpha;
+        incl *= row_shr<1>(incl, 1.f);
+        incl *= row_shr<2>(incl, 1.f);
+        incl *= row_shr<4>(incl, 1.f);
+        incl *= row_shr<8>(incl, 1.f);
+        const float excl = row_shr<1>(incl, 1.f);
+        T = carry * excl;
+        w = T * alpha;
+        carry *= __shfl(incl, (lane & 48) | 15, 64);
+      } else {
+        const float sd = live ? a_or_d * (t1 - t0) : 0.f;
+        float incl = sd;
+        incl += row_shr<1>(incl, 0.f);
+        incl += row_shr<2>(incl, 0.f);
+        incl += row_shr<4>(incl, 0.f);
+        incl += row_shr<8>(incl, 0.f);
+        const float excl = row_shr<1>(incl, 0.f);
+        T = expf(-(carry + excl));
+        w = T * (1.f - expf(-sd));
+        carry += __shfl(incl, (lane & 48) | 15, 64);
+      }
+      if (out_w && live && g == 0) out_w[ray * S + s] = w;
+      // ---- C2 accumulation ------------------------------------------------------------------------
+      acc_w += w;
+      if (s < S - 1) acc_d += w * ((t0 + t1) / 2.f);
+      float wf = w;  // weight of this sample's FEATURES: the sky residual 1 - sum w goes on sample S-1
+      float acc = 0.f;
+      if (ray_done) {
+        acc = row_sum16(acc_w);
+        if (last_tile && s == S - 1) wf += 1.f - acc;
+      }
+#pragma unroll
+      for (int k = 0; k < H / 4; ++k) ha[k] = fmaf(hb[k], wf, ha[k]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        fa[0][r] = fmaf(e[0][r], wf, fa[0][r]);
+        fa[1][r] = fmaf(e[1][r], wf, fa[1][r]);
+      }
 
-      // ---- head (F4 / trunc_exp) -------------------------------------------------------------------
-      float a_or_d;  // alpha (sdf mode) or density
-      if (fd.use_sdf) a_or_d = __builtin_amdgcn_rcpf(1.f + __expf(sdf * fd.beta));  // sigmoid(-sdf*beta)
-      else a_or_d = expf(sdf);
-
-      if constexpr (!COMPOSITE) {
-        if (live) {
-          float* fp = out_feat + (ray * S + s) * 32;
-          *reinterpret_cast<f32x4*>(fp + 4 * g) = o[0];
-          *reinterpret_cast<f32x4*>(fp + 16 + 4 * g) = o[1];
+      if (ray_done) {
+        const float dep = row_sum16(acc_d);
+        if (!last_tile && out_w)  // terminated early: the rest of the ray contributes nothing
+          for (int s2 = 16 * (t + 1) + lane; s2 < S; s2 += 64) out_w[ray * S + s2] = 0.f;
+        // features = fw2 . (sum w h2) + fb2 * sum w' + sum w' e ;  sum w' = acc + (1 - acc) on a completed ray
+        const float wsum = last_tile ? acc + (1.f - acc) : acc;
+        f32x4 of2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mfma_layer<2, H / 4>(lw + Ld::F2, lane, ha, of2);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const f32x4 b2 = *reinterpret_cast<const f32x4*>(lw + Ld::BF2 + 16 * mb + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) of2[mb][r] = fmaf(b2[r], wsum, row_sum16(of2[mb][r] + fa[mb][r]));
+        }
+        if (j == 0) {
+          float* fp = out_feat + ray * 32;
+          *reinterpret_cast<f32x4*>(fp + 4 * g) = of2[0];
+          *reinterpret_cast<f32x4*>(fp + 16 + 4 * g) = of2[1];
           if (g == 0) {
-            out_sdf[ray * S + s] = sdf;
-            out_alpha[ray * S + s] = a_or_d;
+            out_acc[ray] = acc;
+            out_depth[ray] = dep;
           }
         }
-      } else {
-        // ---- C1: transmittance scan over the 16 samples of the DPP row, carried across tiles -------
-        float w, T;
-        if (fd.use_sdf) {
-          const float alpha = live ? a_or_d : 0.f;
-          float incl = 1.f - alpha;
-          incl *= row_shr<1>(incl, 1.f);
-          incl *= row_shr<2>(incl, 1.f);
-          incl *= row_shr<4>(incl, 1.f);
-          incl *= row_shr<8>(incl, 1.f);
-          const float excl = row_shr<1>(incl, 1.f);
-          T = carry * excl;
-          w = T * alpha;
-          carry *= __shfl(incl, (lane & 48) | 15, 64);
-        } else {
-          const float sd = live ? a_or_d * (t1 - t0) : 0.f;
-          float incl = sd;
-          incl += row_shr<1>(incl, 0.f);
-          incl += row_shr<2>(incl, 0.f);
-          incl += row_shr<4>(incl, 0.f);
-          incl += row_shr<8>(incl, 0.f);
-          const float excl = row_shr<1>(incl, 0.f);
-          T = expf(-(carry + excl));
-          w = T * (1.f - expf(-sd));
-          carry += __shfl(incl, (lane & 48) | 15, 64);
-        }
-        if (out_w && live && g == 0) out_w[ray * S + s] = w;
-        // ---- C2 accumulation ------------------------------------------------------------------------
-        acc_w += w;
-        if (s < S - 1) acc_d += w * ((t0 + t1) / 2.f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          fa[0][r] = fmaf(o[0][r], w, fa[0][r]);
-          fa[1][r] = fmaf(o[1][r], w, fa[1][r]);
-        }
-        if (s == S - 1) flast[0] = o[0], flast[1] = o[1];
       }
     }
 
-    if constexpr (COMPOSITE) {
-      const float acc = row_sum16(acc_w);
-      const float dep = row_sum16(acc_d);
-      const float resid = 1.f - acc;  // goes onto the last (sky) sample (models/neurad.py:381)
-      fa[0] += flast[0] * resid;      // flast is non-zero only in the lane that owns sample S-1
-      fa[1] += flast[1] * resid;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fa[mb][r] = row_sum16(fa[mb][r]);
-      if (j == 0) {
-        float* fp = out_feat + ray * 32;
-        *reinterpret_cast<f32x4*>(fp + 4 * g) = fa[0];
-        *reinterpret_cast<f32x4*>(fp + 16 + 4 * g) = fa[1];
-        if (g == 0) {
-          out_acc[ray] = acc;
-          out_depth[ray] = dep;
-        }
-      }
-    }
+    if (!have_next) break;
+    pos = npos, ray = nray, t = nt;
   }
 }
 
-int validate_field(const nrhip_field* f) {
+static int validate_field(const nrhip_field* f) {
   NR_REQUIRE(f, NRHIP_ERR_INVALID_ARG, "field descriptor is NULL");
   if (int e = validate_grid(&f->grid)) return e;
   NR_REQUIRE(f->table && f->static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "field: NULL table or non-positive scale");
@@ -317,7 +595,7 @@ int validate_field(const nrhip_field* f) {
   return NRHIP_OK;
 }
 
-FieldDev to_dev(const nrhip_field& f) {
+static FieldDev to_dev(const nrhip_field& f) {
   FieldDev d;
   d.grid = to_dev(f.grid);
   d.table = f.table;
@@ -332,51 +610,40 @@ FieldDev to_dev(const nrhip_field& f) {
   return d;
 }
 
-int persistent_blocks(const void* kernel, size_t lds_bytes, int64_t n_rays, int max_per_cu) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount
-                                                                                              : 256;
-  }
-  int nb = 0;  // persistent grid: as many workgroups per CU as registers + LDS admit
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, lds_bytes) != hipSuccess || nb < 1) nb = 2;
-  if (nb > max_per_cu) nb = max_per_cu;
-  const int64_t cap = (int64_t)n_cu * nb, blocks = (n_rays + 3) / 4;
-  return (int)(blocks < cap ? blocks : cap);
-}
-
 template <int L, int F, int H, bool HALF, bool COMPOSITE>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
-                         float* oal, const SaveDev& sv, hipStream_t st) {
+                         float* oal, const SaveDev& sv, float stop_eps, hipStream_t st) {
   constexpr size_t lds = Lds<H>::TOTAL * sizeof(float);
   auto kern = render_kernel<L, F, H, HALF, COMPOSITE>;
-  static bool configured = false;
-  if (lds > 64 * 1024 && !configured) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = true;
+  static int cap = 0;  // persistent grid: CUs x resident workgroups per CU, queried once per instantiation
+  if (!cap) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0, n_cu = 256, nb = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+    cap = n_cu * (nb > 4 ? 4 : nb);
   }
-  static int per_cu_blocks = 0;  // occupancy query once per instantiation
-  if (!per_cu_blocks) per_cu_blocks = persistent_blocks((const void*)kern, lds, INT64_C(1) << 40, 4);
   const int64_t want = (rd.R + 3) / 4;
-  const int blocks = (int)(want < per_cu_blocks ? want : per_cu_blocks);
-  kern<<<blocks, 256, lds, st>>>(fd, rd, of, od, oa, ow, os, oal, sv);
+  const int blocks = (int)(want < cap ? want : cap);
+  kern<<<blocks, 256, lds, st>>>(fd, rd.R, rd.S, rd.stride, rd.order, rd.o, rd.d, rd.area, rd.starts, rd.ends, of, od, oa,
+                                 ow, os, oal, sv, stop_eps);
   return check_launch("render/field fused kernel");
 }
 
 template <bool COMPOSITE>
-static int dispatch_render_serial(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa,
-                                  float* ow, float* os, float* oal, void* stream, const SaveDev& sv) {
+static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
+                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{}, float stop_eps = 0.f) {
   const FieldDev fd = to_dev(*f);
   const RaysDev rd = to_dev(*rays);
   const hipStream_t st = (hipStream_t)stream;
   const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
   const bool half = f->grid.param_dtype == 1;
-#define CASE(L_, F_, H_)                                                                                   \
-  if (L == L_ && F == F_ && H == H_) {                                                                     \
-    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, st)      \
-                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, st);    \
+#define CASE(L_, F_, H_)                                                                                          \
+  if (L == L_ && F == F_ && H == H_) {                                                                            \
+    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st)   \
+                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st); \
   }
   CASE(16, 2, 64)
   CASE(16, 2, 32)
@@ -387,31 +654,6 @@ static int dispatch_render_serial(const nrhip_field* f, const nrhip_rays* rays, 
 #undef CASE
   set_error("fused field kernel: no instantiation for L=%d F=%d H=%d", L, F, H);
   return NRHIP_ERR_UNSUPPORTED;
-}
-
-// A/B switch (read once per process): NRHIP_RENDER_VARIANT = 1 tile-serial, 2 pipelined, 3 pipelined + deferred
-// last feature layer.  Unset / 0 = the default chosen from measurements.
-static int env_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("NRHIP_RENDER_VARIANT");
-    v = e ? atoi(e) : 0;
-    if (v < 0 || v > 3) v = 0;
-  }
-  return v;
-}
-
-template <bool COMPOSITE>
-static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
-                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{},
-                           RenderOpts opts = RenderOpts{0.f, 0}) {
-  if (opts.variant == 0) opts.variant = env_variant();
-  if (opts.variant == 0) opts.variant = COMPOSITE ? 3 : 2;
-  if (opts.variant == 1) {
-    NR_REQUIRE(opts.stop_eps == 0.f, NRHIP_ERR_UNSUPPORTED, "early ray termination needs the pipelined kernel");
-    return dispatch_render_serial<COMPOSITE>(f, rays, of, od, oa, ow, os, oal, stream, sv);
-  }
-  return dispatch_render_pipelined<COMPOSITE>(f, rays, of, od, oa, ow, os, oal, stream, sv, opts);
 }
 
 }  // namespace nrhip
@@ -442,29 +684,20 @@ extern "C" int nrhip_field_fwd_train(const nrhip_field* f, const nrhip_rays* ray
   return dispatch_render<false>(f, rays, feature, nullptr, nullptr, nullptr, sdf, alpha, stream, sv);
 }
 
-static int render_fwd_impl(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
-                           float* out_acc, float* out_weights, const RenderOpts& opts, void* stream) {
+extern "C" int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
+                                   float* out_acc, float* out_weights, float early_stop_eps, void* stream) {
   if (int e = validate_field(f)) return e;
   if (int e = validate_rays(rays)) return e;
   if (rays->n_rays == 0) return NRHIP_OK;
   NR_REQUIRE(out_features && out_depth && out_acc, NRHIP_ERR_INVALID_ARG, "render_fwd: NULL output");
   NR_REQUIRE(rays->n_samples >= 1, NRHIP_ERR_INVALID_ARG, "render_fwd: needs >= 1 sample per ray");
-  NR_REQUIRE(opts.stop_eps >= 0.f && opts.stop_eps < 1.f, NRHIP_ERR_INVALID_ARG, "render_fwd: early_stop_eps %g not in [0,1)",
-             (double)opts.stop_eps);
-  NR_REQUIRE(opts.variant >= 0 && opts.variant <= 3, NRHIP_ERR_INVALID_ARG, "render_fwd: unknown kernel variant %d",
-             opts.variant);
+  NR_REQUIRE(early_stop_eps >= 0.f && early_stop_eps < 1.f, NRHIP_ERR_INVALID_ARG,
+             "render_fwd: early_stop_eps %g not in [0,1)", (double)early_stop_eps);
   return dispatch_render<true>(f, rays, out_features, out_depth, out_acc, out_weights, nullptr, nullptr, stream,
-                               SaveDev{}, opts);
+                               SaveDev{}, early_stop_eps);
 }
 
 extern "C" int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
                                 float* out_acc, float* out_weights, void* stream) {
-  return render_fwd_impl(f, rays, out_features, out_depth, out_acc, out_weights, RenderOpts{0.f, 0}, stream);
-}
-
-extern "C" int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
-                                   float* out_acc, float* out_weights, float early_stop_eps, int32_t variant,
-                                   void* stream) {
-  return render_fwd_impl(f, rays, out_features, out_depth, out_acc, out_weights, RenderOpts{early_stop_eps, variant},
-                         stream);
+  return nrhip_render_fwd_ex(f, rays, out_features, out_depth, out_acc, out_weights, 0.f, stream);
 }

@@ -109,8 +109,10 @@ def _c_mlp(weights: Sequence[Tensor], biases: Sequence[Optional[Tensor]]) -> Tup
     return m, keep
 
 
-def _c_rays(origins: Tensor, directions: Tensor, pixel_area: Tensor, starts: Tensor, ends: Tensor):
-    """starts/ends: [R,S] each, or views into one [R,S+1] edge tensor (stride S+1) -- no copies are made."""
+def _c_rays(origins: Tensor, directions: Tensor, pixel_area: Tensor, starts: Tensor, ends: Tensor,
+            order: Optional[Tensor] = None):
+    """starts/ends: [R,S] each, or views into one [R,S+1] edge tensor (stride S+1) -- no copies are made.
+    order: optional int32 [R] processing order from ``ray_order`` (locality hint for the fused kernels)."""
     o = _chk(origins, "origins")
     d = _chk(directions, "directions")
     a = _chk(pixel_area.reshape(-1), "pixel_area")
@@ -127,7 +129,25 @@ def _c_rays(origins: Tensor, directions: Tensor, pixel_area: Tensor, starts: Ten
     r.origins, r.directions, r.pixel_area = o.data_ptr(), d.data_ptr(), a.data_ptr()
     r.starts, r.ends = starts.data_ptr(), ends.data_ptr()
     r.sample_stride = starts.stride(0) if R > 1 else max(S, 1)
-    return r, (o, d, a, starts, ends)
+    if order is not None:
+        order = _chk(order, "order", torch.int32)
+        if order.shape != (R,):
+            raise ValueError(f"order must be int32 [R={R}], got {tuple(order.shape)}")
+        r.order = order.data_ptr()
+    return r, (o, d, a, starts, ends, order)
+
+
+def ray_order(origins: Tensor, directions: Tensor, static_scale: float, t_ref: Optional[float] = None,
+              key_bits: int = 0) -> Tensor:
+    """Processing order that groups rays looking at the same region (csrc/rayorder.hip) -> int32 [R] permutation to pass
+    as ``order=`` to field_fwd / field_fwd_train / render_fwd.  t_ref: distance of the key point along the ray; default
+    = static_scale, the contraction boundary, where the key cell is set by where the ray leaves the scene."""
+    t_ref = float(static_scale) if t_ref is None else t_ref
+    o, d = _chk(origins, "origins"), _chk(directions, "directions")
+    out = torch.empty((o.shape[0],), device=o.device, dtype=torch.int32)
+    call("nrhip_ray_order", _ptr(o), _ptr(d), o.shape[0], float(t_ref), float(static_scale), int(key_bits), _ptr(out),
+         _stream())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -311,9 +331,9 @@ class FieldSpec:
         return f, (k1, k2)
 
 
-def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends):
+def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, order: Optional[Tensor] = None):
     """-> feature [R,S,32], sdf (or raw geo output) [R,S], alpha (or density) [R,S]"""
-    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends, order)
     f, keep2 = fs.c_field()
     R, S = r.n_rays, r.n_samples
     dev = origins.device
@@ -324,10 +344,10 @@ def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends):
     return feature, sdf, alpha
 
 
-def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends):
+def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends, order: Optional[Tensor] = None):
     """field_fwd + the activations the backward needs: -> (feature [N,32], geo_out [N], head [N]),
     (enc [N,32], geo_hidden [N,H], feat_in [N,48], feat_hidden [N,2H])"""
-    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends, order)
     f, keep2 = fs.c_field()
     n, dev = r.n_rays * r.n_samples, origins.device
     H = fs.geo_w[0].shape[0]
@@ -341,11 +361,12 @@ def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends
 
 
 def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, return_weights: bool = False,
-               out: Optional[Tuple[Tensor, Tensor, Tensor]] = None, early_stop_eps: float = 0.0, variant: int = 0):
+               out: Optional[Tuple[Tensor, Tensor, Tensor]] = None, early_stop_eps: float = 0.0,
+               order: Optional[Tensor] = None):
     """The fused headline kernel.  -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S]).
     early_stop_eps > 0 (eval option, default exact): rays stop once their transmittance is below it.
-    variant: 0 default, 1 tile-serial, 2 pipelined gathers, 3 pipelined + deferred last feature layer (A/B)."""
-    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    order: processing order from ``ray_order`` (locality hint; outputs stay in batch order)."""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends, order)
     f, keep2 = fs.c_field()
     R, S = r.n_rays, r.n_samples
     dev = origins.device
@@ -357,7 +378,7 @@ def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, ret
         feats, depth, acc = out
     w = torch.empty((R, S), device=dev, dtype=torch.float32) if return_weights else None
     call("nrhip_render_fwd_ex", C.byref(f), C.byref(r), _ptr(feats), _ptr(depth), _ptr(acc), _ptr(w),
-         float(early_stop_eps), int(variant), _stream())
+         float(early_stop_eps), _stream())
     return (feats, depth, acc, w) if return_weights else (feats, depth, acc)
 
 

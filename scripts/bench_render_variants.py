@@ -1,15 +1,10 @@
-"""A/B of the fused kernels' variants on the GPU (HIP-event timing, no profiler):
+"""Fused field/render kernels on the GPU (HIP-event timing, no profiler): batch order as given vs the processing order
+from nrhip_ray_order, on random rays and on 32x32 camera patches; early ray termination; the ordering pass itself.
 
-  composited render (nrhip_render_fwd_ex, variant 1/2/3, + early ray termination) on BASELINE config[1] and on
-  NeuRAD's default grid, and -- in one subprocess per NRHIP_RENDER_VARIANT value, because the per-sample entry points
-  pick their kernel from the environment -- field_fwd (eval) and field_fwd_train (training forward).
-
-    python scripts/bench_render_variants.py            # everything
-    python scripts/bench_render_variants.py --child    # (internal) per-sample paths under the current environment
+    python scripts/bench_render_variants.py
 """
 import json
 import os
-import subprocess
 import sys
 
 sys.path.insert(0, os.getcwd())
@@ -49,7 +44,7 @@ def timeit(fn, iters=30, warm=5):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3  # us
+    return round(e0.elapsed_time(e1) / iters * 1e3, 1)  # us
 
 
 CFGS = {"config1_16x2_T19_H64_4096x128": (16, 2, 19, 64, 16, 1024, 4096, 128),
@@ -57,64 +52,71 @@ CFGS = {"config1_16x2_T19_H64_4096x128": (16, 2, 19, 64, 16, 1024, 4096, 128),
         "neurad_8x4_T22_H32_4096x128": (8, 4, 22, 32, 32, 8192, 4096, 128)}
 
 
-def workload(cfg):
-    L, F, lg, H, mn, mx, R, S = cfg
-    fs = mk(L, F, lg, H, mn, mx)
-    g = torch.Generator(device="cuda")
-    g.manual_seed(1234)
-    o = torch.randn((R, 3), device="cuda", generator=g) * 5.0
-    d = torch.randn((R, 3), device="cuda", generator=g)
+def rays(R, mode, g):
+    if mode == "patches":  # R/1024 cameras, one 32x32 pixel patch each (pinhole f=1900 px, 1920x1280)
+        n = R // 1024
+        o = (torch.randn((n, 1, 3), device="cuda", generator=g) * 5.0).expand(n, 1024, 3).reshape(R, 3)
+        fwd = torch.randn((n, 3), device="cuda", generator=g)
+        fwd = fwd / fwd.norm(dim=-1, keepdim=True)
+        up = torch.tensor([0.0, 0.0, 1.0], device="cuda").expand(n, 3)
+        right = torch.cross(fwd, up, dim=-1)
+        right = right / right.norm(dim=-1, keepdim=True)
+        up2 = torch.cross(right, fwd, dim=-1)
+        u0 = torch.randint(0, 1920 - 32, (n,), device="cuda", generator=g)
+        v0 = torch.randint(0, 1280 - 32, (n,), device="cuda", generator=g)
+        vv, uu = torch.meshgrid(torch.arange(32, device="cuda"), torch.arange(32, device="cuda"), indexing="ij")
+        x = ((u0[:, None, None] + uu[None]) - 960.0) / 1900.0
+        y = ((v0[:, None, None] + vv[None]) - 640.0) / 1900.0
+        d = fwd[:, None, None, :] + x[..., None] * right[:, None, None, :] - y[..., None] * up2[:, None, None, :]
+        d = d.reshape(R, 3)
+    else:
+        o = torch.randn((R, 3), device="cuda", generator=g) * 5.0
+        d = torch.randn((R, 3), device="cuda", generator=g)
     d = d / d.norm(dim=-1, keepdim=True)
-    area = torch.full((R,), 2.43e-6, device="cuda")
-    eu = ops.power_sampler(None, torch.full((R,), 20000.0, device="cuda"), S, last_edge=20000.0)[1]
-    return fs, o.contiguous(), d.contiguous(), area, eu
-
-
-def child():
-    out = {}
-    for name, cfg in CFGS.items():
-        fs, o, d, area, eu = workload(cfg)
-        out[name] = {
-            "field_fwd_us": timeit(lambda: ops.field_fwd(fs, o, d, area, eu[:, :-1], eu[:, 1:])),
-            "field_fwd_train_us": timeit(lambda: ops.field_fwd_train(fs, o, d, area, eu[:, :-1], eu[:, 1:]), iters=15),
-        }
-    print("CHILD " + json.dumps(out))
+    return o.contiguous(), d.contiguous()
 
 
 def main():
     res = {}
     for name, cfg in CFGS.items():
-        fs, o, d, area, eu = workload(cfg)
-        R, S = cfg[6], cfg[7]
-        outs = {}
-        row = {}
-        for v in (1, 2, 3):
-            row[f"render_v{v}_us"] = timeit(lambda: ops.render_fwd(fs, o, d, area, eu[:, :-1], eu[:, 1:], variant=v))
-            outs[v] = ops.render_fwd(fs, o, d, area, eu[:, :-1], eu[:, 1:], variant=v)
-        for v in (2, 3):
-            row[f"rel_l2_v{v}_vs_v1"] = float((outs[v][0] - outs[1][0]).norm() / outs[1][0].norm())
-        for eps in (1e-4, 1e-2):
-            row[f"render_v3_stop{eps:g}_us"] = timeit(
-                lambda: ops.render_fwd(fs, o, d, area, eu[:, :-1], eu[:, 1:], variant=3, early_stop_eps=eps))
-            fe = ops.render_fwd(fs, o, d, area, eu[:, :-1], eu[:, 1:], variant=3, early_stop_eps=eps)[0]
-            row[f"max_abs_err_stop{eps:g}"] = float((fe - outs[3][0]).abs().max())
-        row["samples"] = R * S
-        res[name] = row
-        print(name, json.dumps(row), flush=True)
+        L, F, lg, H, mn, mx, R, S = cfg
+        fs = mk(L, F, lg, H, mn, mx)
+        area = torch.full((R,), 2.43e-6, device="cuda")
+        eu = ops.power_sampler(None, torch.full((R,), 20000.0, device="cuda"), S, last_edge=20000.0)[1]
+        st, en = eu[:, :-1], eu[:, 1:]
+        for mode in ("random", "patches"):
+            g = torch.Generator(device="cuda")
+            g.manual_seed(1234)
+            o, d = rays(R, mode, g)
+            order = ops.ray_order(o, d, 100.0)
+            row = {"ray_order_us": timeit(lambda: ops.ray_order(o, d, 100.0)),
+                   "render_us": timeit(lambda: ops.render_fwd(fs, o, d, area, st, en)),
+                   "render_ordered_us": timeit(lambda: ops.render_fwd(fs, o, d, area, st, en, order=order)),
+                   "order+render_us": timeit(lambda: ops.render_fwd(fs, o, d, area, st, en,
+                                                                    order=ops.ray_order(o, d, 100.0))),
+                   "field_fwd_us": timeit(lambda: ops.field_fwd(fs, o, d, area, st, en)),
+                   "field_fwd_ordered_us": timeit(lambda: ops.field_fwd(fs, o, d, area, st, en, order=order)),
+                   "field_fwd_train_us": timeit(lambda: ops.field_fwd_train(fs, o, d, area, st, en), iters=15),
+                   "field_fwd_train_ordered_us": timeit(lambda: ops.field_fwd_train(fs, o, d, area, st, en, order=order),
+                                                        iters=15)}
+            for tr in (20.0, 300.0):
+                od = ops.ray_order(o, d, 100.0, t_ref=tr)
+                row[f"render_ordered_tref{tr:g}_us"] = timeit(lambda: ops.render_fwd(fs, o, d, area, st, en, order=od))
+            for kb in (4, 5):
+                od = ops.ray_order(o, d, 100.0, key_bits=kb)
+                row[f"ray_order_bits{kb}_us"] = timeit(lambda: ops.ray_order(o, d, 100.0, key_bits=kb))
+                row[f"render_ordered_bits{kb}_us"] = timeit(lambda: ops.render_fwd(fs, o, d, area, st, en, order=od))
+            exact = ops.render_fwd(fs, o, d, area, st, en)[0]
+            for eps in (1e-4, 1e-2):
+                row[f"render_stop{eps:g}_us"] = timeit(lambda: ops.render_fwd(fs, o, d, area, st, en, early_stop_eps=eps))
+                fe = ops.render_fwd(fs, o, d, area, st, en, early_stop_eps=eps)[0]
+                row[f"max_abs_err_stop{eps:g}"] = float((fe - exact).abs().max())
+            res[f"{name}/{mode}"] = row
+            print(f"{name}/{mode}", json.dumps(row), flush=True)
         del fs
         torch.cuda.empty_cache()
-    for v in ("1", "2"):
-        env = dict(os.environ, NRHIP_RENDER_VARIANT=v)
-        p = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
-        line = [l for l in p.stdout.splitlines() if l.startswith("CHILD ")]
-        if not line:
-            print("child failed:", p.stderr[-2000:])
-            continue
-        for name, r in json.loads(line[0][6:]).items():
-            for k, val in r.items():
-                res[name][f"{k[:-3]}_v{v}_us"] = val
     print("RESULT " + json.dumps(res))
 
 
 if __name__ == "__main__":
-    child() if "--child" in sys.argv else main()
+    main()

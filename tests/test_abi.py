@@ -56,7 +56,7 @@ def test_struct_layouts_match_header_sizes(lib):
 
     assert ctypes.sizeof(_lib.Grid) == 16 + 4 * 32
     assert ctypes.sizeof(_lib.Mlp) == 16 + 8 * 8 * 2
-    assert ctypes.sizeof(_lib.Rays) == 64
+    assert ctypes.sizeof(_lib.Rays) == 72
 
 
 def test_version_and_error_string(lib):

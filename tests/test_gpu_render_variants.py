@@ -1,6 +1,6 @@
-"""The fused render kernel's variants (nrhip_render_fwd_ex: tile-serial / software-pipelined gathers / pipelined with the
-last feature layer applied once per ray) against the CPU oracle and against each other, plus the early-ray-termination
-option: exact when off, bounded by `early_stop_eps` when on."""
+"""The fused render kernel's scheduling features against the CPU oracle: the software pipeline across ray boundaries,
+processing orders (`nrhip_rays.order` from nrhip_ray_order -- a locality hint that must never change a result) and the
+early-ray-termination option: exact when off, bounded by `early_stop_eps` when on."""
 import numpy as np
 import pytest
 import torch
@@ -11,8 +11,6 @@ from test_gpu_parity import RENDER_CFGS, TOL, _sample_rays, dev, field_params, h
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"serial": 1, "pipelined": 2, "pipelined_deferred": 3}
-
 
 @pytest.fixture(scope="module")
 def ops():
@@ -22,9 +20,29 @@ def ops():
     return _ops
 
 
-@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_ray_order_is_a_permutation_grouped_by_region(ops):
+    R = 5000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    o = torch.randn((R, 3), device="cuda", generator=g) * 5
+    d = torch.randn((R, 3), device="cuda", generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    order = ops.ray_order(o, d, static_scale=100.0, t_ref=20.0)
+    assert order.dtype == torch.int32 and order.shape == (R,)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(R, device="cuda"))
+    # neighbours in the order look at nearby points: mean distance of consecutive key points far below a random order's
+    p = (o + 20.0 * d)[order.long()]
+    near = (p[1:] - p[:-1]).norm(dim=-1).mean()
+    rand = ((o + 20.0 * d)[1:] - (o + 20.0 * d)[:-1]).norm(dim=-1).mean()
+    assert float(near) < 0.5 * float(rand)
+    assert ops.ray_order(o[:0], d[:0], 100.0).shape == (0,)
+    nan = o.clone()
+    nan[3] = float("nan")  # garbage rays must still yield a valid permutation
+    assert torch.equal(torch.sort(ops.ray_order(nan, d, 100.0).long()).values, torch.arange(R, device="cuda"))
+
+
+@pytest.mark.parametrize("ordered", [False, True])
 @pytest.mark.parametrize("cfg", RENDER_CFGS)
-def test_render_variant_vs_oracle(ops, cfg, variant):
+def test_render_with_processing_order_vs_oracle(ops, cfg, ordered):
     L, F, lg, mn, mx, H, use_sdf, R, S = cfg
     p = field_params(use_sdf=use_sdf, L=L, F=F, lg=lg, H=H, mn=mn, mx=mx, scale=2.0 if use_sdf else 0.5)
     if use_sdf:
@@ -33,57 +51,78 @@ def test_render_variant_vs_oracle(ops, cfg, variant):
     o, d, area, s, e, eu = _sample_rays(R, S, seed=R + S)
     ref = O.render_rays(p, o, d, area, s, e)
     edges = dev(eu)
+    order = ops.ray_order(dev(o), dev(d), p.static_scale) if ordered else None
     feats, depth, acc, w = ops.render_fwd(fs, dev(o), dev(d), dev(area), edges[:, :-1], edges[:, 1:],
-                                          return_weights=True, variant=VARIANTS[variant])
+                                          return_weights=True, order=order)
     assert rel_l2(host(w), ref["weights"]) < TOL
     assert rel_l2(host(feats), ref["features"]) < TOL
     assert rel_l2(host(depth), ref["depth"]) < TOL or np.abs(host(depth) - ref["depth"]).max() < 1e-5
     assert rel_l2(host(acc), ref["accumulation"]) < TOL
 
 
-def test_render_variants_agree_more_rays_than_waves(ops):
+def test_order_never_changes_results_more_rays_than_waves(ops):
     """R far above the persistent grid's wave count: every wave walks several rays, the flattened (ray, tile) pipeline
-    crosses ray boundaries, ragged S.  All variants must agree to fp32 reassociation."""
+    crosses ray boundaries, ragged S.  Any processing order gives bit-identical per-ray results (each ray is computed by
+    one wave with the same arithmetic), for the composited and the per-sample / training entry points."""
     p = field_params(use_sdf=True, L=16, F=2, lg=14, H=64, mn=16, mx=1024, scale=1.0)
     p.beta = 2.0
     fs = to_spec(ops, p)
     R, S = 9000, 37
     o, d, area, s, e, eu = _sample_rays(R, S, seed=3)
-    edges = dev(eu)
-    outs = {k: ops.render_fwd(fs, dev(o), dev(d), dev(area), edges[:, :-1], edges[:, 1:], return_weights=True, variant=v)
-            for k, v in VARIANTS.items()}
-    base = outs["serial"]
-    for k in ("pipelined", "pipelined_deferred"):
-        for a, b in zip(outs[k], base):
-            assert rel_l2(host(a), host(b)) < 5e-6, k
-    assert torch.equal(outs["pipelined"][3], base[3])  # weights: same arithmetic in the same order
+    edges, do, dd, da = dev(eu), dev(o), dev(d), dev(area)
+    orders = [None, ops.ray_order(do, dd, p.static_scale), torch.randperm(R, device="cuda").to(torch.int32),
+              torch.arange(R - 1, -1, -1, device="cuda", dtype=torch.int32)]
+    base = ops.render_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], return_weights=True)
+    fbase = ops.field_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:])
+    tbase = ops.field_fwd_train(fs, do, dd, da, edges[:, :-1], edges[:, 1:])
+    for od in orders[1:]:
+        for a, b in zip(ops.render_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], return_weights=True, order=od), base):
+            assert torch.equal(a, b)
+        for a, b in zip(ops.field_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], order=od), fbase):
+            assert torch.equal(a, b)
+        got = ops.field_fwd_train(fs, do, dd, da, edges[:, :-1], edges[:, 1:], order=od)
+        for a, b in zip(got[0] + got[1], tbase[0] + tbase[1]):
+            assert torch.equal(a, b)
     sl = slice(8990, 9000)  # the tail rays (last pipeline stages) against the oracle
     ref = O.render_rays(p, o[sl], d[sl], area[sl], s[sl], e[sl])
-    assert rel_l2(host(outs["pipelined_deferred"][0][sl]), ref["features"]) < TOL
+    assert rel_l2(host(base[0][sl]), ref["features"]) < TOL
+    with pytest.raises(ValueError):
+        ops.render_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], order=orders[1][:-1])
 
 
 @pytest.mark.parametrize("use_sdf", [True, False])
-@pytest.mark.parametrize("variant", [2, 3])
-def test_early_ray_termination_bounded(ops, use_sdf, variant):
+def test_early_ray_termination_bounded(ops, use_sdf):
     """early_stop_eps: rays stop once their transmittance is below eps.  What is dropped weighs < eps in total, so
     accumulation changes by < eps, features by < eps * max|feature|; weights of skipped samples come back as zeros and
     everything before the cut is bit-identical.  eps = 0 is the exact path."""
     p = field_params(use_sdf=use_sdf, L=8, F=4, lg=11, H=32, scale=2.0 if use_sdf else 0.5)
     if use_sdf:
         p.beta = 6.0  # alphas around 0.5: transmittance falls below 1e-3 after a dozen samples
-    fs = to_spec(ops, p)
     R, S = 300, 96
-    o, d, area, s, e, eu = _sample_rays(R, S, seed=21)
-    if not use_sdf:  # make the medium dense enough to saturate
-        p.geo_b[1][0] += 4.0
-        fs = to_spec(ops, p)
-    args = (fs, dev(o), dev(d), dev(area), dev(s), dev(e))
-    f0, d0, a0, w0 = ops.render_fwd(*args, return_weights=True, variant=variant)
     eps = 1e-3
-    f1, d1, a1, w1 = ops.render_fwd(*args, return_weights=True, variant=variant, early_stop_eps=eps)
-    n_skipped = int((w1 == 0).sum() - (w0 == 0).sum())
-    assert n_skipped > R * S // 4, "the test scene must actually terminate rays early"
-    kept = w1 != 0
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=21)
+    # density head: shift the logit until the medium is opaque enough to cut rays but not so dense that the exact
+    # weights underflow to 0 on their own
+    for bump in (0.0, -3.0, -2.0, -1.0, 1.0, 2.0, 3.0):
+        if not use_sdf:
+            p.geo_b[1][0] += bump
+        fs = to_spec(ops, p)
+        args = (fs, dev(o), dev(d), dev(area), dev(s), dev(e))
+        f0, d0, a0, w0 = ops.render_fwd(*args, return_weights=True)
+        # the kernel's rule: the tile whose ENTERING transmittance is below eps is the last one evaluated
+        T_enter = 1.0 - torch.cumsum(w0.double(), -1)[:, 15::16]          # behind tiles 0, 1, ...
+        T_enter = torch.cat([torch.ones_like(T_enter[:, :1]), T_enter[:, :-1]], 1)
+        stop = T_enter < eps * 0.5                                         # margin: fp32 carry vs this fp64 sum
+        last = torch.where(stop.any(1), stop.float().argmax(1), torch.full((R,), S // 16 - 1, device="cuda"))
+        skipped = torch.arange(S, device="cuda")[None, :] >= (16 * (last + 1))[:, None]
+        if use_sdf or (skipped.float().mean() > 0.25 and bool((w0[skipped] > 0).float().mean() > 0.5)):
+            break
+        if not use_sdf:
+            p.geo_b[1][0] -= bump
+    assert skipped.float().mean() > 0.25, "the test scene must actually terminate rays early"
+    f1, d1, a1, w1 = ops.render_fwd(*args, return_weights=True, early_stop_eps=eps)
+    assert bool((w1[skipped] == 0).all())
+    kept = ~((w1 == 0) & (w0 != 0))
     assert torch.equal(w1[kept], w0[kept])
     assert float((w0 * (~kept)).sum(-1).max()) <= eps * 1.01  # per ray: what was skipped weighs < eps
     assert float((a1 - a0).abs().max()) <= eps * 1.01
@@ -92,17 +131,9 @@ def test_early_ray_termination_bounded(ops, use_sdf, variant):
     # the sky residual (1 - acc on the last sample) is dropped with the tail: it is < eps on a terminated ray
     assert float((d1 - d0).abs().max()) <= eps * float(e.max())
     # a threshold nothing reaches: same arithmetic, same result
-    f2, d2, a2, w2 = ops.render_fwd(*args, return_weights=True, variant=variant, early_stop_eps=1e-30)
+    f2, d2, a2, w2 = ops.render_fwd(*args, return_weights=True, early_stop_eps=1e-30)
     assert torch.equal(f2, f0) and torch.equal(w2, w0) and torch.equal(a2, a0)
-
-
-def test_early_stop_rejected_by_serial_kernel(ops):
     from neurad_studio_amd._lib import NeuradHipError
 
-    p = field_params()
-    fs = to_spec(ops, p)
-    o, d, area, s, e, _ = _sample_rays(8, 32, seed=1)
     with pytest.raises(NeuradHipError):
-        ops.render_fwd(fs, dev(o), dev(d), dev(area), dev(s), dev(e), variant=1, early_stop_eps=1e-3)
-    with pytest.raises(NeuradHipError):
-        ops.render_fwd(fs, dev(o), dev(d), dev(area), dev(s), dev(e), variant=7)
+        ops.render_fwd(*args, early_stop_eps=1.5)
