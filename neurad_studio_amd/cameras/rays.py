@@ -15,6 +15,33 @@ from torch import Tensor
 from .. import autograd as ag
 
 
+def per_ray(frustums):
+    """(origins [R,3], directions [R,3], pixel_area [R]) of a [R,S] frustum batch -- of THIS package's Frustums or of
+    the reference's (nerfstudio/cameras/rays.py:33-59): both hold the per-ray fields as stride-0 broadcast views
+    [R,1,C] -> [R,S,C] (rays.py:336-355), so column 0 is the ray's value and no copy is made for the common case."""
+    o, d, a = frustums.origins, frustums.directions, frustums.pixel_area
+    if o.dim() == 3:
+        o, d, a = o[:, 0], d[:, 0], a[:, 0]
+    elif o.dim() != 2:
+        raise ValueError(f"frustums must be [R,S,*] (or per-ray [R,*]); got origins of shape {tuple(o.shape)}")
+    return o.contiguous(), d.contiguous(), a.reshape(-1).contiguous()
+
+
+def sample_times(ray_samples):
+    """per-ray times [R] of a [R,S] RaySamples (times are broadcast over the samples like the other ray fields)"""
+    t = ray_samples.times
+    if t is None:
+        return None
+    return (t[:, 0] if t.dim() == 3 else t).reshape(-1)
+
+
+def get_weights(ray_samples, densities: Tensor) -> Tensor:
+    """RaySamples.get_weights (rays.py:188-210) for any RaySamples-shaped object, on the GPU: wave-per-ray
+    exclusive-sum scan (nrhip_weights_from_density)."""
+    w = ag.WeightsFromDensityFn.apply(ray_samples.deltas[..., 0].contiguous(), densities[..., 0].contiguous())
+    return w[..., None]
+
+
 @dataclass
 class Frustums:
     origins: Tensor      # [*bs, 3]
@@ -34,12 +61,7 @@ class Frustums:
         return self.starts.shape[:-1]
 
     def per_ray(self):
-        """(origins [R,3], directions [R,3], pixel_area [R]) of a [R,S] frustum batch (no copies when the fields
-        are the broadcast views built by RayBundle.get_ray_samples)."""
-        o, d, a = self.origins, self.directions, self.pixel_area
-        if o.dim() == 3:
-            o, d, a = o[:, 0], d[:, 0], a[:, 0]
-        return o.contiguous(), d.contiguous(), a.reshape(-1).contiguous()
+        return per_ray(self)
 
 
 @dataclass
@@ -58,9 +80,7 @@ class RaySamples:
         return self.frustums.shape
 
     def get_weights(self, densities: Tensor) -> Tensor:
-        """rays.py:188-210 on the GPU: wave-per-ray exclusive-sum scan (nrhip_weights_from_density)."""
-        w = ag.WeightsFromDensityFn.apply(self.deltas[..., 0].contiguous(), densities[..., 0].contiguous())
-        return w[..., None]
+        return get_weights(self, densities)
 
     def __getitem__(self, idx):
         """slicing along the sample axis, e.g. ray_samples[..., :-1] (models/neurad.py:388)."""
@@ -72,8 +92,8 @@ class RaySamples:
             return None if t is None else t[(*bidx, slice(None))] if Ellipsis in bidx else t[bidx]
         fr = self.frustums
         return replace(self, frustums=Frustums(sl(fr.origins), sl(fr.directions), sl(fr.starts), sl(fr.ends),
-                                               sl(fr.pixel_area)),
-                       deltas=sl(self.deltas), spacing_starts=sl(self.spacing_starts),
+                                               sl(fr.pixel_area), sl(fr.offsets)),
+                       camera_indices=sl(self.camera_indices), deltas=sl(self.deltas), spacing_starts=sl(self.spacing_starts),
                        spacing_ends=sl(self.spacing_ends), times=sl(self.times),
                        metadata=None if self.metadata is None else {k: sl(v) for k, v in self.metadata.items()})
 

@@ -75,7 +75,7 @@ class NeuRADHashEncoding(nn.Module):
         super().__init__()
         self.config, self.implementation = config, implementation
         self.actors = dynamic_actors
-        self.static_scale = float(static_scale)
+        self.static_scale = float(static_scale)  # the reference passes scene_box.aabb.max() (a 0-d tensor)
         s, a = config.static, config.actor
         self.static_grid = HashEncoding(num_levels=s.num_levels, min_res=s.base_res, max_res=s.max_res,
                                         log2_hashmap_size=s.log2_hashmap_size, features_per_level=s.hashgrid_dim,
@@ -137,9 +137,7 @@ class NeuRADHashEncoding(nn.Module):
             spec, cand = self.prepare_actors(origins, directions, pixel_area, starts, ends, times)
             merged = feats.detach().clone()
             dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, merged, flip)
-        want_actor_grad = torch.is_grad_enabled() and self.config.require_actor_grad and (
-            any(gr.hash_table.requires_grad for gr in self.actor_grids) or self.actors.actor_positions.requires_grad)
-        if want_actor_grad:
+        if self.wants_actor_grad():
             with torch.no_grad():
                 hits = ops.actor_hits(spec, cand, origins, directions, pixel_area, starts, ends)
             feats = self._actor_rows_with_grad(feats, hit, hits, origins, directions, pixel_area, starts, ends, times,
@@ -151,41 +149,61 @@ class NeuRADHashEncoding(nn.Module):
             feats = merged
         return feats, dirs
 
-    def _actor_rows_with_grad(self, feats, hit, hits, origins, directions, pixel_area, starts, ends, times, flip):
+    def wants_actor_grad(self) -> bool:
+        """Does the actor branch have to be differentiable?  ``require_actor_grad`` governs the POSE gradient only
+        (the reference wraps just ``_split_static_vs_actors`` in no_grad, neurad_encoding.py:174-176): the actor grids
+        (and whatever consumes their features) train in both the main field and the proposal fields."""
+        if not torch.is_grad_enabled():
+            return False
+        return any(gr.hash_table.requires_grad for gr in self.actor_grids) or (
+            self.config.require_actor_grad and self.actors.actor_positions.requires_grad)
+
+    def actor_pair_rows(self, hit, hits, origins, directions, pixel_area, starts, ends, times, flip):
         """Training path of the actor rows (B1): the kernels found WHICH samples lie in WHICH actor; the few hit rows
-        are recomputed differentiably -- box-frame position through torch (gradient to the trajectories), the
-        actor grid through HashGridFn (table scatter-add + nrhip_hashgrid_bwd_input for dL/dx) -- and spliced in
-        with index_put, whose autograd zeroes the static-table gradient of the replaced rows."""
+        are recomputed differentiably -- box-frame position through torch (gradient to the trajectories when
+        ``require_actor_grad``), the actor grids through MultiHashGridFn (table scatter-add, and
+        nrhip_hashgrid_bwd_input for dL/dx).  -> None, or (idx [P] flat sample index, winner [P] bool: the actor the
+        forward kernels used for that sample (highest index), rows [P, La*Fa] rescaled actor features)."""
         pair = (hits >= 0).nonzero()                  # every (sample, candidate slot) containment
         if pair.shape[0] == 0:
-            return feats
+            return None
+        from ..model_components.dynamic_actors import world2box_pairs
+
         idx, act = pair[:, 0], hits[pair[:, 0], pair[:, 1]].long()
         winner = act == hit[idx].long()               # the row the forward actually used (highest actor index)
         S = starts.shape[1]
         ray, smp = idx // S, idx % S
-        t0, t1 = starts[ray, smp], ends[ray, smp]
-        dist = (t1 - t0) / 2
-        t = t0 + dist
-        mean = origins[ray] + directions[ray] * t[:, None]                       # cameras/rays.py:118-121
-        std = (pixel_area.reshape(-1)[ray] * t.pow(2) * dist).pow(1 / 3)
-        r_inv, t_inv = self.actors.world2box_pairs(times[ray], act)
-        pos = (r_inv @ mean[:, :, None])[..., 0] + t_inv                         # transform_points_pairwise
-        if flip is not None:
-            pos = torch.cat([pos[:, :1] * flip[ray, None], pos[:, 1:]], dim=-1)
-        scale = self.config.actor.actor_scale                                    # ScaledSceneContraction(inf)
-        m, s = pos / scale, std / scale
-        mag = m.abs().amax(dim=-1, keepdim=True)
-        cm = mag.clamp_min(1.0)
-        m = torch.where(mag < 1, m, (2 - 1 / cm) * (m / cm))
-        s = torch.where(mag[:, 0] < 1, s, s * (((2 * cm[:, 0] - 1).pow(1 / 3) / cm[:, 0]) ** 2))
-        x01, cstd = (m + 2.0) / 4.0, s / 4.0
+        with torch.set_grad_enabled(torch.is_grad_enabled() and self.config.require_actor_grad):
+            t0, t1 = starts[ray, smp], ends[ray, smp]
+            dist = (t1 - t0) / 2
+            t = t0 + dist
+            mean = origins[ray] + directions[ray] * t[:, None]                       # cameras/rays.py:118-121
+            std = (pixel_area.reshape(-1)[ray] * t.pow(2) * dist).pow(1 / 3)
+            r_inv, t_inv = world2box_pairs(self.actors, times[ray], act)
+            pos = (r_inv @ mean[:, :, None])[..., 0] + t_inv                         # transform_points_pairwise
+            if flip is not None:
+                pos = torch.cat([pos[:, :1] * flip[ray, None], pos[:, 1:]], dim=-1)
+            scale = self.config.actor.actor_scale                                    # ScaledSceneContraction(inf)
+            m, s = pos / scale, std / scale
+            mag = m.abs().amax(dim=-1, keepdim=True)
+            cm = mag.clamp_min(1.0)
+            m = torch.where(mag < 1, m, (2 - 1 / cm) * (m / cm))
+            s = torch.where(mag[:, 0] < 1, s, s * (((2 * cm[:, 0] - 1).pow(1 / 3) / cm[:, 0]) ** 2))
+            x01, cstd = (m + 2.0) / 4.0, s / 4.0
         ids = self.actors.actor_to_id[act]
         # _get_actor_features_slow loops over the actor ids; all actor grids share one shape, so one multi-grid
         # lookup (row i -> actor_grids[ids[i]]) does the same without the per-id launches and host syncs
         grid = self.actor_grids[0]
         f = ag.MultiHashGridFn.apply(x01, ids, grid.spec, *[g.hash_table for g in self.actor_grids])
         w = 1 / (grid.scalings[None, :] * 2 * cstd[:, None]).clamp_min(1.0)
-        f = (f.view(-1, grid.num_levels, grid.features_per_level) * w[..., None]).flatten(1)
+        return idx, winner, (f.view(-1, grid.num_levels, grid.features_per_level) * w[..., None]).flatten(1)
+
+    def _actor_rows_with_grad(self, feats, hit, hits, origins, directions, pixel_area, starts, ends, times, flip):
+        """spliced in with index_put, whose autograd zeroes the static-table gradient of the replaced rows."""
+        pr = self.actor_pair_rows(hit, hits, origins, directions, pixel_area, starts, ends, times, flip)
+        if pr is None:
+            return feats
+        idx, winner, f = pr
         rows = torch.nn.functional.pad(f, (0, self.scene_repr_dim - f.shape[1]))
         out = feats.index_put((idx[winner],), rows[winner])
         if not bool(winner.all()):
@@ -198,8 +216,10 @@ class NeuRADHashEncoding(nn.Module):
     def forward(self, ray_samples, times=None, directions: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """Reference signature is forward(GaussiansStd, times, directions); here the frustums are passed directly
         (the gaussian is computed inside the kernel).  Returns (features [N, L*F], directions)."""
+        from ..cameras.rays import per_ray
+
         fr = ray_samples.frustums
-        o, d, a = fr.per_ray()
+        o, d, a = per_ray(fr)
         t = times if times is not None else ray_samples.times
         t = None if t is None else (t[:, 0] if t.dim() == 3 else t).reshape(-1)
         feats, dirs = self.forward_rays(o, d, a, fr.starts[..., 0], fr.ends[..., 0], t)

@@ -24,7 +24,7 @@ from torch import Tensor, nn
 
 from .. import autograd as ag
 from .. import ops
-from ..cameras.rays import RaySamples
+from ..cameras.rays import RaySamples, per_ray, sample_times
 from ..field_components.encodings import SHEncoding
 from ..field_components.field_heads import FieldHeadNames
 from ..field_components.mlp import MLP
@@ -91,8 +91,10 @@ class NeuRADField(nn.Module):
         self.fused_training = True
         """Training forward through the fused field kernel + hand-chained backward (autograd.FieldTrainFn); False
         runs the reference orchestration over operator-level autograd functions (same numbers, 2x the launches)."""
-        self.hashgrid: NeuRADHashEncoding = config.grid.setup(dynamic_actors=actors, static_scale=static_scale,
-                                                              implementation=implementation)
+        # built directly (not through config.grid.setup): ``config`` may be the REFERENCE's NeuRADFieldConfig, whose
+        # grid._target is the reference's own NeuRADHashEncoding (field names are identical, neurad_encoding.py:34-82)
+        self.hashgrid = NeuRADHashEncoding(config.grid, dynamic_actors=actors, static_scale=static_scale,
+                                           implementation=implementation)
         self.geo_feat_dim = config.nff_out_dim
         self.mlp_geo = MLP(in_dim=self.hashgrid.get_out_dim(), num_layers=config.geo_num_layers,
                            layer_width=config.geo_hidden_dim, out_dim=self.geo_feat_dim + 1)
@@ -116,25 +118,39 @@ class NeuRADField(nn.Module):
         return (g.get_out_dim() == 32 and g.num_levels % 4 == 0 and c.geo_num_layers == 2 and c.nff_num_layers == 3
                 and c.geo_hidden_dim == c.nff_hidden_dim and c.geo_hidden_dim in (32, 64) and c.nff_out_dim == 32)
 
+    def _beta_value(self) -> float:
+        """|beta| + beta_min as a host float, read from the device only when the parameter changed (an optimizer step or
+        a checkpoint load bumps its version counter) -- not once per eval chunk."""
+        if not self.config.use_sdf:
+            return 0.0
+        b = self.sdf_to_density.beta
+        key = (b._version, b.data_ptr())
+        if getattr(self, "_beta_cache", (None, 0.0))[0] != key:
+            self._beta_cache = (key, float(self.sdf_to_density.get_beta()))
+        return self._beta_cache[1]
+
     def field_spec(self) -> ops.FieldSpec:
         g = self.hashgrid.static_grid
-        beta = float(self.sdf_to_density.get_beta()) if self.config.use_sdf else 0.0
+        beta = self._beta_value()
         return ops.FieldSpec(g.spec, g.hash_table.detach(), self.hashgrid.static_scale,
                              [l.weight.detach() for l in self.mlp_geo.layers], [l.bias.detach() for l in self.mlp_geo.layers],
                              [l.weight.detach() for l in self.mlp_feature.layers],
                              [l.bias.detach() for l in self.mlp_feature.layers], use_sdf=self.config.use_sdf, beta=beta)
 
     @torch.no_grad()
-    def render(self, origins, directions, pixel_area, starts, ends, return_weights=False):
-        """F1+C1+C2 in one kernel: -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S])."""
+    def render(self, origins, directions, pixel_area, starts, ends, return_weights=False, early_stop_eps: float = 0.0,
+               order: Optional[Tensor] = None):
+        """F1+C1+C2 in one kernel: -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S]).
+        early_stop_eps / order: see ops.render_fwd (eval-time ray termination; processing order from ops.ray_order)."""
         if not self.fused_supported():
             raise NotImplementedError("fused render kernel: configuration not instantiated; use forward() + renderers")
-        return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights)
+        return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights,
+                              early_stop_eps=early_stop_eps, order=order)
 
     # ---- Field.forward (neurad_field.py:128-152) ------------------------------------------------
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[FieldHeadNames, Tensor]:
-        fr = ray_samples.frustums
-        o, d, a = fr.per_ray()
+        fr = ray_samples.frustums  # this package's RaySamples or the reference's (cameras/rays.py:142-187)
+        o, d, a = per_ray(fr)
         starts, ends = fr.starts[..., 0], fr.ends[..., 0]
         R, S = starts.shape
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
@@ -155,14 +171,16 @@ class NeuRADField(nn.Module):
                 *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
                 *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])
             return self._heads(feature.view(R, S, self.config.nff_out_dim), geo_out.view(R, S, 1))
-        times = None if ray_samples.times is None else ray_samples.times[:, 0].reshape(-1)
-        features, sample_dirs = self.hashgrid.forward_rays(o, d, a, starts, ends, times)
+        features, sample_dirs = self.hashgrid.forward_rays(o, d, a, starts, ends, sample_times(ray_samples))
         geo = self.mlp_geo(features)
         geo_out, geo_embedding = geo[:, :1], geo[:, 1:]
         if sample_dirs is None:
             sh = self.direction_encoding(get_normalized_directions(d))  # per ray; broadcast over the samples
             sh = sh[:, None, :].expand(R, S, 16).reshape(-1, 16)
         else:  # samples inside actors carry box-frame directions (neurad_encoding.py:203-208)
+            # Known deviation: SH is evaluated without gradient (the reference's SHEncoding.pytorch_fwd is @no_grad too
+            # for its OUTPUT, encodings.py:797, so no gradient reaches actor_rotations_6d through the view direction
+            # there either; only tcnn's SH would propagate it).
             sh = self.direction_encoding(get_normalized_directions(sample_dirs))
         feature = geo_embedding + self.mlp_feature(torch.cat([geo_embedding, sh], dim=-1))
         return self._heads(feature.view(R, S, self.config.nff_out_dim), geo_out.reshape(R, S, 1))
@@ -200,8 +218,8 @@ class NeuRADProposalField(nn.Module):
                  implementation: str = "hip") -> None:
         super().__init__()
         self.config, self.implementation = config, implementation
-        self.hashgrid: NeuRADHashEncoding = config.grid.setup(dynamic_actors=actors, static_scale=static_scale,
-                                                              implementation=implementation)
+        self.hashgrid = NeuRADHashEncoding(config.grid, dynamic_actors=actors, static_scale=static_scale,
+                                           implementation=implementation)
         self.density_decoder = nn.Linear(self.hashgrid.get_out_dim(), 1, bias=False)
 
     def get_param_groups(self, param_groups: Dict):
@@ -216,21 +234,55 @@ class NeuRADProposalField(nn.Module):
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         """neurad_field.py:208-213, one kernel: gaussian -> contraction -> 6-level lookup -> rescale -> dot -> exp."""
         fr = ray_samples.frustums
-        o, d, a = fr.per_ray()
-        g = self.hashgrid.static_grid
+        o, d, a = per_ray(fr)
+        hg = self.hashgrid
+        g = hg.static_grid
         starts, ends = fr.starts[..., 0], fr.ends[..., 0]
-        dens = ag.ProposalDensityFn.apply(g.hash_table, self.density_decoder.weight, g.spec, self.hashgrid.static_scale,
-                                          o, d, a, starts, ends)
-        if self.hashgrid.has_actors():  # actor branch runs without gradient (require_actor_grad=False, :177)
-            if ray_samples.times is None:
+        need_graph = torch.is_grad_enabled() and (g.hash_table.requires_grad or self.density_decoder.weight.requires_grad)
+        if need_graph:
+            dens = ag.ProposalDensityFn.apply(g.hash_table, self.density_decoder.weight, g.spec, hg.static_scale, o, d, a,
+                                              starts, ends)
+        else:  # eval / no_grad / frozen: nothing to save for a backward
+            dens = ops.proposal_density_fwd(self.proposal_spec(), o, d, a, starts, ends)
+        if hg.has_actors():
+            times = sample_times(ray_samples)
+            if times is None:
                 raise ValueError("dynamic actors need ray times")
-            with torch.no_grad():
-                spec, cand = self.hashgrid.prepare_actors(o, d, a, starts, ends, ray_samples.times[:, 0].reshape(-1))
+            flip = hg.sample_ray_flip(o)
+            with torch.no_grad():  # geometry of the actor branch: never differentiated here (require_actor_grad=False)
+                spec, cand = hg.prepare_actors(o, d, a, starts, ends, times)
                 merged = dens.detach().clone()
                 hit = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged,
-                                        self.hashgrid.sample_ray_flip(o))
-            dens = torch.where(hit, merged, dens)
+                                        flip)
+            if hg.wants_actor_grad() or (need_graph and self.density_decoder.weight.requires_grad):
+                dens = self._splice_actor_density(dens, hit, spec, cand, o, d, a, starts, ends, times, flip)
+            else:
+                dens = torch.where(hit, merged, dens)
         return dens[..., None], None
+
+    def _splice_actor_density(self, dens, hit, spec, cand, o, d, a, starts, ends, times, flip):
+        """Differentiable actor rows of the proposal density.  ``require_actor_grad=False`` (neurad_field.py:177) only
+        keeps the POSES out of the graph (neurad_encoding.py:174-176); the actor grids and the decoder are trained
+        through the in-box samples exactly as through the static ones: density = trunc_exp(decoder(pad(actor_feat)))."""
+        hg = self.hashgrid
+        with torch.no_grad():
+            hits = ops.actor_hits(spec, cand, o, d, a, starts, ends)
+            hit_actor = hits.max(dim=-1).values  # the actor the kernel used: the highest index containing the sample
+        pr = hg.actor_pair_rows(hit_actor, hits, o, d, a, starts, ends, times, flip)
+        if pr is None:
+            return dens
+        idx, winner, rows = pr
+        w = self.density_decoder.weight[0, : rows.shape[1]]     # features are zero-padded up to the static width
+        logit = rows @ w
+        shape = dens.shape
+        flat = dens.reshape(-1).index_put((idx[winner],), trunc_exp(logit[winner]))
+        if not bool(winner.all()):
+            # overlapping boxes: the reference's features[ray, sample] = ... hands the merged row's gradient to every
+            # duplicate (neurad_encoding.py:184-185); value unchanged
+            lose = ~winner
+            flat = flat.index_put((idx[lose],), (logit[lose] - logit[lose].detach()) * flat[idx[lose]].detach(),
+                                  accumulate=True)
+        return flat.view(shape)
 
     def get_outputs(self, ray_samples, density_embedding=None) -> dict:
         return {}

@@ -1,0 +1,131 @@
+"""``neurad-hip``: NeuRAD with its volumetric hot path on libneurad_hip.so, as a nerfstudio method plugin.
+
+    export NERFSTUDIO_METHOD_CONFIGS="neurad-hip=neurad_studio_amd.integration.neurad_hip:neurad_hip"
+    ns-train neurad-hip pandaset-data ...
+
+(or list ``neurad_hip`` under the ``nerfstudio.method_configs`` entry-point group -- plugins/registry.py:34-79).
+
+Nothing of neurad-studio is edited or re-typed: ``NeuRADHipModel`` IS the reference's NeuRADModel
+(nerfstudio/models/neurad.py:164) -- same config, decoders, losses, metrics, checkpoints -- with
+  * ``field`` / ``proposal_fields`` built from this package's NeuRADField / NeuRADProposalField through the configs'
+    ``_target`` (configs/base_config.py:47-54); same state_dict names, so neurad checkpoints load;
+  * ``sampler``, the renderers, ``lidar_decoder`` and the two sampler losses replaced by their HIP-backed namesakes
+    after ``populate_modules``;
+  * ``get_nff_outputs`` running the two fused kernels for eval chunks (FusedEvalMixin) and the reference's OWN
+    ``get_nff_outputs`` (models/neurad.py:368-421) for training.
+Per-actor 3-D grids are used (``use_4d_hashgrid=False``): the 4-D grid exists only inside tiny-cuda-nn.
+"""
+from __future__ import annotations
+
+import contextlib
+import dataclasses
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Type
+
+import nerfstudio.models.neurad as _ref_neurad
+from nerfstudio.configs.method_configs import method_configs
+from nerfstudio.field_components.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig
+from nerfstudio.fields.neurad_field import NeuRADFieldConfig, NeuRADProposalFieldConfig
+from nerfstudio.models.neurad import NeuRADModel, NeuRADModelConfig, SamplingSettings
+from nerfstudio.plugins.types import MethodSpecification
+
+from ..field_components.mlp import MLP as HipMLP
+from ..fields.neurad_field import NeuRADField as HipNeuRADField
+from ..fields.neurad_field import NeuRADProposalField as HipNeuRADProposalField
+from ..model_components import losses as hip_losses
+from ..model_components import ray_samplers as hip_samplers
+from ..model_components import renderers as hip_renderers
+from ..models.neurad import FusedEvalMixin
+from ..shims import nerfacc as hip_nerfacc
+
+
+def _field_config() -> NeuRADFieldConfig:
+    """the reference's default main-field config (fields/neurad_field.py:46-52) -> HIP field, 3-D actor grids"""
+    return NeuRADFieldConfig(_target=HipNeuRADField, grid=NeuRADHashEncodingConfig(
+        require_actor_grad=True, actor=ActorSettings(flip_prob=0.25, use_4d_hashgrid=False)))
+
+
+def _proposal_config() -> NeuRADProposalFieldConfig:
+    cfg = NeuRADProposalFieldConfig()  # the reference's defaults (fields/neurad_field.py:158-179)
+    cfg._target = HipNeuRADProposalField
+    cfg.grid.actor.use_4d_hashgrid = False
+    return cfg
+
+
+def _sampling() -> SamplingSettings:
+    return SamplingSettings(proposal_field_1=_proposal_config(), proposal_field_2=_proposal_config())
+
+
+@dataclass
+class NeuRADHipModelConfig(NeuRADModelConfig):
+    _target: Type = dataclasses.field(default_factory=lambda: NeuRADHipModel)
+    sampling: SamplingSettings = dataclasses.field(default_factory=_sampling)
+    field: NeuRADFieldConfig = dataclasses.field(default_factory=_field_config)  # (shadows dataclasses.field below)
+    fused_eval: bool = True
+    """Eval chunks through the two fused kernels (False: operator-level path everywhere)."""
+    early_stop_eps: float = 0.0
+    """> 0: eval rays stop marching once their transmittance is below it (bounded error); 0 = exact."""
+    order_rays: bool = False
+    """Cache-coherent processing order per eval chunk (pays for lidar scans / random pixels, not for image patches)."""
+
+
+@contextlib.contextmanager
+def _patched(module, name, value):
+    old = getattr(module, name)
+    setattr(module, name, value)
+    try:
+        yield
+    finally:
+        setattr(module, name, old)
+
+
+class NeuRADHipModel(FusedEvalMixin, NeuRADModel):
+    config: NeuRADHipModelConfig
+
+    def populate_modules(self):
+        super().populate_modules()  # fields come out of config._target -> this package's classes
+        cfg = self.config
+        assert isinstance(self.field, HipNeuRADField), "config.field._target must be the HIP NeuRADField"
+        self.fused_eval, self.early_stop_eps, self.order_rays = cfg.fused_eval, cfg.early_stop_eps, cfg.order_rays
+        s = cfg.sampling
+        self.sampler = hip_samplers.ProposalNetworkSampler(
+            num_proposal_samples_per_ray=s.num_proposal_samples, num_nerf_samples_per_ray=s.num_nerf_samples,
+            num_proposal_network_iterations=cfg.num_proposal_rounds, single_jitter=s.single_jitter,
+            initial_sampler=hip_samplers.PowerSampler(lambda_=s.power_lambda, scaling=s.power_scaling),
+            update_sched=lambda x: 0)
+        self.lidar_decoder = HipMLP(in_dim=cfg.field.nff_out_dim + cfg.appearance_dim, layer_width=32, out_dim=2,
+                                    num_layers=3, out_activation=None)
+        self.renderer_feat = hip_renderers.FeatureRenderer()
+        self.renderer_accumulation = hip_renderers.AccumulationRenderer()
+        self.renderer_depth = (hip_renderers.DepthRenderer(method="expected") if cfg.normalize_depth
+                               else hip_renderers.render_depth_simple)
+        self.interlevel_loss = hip_losses.zipnerf_interlevel_loss
+
+    def _render_weights(self, outputs, ray_samples):
+        """models/neurad.py:711-724 without the cpu placeholder and independent of which ``nerfacc`` is importable"""
+        with _patched(_ref_neurad, "nerfacc", hip_nerfacc):
+            return super()._render_weights(outputs, ray_samples)
+
+    def get_nff_outputs(self, ray_bundle, calc_lidar_losses: bool = False):
+        if self.fused_eval_possible():
+            return self.fused_nff_outputs(ray_bundle)
+        return super().get_nff_outputs(ray_bundle, calc_lidar_losses)
+
+    def get_metrics_dict(self, outputs, batch):
+        # the reference calls the module-level distortion_loss (models/neurad.py:524): the HIP one for this call only
+        with _patched(_ref_neurad, "distortion_loss", hip_losses.distortion_loss):
+            return super().get_metrics_dict(outputs, batch)
+
+
+def _trainer_config():
+    cfg = deepcopy(method_configs["neurad"])  # optimizers, schedules, data manager: the reference's own
+    cfg.method_name = "neurad-hip"
+    ref_model = cfg.pipeline.model
+    cfg.pipeline.model = NeuRADHipModelConfig(eval_num_rays_per_chunk=ref_model.eval_num_rays_per_chunk,
+                                              camera_optimizer=ref_model.camera_optimizer)
+    return cfg
+
+
+neurad_hip = MethodSpecification(config=_trainer_config(),
+                                 description="NeuRAD with the volumetric hot path on MI355X HIP kernels (libneurad_hip.so)")

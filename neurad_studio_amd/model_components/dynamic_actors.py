@@ -25,6 +25,34 @@ def matrix_to_rotation_6d(matrix: Tensor) -> Tensor:  # cameras/camera_utils.py:
     return matrix[..., :2, :].clone().reshape(*matrix.shape[:-2], 6)
 
 
+def world2box_pairs(actors, query_times: Tensor, actor_idx: Tensor) -> Tuple[Tensor, Tensor]:
+    """``actors``: this package's DynamicActors or the reference's (same parameter / buffer names,
+    model_components/dynamic_actors.py:153-170).  Differentiable (w.r.t. actor_positions / actor_rotations_6d) world->box transform of ``actor_idx[m]`` at
+    ``query_times[m]``: interpolate_trajectories_6d (utils/poses.py:90-150) + rotation_6d_to_matrix
+    (cameras/camera_utils.py:422-443) + pose inverse (utils/poses.py:42-55), evaluated only for the (few)
+    sample/actor pairs the HIP kernels reported as hits.  -> (R_inv [M,3,3], t_inv [M,3])"""
+    F = torch.nn.functional
+    poses = torch.cat([actors.actor_rotations_6d, actors.actor_positions], dim=-1)
+    a1 = F.normalize(poses[..., :3], dim=-1)
+    a2 = poses[..., 3:6]
+    a2 = F.normalize(a2 - (a1 * a2).sum(-1, keepdim=True) * a1, dim=-1)
+    poses = torch.cat([a1, a2, poses[..., 6:9]], dim=-1)
+    ts = actors.unique_timestamps
+    right = torch.searchsorted(ts, query_times.contiguous())
+    left = (right - 1).clamp(min=0)
+    right = right.clamp(max=len(ts) - 1)
+    frac = ((query_times - ts[left]) / (ts[right] - ts[left] + 1e-6)).clamp(0.0, 1.0)
+    pl, pr = poses[left, actor_idx], poses[right, actor_idx]
+    ip = pl + (pr - pl) * frac[:, None]
+    b1 = F.normalize(ip[:, :3], dim=-1)
+    b2 = F.normalize(ip[:, 3:6] - (b1 * ip[:, 3:6]).sum(-1, keepdim=True) * b1, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    rot = torch.stack((b1, b2, b3), dim=-2)          # boxes2world rotation (rows b1,b2,b3)
+    r_inv = rot.transpose(-2, -1)
+    t_inv = -(r_inv @ ip[:, 6:, None])[..., 0]
+    return r_inv, t_inv
+
+
 class DynamicActors(nn.Module):
     def __init__(self, config: DynamicActorsConfig, trajectories: List[dict]):
         super().__init__()
@@ -69,30 +97,7 @@ class DynamicActors(nn.Module):
         self.actor_vel_angular = nn.Parameter(torch.zeros((self.n_times, self.n_actors, 3)))
 
     def world2box_pairs(self, query_times: Tensor, actor_idx: Tensor) -> Tuple[Tensor, Tensor]:
-        """Differentiable (w.r.t. actor_positions / actor_rotations_6d) world->box transform of ``actor_idx[m]`` at
-        ``query_times[m]``: interpolate_trajectories_6d (utils/poses.py:90-150) + rotation_6d_to_matrix
-        (cameras/camera_utils.py:422-443) + pose inverse (utils/poses.py:42-55), evaluated only for the (few)
-        sample/actor pairs the HIP kernels reported as hits.  -> (R_inv [M,3,3], t_inv [M,3])"""
-        F = torch.nn.functional
-        poses = torch.cat([self.actor_rotations_6d, self.actor_positions], dim=-1)
-        a1 = F.normalize(poses[..., :3], dim=-1)
-        a2 = poses[..., 3:6]
-        a2 = F.normalize(a2 - (a1 * a2).sum(-1, keepdim=True) * a1, dim=-1)
-        poses = torch.cat([a1, a2, poses[..., 6:9]], dim=-1)
-        ts = self.unique_timestamps
-        right = torch.searchsorted(ts, query_times.contiguous())
-        left = (right - 1).clamp(min=0)
-        right = right.clamp(max=len(ts) - 1)
-        frac = ((query_times - ts[left]) / (ts[right] - ts[left] + 1e-6)).clamp(0.0, 1.0)
-        pl, pr = poses[left, actor_idx], poses[right, actor_idx]
-        ip = pl + (pr - pl) * frac[:, None]
-        b1 = F.normalize(ip[:, :3], dim=-1)
-        b2 = F.normalize(ip[:, 3:6] - (b1 * ip[:, 3:6]).sum(-1, keepdim=True) * b1, dim=-1)
-        b3 = torch.cross(b1, b2, dim=-1)
-        rot = torch.stack((b1, b2, b3), dim=-2)          # boxes2world rotation (rows b1,b2,b3)
-        r_inv = rot.transpose(-2, -1)
-        t_inv = -(r_inv @ ip[:, 6:, None])[..., 0]
-        return r_inv, t_inv
+        return world2box_pairs(self, query_times, actor_idx)
 
     def requires_grad_(self, requires: bool = True):
         self.actor_positions.requires_grad_(requires)

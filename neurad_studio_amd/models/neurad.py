@@ -1,12 +1,17 @@
 """The hot path of NeuRADModel: ``get_nff_outputs`` and what it calls
-(mirror of nerfstudio/models/neurad.py:96-117,226-254,368-459,677-734).
+(nerfstudio/models/neurad.py:96-117,226-254,368-459,677-734).
 
-Decoders, losses, metrics, camera optimisation and data loading stay in neurad-studio (out of scope);
-this module owns: far clamp + sampler + sky stretch (M1), field (F1), weights (C1), compositing (C2),
-appearance embedding (C3), proposal outputs (C4).
+Two users:
+  * ``FusedEvalMixin`` -- mixed into the nerfstudio plugin model (integration/neurad_hip.py: a subclass of the
+    reference's own NeuRADModel) so that eval chunks run as two kernels (fused proposal sampler + fused
+    field/compositing) while training keeps the reference's own ``get_nff_outputs`` over this package's fields,
+    sampler and renderers;
+  * ``NeuRADHotPath`` -- the same path as a standalone module (no nerfstudio import), used by the GPU tests, the
+    benchmarks and by anyone who wants the path without the trainer.  Decoders, image losses, metrics, camera
+    optimisation and data loading stay in neurad-studio.
 
-eval / no-grad -> 2 kernels per ray batch: fused proposal sampler + fused field/compositing.
-training        -> reference orchestration over operator-level HIP ops with hand-written backward."""
+eval / no-grad -> 2 kernels per ray batch (+ the optional ray-ordering pass);
+training       -> operator-level HIP ops with hand-written backward (fields: one autograd node each)."""
 from __future__ import annotations
 
 import math
@@ -16,7 +21,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
-from ..cameras.rays import RayBundle, RaySamples
+from .. import ops
+from ..cameras.rays import RayBundle
 from ..field_components.field_heads import FieldHeadNames
 from ..fields.neurad_field import NeuRADField, NeuRADFieldConfig, NeuRADProposalField, NeuRADProposalFieldConfig
 from ..model_components.ray_samplers import PowerSampler, ProposalNetworkSampler
@@ -24,6 +30,63 @@ from ..model_components.renderers import AccumulationRenderer, DepthRenderer, Fe
 from ..shims import nerfacc
 
 EPS = 1e-7
+
+
+class FusedEvalMixin:
+    """Eval-time ``get_nff_outputs`` on the fused kernels.  Expects on ``self`` what NeuRADModel.populate_modules builds
+    (models/neurad.py:167-254): ``config`` (sampling.*, field.use_sdf, appearance_dim, normalize_depth), ``field``,
+    ``proposal_fields``, ``sampler`` (this package's ProposalNetworkSampler), ``renderer_depth``,
+    ``_scale_pixel_area`` and ``_get_appearance_embedding``."""
+
+    fused_eval: bool = True
+    """False forces the operator-level path in eval too (A/B, debugging)."""
+    early_stop_eps: float = 0.0
+    """> 0: eval rays stop marching once their transmittance is below it (error bounded by it; 0 = exact)."""
+    order_rays: bool = False
+    """Compute a cache-coherent processing order per eval chunk (ops.ray_order).  Pays for incoherent batches (lidar
+    scans, random pixels); camera patches are coherent as they come."""
+    reproduce_late_binding_quirk: bool = True
+    """models/neurad.py:248 builds density_fns with a late-binding closure, so BOTH proposal rounds evaluate
+    proposal_fields[1]; the fused sampler has to be told the same."""
+
+    def fused_eval_possible(self) -> bool:
+        return (self.fused_eval and not torch.is_grad_enabled() and not self.training
+                and self.field.fused_supported() and not self.field.hashgrid.has_actors())
+
+    def fused_nff_outputs(self, ray_bundle) -> Dict[str, Tensor]:
+        cfg = self.config
+        sky = cfg.sampling.sky_distance
+        self._scale_pixel_area(ray_bundle)
+        if ray_bundle.fars is not None:  # M1: far clamp, near default (models/neurad.py:443-449)
+            ray_bundle.fars.clamp_max_(sky)
+        else:
+            ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
+        if ray_bundle.nears is None:
+            ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
+        pf = list(self.proposal_fields)
+        if self.reproduce_late_binding_quirk:
+            pf = [pf[-1]] * len(pf)
+        ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky)
+        fr = ray_samples.frustums
+        starts = fr.starts[..., 0]
+        ends = fr.ends[..., 0].clone()
+        ends[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
+        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        order = ops.ray_order(o, d, self.field.hashgrid.static_scale) if self.order_rays else None
+        want_w = bool(cfg.normalize_depth)
+        out = self.field.render(o, d, ray_bundle.pixel_area, starts, ends, return_weights=want_w,
+                                early_stop_eps=self.early_stop_eps, order=order)
+        features, depth, accumulation = out[:3]
+        if want_w:  # DepthRenderer("expected") over the non-sky samples (renderers.py:398-416)
+            w = out[3][:, :-1]
+            steps = (starts[:, :-1] + ends[:, :-1]) / 2
+            depth = (depth / (w.sum(-1, keepdim=True) + 1e-10)).clip(steps.min(), steps.max())
+        if cfg.appearance_dim > 0:
+            features = torch.cat([features, self._get_appearance_embedding(ray_bundle, features)], dim=-1)
+        nff = {"features": features, "depth": depth, "accumulation": accumulation}
+        for i, (pw, prs) in enumerate(zip(prop_weights, prop_ray_samples)):
+            nff[f"prop_depth_{i}"] = self.renderer_depth(pw, prs)
+        return nff
 
 
 @dataclass
@@ -50,15 +113,15 @@ class NeuRADHotPathConfig:
     carving_epsilon: float = 0.1
     non_return_lidar_distance: float = 150.0
     reproduce_late_binding_quirk: bool = True
-    """models/neurad.py:248 builds density_fns with a late-binding closure, so BOTH proposal rounds evaluate
-    proposal_fields[1].  True keeps parity with the reference; False uses field i in round i."""
+    """see FusedEvalMixin; False uses field i in round i."""
 
 
-class NeuRADHotPath(nn.Module):
+class NeuRADHotPath(FusedEvalMixin, nn.Module):
     def __init__(self, config: NeuRADHotPathConfig, static_scale: float, num_sensors: int = 1, duration: float = 1.0,
                  actors=None) -> None:
         super().__init__()
         self.config = config
+        self.reproduce_late_binding_quirk = config.reproduce_late_binding_quirk
         self.field = config.field.setup(actors=actors, static_scale=static_scale)
         self._duration = duration
         if config.appearance_dim > 0:
@@ -93,129 +156,104 @@ class NeuRADHotPath(nn.Module):
             groups["fields"] += list(self.appearance_embedding.parameters())
         return groups
 
-    # ---- M1 (models/neurad.py:443-459) ------------------------------------------------------------
-    def _prepare_bundle(self, ray_bundle: RayBundle) -> float:
+    # ---- M1 (models/neurad.py:443-459), operator-level path ---------------------------------------
+    def _get_ray_samples(self, ray_bundle: RayBundle):
         sky = self.config.sampling.sky_distance
-        if ray_bundle.fars is not None:
-            ray_bundle.fars.clamp_max_(sky)
-        else:
+        if ray_bundle.fars is None:
             ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
+        else:
+            ray_bundle.fars.clamp_max_(sky)
         if ray_bundle.nears is None:
             ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
-        return sky
-
-    @staticmethod
-    def _stretch_sky(ray_samples: RaySamples, sky: float) -> None:
-        dist_to_sky = sky - ray_samples.frustums.ends[..., -1, 0]
-        ray_samples.frustums.ends[..., -1, 0] += dist_to_sky
-        ray_samples.deltas[..., -1, 0] += dist_to_sky
+        ray_samples, prop_weights, prop_ray_samples = self.sampler(ray_bundle, self.density_fns, pass_ray_samples=True)
+        # sky stretch, in place on the sampler's edge tensors: the last bin ends at sky_distance
+        fr = ray_samples.frustums
+        stretch = sky - fr.ends[..., -1, 0]
+        fr.ends[..., -1, 0] += stretch
+        ray_samples.deltas[..., -1, 0] += stretch
         ray_samples.spacing_ends[..., -1, 0] = 1 - EPS
-
-    def _get_ray_samples(self, ray_bundle: RayBundle):
-        sky = self._prepare_bundle(ray_bundle)
-        if torch.is_grad_enabled() or self.training or self.field.hashgrid.has_actors():
-            ray_samples, prop_weights, prop_ray_samples = self.sampler(ray_bundle, self.density_fns, pass_ray_samples=True)
-            # bins come out of the kernels as views of one [R,S+1] edge tensor: materialise before the in-place stretch
-            fr = ray_samples.frustums
-            fr.ends, ray_samples.deltas = fr.ends.clone(), ray_samples.deltas.clone()
-            ray_samples.spacing_ends = ray_samples.spacing_ends.clone()
-        else:
-            pf = list(self.proposal_fields)
-            if self.config.reproduce_late_binding_quirk:
-                pf = [pf[-1]] * len(pf)
-            ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky)
-            fr = ray_samples.frustums
-            fr.ends, ray_samples.deltas = fr.ends.clone(), ray_samples.deltas.clone()
-            ray_samples.spacing_ends = ray_samples.spacing_ends.clone()
-        self._stretch_sky(ray_samples, sky)
         if self.training and "is_lidar" in ray_bundle.metadata:
-            self._compute_is_close_to_lidar(ray_samples, *prop_ray_samples)
+            for rs in (ray_samples, *prop_ray_samples):
+                self._mark_close_to_lidar(rs)
         return ray_samples, prop_ray_samples, prop_weights
 
-    def _scale_pixel_area(self, ray_bundle: RayBundle):  # models/neurad.py:702-709
+    def _scale_pixel_area(self, ray_bundle: RayBundle) -> None:
+        """camera rays cover rgb_upsample_factor^2 pixels, lidar rays one beam (models/neurad.py:702-709)"""
+        up2 = float(self.config.rgb_upsample_factor**2)
         is_lidar = ray_bundle.metadata.get("is_lidar")
-        if is_lidar is not None:
-            scaling = torch.ones_like(ray_bundle.pixel_area)
-            scaling[~is_lidar] = self.config.rgb_upsample_factor**2
+        if is_lidar is None:
+            ray_bundle.pixel_area = ray_bundle.pixel_area * up2
         else:
-            scaling = self.config.rgb_upsample_factor**2
-        ray_bundle.pixel_area = ray_bundle.pixel_area * scaling
+            ray_bundle.pixel_area = torch.where(is_lidar, ray_bundle.pixel_area, ray_bundle.pixel_area * up2)
 
     def _render_weights(self, outputs, ray_samples):  # models/neurad.py:711-724 (no cpu placeholder: GPU only)
         if self.config.field.use_sdf:
-            weights, _ = nerfacc.render_weight_from_alpha(outputs[FieldHeadNames.ALPHA].squeeze(-1))
-        else:
-            weights, _, _ = nerfacc.render_weight_from_density(
-                t_ends=ray_samples.frustums.ends.squeeze(-1), t_starts=ray_samples.frustums.starts.squeeze(-1),
-                sigmas=outputs[FieldHeadNames.DENSITY].squeeze(-1))
-        return weights
+            return nerfacc.render_weight_from_alpha(outputs[FieldHeadNames.ALPHA].squeeze(-1))[0]
+        fr = ray_samples.frustums
+        return nerfacc.render_weight_from_density(t_starts=fr.starts.squeeze(-1), t_ends=fr.ends.squeeze(-1),
+                                                  sigmas=outputs[FieldHeadNames.DENSITY].squeeze(-1))[0]
 
-    def _get_appearance_embedding(self, ray_bundle, features):  # models/neurad.py:423-441
-        sensor_idx = ray_bundle.metadata.get("sensor_idxs")
-        if sensor_idx is None:
+    def _get_appearance_embedding(self, ray_bundle, features):
+        """per-ray lerp of the two temporally adjacent embeddings of the ray's sensor (models/neurad.py:423-441)"""
+        sensor = ray_bundle.metadata.get("sensor_idxs")
+        if sensor is None:
             assert not self.training, "sensor_idxs must be present in metadata during training"
-            sensor_idx = torch.zeros_like(features[..., :1], dtype=torch.long)
-        if self.config.use_temporal_appearance:
-            n = self._num_embeds_per_sensor
-            time_idx = ray_bundle.times / self._duration * n
-            before = time_idx.floor().clamp(0, n - 1)
-            after = (before + 1).clamp(0, n - 1)
-            ratio = time_idx - before
-            before, after = (x + sensor_idx * n for x in (before, after))
-            be = self.appearance_embedding(before.squeeze(-1).long())
-            ae = self.appearance_embedding(after.squeeze(-1).long())
-            return be * (1 - ratio) + ae * ratio
-        return self.appearance_embedding(sensor_idx.squeeze(-1))
+            sensor = torch.zeros_like(features[..., :1], dtype=torch.long)
+        if not self.config.use_temporal_appearance:
+            return self.appearance_embedding(sensor.squeeze(-1))
+        n = self._num_embeds_per_sensor
+        slot = ray_bundle.times / self._duration * n
+        lo = slot.floor().clamp(0, n - 1)
+        hi = (lo + 1).clamp(0, n - 1)
+        frac = slot - lo
+        base = sensor * n
+        e_lo = self.appearance_embedding((lo + base).squeeze(-1).long())
+        e_hi = self.appearance_embedding((hi + base).squeeze(-1).long())
+        return e_lo * (1 - frac) + e_hi * frac
 
-    def _compute_is_close_to_lidar(self, *all_ray_samples):  # models/neurad.py:677-700
-        for rs in all_ray_samples:
-            if rs is None:
-                continue
-            md, fr = rs.metadata, rs.frustums
-            sample_distance = (fr.starts + fr.ends) * 0.5
-            mask = md["is_lidar"].clone()
-            idx = mask.nonzero(as_tuple=True)
-            sd = sample_distance[idx]
-            dist = md["directions_norm"][idx] - sd
-            close = dist.abs() < self.config.carving_epsilon
-            if "did_return" in md:
-                did_return = md["did_return"][idx]
-                mask[idx] = (did_return & close) | ((~did_return) & (sd < self.config.non_return_lidar_distance))
-            else:
-                mask[idx] = close
-            md["is_close_to_lidar"] = mask
+    def _mark_close_to_lidar(self, rs) -> None:
+        """metadata["is_close_to_lidar"] per sample (models/neurad.py:677-700): a lidar sample is "close" when it lies
+        within carving_epsilon of the measured return, or -- for beams without a return -- anywhere inside the sensor's
+        range; camera samples never are."""
+        md, fr = rs.metadata, rs.frustums
+        mid = (fr.starts + fr.ends) * 0.5
+        close = (md["directions_norm"] - mid).abs() < self.config.carving_epsilon
+        if "did_return" in md:
+            close = torch.where(md["did_return"], close, mid < self.config.non_return_lidar_distance)
+        md["is_close_to_lidar"] = md["is_lidar"] & close
 
     # ---- get_nff_outputs (models/neurad.py:368-421) ------------------------------------------------
     def get_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool = False) -> Dict[str, Tensor]:
+        if self.fused_eval_possible():
+            return self.fused_nff_outputs(ray_bundle)
         self._scale_pixel_area(ray_bundle)
         ray_samples, proposal_ray_samples, proposal_weights = self._get_ray_samples(ray_bundle)
-        fused = not (torch.is_grad_enabled() or self.training) and self.field.fused_supported()
-        fr = ray_samples.frustums
-        if fused:
-            feats, depth, accumulation = self.field.render(ray_bundle.origins, ray_bundle.directions,
-                                                           ray_bundle.pixel_area, fr.starts[..., 0], fr.ends[..., 0])
-            if self.config.normalize_depth:
-                raise NotImplementedError("normalize_depth with the fused kernel")
-            features, weights = feats, None
-        else:
-            outputs = self.field(ray_samples)
-            weights = self._render_weights(outputs, ray_samples)
-            accumulation = self.renderer_accumulation(weights=weights[..., None])
-            weights = torch.cat((weights[..., :-1], weights[..., -1:] + 1 - accumulation), dim=-1).unsqueeze(-1)
-            features = self.renderer_feat(features=outputs[FieldHeadNames.FEATURE], weights=weights)
-            weights, ray_samples = weights[..., :-1, :], ray_samples[..., :-1]
-            depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)
+        outputs = self.field(ray_samples)
+        weights = self._render_weights(outputs, ray_samples)
+        accumulation = self.renderer_accumulation(weights=weights[..., None])
+        # the transmittance left behind the last sample is sky: it goes onto the last sample's features
+        weights = torch.cat((weights[..., :-1], weights[..., -1:] + 1 - accumulation), dim=-1).unsqueeze(-1)
+        features = self.renderer_feat(features=outputs[FieldHeadNames.FEATURE], weights=weights)
         if self.config.appearance_dim > 0:
             features = torch.cat([features, self._get_appearance_embedding(ray_bundle, features)], dim=-1)
-        nff = {"features": features, "depth": depth, "accumulation": accumulation}
+        weights, ray_samples = weights[..., :-1, :], ray_samples[..., :-1]  # the sky sample plays no further role
+        nff = {"features": features, "depth": self.renderer_depth(weights=weights, ray_samples=ray_samples),
+               "accumulation": accumulation}
+        lidar_terms = self.training and calc_lidar_losses
         for i, (pw, prs) in enumerate(zip(proposal_weights, proposal_ray_samples)):
             nff[f"prop_depth_{i}"] = self.renderer_depth(pw, prs)
-            if self.training and calc_lidar_losses:
-                m = (~prs.metadata["is_close_to_lidar"]) & prs.metadata["is_lidar"]
-                nff[f"prop_weights_loss_{i}"] = ((pw * m) ** 2).sum()
+            if lidar_terms:  # carving: lidar weight away from the measured surface
+                far_from_hit = prs.metadata["is_lidar"] & ~prs.metadata["is_close_to_lidar"]
+                nff[f"prop_weights_loss_{i}"] = (pw * far_from_hit).square().sum()
         if self.training:
             nff["weights_list"] = proposal_weights + [weights]
             nff["ray_samples_list"] = proposal_ray_samples + [ray_samples]
+        if lidar_terms:  # models/neurad.py:410-419
+            md = ray_samples.metadata
+            sel = (md["is_lidar"] & ~md["is_close_to_lidar"]).squeeze(-1).nonzero(as_tuple=True)
+            nff["non_nearby_weights"] = weights[sel]
+            first_lidar_ray = ray_bundle.metadata["is_lidar"].int().argmax()
+            nff["non_nearby_lidar_ray_indices"] = sel[0] - first_lidar_ray
         return nff
 
     def forward(self, ray_bundle: RayBundle, calc_lidar_losses: bool = False):

@@ -51,9 +51,69 @@ class _Magic(types.ModuleType):
     def __getattr__(self, item):
         if item.startswith("__"):
             raise AttributeError(item)
-        v = mock.MagicMock(name=f"{self.__name__}.{item}")
+        full = f"{self.__name__}.{item}"
+        if full in sys.modules:  # `import viser.infra; viser.infra.Message`: the submodule, not a fresh mock
+            v = sys.modules[full]
+        elif item[:1].isupper() and not item.isupper():
+            # CamelCase -> a real (empty) class: the reference subclasses such names (dataclass configs, nn.Modules of
+            # absent packages), which a MagicMock instance cannot stand in for
+            v = type(item, (_StubClass,), {"__module__": self.__name__})
+        else:
+            v = mock.MagicMock(name=f"{self.__name__}.{item}")
         setattr(self, item, v)
         return v
+
+
+class _StubMeta(type):
+    def __getattr__(cls, item):  # class-level constants of absent packages (enum members, ...)
+        if item.startswith("__"):
+            raise AttributeError(item)
+        v = mock.MagicMock(name=f"{cls.__name__}.{item}")
+        setattr(cls, item, v)
+        return v
+
+
+class _StubClass(metaclass=_StubMeta):
+    """base of every stubbed class: accepts any constructor call, any attribute is a MagicMock"""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __init_subclass__(cls, **kwargs):
+        pass
+
+    def __class_getitem__(cls, item):
+        return cls
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        v = mock.MagicMock(name=f"{type(self).__name__}.{item}")
+        object.__setattr__(self, item, v)
+        return v
+
+
+class _StubFinder:
+    """meta-path finder: any submodule of a stubbed top-level package (av2.utils.io, nuscenes.utils.data_classes, ...)
+    resolves to another all-MagicMock module, so deep import chains of dataset devkits do not have to be listed."""
+
+    def __init__(self):
+        self.tops = set()
+
+    def find_spec(self, fullname, path=None, target=None):
+        top = fullname.split(".")[0]
+        if top in self.tops and "." in fullname:
+            return importlib.machinery.ModuleSpec(fullname, self)
+        return None
+
+    def create_module(self, spec):
+        return _Magic(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+_FINDER = _StubFinder()
 
 
 def install() -> None:
@@ -86,5 +146,8 @@ def install() -> None:
         except Exception:
             pass
         sys.modules[name] = _Magic(name)
+        _FINDER.tops.add(name.split(".")[0])
+    if _FINDER not in sys.meta_path:
+        sys.meta_path.append(_FINDER)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
