@@ -280,8 +280,10 @@ class NeuRADProposalField(nn.Module):
             # overlapping boxes: the reference's features[ray, sample] = ... hands the merged row's gradient to every
             # duplicate (neurad_encoding.py:184-185); value unchanged
             lose = ~winner
-            flat = flat.index_put((idx[lose],), (logit[lose] - logit[lose].detach()) * flat[idx[lose]].detach(),
-                                  accumulate=True)
+            # (only the shadowed actors' FEATURES see that gradient; the decoder's own gradient comes from the merged
+            # row, i.e. from the winner -> the weight is detached here)
+            shadow = rows[lose] @ w.detach()
+            flat = flat.index_put((idx[lose],), (shadow - shadow.detach()) * flat[idx[lose]].detach(), accumulate=True)
         return flat.view(shape)
 
     def get_outputs(self, ray_samples, density_embedding=None) -> dict:

@@ -1,0 +1,69 @@
+"""The lidar supervision terms NeuRAD puts on the hot path's outputs every training step:
+depth / intensity / ray-drop / carving losses for the final samples and depth / carving for each proposal round
+(nerfstudio/models/neurad.py:485-521 in get_metrics_dict, weighted at :534-560 in get_loss_dict).
+
+Inputs are exactly what ``get_nff_outputs(..., calc_lidar_losses=True)`` returns plus the decoded lidar head and the
+lidar part of the batch.  A handful of elementwise GPU ops over the n_lidar rays -- the work is in the kernels that
+produce the depths and weights; the sampler-side terms (interlevel, distortion) are HIP kernels in ``losses.py``."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+from torch import Tensor
+from torch.nn.functional import binary_cross_entropy_with_logits
+
+
+@dataclass
+class LidarLossSettings:
+    """the lidar-related members of the reference's LossSettings (models/neurad.py:65-94), same names and defaults"""
+
+    depth_mult: float = 0.01
+    intensity_mult: float = 0.1
+    carving_mult: float = 0.01
+    quantile_threshold: float = 0.95
+    non_return_lidar_distance: float = 150.0
+    non_return_loss_mult: float = 0.1
+    ray_drop_loss_mult: float = 0.01
+    prop_lidar_loss_mult: float = 0.1
+
+
+def _depth_l1(pred: Tensor, measured: Tensor, returned: Tensor, cfg: LidarLossSettings) -> Tensor:
+    """per-ray |target - pred|: beams without a return are pulled beyond non_return_lidar_distance (never closer than
+    where they already are) and down-weighted (models/neurad.py:491-495,513-517)"""
+    beyond = pred.detach().clamp_min(cfg.non_return_lidar_distance)
+    err = (torch.where(returned[:, None], measured, beyond) - pred).abs()
+    return torch.where(returned[:, None], err, err * cfg.non_return_loss_mult)
+
+
+def lidar_metrics(outputs: Dict[str, Tensor], is_lidar: Tensor, did_return: Tensor, distance: Tensor,
+                  intensity_target: Tensor, cfg: LidarLossSettings, num_proposal_rounds: int = 2) -> Dict[str, Tensor]:
+    """is_lidar [R] bool over the whole batch; did_return [n_lidar] bool, distance [n_lidar,1], intensity_target
+    [n_lidar,1] for the lidar rays in batch order.  outputs: depth [R,1], prop_depth_i [R,1], prop_weights_loss_i,
+    non_nearby_weights, and the lidar head's intensity / ray_drop_logits [n_lidar,1]."""
+    n_lidar = is_lidar.sum()
+    err = _depth_l1(outputs["depth"][is_lidar], distance, did_return, cfg)
+    # robust mean: the worst (1 - quantile_threshold) of the rays are left out of the depth and intensity terms
+    keep = (err < torch.quantile(err, cfg.quantile_threshold)).squeeze(-1)
+    m = {"depth_loss": err[keep].mean()}
+    sel = keep & did_return
+    m["intensity_loss"] = (intensity_target[sel] - outputs["intensity"][sel]).square().mean()
+    logits = outputs["ray_drop_logits"]
+    m["ray_drop_loss"] = binary_cross_entropy_with_logits(logits, (~did_return)[:, None].to(logits))
+    m["carving_loss"] = outputs["non_nearby_weights"].square().sum() / n_lidar  # average per lidar ray
+    for i in range(num_proposal_rounds):
+        m[f"depth_loss_{i}"] = _depth_l1(outputs[f"prop_depth_{i}"][is_lidar], distance, did_return, cfg).mean()
+        m[f"carving_loss_{i}"] = outputs[f"prop_weights_loss_{i}"] / n_lidar
+    return m
+
+
+def lidar_loss_dict(metrics: Dict[str, Tensor], cfg: LidarLossSettings, num_proposal_rounds: int = 2) -> Dict[str, Tensor]:
+    out = {"depth_loss": cfg.depth_mult * metrics["depth_loss"],
+           "intensity_loss": cfg.intensity_mult * metrics["intensity_loss"],
+           "carving_loss": cfg.carving_mult * metrics["carving_loss"],
+           "ray_drop_loss": cfg.ray_drop_loss_mult * metrics["ray_drop_loss"]}
+    for i in range(num_proposal_rounds):
+        out[f"depth_loss_{i}"] = cfg.prop_lidar_loss_mult * cfg.depth_mult * metrics[f"depth_loss_{i}"]
+        out[f"carving_loss_{i}"] = cfg.prop_lidar_loss_mult * cfg.carving_mult * metrics[f"carving_loss_{i}"]
+    return out

@@ -114,6 +114,9 @@ class NeuRADHotPathConfig:
     non_return_lidar_distance: float = 150.0
     reproduce_late_binding_quirk: bool = True
     """see FusedEvalMixin; False uses field i in round i."""
+    lidar_decoder: bool = True
+    """Build the lidar head (intensity, ray-drop logit): MLP 48 -> 32 -> 32 -> 2 (models/neurad.py:217-224), the first
+    consumer of the rendered features (SURVEY §8(f) row 1); the RGB CNN decoder stays in neurad-studio."""
 
 
 class NeuRADHotPath(FusedEvalMixin, nn.Module):
@@ -143,6 +146,11 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
         self.renderer_feat = FeatureRenderer()
         self.renderer_accumulation = AccumulationRenderer()
         self.renderer_depth = DepthRenderer(method="expected") if config.normalize_depth else render_depth_simple
+        if config.lidar_decoder:
+            from ..field_components.mlp import MLP
+
+            self.lidar_decoder = MLP(in_dim=config.field.nff_out_dim + config.appearance_dim, num_layers=3,
+                                     layer_width=32, out_dim=2)
 
     @property
     def fields(self):
@@ -152,9 +160,19 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
         groups: Dict[str, List[nn.Parameter]] = {"hashgrids": [], "fields": []}
         for f in self.fields:
             f.get_param_groups(groups)
+        if self.config.lidar_decoder:
+            groups["fields"] += list(self.lidar_decoder.parameters())
         if self.config.appearance_dim > 0:
             groups["fields"] += list(self.appearance_embedding.parameters())
         return groups
+
+    def decode_lidar(self, features: Tensor, is_lidar: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """lidar head of decode_features (models/neurad.py:341-348): rendered features of the lidar rays ->
+        (intensity in [0,1], ray-drop logit), each [n_lidar, 1]"""
+        if is_lidar is not None:
+            features = features[is_lidar.reshape(-1)]
+        intensity, ray_drop_logit = self.lidar_decoder(features).split(1, dim=-1)
+        return intensity.sigmoid(), ray_drop_logit
 
     # ---- M1 (models/neurad.py:443-459), operator-level path ---------------------------------------
     def _get_ray_samples(self, ray_bundle: RayBundle):

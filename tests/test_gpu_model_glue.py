@@ -1,0 +1,183 @@
+"""Model-level glue of the hot path on the GPU against outputs of the reference's own NeuRADModel
+(tests/golden/model_train_glue.npz, tests/golden/proposal_actors.npz -- oracle/make_golden_model.py):
+appearance embedding (C3), is_close_to_lidar / proposal carving terms / non_nearby outputs (C4), the lidar head, the
+lidar loss terms and the proposal field's actor gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def build_model(g):
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    c = NeuRADHotPathConfig(appearance_dim=16)
+    c.field.grid.static.log2_hashmap_size = 10
+    c.field.sdf_beta = 3.0
+    for pf in (c.sampling.proposal_field_1, c.sampling.proposal_field_2):
+        pf.grid.static.log2_hashmap_size = 9
+    m = NeuRADHotPath(c, static_scale=100.0, num_sensors=3, duration=float(g["duration"])).cuda()
+    sd = {k[3:]: dev(v) for k, v in g.items() if k.startswith("sd/") and ".actors." not in k}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)  # the reference checkpoint's names, one to one
+    return m
+
+
+def bundle(g):
+    from neurad_studio_amd.cameras.rays import RayBundle
+
+    return RayBundle(origins=dev(g["o"]), directions=dev(g["d"]), pixel_area=dev(g["area"])[:, None],
+                     times=dev(g["times"])[:, None],
+                     metadata={"is_lidar": dev(g["is_lidar"])[:, None], "did_return": dev(g["did_return"])[:, None],
+                               "directions_norm": dev(g["directions_norm"])[:, None],
+                               "sensor_idxs": dev(g["sensor_idxs"])[:, None]})
+
+
+def test_training_outputs_with_lidar_metadata_and_appearance_vs_reference():
+    g = load_golden("model_train_glue")
+    m = build_model(g).train()
+    m.sampler.eval(), m.field.eval()  # deterministic sampling, as in the generator
+    for p in m.proposal_fields:
+        p.eval()
+    out = m.get_nff_outputs(bundle(g), calc_lidar_losses=True)
+    assert out["features"].shape == (80, 48)
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(host(out[k]), g[k]) < TOL, k
+    for i in range(3):
+        assert rel_l2(host(out["weights_list"][i][..., 0]), g[f"weights_{i}"]) < TOL
+        close = host(out["ray_samples_list"][i].metadata["is_close_to_lidar"][..., 0])
+        # a sample within float rounding of the 0.1 m carving band may flip: allow a handful
+        assert (close != g[f"close_{i}"]).sum() <= 2, i
+    for i in range(2):
+        assert abs(float(out[f"prop_weights_loss_{i}"]) / float(g[f"prop_weights_loss_{i}"]) - 1) < 1e-3
+    assert abs(out["non_nearby_weights"].shape[0] - g["non_nearby_weights"].shape[0]) <= 2
+    if out["non_nearby_weights"].shape == g["non_nearby_weights"].shape:
+        assert rel_l2(host(out["non_nearby_weights"]), g["non_nearby_weights"]) < TOL
+        np.testing.assert_array_equal(host(out["non_nearby_lidar_ray_indices"]), g["non_nearby_lidar_ray_indices"])
+    # ---- lidar head + lidar losses ----
+    from neurad_studio_amd.model_components.lidar_losses import LidarLossSettings, lidar_loss_dict, lidar_metrics
+    from neurad_studio_amd.model_components.losses import distortion_loss, zipnerf_interlevel_loss
+
+    is_lidar = dev(g["is_lidar"])
+    intensity, logits = m.decode_lidar(out["features"], is_lidar)
+    assert rel_l2(host(intensity), g["intensity"]) < TOL and rel_l2(host(logits), g["ray_drop_logits"]) < TOL
+    outputs = dict(out, intensity=intensity, ray_drop_logits=logits)
+    cfg = LidarLossSettings()
+    lc = g["loss_cfg"]
+    assert (cfg.depth_mult, cfg.intensity_mult, cfg.carving_mult, cfg.ray_drop_loss_mult, cfg.prop_lidar_loss_mult,
+            cfg.non_return_loss_mult, cfg.non_return_lidar_distance, cfg.quantile_threshold) == tuple(lc[:8])
+    did_return = dev(g["did_return"])[is_lidar]
+    metrics = lidar_metrics(outputs, is_lidar, did_return, dev(g["directions_norm"])[is_lidar][:, None],
+                            dev(g["lidar_points"])[:, 3:4], cfg)
+    for k in ("depth_loss", "intensity_loss", "ray_drop_loss", "carving_loss", "depth_loss_0", "depth_loss_1",
+              "carving_loss_0", "carving_loss_1"):
+        assert abs(float(metrics[k]) / float(g["metric_" + k]) - 1) < 2e-3, (k, float(metrics[k]), float(g["metric_" + k]))
+    losses = lidar_loss_dict(metrics, cfg)
+    for k, v in losses.items():
+        assert abs(float(v) / float(g["loss_" + k]) - 1) < 2e-3, k
+    losses["interlevel_loss"] = float(lc[9]) * zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
+    losses["distortion_loss"] = float(lc[10]) * distortion_loss(out["weights_list"], out["ray_samples_list"])
+    assert abs(float(losses["interlevel_loss"]) / float(g["loss_interlevel_loss"]) - 1) < 2e-3
+    assert abs(float(losses["distortion_loss"]) / float(g["loss_distortion_loss"]) - 1) < 2e-3
+    # the whole chain backward: the gradients the reference's autograd produced for the same total loss
+    sum(losses.values()).backward()
+    assert rel_l2(host(m.lidar_decoder.layers[0].weight.grad), g["g_lidar_decoder_w0"]) < 2e-3
+    assert rel_l2(host(m.appearance_embedding.weight.grad), g["g_embedding"]) < 2e-3
+    assert abs(float(m.field.sdf_to_density.beta.grad) / float(g["g_beta"]) - 1) < 5e-3
+    got = float(m.field.hashgrid.static_grid.hash_table.grad.abs().sum())
+    assert abs(got / float(g["g_field_table_abs_sum"]) - 1) < 5e-3
+    got = float(m.proposal_fields[1].hashgrid.static_grid.hash_table.grad.abs().sum())
+    assert abs(got / float(g["g_prop1_table_abs_sum"]) - 1) < 5e-3
+    assert m.proposal_fields[0].hashgrid.static_grid.hash_table.grad is None  # the late-binding quirk
+
+
+def test_eval_fused_path_with_appearance_and_normalized_depth():
+    """C3 through the fused eval path, and normalize_depth (DepthRenderer('expected'), renderers.py:398-416) against
+    the operator-level path of the same model."""
+    g = load_golden("model_train_glue")
+    m = build_model(g).eval()
+    with torch.no_grad():
+        fused = m.get_nff_outputs(bundle(g))
+    op = m.get_nff_outputs(bundle(g))  # grad enabled -> operator-level path, eval mode (no jitter)
+    assert fused["features"].shape == (80, 48)
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(host(fused[k]), host(op[k])) < 5e-5, k
+    assert rel_l2(host(fused["features"][:, 32:]), g["features"][:, 32:]) < 1e-5  # the embedding part is mode independent
+    from neurad_studio_amd.model_components.renderers import DepthRenderer
+
+    m.config.normalize_depth, m.renderer_depth = True, DepthRenderer(method="expected")
+    with torch.no_grad():
+        fused_n = m.get_nff_outputs(bundle(g))
+    op_n = m.get_nff_outputs(bundle(g))
+    assert rel_l2(host(fused_n["depth"]), host(op_n["depth"])) < 5e-5
+    assert bool((fused_n["depth"] >= fused["depth"] - 1e-6).all())  # dividing by sum w <= 1 never shortens a depth
+    # early termination and ray ordering are eval options of the same path: bounded / no change
+    from neurad_studio_amd.model_components.renderers import render_depth_simple
+
+    m.config.normalize_depth, m.renderer_depth = False, render_depth_simple
+    m.order_rays = True
+    with torch.no_grad():
+        ordered = m.get_nff_outputs(bundle(g))
+    assert torch.equal(ordered["features"], fused["features"]) and torch.equal(ordered["depth"], fused["depth"])
+    m.early_stop_eps = 1e-3
+    with torch.no_grad():
+        cut = m.get_nff_outputs(bundle(g))
+    assert float((cut["accumulation"] - fused["accumulation"]).abs().max()) <= 1.01e-3
+
+
+def test_proposal_field_with_actors_density_and_gradients_vs_reference():
+    """require_actor_grad=False keeps the POSES out of the graph only -- the proposal fields' actor
+    grids and decoder train through the in-box samples.  Golden = the reference's autograd."""
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.fields.neurad_field import NeuRADProposalField, NeuRADProposalFieldConfig
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+    from neurad_studio_amd.model_components.ray_samplers import PowerSampler
+    from test_gpu_actors import trajectories
+    import synth
+
+    g = load_golden("proposal_actors")
+    actors = DynamicActors(DynamicActorsConfig(), trajectories=trajectories())
+    cfg = NeuRADProposalFieldConfig()
+    cfg.grid.static.log2_hashmap_size = 10
+    cfg.grid.actor.log2_hashmap_size = 8
+    fld = NeuRADProposalField(cfg, actors=actors, static_scale=100.0).cuda().eval()
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.copy_(dev(synth.hash_table(6 * 2**10, 1, seed=61, scale=2.0)))
+        for i, gr in enumerate(fld.hashgrid.actor_grids):
+            gr.hash_table.copy_(dev(synth.hash_table(4 * 2**8, 1, seed=500 + i, scale=2.5)))
+        fld.density_decoder.weight.copy_(dev(synth.uniform((1, 6), -0.6, 0.6, seed=62)))
+    R = g["o"].shape[0]
+    rb = RayBundle(origins=dev(g["o"]), directions=dev(g["d"]), pixel_area=torch.full((R, 1), 2.43e-6, device="cuda"),
+                   times=dev(g["times"])[:, None], nears=torch.zeros(R, 1, device="cuda"),
+                   fars=torch.full((R, 1), 60.0, device="cuda"))
+    rs = PowerSampler(num_samples=40, lambda_=-1.0, scaling=0.1).eval()(rb)
+    with torch.no_grad():
+        d0, _ = fld.get_density(rs)
+    assert rel_l2(host(d0[..., 0]), g["density"]) < TOL
+    dens, _ = fld.get_density(rs)
+    assert rel_l2(host(dens[..., 0]), g["density"]) < TOL
+    (dens[..., 0] * dev(g["g_density"])).sum().backward()
+    tg = host(fld.hashgrid.static_grid.hash_table.grad)
+    ref_tg = np.zeros_like(tg)
+    ref_tg[g["tg_idx"]] = g["tg_val"]
+    assert rel_l2(tg, ref_tg) < TOL
+    assert rel_l2(host(fld.density_decoder.weight.grad), g["g_decoder"]) < TOL
+    for i, gr in enumerate(fld.hashgrid.actor_grids):
+        ref_g = g[f"ag{i}"]
+        got = np.zeros_like(ref_g) if gr.hash_table.grad is None else host(gr.hash_table.grad)
+        assert np.abs(ref_g).sum() == 0 or rel_l2(got, ref_g) < TOL, i
+    assert any(np.abs(g[f"ag{i}"]).sum() > 0 for i in range(3)), "the golden must exercise the actor grids"
+    assert bool(g["dpos_is_none"]) and actors.actor_positions.grad is None  # poses stay out of the graph
