@@ -20,11 +20,28 @@ class NroField(C.Structure):
                 ("beta", C.c_float)]
 
 
+def _cpu_tag() -> str:
+    """identifies the instruction set of THIS host: the library is built with -march=native, and the copy that travels
+    with the repo snapshot to another machine (the GPU box) must not be reused there if the CPUs differ (SIGILL)"""
+    import hashlib
+
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((l for l in f if l.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(" ".join(sorted(flags.split(":")[-1].split())).encode()).hexdigest()[:16]
+
+
 def build() -> str:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+    tag_file, tag = LIB + ".cpu", _cpu_tag()
+    built_for = open(tag_file).read().strip() if os.path.exists(tag_file) else None
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC) or built_for != tag:
         subprocess.run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=gnu11", SRC, "-o", LIB,
                         "-lm"], check=True)
+        with open(tag_file, "w") as f:
+            f.write(tag)
     return LIB
 
 
