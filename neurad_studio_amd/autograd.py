@@ -87,9 +87,12 @@ class FieldTrainFn(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, table, spec, static_scale, use_sdf, beta, origins, directions, pixel_area, starts, ends, *params):
+        params, order = params[:10], (params[10] if len(params) > 10 else None)  # optional processing order (ops.ray_order)
         gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
         fs = ops.FieldSpec(spec, table, static_scale, gw, gb, fw, fb, use_sdf=use_sdf, beta=beta)
-        (feature, geo_out, _head), (enc, hg, xf, hf) = ops.field_fwd_train(fs, origins, directions, pixel_area, starts, ends)
+        (feature, geo_out, _head), (enc, hg, xf, hf) = ops.field_fwd_train(fs, origins, directions, pixel_area, starts, ends,
+                                                                           order=order)
+        ctx.has_order = order is not None
         ctx.spec, ctx.scale = spec, static_scale
         ctx.save_for_backward(origins, directions, pixel_area, starts, ends, enc, hg, xf, hf, *params)
         return feature, geo_out[:, None]
@@ -108,7 +111,7 @@ class FieldTrainFn(torch.autograd.Function):
         genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
         gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc) if ctx.needs_input_grad[0] else None
         grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
-        return (gt, None, None, None, None, None, None, None, None, None, *grads)
+        return (gt, None, None, None, None, None, None, None, None, None, *grads, *([None] if ctx.has_order else []))
 
 
 class MLPFn(torch.autograd.Function):

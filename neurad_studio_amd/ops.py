@@ -292,8 +292,12 @@ def mlp_bwd(x: Tensor, hidden: Optional[Tensor], grad_y: Tensor, weights, biases
     m, keep = _c_mlp(weights, biases)
     n = x.shape[0]
     gx = torch.empty_like(x) if need_grad_x else None
-    gws = [torch.zeros_like(w, dtype=torch.float32) for w in weights]
-    gbs = [None if b is None else torch.zeros_like(b, dtype=torch.float32) for b in biases]
+    # one zero-filled buffer for every weight / bias gradient of the MLP (one fill launch instead of 2 per layer)
+    sizes = [w.numel() for w in weights] + [0 if b is None else b.numel() for b in biases]
+    flat = torch.zeros((sum(sizes),), device=x.device, dtype=torch.float32)
+    views = torch.split(flat, sizes)
+    gws = [v.view_as(w) for v, w in zip(views[:len(weights)], weights)]
+    gbs = [None if b is None else v.view_as(b) for v, b in zip(views[len(weights):], biases)]
     need = C.c_int64(0)
     call("nrhip_mlp_bwd_workspace", C.byref(m), n, C.byref(need))
     ws = torch.empty((max(need.value, 1),), device=x.device, dtype=torch.float32)

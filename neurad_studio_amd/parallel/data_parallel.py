@@ -3,15 +3,21 @@ the gradient all-reduce (reference: DDP over NCCL, pipelines
 
 MI355X-first choices (xGMI is point-to-point, 7 links x ~153 GB/s per GPU; a ring is per-link bound):
   * the hash-table gradients (>= 99.9 % of the bytes: 537 MB fp32 for the default static grid) are reduced as
-    FEW, LARGE flat buffers -- `reduce_scatter_tensor` + `all_gather_into_tensor` on a pre-allocated flat buffer, so
-    RCCL can drive all links concurrently -- instead of DDP's 25 MB buckets;
+    FEW, LARGE flat buffers -- `reduce_scatter_tensor` + `all_gather_into_tensor` in place on the gradient's own storage,
+    so RCCL can drive all links concurrently -- instead of DDP's 25 MB buckets;
+  * OVERLAP: with ``overlap=True`` each large gradient's exchange is enqueued (async) from a post-accumulate-grad hook
+    the moment autograd has finished that gradient -- the two 25 MB proposal-table reductions then run under the main
+    field's backward instead of after it; ``sync()`` only waits for them and exchanges the rest;
   * the < 1 MB of MLP / decoder / embedding gradients travel as one coalesced all-reduce;
-  * parameters that got no gradient this step (the never-evaluated proposal_fields[0], models/neurad.py:248)
-    are skipped symmetrically on every rank -- what DDP's find_unused_parameters=True does with a bitmap.
+  * parameters without a gradient (the never-evaluated proposal_fields[0], models/neurad.py:248; actor grids no ray
+    of the batch hits) are skipped symmetrically on every rank -- what DDP's find_unused_parameters=True does with a
+    bitmap.  ``usage="dynamic"`` agrees on that set every step (one tiny MAX all-reduce + a host read: needed when actor
+    grids come and go); ``usage="static"`` agrees once and from then on only checks, on the host and without any
+    device read, that the local pattern has not changed (static scenes: no per-step host sync at all).
 Backend-agnostic (``"nccl"`` == RCCL on ROCm, ``"gloo"`` in the CPU tests)."""
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -32,22 +38,80 @@ class GradientSynchronizer:
     """Averages (or sums) ``param.grad`` across ranks with large flat collectives."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, average: bool = True,
-                 large_threshold_bytes: int = 8 << 20) -> None:
+                 large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False) -> None:
+        if usage not in ("dynamic", "static"):
+            raise ValueError("usage must be 'dynamic' or 'static'")
+        if overlap and usage != "static":
+            raise ValueError("overlap=True needs usage='static': a hook cannot wait for the other ranks' usage bitmap")
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = process_group
         self.average = average
         self.large_threshold = large_threshold_bytes
-        self._flat: Optional[Tensor] = None
+        self.usage = usage
+        self.overlap = overlap
+        self._agreed: Optional[List[bool]] = None      # usage == "static": the set agreed at the first sync
+        self._local_at_agreement: Optional[List[bool]] = None
+        self._inflight: Dict[int, Tuple[object, Tensor, Tensor]] = {}  # param index -> (work, flat grad, shard)
+        self._hooks = []
+        self.overlapped_last_step = 0
+        if overlap:
+            for i, p in enumerate(self.params):
+                if self._is_large(p):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda param, i=i: self._on_grad_ready(i)))
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def _used_mask(self) -> List[bool]:
-        """Agree on which parameters have a gradient on ANY rank (missing ones are treated as zeros)."""
+    def _is_large(self, t: Tensor) -> bool:
+        n = t.numel()
+        return n * t.element_size() >= self.large_threshold and t.is_contiguous() and n % max(self.world_size(), 1) == 0
+
+    # ---- which parameters take part -------------------------------------------------------------------------------
+    def _local_pattern(self) -> List[bool]:
+        return [p.grad is not None for p in self.params]
+
+    def _agree(self, local: List[bool]) -> List[bool]:
         dev = self.params[0].device
-        m = torch.tensor([0 if p.grad is None else 1 for p in self.params], device=dev, dtype=torch.int32)
+        m = torch.tensor([int(u) for u in local], device=dev, dtype=torch.int32)
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
         return [bool(v) for v in m.tolist()]
+
+    def _used_mask(self) -> List[bool]:
+        """Which parameters have a gradient on ANY rank (missing ones are treated as zeros)."""
+        local = self._local_pattern()
+        if self.usage == "dynamic":
+            return self._agree(local)
+        if self._agreed is None:
+            self._agreed, self._local_at_agreement = self._agree(local), local
+        elif local != self._local_at_agreement:
+            raise RuntimeError("GradientSynchronizer(usage='static'): the set of parameters with a gradient changed on "
+                               "this rank; use usage='dynamic' for models whose used parameters vary (actor grids)")
+        return self._agreed
+
+    # ---- the exchange ----------------------------------------------------------------------------------------------
+    def _start_large(self, i: int, async_op: bool):
+        g = self.params[i].grad
+        flat = g.view(-1)
+        shard = flat.new_empty(flat.numel() // self.world_size())
+        if not async_op:
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._finish_large(flat, shard)
+            return
+        work = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight[i] = (work, flat, shard)
+
+    def _finish_large(self, flat: Tensor, shard: Tensor) -> None:
+        if self.average:
+            shard.div_(self.world_size())
+        dist.all_gather_into_tensor(flat, shard, group=self.group)
+
+    def _on_grad_ready(self, i: int) -> None:
+        """post-accumulate-grad hook (overlap): autograd is done with this gradient -> its reduce-scatter starts now, on
+        the backend's own stream, while the rest of the backward keeps the compute stream busy.  Only after the usage
+        set has been agreed (first step runs without overlap) and only for parameters in it."""
+        if self._agreed is None or not self._agreed[i] or self.world_size() == 1:
+            return
+        self._start_large(i, async_op=True)
 
     @torch.no_grad()
     def sync(self) -> int:
@@ -57,23 +121,24 @@ class GradientSynchronizer:
             return 0
         used = self._used_mask()
         small, nbytes = [], 0
-        for p, u in zip(self.params, used):
+        self.overlapped_last_step = len(self._inflight)
+        for i, (p, u) in enumerate(zip(self.params, used)):
             if not u:
                 continue
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             g = p.grad
             nbytes += g.numel() * g.element_size()
-            if g.numel() * g.element_size() >= self.large_threshold and g.is_contiguous() and g.numel() % world == 0:
+            if i in self._inflight:  # started from the hook: wait for the scatter, finish with the gather
+                work, flat, shard = self._inflight.pop(i)
+                work.wait()
+                self._finish_large(flat, shard)
+            elif self._is_large(g):
                 # reduce-scatter + all-gather in place on the gradient's own storage: every link busy, no staging copy
-                flat = g.view(-1)
-                shard = flat.new_empty(flat.numel() // world)
-                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
-                if self.average:
-                    shard.div_(world)
-                dist.all_gather_into_tensor(flat, shard, group=self.group)
+                self._start_large(i, async_op=False)
             else:
                 small.append(g)
+        assert not self._inflight, "a hooked gradient was not consumed by sync()"
         if small:
             flat = torch.cat([g.reshape(-1) for g in small])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -84,3 +149,8 @@ class GradientSynchronizer:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
         return nbytes
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -15,7 +15,7 @@ for path in sys.argv[1:]:
     print(f"== {path}")
     print("-- kernel-trace stats (top kernels): calls, total_us, avg_us, pct")
     for name, calls, total, avg, pct in cur.execute(
-            "select name,total_calls,total_duration,average,percentage from top_kernels limit 12"):
+            "select name,total_calls,total_duration,average,percentage from top_kernels limit 40"):
         print(f"{calls:6d} {total:12.1f} {avg:10.2f} {pct:6.2f}%  {short(name)}")
     rows = list(cur.execute(
         "select substr(kernel_name,1,200), counter_name, count(*), avg(value), min(value), max(value), avg(duration)"

@@ -65,3 +65,70 @@ def test_gradient_synchronizer_world2_gloo():
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert all(ret[r] for r in range(world)), dict(ret)
+
+
+class _TinyField(torch.nn.Module):
+    """CPU stand-in with the hot path's parameter structure: two 'hash tables' (one of them never evaluated, like
+    proposal_fields[0], models/neurad.py:248) + a small MLP."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(1)
+        self.table = torch.nn.Parameter(torch.randn(4096, 4, generator=g) * 0.1)
+        self.prop_table = torch.nn.Parameter(torch.randn(2048, 4, generator=g) * 0.1)
+        self.unused_table = torch.nn.Parameter(torch.randn(2048, 4, generator=g) * 0.1)
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+        with torch.no_grad():
+            for p in self.mlp.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    def forward(self, idx):
+        prop = self.prop_table[idx % 2048].sum(-1).square().mean()  # an independent branch, like the interlevel loss
+        return self.mlp(self.table[idx]).square().mean() + 0.1 * prop
+
+
+def _worker_model(rank, world, port, ret, overlap):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _TinyField()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-15)
+    sync = GradientSynchronizer(m.parameters(), average=True, large_threshold_bytes=1 << 14, usage="static", overlap=overlap)
+    ref = _TinyField()  # single-process reference: the averaged loss of both shards
+    ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-2, eps=1e-15)
+    overlapped = []
+    for step in range(3):
+        batches = [torch.randint(0, 4096, (512,), generator=torch.Generator().manual_seed(10 * step + r)) for r in range(world)]
+        opt.zero_grad(set_to_none=True)
+        m(batches[rank]).backward()
+        sync.sync()
+        overlapped.append(sync.overlapped_last_step)
+        opt.step()
+        ref_opt.zero_grad(set_to_none=True)
+        (sum(ref(b) for b in batches) / world).backward()
+        ref_opt.step()
+    ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(m.parameters(), ref.parameters()))
+    ok = ok and m.unused_table.grad is None
+    # step 0 agrees on the usage set without overlap; afterwards both large tables are exchanged from their hooks
+    ok = ok and overlapped == ([0, 2, 2] if overlap else [0, 0, 0])
+    # static usage: a parameter that suddenly gets a gradient is an error, not a silent divergence
+    m.unused_table.grad = torch.zeros_like(m.unused_table)
+    try:
+        sync.sync()
+        ok = False
+    except RuntimeError:
+        pass
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_model_replicas_stay_identical_world2_gloo(overlap):
+    """two model replicas, each on its own ray shard, one exchange per step (static usage set, optionally with the large
+    tables' reduce-scatter launched from autograd hooks during the backward): parameters after 3 Adam steps equal a
+    single process trained on the mean loss of both shards"""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_model, args=(world, _free_port(), ret, overlap), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world)), dict(ret)

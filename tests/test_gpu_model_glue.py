@@ -127,6 +127,7 @@ def test_eval_fused_path_with_appearance_and_normalized_depth():
     # early termination and ray ordering are eval options of the same path: bounded / no change
     from neurad_studio_amd.model_components.renderers import render_depth_simple
 
+    del m.renderer_depth  # (an nn.Module attribute cannot be overwritten by a plain function)
     m.config.normalize_depth, m.renderer_depth = False, render_depth_simple
     m.order_rays = True
     with torch.no_grad():
