@@ -274,12 +274,16 @@ typedef struct {
   nrhip_grid grid;               /* geometry shared by all actor grids (ActorSettings) */
   const void* const* tables;     /* DEVICE array of A table pointers, indexed by actor_to_id[actor] */
   float actor_scale;             /* actor contraction scale, 10 m (neurad_encoding.py:52,100) */
+  int32_t max_candidates;        /* K: row length of the per-ray candidate lists below; 0 = NRHIP_DEFAULT_ACTOR_CANDIDATES.
+                                    With K = n_actors no ray can overflow (the reference has no limit,
+                                    neurad_encoding.py:225-263) and the lists cost R*K*52 bytes of HBM.          */
 } nrhip_actors;
 
-#define NRHIP_MAX_ACTOR_CANDIDATES 8
+#define NRHIP_DEFAULT_ACTOR_CANDIDATES 8
+#define NRHIP_MAX_SAMPLE_CONTAINMENTS 8 /* boxes that can contain ONE sample and still all receive gradients */
 /* Per ray: interpolate every actor's pose at the ray's time, cull by distance to the ray's first->last sample line,
  * and compact the survivors: cand_count [R] int32, cand_actor [R,K] int32, cand_w2b [R,K,12] (3x4 world->box),
- * K = NRHIP_MAX_ACTOR_CANDIDATES.  overflow (device int32, caller zeroes) is set if a ray has more than K.   */
+ * K = actors->max_candidates.  overflow (device int32, caller zeroes; may be NULL) is set if a ray has more than K. */
 int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const float* times /*[R]*/,
                         int32_t* cand_count, int32_t* cand_actor, float* cand_w2b, int32_t* overflow, void* stream);
 /* Field features: for every sample inside an actor box, OVERWRITE its feature row [out_dim] with the actor grid's
@@ -290,11 +294,12 @@ int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int3
                        float* directions /*[N,3]*/, int32_t* hit /*[N] actor index or -1*/,
                        const float* ray_flip /*[R] +-1 (training x-flip, neurad_encoding.py:212-219) or NULL*/,
                        void* stream);
-/* All containments: hits [N,K] = actor index of every candidate whose box contains the sample, else -1 (ascending
- * actor order; the last non-negative entry is the one nrhip_actor_encode used).  The reference's index_put backward
+/* All containments: hits [N, NRHIP_MAX_SAMPLE_CONTAINMENTS] = the actors whose boxes contain the sample, compacted in
+ * ascending actor order and padded with -1 (the last non-negative entry is the one nrhip_actor_encode used; if more
+ * boxes than that overlap at one point, the lowest indices drop out).  The reference's index_put backward
  * gives EVERY duplicate (ray, sample) row the upstream gradient, so training needs the whole list.            */
 int nrhip_actor_hits(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,
-                     const int32_t* cand_actor, const float* cand_w2b, int32_t* hits /*[N,K]*/, void* stream);
+                     const int32_t* cand_actor, const float* cand_w2b, int32_t* hits /*[N,8]*/, void* stream);
 /* Proposal density: density = exp(decoder . padded actor features) for samples inside an actor box
  * (fields/neurad_field.py:208-213 with the actor branch of neurad_encoding.py:170-185).                      */
 int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,

@@ -51,14 +51,14 @@ class SamplerCfg(C.Structure):
 class Actors(C.Structure):
     _fields_ = [("n_actors", C.c_int32), ("n_times", C.c_int32), ("timestamps", C.c_void_p), ("positions", C.c_void_p),
                 ("rotations_6d", C.c_void_p), ("present", C.c_void_p), ("bounds", C.c_void_p), ("grid", Grid),
-                ("tables", C.c_void_p), ("actor_scale", C.c_float)]
+                ("tables", C.c_void_p), ("actor_scale", C.c_float), ("max_candidates", C.c_int32)]
 
 
 class OccGrid(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
 
 
-MAX_ACTOR_CANDIDATES = 8
+MAX_SAMPLE_CONTAINMENTS = 8  # NRHIP_MAX_SAMPLE_CONTAINMENTS
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes : exactly the prototypes of include/neurad_hip.h (tests/test_abi.py cross-checks this

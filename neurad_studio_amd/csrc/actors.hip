@@ -17,9 +17,10 @@ struct ActorsDev {
   const void* const* tables;
   float scale;
   const float* flip;  // [R] +-1 per ray (training-mode x flip, neurad_encoding.py:212-219) or NULL
+  int K;              // row length of the per-ray candidate lists (nrhip_actors.max_candidates; == A: no ray overflows)
 };
 
-constexpr int K = NRHIP_MAX_ACTOR_CANDIDATES;
+constexpr int KH = NRHIP_MAX_SAMPLE_CONTAINMENTS;  // containing boxes recorded per SAMPLE by nrhip_actor_hits
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {  // F.normalize, eps 1e-12
   const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
@@ -96,17 +97,17 @@ __global__ __launch_bounds__(256) void actor_prepare_kernel(ActorsDev a, RaysDev
     const unsigned long long m = __ballot(close);
     const int slot = count + __popcll(m & ((1ull << lane) - 1ull));
     if (close) {
-      if (slot < K) {
-        cand_actor[ray * K + slot] = act;
+      if (slot < a.K) {
+        cand_actor[ray * a.K + slot] = act;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) cand_w2b[(ray * K + slot) * 12 + k] = w2b[k];
-      } else {
+        for (int k = 0; k < 12; ++k) cand_w2b[(ray * a.K + slot) * 12 + k] = w2b[k];
+      } else if (overflow) {
         *overflow = 1;
       }
     }
     count += __popcll(m);
   }
-  if (lane == 0) cand_count[ray] = min(count, K);
+  if (lane == 0) cand_count[ray] = min(count, a.K);
 }
 
 // shared per-sample part: which actor (if any) contains the sample; box-frame position/direction
@@ -130,8 +131,8 @@ __device__ __forceinline__ ActorHit find_hit(const ActorsDev& a, const RaysDev& 
   h.std = g.std;
   const float* wsel = nullptr;
   for (int c = 0; c < n; ++c) {  // ascending actor index; the LAST hit wins (neurad_encoding.py:184-185 on CPU)
-    const float* w = cand_w2b + (ray * K + c) * 12;
-    const int act = cand_actor[ray * K + c];
+    const float* w = cand_w2b + (ray * a.K + c) * 12;
+    const int act = cand_actor[ray * a.K + c];
     const float bx = w[0] * g.x + w[1] * g.y + w[2] * g.z + w[3];
     const float by = w[4] * g.x + w[5] * g.y + w[6] * g.z + w[7];
     const float bz = w[8] * g.x + w[9] * g.y + w[10] * g.z + w[11];
@@ -216,19 +217,26 @@ __global__ __launch_bounds__(256) void actor_hits_kernel(ActorsDev a, RaysDev r,
   const int s = (int)(i - ray * r.S);
   const int n = cand_count[ray];
 #pragma unroll
-  for (int c = 0; c < K; ++c) hits[i * K + c] = -1;
+  for (int c = 0; c < KH; ++c) hits[i * KH + c] = -1;
   if (n == 0) return;
   const SamplePos g = sample_gaussian(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray], r.d[3 * ray + 1],
                                       r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
                                       r.ends[ray * r.stride + s]);
+  int slot = 0;  // compacted, ascending actor order; beyond KH overlapping boxes the lowest indices drop out, the
+                 // winner (highest index = last entry) stays
   for (int c = 0; c < n; ++c) {
-    const float* w = cand_w2b + (ray * K + c) * 12;
-    const int act = cand_actor[ray * K + c];
+    const float* w = cand_w2b + (ray * a.K + c) * 12;
+    const int act = cand_actor[ray * a.K + c];
     const float bx = w[0] * g.x + w[1] * g.y + w[2] * g.z + w[3];
     const float by = w[4] * g.x + w[5] * g.y + w[6] * g.z + w[7];
     const float bz = w[8] * g.x + w[9] * g.y + w[10] * g.z + w[11];
-    if (fabsf(bx) < a.bounds[3 * act] && fabsf(by) < a.bounds[3 * act + 1] && fabsf(bz) < a.bounds[3 * act + 2])
-      hits[i * K + c] = act;
+    if (fabsf(bx) < a.bounds[3 * act] && fabsf(by) < a.bounds[3 * act + 1] && fabsf(bz) < a.bounds[3 * act + 2]) {
+      if (slot == KH) {
+        for (int k = 1; k < KH; ++k) hits[i * KH + k - 1] = hits[i * KH + k];
+        slot = KH - 1;
+      }
+      hits[i * KH + slot++] = act;
+    }
   }
 }
 
@@ -238,6 +246,7 @@ static int to_dev(const nrhip_actors* a, ActorsDev& d) {
   NR_REQUIRE(a->timestamps && a->positions && a->rotations_6d && a->present && a->bounds, NRHIP_ERR_INVALID_ARG,
              "actors descriptor has a NULL pointer");
   d.A = a->n_actors, d.Tn = a->n_times;
+  d.K = a->max_candidates > 0 ? a->max_candidates : NRHIP_DEFAULT_ACTOR_CANDIDATES;
   d.ts = a->timestamps, d.pos = a->positions, d.rot6 = a->rotations_6d, d.present = a->present, d.bounds = a->bounds;
   d.grid = to_dev(a->grid);
   d.tables = a->tables;
@@ -257,8 +266,11 @@ extern "C" int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays
   if (int e = to_dev(a, d)) return e;
   if (int e = validate_rays(rays)) return e;
   if (rays->n_rays == 0) return NRHIP_OK;
-  NR_REQUIRE(rays->n_samples >= 1 && times && cand_count && cand_actor && cand_w2b && overflow, NRHIP_ERR_INVALID_ARG,
+  NR_REQUIRE(rays->n_samples >= 1 && times && cand_count && cand_actor && cand_w2b, NRHIP_ERR_INVALID_ARG,
              "actor_prepare: bad argument");
+  NR_REQUIRE(overflow || d.K >= d.A, NRHIP_ERR_INVALID_ARG,
+             "actor_prepare: without an overflow flag the candidate lists must hold all %d actors (max_candidates = %d)",
+             d.A, d.K);
   actor_prepare_kernel<<<(int)((rays->n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(d, to_dev(*rays), times,
                                                                                      cand_count, cand_actor, cand_w2b,
                                                                                      overflow);

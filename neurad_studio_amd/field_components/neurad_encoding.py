@@ -103,7 +103,10 @@ class NeuRADHashEncoding(nn.Module):
 
     def actor_spec(self) -> ops.ActorSpec:
         act = self.actors
-        ids = act.actor_to_id.tolist()
+        key = (act.actor_to_id._version, act.actor_to_id.data_ptr())
+        if getattr(self, "_actor_ids", (None, None))[0] != key:  # buffer -> host list once, not once per forward
+            self._actor_ids = (key, act.actor_to_id.tolist())
+        ids = self._actor_ids[1]
         g0 = self.actor_grids[0]
         return ops.ActorSpec(act.unique_timestamps.float(), act.actor_positions.detach(),
                              act.actor_rotations_6d.detach(), act.actor_present_at_time, act.actor_bounds(), g0.spec,
@@ -112,10 +115,7 @@ class NeuRADHashEncoding(nn.Module):
     def prepare_actors(self, origins, directions, pixel_area, starts, ends, times):
         """per-ray candidate lists (shared by every field evaluated on the same ray bundle)."""
         spec = self.actor_spec()
-        cand = ops.actor_prepare(spec, origins, directions, pixel_area, starts, ends, times)
-        if int(cand[3].item()):
-            raise _lib.NeuradHipError(f"a ray passes more than {_lib.MAX_ACTOR_CANDIDATES} actors' bounding spheres")
-        return spec, cand
+        return spec, ops.actor_prepare(spec, origins, directions, pixel_area, starts, ends, times)
 
     def sample_ray_flip(self, origins) -> Optional[Tensor]:
         """-1 with prob flip_prob else +1, per ray, training only (neurad_encoding.py:212-215)."""

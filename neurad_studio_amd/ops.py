@@ -611,21 +611,22 @@ class ActorSpec:
         a.grid = self.grid.c_grid(tabs[0])
         a.tables = ptrs.data_ptr()
         a.actor_scale = float(self.actor_scale)
+        a.max_candidates = a.n_actors  # per-ray lists as long as the actor count: no ray can overflow, no host check
         return a, (keep, tabs, ptrs)
 
 
 def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times):
-    """-> (cand_count [R] i32, cand_actor [R,K] i32, cand_w2b [R,K,12]); raises if a ray has more than K candidates."""
+    """-> (cand_count [R] i32, cand_actor [R,K] i32, cand_w2b [R,K,12], None) with K = the number of actors, so every
+    actor a ray passes fits (the reference has no limit either); R*K*52 bytes, e.g. 300 MB for 57 344 rays x 100 actors."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
-    R, K, dev = r.n_rays, _lib.MAX_ACTOR_CANDIDATES, origins.device
+    R, K, dev = r.n_rays, a.max_candidates, origins.device
     t = _chk(times.reshape(-1), "times")
-    cnt = torch.zeros((R,), dtype=torch.int32, device=dev)
-    act = torch.zeros((R, K), dtype=torch.int32, device=dev)
-    w2b = torch.zeros((R, K, 12), dtype=torch.float32, device=dev)
-    ovf = torch.zeros((1,), dtype=torch.int32, device=dev)
-    call("nrhip_actor_prepare", C.byref(a), C.byref(r), _ptr(t), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(ovf), _stream())
-    return cnt, act, w2b, ovf
+    cnt = torch.empty((R,), dtype=torch.int32, device=dev)
+    act = torch.empty((R, K), dtype=torch.int32, device=dev)  # only the first cnt[r] entries of a row are ever read
+    w2b = torch.empty((R, K, 12), dtype=torch.float32, device=dev)
+    call("nrhip_actor_prepare", C.byref(a), C.byref(r), _ptr(t), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(None), _stream())
+    return cnt, act, w2b, None
 
 
 def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, features: Tensor,
@@ -646,11 +647,11 @@ def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts,
 
 
 def actor_hits(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends) -> Tensor:
-    """-> hits [N,K] int32: every candidate actor whose box contains the sample (-1 = no)"""
+    """-> hits [N,8] int32: the actors whose boxes contain the sample, ascending, padded with -1"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
     cnt, act, w2b, _ = cand
-    hits = torch.empty((r.n_rays * r.n_samples, _lib.MAX_ACTOR_CANDIDATES), dtype=torch.int32, device=origins.device)
+    hits = torch.empty((r.n_rays * r.n_samples, _lib.MAX_SAMPLE_CONTAINMENTS), dtype=torch.int32, device=origins.device)
     call("nrhip_actor_hits", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(hits), _stream())
     return hits
 
