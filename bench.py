@@ -96,11 +96,34 @@ def timed(step, steps, warmup, world, device):
     return el
 
 
+class _Optimizers:
+    """the reference's two Adam groups (configs/method_configs.py:415-426): hash tables -> HashGridAdam (csrc/adam.hip,
+    torch.optim.Adam arithmetic, one streaming kernel per table), everything else -> torch's fused Adam"""
+
+    def __init__(self, params):
+        from neurad_studio_amd.optim import HashGridAdam
+
+        params = list(params)
+        tables = [p for p in params if p.numel() >= 1 << 16]
+        small = [p for p in params if p.numel() < 1 << 16]
+        self.opts = [HashGridAdam(tables, lr=1e-3, eps=1e-15)] if tables else []
+        if small:
+            try:
+                self.opts.append(torch.optim.Adam(small, lr=1e-3, eps=1e-15, fused=True))
+            except (RuntimeError, TypeError):
+                self.opts.append(torch.optim.Adam(small, lr=1e-3, eps=1e-15))
+
+    def zero_grad(self, set_to_none=True):
+        for o in self.opts:
+            o.zero_grad(set_to_none=set_to_none)
+
+    def step(self):
+        for o in self.opts:
+            o.step()
+
+
 def make_optimizer(params):
-    try:  # one pass over (param, grad, m, v) instead of torch's eight foreach kernels
-        return torch.optim.Adam(params, lr=1e-3, eps=1e-15, fused=True), "Adam (dense, torch fused)"
-    except (RuntimeError, TypeError):
-        return torch.optim.Adam(params, lr=1e-3, eps=1e-15), "Adam (dense, torch foreach)"
+    return _Optimizers(params), "Adam: hash tables on nrhip_adam_step (dense, torch.optim.Adam arithmetic), MLPs on torch fused Adam"
 
 
 def train_section(device, rank, world, steps, warmup):

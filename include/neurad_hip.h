@@ -213,6 +213,14 @@ int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_fe
 int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
                         float* out_acc, float* out_weights, float early_stop_eps, void* stream);
 
+/* ---- optimizer step of a hash table == torch.optim.Adam / AdamW on one fp32 tensor
+ * (engine/optimizers.py:168-181; hashgrids group: lr 1e-2, eps 1e-15, configs/method_configs.py:423-426).  In place on
+ * param / exp_avg / exp_avg_sq [n], 16-byte aligned; step = 1 for the first update; weight_decay is decoupled (AdamW),
+ * 0 = plain Adam; grad_scale multiplies the gradient first (1 = off).  Rows with grad = exp_avg = exp_avg_sq = 0 are
+ * skipped: their update is exactly zero. */
+int nrhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
 /* Processing order for cache locality (fills nrhip_rays.order): a permutation that groups rays looking at the same
  * region -- counting sort by the Morton code of the contracted position (ScaledSceneContraction, static_scale as in
  * nrhip_field) of the point origin + direction * t_ref, t_ref = a representative sample distance (the sampler's

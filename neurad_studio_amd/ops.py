@@ -722,6 +722,16 @@ def packed_visibility_from_alpha(alphas: Tensor, segments: Tensor, early_stop_ep
     return mask.bool()
 
 
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float, beta1: float = 0.9,
+              beta2: float = 0.999, eps: float = 1e-15, weight_decay: float = 0.0, grad_scale: float = 1.0) -> None:
+    """torch.optim.Adam / AdamW update of one fp32 tensor, in place (csrc/adam.hip)"""
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if _chk(t, n).data_ptr() != t.data_ptr() or t.shape != param.shape:
+            raise ValueError(f"adam_step: {n} must be a contiguous fp32 GPU tensor of the parameter's shape")
+    call("nrhip_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step), float(lr),
+         float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream())
+
+
 def device_info():
     cus, xcds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
     call("nrhip_device_info", C.byref(cus), C.byref(xcds), C.byref(hbm))

@@ -1,0 +1,45 @@
+"""Optimizer step of the hash tables on the HIP kernel.
+
+``HashGridAdam`` is torch.optim.Adam / AdamW for large fp32 tables: same hyper-parameters, same arithmetic, same
+``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter -- checkpoints written by the reference's
+``Optimizers`` wrapper, engine/optimizers.py:168-181, load into it and vice versa), one streaming kernel per table that
+skips the rows whose update is provably a no-op (csrc/adam.hip).  The reference's settings for its ``hashgrids`` group
+are ``AdamOptimizerConfig(lr=1e-2, eps=1e-15)`` (configs/method_configs.py:423-426)."""
+from __future__ import annotations
+
+from typing import Iterable, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+class HashGridAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-2, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-15,
+                 weight_decay: float = 0.0, decoupled_weight_decay: bool = True) -> None:
+        if weight_decay and not decoupled_weight_decay:
+            raise NotImplementedError("L2-in-gradient weight decay; use decoupled (AdamW) decay or 0")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: Optional[float] = None):
+        """grad_scale: multiply every gradient by it inside the kernel (1 / GradScaler scale when the caller does not
+        want a separate unscale pass over 600 MB of gradients)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue  # untouched tables (an actor no ray hit): state must not decay, as in torch
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)  # host scalar, like torch.optim.Adam(capturable=False)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                ops.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), group["lr"], b1, b2,
+                              group["eps"], group["weight_decay"], 1.0 if grad_scale is None else grad_scale)
+        return loss
