@@ -216,10 +216,11 @@ int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out
 /* ---- optimizer step of a hash table == torch.optim.Adam / AdamW on one fp32 tensor
  * (engine/optimizers.py:168-181; hashgrids group: lr 1e-2, eps 1e-15, configs/method_configs.py:423-426).  In place on
  * param / exp_avg / exp_avg_sq [n], 16-byte aligned; step = 1 for the first update; weight_decay is decoupled (AdamW),
- * 0 = plain Adam; grad_scale multiplies the gradient first (1 = off).  Rows with grad = exp_avg = exp_avg_sq = 0 are
+ * 0 = plain Adam; grad_scale multiplies the gradient first (1 = off).  Hyper-parameters are doubles: torch derives 1 - beta,
+ * lr / (1 - beta1^t) ... from Python floats and rounds once (1.f - 0.999f would be 1.3e-5 off).  Rows with grad = exp_avg = exp_avg_sq = 0 are
  * skipped: their update is exactly zero. */
-int nrhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int nrhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
 /* Processing order for cache locality (fills nrhip_rays.order): a permutation that groups rays looking at the same
  * region -- counting sort by the Morton code of the contracted position (ScaledSceneContraction, static_scale as in

@@ -93,7 +93,7 @@ PROTOTYPES = {
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_render_fwd_ex": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, F32, P],
     "nrhip_ray_order": [P, P, I64, F32, F32, I32, P, P],
-    "nrhip_adam_step": [P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P],
+    "nrhip_adam_step": [P, P, P, P, I64, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],

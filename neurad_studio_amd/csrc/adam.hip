@@ -17,7 +17,8 @@ namespace nrhip {
 
 struct AdamArgs {
   float step_size;     // lr / (1 - b1^t)
-  float b1, b2;
+  float b2;
+  float omb1, omb2;    // 1 - b1, 1 - b2 rounded from double like torch's Python scalars (1.f - 0.999f is 1.3e-5 off)
   float inv_bc2_sqrt;  // 1 / sqrt(1 - b2^t)
   float eps;
   float decay;         // 1 - lr * weight_decay (decoupled), 1 = off
@@ -26,8 +27,8 @@ struct AdamArgs {
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
   g *= a.grad_scale;
-  m = fmaf(g - m, 1.f - a.b1, m);
-  v = fmaf(a.b2, v, (1.f - a.b2) * g * g);
+  m = fmaf(g - m, a.omb1, m);
+  v = fmaf(a.b2, v, a.omb2 * g * g);
   const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
   p = p * a.decay - a.step_size * (m / denom);
 }
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 using namespace nrhip;
 
 extern "C" int nrhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
-                               float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                               double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
                                void* stream) {
   NR_REQUIRE(n >= 0 && step >= 1, NRHIP_ERR_INVALID_ARG, "adam_step: n >= 0 and step >= 1 required");
   if (n == 0) return NRHIP_OK;
@@ -71,16 +72,19 @@ extern "C" int nrhip_adam_step(float* param, const float* grad, float* exp_avg, 
   NR_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
              NRHIP_ERR_INVALID_ARG, "adam_step: tensors must be 16-byte aligned");
-  NR_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, NRHIP_ERR_INVALID_ARG,
+  NR_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., NRHIP_ERR_INVALID_ARG,
              "adam_step: bad hyper-parameter");
+  // hyper-parameters arrive as doubles and every derived scalar is formed in double, then rounded once -- exactly what
+  // torch does with its Python floats
   AdamArgs a;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.step_size = (float)((double)lr / bc1);
-  a.b1 = beta1, a.b2 = beta2;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  a.step_size = (float)(lr / bc1);
+  a.b2 = (float)beta2;
+  a.omb1 = (float)(1.0 - beta1), a.omb2 = (float)(1.0 - beta2);
   a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  a.eps = eps;
-  a.decay = 1.f - lr * weight_decay;
-  a.grad_scale = grad_scale;
+  a.eps = (float)eps;
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.grad_scale = (float)grad_scale;
   int64_t blocks = ((n >> 2) + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride: 16 workgroups per CU
