@@ -213,6 +213,45 @@ int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_fe
 int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
                         float* out_acc, float* out_weights, float early_stop_eps, void* stream);
 
+/* ---- ray generation on the device (the step before the path) -------------------------------------
+ * Sensor tables are device arrays indexed by camera / lidar; one call turns R (sensor index, pixel | point) pairs into
+ * the per-ray part of a RayBundle.  Outputs: origins [R,3], directions [R,3] (unit), pixel_area [R], times [R]. */
+typedef struct {
+  const float* camera_to_worlds;     /* [C,3,4] row major (Cameras.camera_to_worlds) */
+  const float* fx; const float* fy;  /* [C] */
+  const float* cx; const float* cy;  /* [C] */
+  const float* times;                /* [C] or NULL */
+  int32_t rolling_shutter;           /* 0 none; 1 rows (PandaSet, top to bottom); 2 columns; 3 columns reversed
+                                        (metadata["rs_direction"], cameras.py:941-953) */
+  const float* rolling_shutter_time; /* [C] metadata["rolling_shutter_time"]   (NULL when rolling_shutter == 0) */
+  const float* time_to_center_pixel; /* [C] metadata["time_to_center_pixel"] */
+  const float* velocities;           /* [C,3] metadata["velocities"] */
+  const float* shutter_extent;       /* [C] image height (mode 1) or width (modes 2, 3) as float */
+} nrhip_camera_table;
+/* == Cameras._generate_rays_from_coords (cameras.py:560-968) for PERSPECTIVE cameras without lens distortion (the
+ * caller checks camera_type / distortion_params and keeps the reference's generator for anything else).  coords [R,2]
+ * = (y, x) pixel-centre coordinates as in Cameras.get_image_coords.  directions_norm [R] = the pre-normalisation norm
+ * (metadata["directions_norm"]).  times may be NULL when the table has no times. */
+int nrhip_camera_rays(const nrhip_camera_table* cams, const int64_t* camera_indices /*[R]*/, const float* coords /*[R,2]*/,
+                      int64_t n_rays, float* origins, float* directions, float* pixel_area, float* directions_norm,
+                      float* times, void* stream);
+
+typedef struct {
+  const float* lidar_to_worlds;             /* [Ln,3,4] */
+  const float* times;                       /* [Ln] or NULL */
+  const float* velocities;                  /* [Ln,3] metadata["velocities"] or NULL */
+  const float* horizontal_beam_divergence;  /* [Ln] */
+  const float* vertical_beam_divergence;    /* [Ln] */
+  int32_t assume_ego_compensated;           /* Lidars.assume_ego_compensated */
+  float valid_lidar_distance_threshold;     /* did_return = distance < threshold (lidars.py:447) */
+} nrhip_lidar_table;
+/* == Lidars._generate_rays_from_points (lidars.py:399-460).  points [R,point_dim]: xyz in the lidar frame, intensity,
+ * time offset within the sweep (point_dim >= 5 for the motion / time terms).  distance [R] = range of the point
+ * (metadata["directions_norm"]), did_return [R] uint8. */
+int nrhip_lidar_rays(const nrhip_lidar_table* lidars, const int64_t* lidar_indices /*[R]*/, const float* points,
+                     int32_t point_dim, int64_t n_rays, float* origins, float* directions, float* pixel_area,
+                     float* distance, uint8_t* did_return, float* times, void* stream);
+
 /* ---- optimizer step of a hash table == torch.optim.Adam / AdamW on one fp32 tensor
  * (engine/optimizers.py:168-181; hashgrids group: lr 1e-2, eps 1e-15, configs/method_configs.py:423-426).  In place on
  * param / exp_avg / exp_avg_sq [n], 16-byte aligned; step = 1 for the first update; weight_decay is decoupled (AdamW),

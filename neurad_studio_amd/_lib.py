@@ -58,6 +58,19 @@ class OccGrid(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
 
 
+class CameraTable(C.Structure):
+    _fields_ = [("camera_to_worlds", C.c_void_p), ("fx", C.c_void_p), ("fy", C.c_void_p), ("cx", C.c_void_p),
+                ("cy", C.c_void_p), ("times", C.c_void_p), ("rolling_shutter", C.c_int32),
+                ("rolling_shutter_time", C.c_void_p), ("time_to_center_pixel", C.c_void_p), ("velocities", C.c_void_p),
+                ("shutter_extent", C.c_void_p)]
+
+
+class LidarTable(C.Structure):
+    _fields_ = [("lidar_to_worlds", C.c_void_p), ("times", C.c_void_p), ("velocities", C.c_void_p),
+                ("horizontal_beam_divergence", C.c_void_p), ("vertical_beam_divergence", C.c_void_p),
+                ("assume_ego_compensated", C.c_int32), ("valid_lidar_distance_threshold", C.c_float)]
+
+
 MAX_SAMPLE_CONTAINMENTS = 8  # NRHIP_MAX_SAMPLE_CONTAINMENTS
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -93,6 +106,8 @@ PROTOTYPES = {
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_render_fwd_ex": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, F32, P],
     "nrhip_ray_order": [P, P, I64, F32, F32, I32, P, P],
+    "nrhip_camera_rays": [C.POINTER(CameraTable), P, P, I64, P, P, P, P, P, P],
+    "nrhip_lidar_rays": [C.POINTER(LidarTable), P, P, I32, I64, P, P, P, P, P, P, P],
     "nrhip_adam_step": [P, P, P, P, I64, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
