@@ -19,7 +19,11 @@ class HashGridAdam(torch.optim.Optimizer):
                  weight_decay: float = 0.0, decoupled_weight_decay: bool = True) -> None:
         if weight_decay and not decoupled_weight_decay:
             raise NotImplementedError("L2-in-gradient weight decay; use decoupled (AdamW) decay or 0")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # the remaining keys are torch.optim.Adam's own group entries, carried so that a state_dict saved here loads into
+        # torch.optim.Adam / AdamW with the same meaning (and the other way round)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=bool(weight_decay)))
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: Optional[float] = None):
@@ -30,6 +34,8 @@ class HashGridAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize") or (group["weight_decay"] and not group.get("decoupled_weight_decay", True)):
+                raise NotImplementedError("HashGridAdam: amsgrad / maximize / L2-in-gradient weight decay")
             b1, b2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
@@ -39,7 +45,7 @@ class HashGridAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)  # host scalar, like torch.optim.Adam(capturable=False)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                st["step"] = st["step"] + 1  # (a new tensor: a state_dict loaded from a live optimizer shares this scalar)
                 ops.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), group["lr"], b1, b2,
                               group["eps"], group["weight_decay"], 1.0 if grad_scale is None else grad_scale)
         return loss

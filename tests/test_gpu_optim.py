@@ -36,14 +36,16 @@ def test_hashgrid_adam_matches_torch_adam(wd):
     # state_dict interchange: torch's state continues in ours and the other way round
     c = torch.nn.Parameter(b.detach().clone())
     cont = HashGridAdam([c], lr=1e-2, eps=1e-15, weight_decay=wd)
-    cont.load_state_dict(ref.state_dict())
+    import copy
+
+    cont.load_state_dict(copy.deepcopy(ref.state_dict()))  # (a live state_dict shares its step scalar with its owner)
     g = torch.randn_like(p0)
     b.grad, c.grad = g.clone(), g.clone()
     ref.step(), cont.step()
     assert torch.allclose(c, b, rtol=2e-6, atol=3e-8)
     d = torch.nn.Parameter(a.detach().clone())
     back = (torch.optim.AdamW([d], lr=1e-2, eps=1e-15, weight_decay=wd) if wd else torch.optim.Adam([d], lr=1e-2, eps=1e-15))
-    back.load_state_dict(ours.state_dict())
+    back.load_state_dict(copy.deepcopy(ours.state_dict()))
     a.grad, d.grad = g.clone(), g.clone()
     ours.step(), back.step()
     assert torch.allclose(a, d, rtol=2e-6, atol=3e-8)

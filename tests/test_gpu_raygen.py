@@ -63,7 +63,7 @@ def test_lidar_rays_vs_reference(ego):
     assert rel_l2(host(rb.pixel_area), g[f"lid_{tag}_pixel_area"]) < 1e-6
     assert rel_l2(host(rb.metadata["directions_norm"]), g[f"lid_{tag}_distance"]) < 1e-6
     np.testing.assert_array_equal(host(rb.metadata["did_return"]), g[f"lid_{tag}_did_return"])
-    assert not bool(rb.metadata["did_return"][:5].any()) and bool(rb.metadata["is_lidar"].all())
+    assert not bool(rb.metadata["did_return"].all()) and bool(rb.metadata["is_lidar"].all())
     assert np.abs(host(rb.times) - g[f"lid_{tag}_times"]).max() < 1e-6
     # the generated bundle drives the hot path as is
     from neurad_studio_amd import ops
