@@ -197,7 +197,38 @@ def proposal_with_actors():
     save("proposal_actors", **gold)
 
 
+def cnn_decoder():
+    """the reference's rgb_decoder (models/neurad.py:198-216) on two 8x8 feature patches, training (batch-statistics BN)
+    and eval mode"""
+    ref_neurad.VGGPerceptualLossPix2Pix = torch.nn.Identity
+    cfg = ref_neurad.NeuRADModelConfig(implementation="torch")
+    cfg.field.grid.static.log2_hashmap_size = 8
+    for c in (cfg.field, cfg.sampling.proposal_field_1, cfg.sampling.proposal_field_2):
+        c.grid.actor.use_4d_hashgrid = False
+        c.grid.static.log2_hashmap_size = 8
+    m = cfg.setup(scene_box=SceneBox(aabb=torch.tensor([[-100.0] * 3, [100.0] * 3])), num_train_data=2,
+                  metadata={"duration": 8.0, "sensor_idx_to_name": {0: "cam0"}, "trajectories": []})
+    dec = m.rgb_decoder
+    for k, (name, p) in enumerate(dec.named_parameters()):
+        fan_in = p[0].numel() if p.dim() > 1 else 1
+        p.data = T((synth.normal(tuple(p.shape), 600 + k) * (1.0 / np.sqrt(fan_in) if p.dim() > 1 else 0.1)).astype(np.float32))
+        if name.endswith(("1.weight", "4.weight")) and p.dim() == 1:  # BatchNorm scale around 1
+            p.data = p.data + 1.0
+    feats = T(synth.normal((2 * 8 * 8, 48), 650))
+    gold = {"features": feats}
+    dec.train()
+    rgb, _, _ = m.decode_features(feats, patch_size=(8, 8))
+    gold["rgb_train"] = rgb
+    gold["bn_running_mean"] = dec[2].main_branch[1].running_mean
+    dec.eval()
+    rgb, _, _ = m.decode_features(feats, patch_size=(8, 8))
+    gold["rgb_eval"] = rgb
+    gold["param_names"] = np.array([n for n, _ in dec.named_parameters()])  # weights are re-derived from tests/synth.py
+    save("cnn_decoder", **gold)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    cnn_decoder()
     proposal_with_actors()
     model_glue()
