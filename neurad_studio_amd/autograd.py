@@ -20,7 +20,7 @@ class HashGridFn(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, table, spec):
-        ctx.spec = spec
+        ctx.spec, ctx.table_dtype = spec, table.dtype
         ctx.save_for_backward(x, table)
         return ops.hashgrid_fwd(spec, table, x)
 
@@ -31,7 +31,7 @@ class HashGridFn(torch.autograd.Function):
         g = g.contiguous()
         gt = ops.hashgrid_bwd(ctx.spec, None, x, g) if ctx.needs_input_grad[1] else None
         gx = ops.hashgrid_bwd_input(ctx.spec, table, x, g) if ctx.needs_input_grad[0] else None  # actor poses only
-        return gx, gt, None
+        return gx, _like_param(gt, ctx.table_dtype), None
 
 
 class MultiHashGridFn(torch.autograd.Function):
@@ -64,7 +64,7 @@ class EncodeFn(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, table, spec, static_scale, origins, directions, pixel_area, starts, ends):
-        ctx.spec, ctx.scale = spec, static_scale
+        ctx.spec, ctx.scale, ctx.table_dtype = spec, static_scale, table.dtype
         ctx.save_for_backward(origins, directions, pixel_area, starts, ends)
         return ops.encode_fwd(spec, table, static_scale, origins, directions, pixel_area, starts, ends)
 
@@ -73,7 +73,7 @@ class EncodeFn(torch.autograd.Function):
     def backward(ctx, g):
         o, d, a, s, e = ctx.saved_tensors
         gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, g.contiguous())
-        return gt, None, None, None, None, None, None, None
+        return _like_param(gt, ctx.table_dtype), None, None, None, None, None, None, None
 
 
 class FieldTrainFn(torch.autograd.Function):
@@ -92,7 +92,7 @@ class FieldTrainFn(torch.autograd.Function):
         fs = ops.FieldSpec(spec, table, static_scale, gw, gb, fw, fb, use_sdf=use_sdf, beta=beta)
         (feature, geo_out, _head), (enc, hg, xf, hf) = ops.field_fwd_train(fs, origins, directions, pixel_area, starts, ends,
                                                                            order=order)
-        ctx.has_order = order is not None
+        ctx.has_order, ctx.table_dtype = order is not None, table.dtype
         ctx.spec, ctx.scale = spec, static_scale
         ctx.save_for_backward(origins, directions, pixel_area, starts, ends, enc, hg, xf, hf, *params)
         return feature, geo_out[:, None]
@@ -109,7 +109,8 @@ class FieldTrainFn(torch.autograd.Function):
         g_geo[:, 0] = g_geo_out.reshape(-1)
         torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
         genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
-        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc) if ctx.needs_input_grad[0] else None
+        gt = _like_param(ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc), ctx.table_dtype) \
+            if ctx.needs_input_grad[0] else None
         grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
         return (gt, None, None, None, None, None, None, None, None, None, *grads, *([None] if ctx.has_order else []))
 
@@ -141,6 +142,12 @@ class MLPFn(torch.autograd.Function):
         for k in range(n):
             out += [gws[k], gbs[k]]
         return tuple(out)
+
+
+def _like_param(grad, dtype):
+    """table gradients are accumulated in fp32 by the kernels; autograd wants the parameter's dtype (fp16-storage tables,
+    BASELINE config 5: the optimizer keeps what precision it needs, see optim.HashGridAdam)"""
+    return grad if grad is None or grad.dtype == dtype else grad.to(dtype)
 
 
 def mlp(x, weights, biases):

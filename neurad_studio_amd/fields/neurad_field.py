@@ -200,9 +200,8 @@ class NeuRADField(nn.Module):
         return out
 
     def _fused_train_ok(self) -> bool:
-        """The fused training forward needs an fp32 table, biases on every layer and fp32 parameters."""
-        if self.hashgrid.static_grid.hash_table.dtype != torch.float32:
-            return False
+        """The fused training forward needs biases on every layer (fp32 or fp16-storage table: the kernel reads either,
+        the table gradient is formed in fp32 and handed to autograd in the table's dtype)."""
         return all(l.bias is not None for l in list(self.mlp_geo.layers) + list(self.mlp_feature.layers))
 
 

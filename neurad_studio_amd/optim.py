@@ -46,6 +46,16 @@ class HashGridAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = st["step"] + 1  # (a new tensor: a state_dict loaded from a live optimizer shares this scalar)
-                ops.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), group["lr"], b1, b2,
+                target, grad = p, p.grad
+                if p.dtype != torch.float32:
+                    # fp16-storage table (BASELINE config 5): the update runs on an fp32 master copy kept in the
+                    # optimizer state (what tiny-cuda-nn does for its fp16 parameters); the table is its rounded image
+                    if "master" not in st:
+                        st["master"] = p.detach().float()
+                        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].float(), st["exp_avg_sq"].float()
+                    target, grad = st["master"], p.grad.float()
+                ops.adam_step(target, grad, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), group["lr"], b1, b2,
                               group["eps"], group["weight_decay"], 1.0 if grad_scale is None else grad_scale)
+                if target is not p:
+                    p.copy_(target)
         return loss

@@ -62,3 +62,50 @@ def test_hashgrid_adam_skips_parameters_without_gradient_and_scales():
     assert b.grad is None and not opt.state[b] and torch.equal(b, torch.ones_like(b))
     assert torch.allclose(a, torch.full_like(a, 0.9), atol=1e-6)  # first Adam step moves by lr * sign(g)
     assert torch.allclose(opt.state[a]["exp_avg"], torch.full_like(a, 0.1), atol=1e-7)  # (1 - b1) * unscaled g = 0.1
+
+
+def test_fp16_storage_table_trains_through_the_fused_field_and_master_weights():
+    """BASELINE config 5's fp16 hash table under autograd: the fused training forward reads the half table, the table
+    gradient is formed in fp32 and arrives in the table's dtype, HashGridAdam updates an fp32 master copy."""
+    import synth
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.field_components.field_heads import FieldHeadNames
+    from neurad_studio_amd.fields.neurad_field import NeuRADField, NeuRADFieldConfig
+    from neurad_studio_amd.model_components.ray_samplers import PowerSampler
+    from neurad_studio_amd.optim import HashGridAdam
+
+    def make(dtype):
+        torch.manual_seed(0)
+        cfg = NeuRADFieldConfig()
+        cfg.grid.static.log2_hashmap_size = 12
+        f = NeuRADField(cfg, actors=None, static_scale=100.0).cuda().train()
+        with torch.no_grad():
+            f.hashgrid.static_grid.hash_table.mul_(500.0)
+        f.hashgrid.static_grid.hash_table.data = f.hashgrid.static_grid.hash_table.data.half().to(dtype)  # same rounded values
+        return f
+
+    R, S = 2048, 32
+    o, d, area, _ = synth.rays(R, 5)
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    rb = RayBundle(origins=dev(o), directions=dev(d), pixel_area=dev(area)[:, None], nears=torch.zeros(R, 1, device="cuda"),
+                   fars=torch.full((R, 1), 200.0, device="cuda"))
+    rs = PowerSampler(num_samples=S, lambda_=-1.0, scaling=0.1).cuda().eval()(rb)
+    outs = {}
+    for dtype in (torch.float32, torch.float16):
+        f = make(dtype)
+        out = f(rs)
+        (out[FieldHeadNames.FEATURE].square().mean() + out[FieldHeadNames.ALPHA].mean()).backward()
+        g = f.hashgrid.static_grid.hash_table.grad
+        assert g.dtype == dtype
+        outs[dtype] = (out[FieldHeadNames.FEATURE].detach(), g.float(), f)
+    assert torch.equal(outs[torch.float16][0], outs[torch.float32][0])  # same table values -> same forward, bit for bit
+    g32, g16 = outs[torch.float32][1], outs[torch.float16][1]
+    assert float((g16 - g32).norm() / g32.norm()) < 2e-3  # fp16 rounding of the gradient only
+    f = outs[torch.float16][2]
+    table = f.hashgrid.static_grid.hash_table
+    before = table.detach().clone()
+    opt = HashGridAdam([table], lr=1e-2)
+    opt.step()
+    st = opt.state[table]
+    assert st["master"].dtype == torch.float32 and table.dtype == torch.float16
+    assert torch.equal(table, st["master"].half()) and float((table.float() - before.float()).abs().max()) > 1e-3
