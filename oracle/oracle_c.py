@@ -89,5 +89,43 @@ def render_fwd(p, origins, directions, pixel_area, starts, ends, per_sample=Fals
     return out
 
 
+def _grid_field(grid, static_scale, keep):
+    """an NroField of which only the grid members are set (what the proposal chain reads)"""
+    f32 = np.float32
+    keep.append((np.ascontiguousarray(grid.table, f32), np.ascontiguousarray(grid.scalings, f32)))
+    f = NroField()
+    f.L, f.F, f.log2T = grid.num_levels, grid.n_feat, grid.log2_hashmap_size
+    f.table, f.scalings, f.static_scale = _p(keep[-1][0]), _p(keep[-1][1]), static_scale
+    return f
+
+
+def proposal_sampler(props, origins, directions, pixel_area, nears, fars, num_proposal_samples=(128, 64),
+                     num_nerf_samples=32, lam=-1.0, scaling=0.1, sky_distance=20000.0, late_binding_quirk=True,
+                     stretch_sky=True):
+    """Eval-mode chain; same arguments and outputs (starts, ends, prop_weights, prop_starts, prop_ends) as
+    neurad_oracle.proposal_sampler.  props: neurad_oracle.ProposalParams."""
+    f32 = np.float32
+    n = len(num_proposal_samples)
+    keep = []
+    used = [props[-1] if late_binding_quirk else props[i] for i in range(n)]
+    fields = [_grid_field(p.grid, p.static_scale, keep) for p in used]
+    decs = [np.ascontiguousarray(p.decoder_w, f32).reshape(-1) for p in used]
+    o, d, a = (np.ascontiguousarray(v, f32) for v in (origins, directions, pixel_area))
+    R = o.shape[0]
+    nr, fr = (np.ascontiguousarray(np.broadcast_to(np.asarray(v, f32).reshape(-1), (R,))) for v in (nears, fars))
+    starts, ends = np.empty((R, num_nerf_samples), f32), np.empty((R, num_nerf_samples), f32)
+    pw = [np.empty((R, k), f32) for k in num_proposal_samples]
+    pe = [np.empty((R, k + 1), f32) for k in num_proposal_samples]
+    FieldPtr = C.POINTER(NroField)
+    rc = lib().nro_proposal_sampler((FieldPtr * n)(*[C.pointer(f) for f in fields]), (FP * n)(*[_p(x) for x in decs]), n,
+                                    (C.c_int * n)(*num_proposal_samples), num_nerf_samples, C.c_int64(R), _p(o), _p(d),
+                                    _p(a.reshape(-1)), _p(nr), _p(fr), C.c_float(lam), C.c_float(scaling),
+                                    C.c_float(sky_distance), int(stretch_sky), _p(starts), _p(ends),
+                                    (FP * n)(*[_p(x) for x in pw]), (FP * n)(*[_p(x) for x in pe]))
+    assert rc == 0, "unsupported configuration for the C oracle"
+    return {"starts": starts, "ends": ends, "prop_weights": pw, "prop_starts": [e[:, :-1] for e in pe],
+            "prop_ends": [e[:, 1:] for e in pe]}
+
+
 def num_threads() -> int:
     return lib().nro_num_threads()

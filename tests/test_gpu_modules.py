@@ -253,3 +253,41 @@ def test_full_size_neurad_default_chain_properties():
     out2 = m.get_nff_outputs(bundle(o[sl], d[sl], area[sl] / 9))
     for k in ("features", "accumulation", "depth"):
         assert rel_l2(host(out2[k]), host(out[k][sl])) < 5e-5, k
+
+
+def test_full_size_neurad_default_chain_vs_c_oracle():
+    """BASELINE config[2]/[3] at FULL size (static 8 x 2^22 x 4, proposals 6 x 2^20, 8192 rays, (128, 64) -> 32) against
+    the independent C restatement of the whole chain (oracle/neurad_oracle_c.c: S1-S5 + M1 + H1-H4 + F1-F4 + C1/C2,
+    pinned to the numpy oracle -- and through it to the reference's goldens -- by tests/test_oracle_c.py)."""
+    import oracle_c
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    torch.manual_seed(0)
+    m = NeuRADHotPath(NeuRADHotPathConfig(appearance_dim=0), static_scale=100.0).cuda().eval()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(300.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(1000.0)
+    R = 8192
+    o, d, area, _ = synth.rays(R, 21)
+    with torch.no_grad():
+        out = m.get_nff_outputs(bundle(o, d, area / 9))
+        rs, wl, _ = m.sampler.generate_fused(bundle(o, d, area), [m.proposal_fields[1]] * 2)
+    props = [O.ProposalParams(O.GridParams(host(p.hashgrid.static_grid.hash_table), 6, 128, 4096, 20), 100.0,
+                              host(p.density_decoder.weight)) for p in m.proposal_fields]
+    so = oracle_c.proposal_sampler(props, o, d, area, np.zeros(R, np.float32), np.full(R, 20000.0, np.float32))
+    for i in range(2):
+        assert rel_l2(host(wl[i][..., 0]), so["prop_weights"][i]) < TOL, i
+    # final bins: inverse-CDF sampling is continuous but ill-conditioned where the CDF is flat -> robust comparison
+    for k, got in (("starts", host(rs.frustums.starts[..., 0])), ("ends", host(rs.frustums.ends[..., 0]))):
+        got, want = got[:, :-1], so[k][:, :-1]  # (the last end is the sky stretch, applied by the model, not the sampler)
+        bad = np.abs(got - want) > 2e-4 * np.abs(want) + 2e-5
+        assert bad.mean() < 1e-3, (k, bad.mean())
+    f = m.field
+    fp = O.FieldParams(O.GridParams(host(f.hashgrid.static_grid.hash_table), 8, 32, 8192, 22), 100.0,
+                       [host(l.weight) for l in f.mlp_geo.layers], [host(l.bias) for l in f.mlp_geo.layers],
+                       [host(l.weight) for l in f.mlp_feature.layers], [host(l.bias) for l in f.mlp_feature.layers],
+                       beta=float(f.sdf_to_density.beta), use_sdf=True)
+    ref = oracle_c.render_fwd(fp, o, d, area, so["starts"], so["ends"])
+    for k in ("features", "accumulation", "depth"):
+        assert rel_l2(host(out[k]), ref[k]) < TOL, k

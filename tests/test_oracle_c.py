@@ -36,3 +36,24 @@ def test_c_oracle_matches_numpy_oracle(cfg):
     assert rel_l2(got["accumulation"], ref["accumulation"]) < 1e-5
     assert rel_l2(got["depth"], ref["depth"]) < 1e-5 or np.abs(got["depth"] - ref["depth"]).max() < 1e-5
     assert oracle_c.num_threads() >= 1
+
+
+@pytest.mark.parametrize("quirk", [True, False])
+def test_c_proposal_sampler_chain_matches_numpy_oracle(quirk):
+    """S1-S5 + M1 in C (what the full-size config-3 GPU parity test checks against) == the numpy oracle's chain,
+    which tests/test_oracle_golden.py pins to the reference's own sampler outputs."""
+    R = 96
+    # table scale 0.3 -> densities O(1): well conditioned.  (With saturated densities exp(-cumsum) amplifies the 1-ulp
+    # powf differences in the bin edges to 1e-4 in the weights, in ANY two implementations.)
+    props = [O.ProposalParams(O.GridParams(synth.hash_table(6 * 2**11, 1, seed=70 + i, scale=0.3), 6, 128, 4096, 11), 100.0,
+                              synth.normal((1, 6), 80 + i)) for i in range(2)]
+    o, d, area, _ = synth.rays(R, 13)
+    nears, fars = np.zeros(R, np.float32), np.full(R, 1e9, np.float32)  # far beyond the sky distance: clamped
+    ref = O.proposal_sampler(props, o, d, area, nears, fars, late_binding_quirk=quirk)
+    got = oracle_c.proposal_sampler(props, o, d, area, nears, fars, late_binding_quirk=quirk)
+    for i in range(2):
+        assert np.allclose(got["prop_starts"][i], ref.prop_starts[i], rtol=2e-5, atol=1e-5)
+        assert rel_l2(got["prop_weights"][i], ref.prop_weights[i]) < 5e-5
+    for k, r in (("starts", ref.starts), ("ends", ref.ends)):
+        assert np.allclose(got[k], r, rtol=1e-4, atol=1e-5), k
+    assert np.all(got["ends"][:, -1] == np.float32(20000.0))
