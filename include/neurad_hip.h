@@ -355,6 +355,20 @@ int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int
                         float* density /*[R,S] overwritten where hit*/, int32_t* hit /*actor index or -1*/, const float* ray_flip,
                         void* stream);
 
+/* F1+C1+C2 with dynamic actors in ONE kernel (eval): nrhip_render_fwd_ex where a sample inside an actor's box reads
+ * that actor's grid at its box-frame position and uses the box-frame view direction -- NeuRADHashEncoding.forward
+ * (field_components/neurad_encoding.py:150-187, 203-208) + NeuRADField.forward (fields/neurad_field.py:128-152) +
+ * compositing (models/neurad.py:373-395).  cand_*: the per-ray candidate lists of nrhip_actor_prepare (row length
+ * a->max_candidates).  NRHIP_ERR_UNSUPPORTED unless both grids are fp32, the actor grid has the static grid's
+ * features per level and at most its number of levels (the reference's defaults: static 8x4, actors 4x4).
+ * Three launches, no host round trip: a device-side split of the processing order into rays without / with candidate
+ * actors, the plain static kernel over the first slice, the actor-aware instantiation over the second.
+ * workspace: device scratch of (n_rays + 4) int32.                                                                  */
+int nrhip_render_fwd_actors(const nrhip_field* f, const nrhip_actors* a, const nrhip_rays* rays,
+                            const int32_t* cand_count, const int32_t* cand_actor, const float* cand_w2b,
+                            float* out_features, float* out_depth, float* out_acc, float* out_weights /*or NULL*/,
+                            float early_stop_eps, int32_t* workspace, void* stream);
+
 /* ---- S6: occupancy-grid ray march (VolumetricSampler.forward -> nerfacc OccGridEstimator.sampling,
  *      model_components/ray_samplers.py:483-566).  nerfacc is un-vendored and nothing in neurad-studio instantiates
  *      VolumetricSampler: the marching rule is this library's own statement (csrc/occgrid.hip header), parity

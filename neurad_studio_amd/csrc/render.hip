@@ -31,6 +31,11 @@
 //     copies of their lines in all eight.  `rays.order` (optional permutation) supplies that order without moving data.
 //   * EARLY RAY TERMINATION (eval option, off by default = exact): a ray stops once the transmittance entering a tile
 //     is below `stop_eps`; what is skipped weighs less than stop_eps in total.
+//   * DYNAMIC ACTORS (ACT instantiations, eval): a sample inside an actor's box reads THAT actor's hash grid at its
+//     box-frame position instead of the static grid (neurad_encoding.py:150-187: per-sample table select, highest actor
+//     index wins, features zero-padded to 32) and feeds its box-frame direction to the SH encoding.  The ray's candidate
+//     list (nrhip_actor_prepare) is walked with scalar loads -- empty for most rays -- and only tiles that contain a hit
+//     replace the per-ray SH bias row by four extra k-steps with per-sample SH values.
 // The sky residual (models/neurad.py:381: w_{S-1} += 1 - sum w) is folded into the last tile -- the accumulated weight is
 // complete there, so no copy of the last sample's features has to be kept.
 #include "common.h"
@@ -79,6 +84,20 @@ struct Lds {
   static constexpr int SCAL = BF2 + 32;    // per-level scalings
   static constexpr int RB = SCAL + NRHIP_MAX_LEVELS;  // per wave: this ray's bias of feat L0 (fb0 + SH part), 4 x H
   static constexpr int TOTAL = RB + 4 * H;
+  // ACT instantiations only:
+  static constexpr int SHF = TOTAL;             // feat L0 SH part in fragment order: NB blocks x 4 steps
+  static constexpr int ASCAL = SHF + 16 * H;    // actor grid: per-level scalings
+  static constexpr int TOTAL_ACT = ASCAL + NRHIP_MAX_LEVELS;
+};
+
+// Fused-kernel view of the dynamic actors.  The arrays that are read at wave-uniform addresses are separate
+// `const __restrict__` kernel arguments (scalar loads); this struct carries the scalars.
+struct ActorFieldDev {
+  int K;        // row length of the candidate lists
+  int La;       // actor grid levels (<= L; same features per level as the static grid)
+  int log2T;    // actor table rows per level
+  float scale;  // actor_scale of the actor-frame contraction
+  float scal[NRHIP_MAX_LEVELS];  // actor grid scalings
 };
 
 // Weight staging.  W[row_off + 16mb + i][col(g,s)] goes to fragment order [mb][s4][lane][s3]; CHAIN: col =
@@ -175,6 +194,8 @@ struct TileFetch {
                         // them at blend time (3 VALU per level and axis) instead of holding 4*LPL more registers
   float t0, t1;
 };
+// An ACT tile carries, next to its fetch, one register: the slot (in the ray's candidate list) of the actor whose box
+// contains the lane's sample, -1 = static scene.
 
 // Range of the processing order one wave walks.  The ray-side pointers are separate `const __restrict__` kernel
 // arguments: the per-ray constants are read at wave-uniform addresses, and only noalias/readonly arguments let the
@@ -193,12 +214,14 @@ struct PendingTile {
   bool valid;
   float t0, t1;
   float ox, oy, oz, dx, dy, dz, area;
+  int ncand;  // ACT: number of candidate actors of the ray (wave-uniform)
 };
 
 __device__ __forceinline__ void load_pending(PendingTile& p, int64_t pos, int t, const RayRange& rr, int j,
                                              const int32_t* __restrict__ order, const float* __restrict__ ro,
                                              const float* __restrict__ rd, const float* __restrict__ rarea,
-                                             const float* __restrict__ rstarts, const float* __restrict__ rends) {
+                                             const float* __restrict__ rstarts, const float* __restrict__ rends,
+                                             const int32_t* __restrict__ cand_count = nullptr) {
   // Past the end of this wave's range the loads still go out (clamped to the last position, tile 0) and their gathers
   // are issued and dropped: an `if (valid)` around them makes every fetched register a phi at the join, and the copies
   // the compiler puts there wait for ALL gathers before the MFMA phase -- exactly the stall the pipeline removes.
@@ -213,6 +236,7 @@ __device__ __forceinline__ void load_pending(PendingTile& p, int64_t pos, int t,
   p.ox = ro[3 * ray], p.oy = ro[3 * ray + 1], p.oz = ro[3 * ray + 2];
   p.dx = rd[3 * ray], p.dy = rd[3 * ray + 1], p.dz = rd[3 * ray + 2];
   p.area = rarea[ray];
+  p.ncand = cand_count ? cand_count[ray] : 0;
 }
 
 // H2 + H3 + the hash of H1 for one pending tile, then all gathers issued back to back (no waits in here beyond the
@@ -234,6 +258,126 @@ __device__ __forceinline__ void issue_tile(const FieldDev& fd, const PendingTile
   }
 }
 
+// ACT: (1) the ray's candidate actors are walked -- a wave-uniform loop over scalar loads, empty for most rays -- and
+// every lane notes the LAST candidate whose box contains its sample (ascending actor index: the highest wins,
+// neurad_encoding.py:184-185 on CPU); (2) the static gathers go out for every lane exactly as above; (3) in the rare tile
+// with a hit, the lanes inside a box re-issue their gathers against that actor's table, one wave-uniform pass per
+// distinct winner, so the table base stays in SGPRs and the loads keep the SGPR-base + 32-bit-offset form.  Vector loads
+// return in order: the later (actor) data is what the registers end up holding.  Nothing of (1)/(3) is live across the
+// gathers on the common path except one register (the winning slot).
+template <int L, int F>
+__device__ __forceinline__ void issue_tile_actors(const FieldDev& fd, const ActorFieldDev& ad, const PendingTile& pt, int g,
+                                                  uint32_t mask, const float* scal_lds, const float* ascal_lds,
+                                                  const int32_t* __restrict__ cand_actor,
+                                                  const float* __restrict__ cand_w2b, const float* __restrict__ bounds,
+                                                  const void* const* __restrict__ tables, TileFetch<L / 4, F>& tf,
+                                                  int& slot_out) {
+  constexpr int LPL = L / 4;
+  const int n = __builtin_amdgcn_readfirstlane(pt.ncand);
+  // 32-bit row index, made scalar explicitly: a 64-bit multiply has no scalar form
+  const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)pt.ray * (uint32_t)ad.K));
+  int slot = -1;
+  if (n > 0) {
+    const SamplePos gs = sample_gaussian(pt.ox, pt.oy, pt.oz, pt.dx, pt.dy, pt.dz, pt.area, pt.t0, pt.t1);
+    for (int c = 0; c < n; ++c) {
+      const float* w = cand_w2b + (row + (uint32_t)c) * 12u;
+      const int act = cand_actor[row + (uint32_t)c];
+      const float bx = w[0] * gs.x + w[1] * gs.y + w[2] * gs.z + w[3];
+      const float by = w[4] * gs.x + w[5] * gs.y + w[6] * gs.z + w[7];
+      const float bz = w[8] * gs.x + w[9] * gs.y + w[10] * gs.z + w[11];
+      if (fabsf(bx) < bounds[3 * act] && fabsf(by) < bounds[3 * act + 1] && fabsf(bz) < bounds[3 * act + 2]) slot = c;
+    }
+  }
+  slot_out = slot;
+  tf.t0 = pt.t0;
+  tf.t1 = pt.t1;
+  unsigned long long todo = __ballot(slot >= 0);
+  const SamplePos gs = sample_gaussian(pt.ox, pt.oy, pt.oz, pt.dx, pt.dy, pt.dz, pt.area, pt.t0, pt.t1);
+  const uint32_t amask = (1u << ad.log2T) - 1u;
+  while (todo) {  // rare: the lanes inside a box, one pass per distinct winner
+    const int c = __builtin_amdgcn_readlane(slot, (int)__builtin_ctzll(todo));
+    const bool mine = slot == c;
+    todo &= ~__ballot(mine);
+    const float* w = cand_w2b + (row + (uint32_t)c) * 12u;
+    const int act = cand_actor[row + (uint32_t)c];
+    const void* tb = tables[act];  // scalar load: the table base stays in SGPRs
+    if (mine) {
+      const float bx = w[0] * gs.x + w[1] * gs.y + w[2] * gs.z + w[3];
+      const float by = w[4] * gs.x + w[5] * gs.y + w[6] * gs.z + w[7];
+      const float bz = w[8] * gs.x + w[9] * gs.y + w[10] * gs.z + w[11];
+      const SamplePos p = contract_gaussian(bx, by, bz, gs.std, ad.scale);
+      tf.x = p.x, tf.y = p.y, tf.z = p.z, tf.std = p.std;
+#pragma unroll
+      for (int q = 0; q < LPL; ++q) {
+        // levels beyond the actor grid are the zero padding of F.pad (neurad_encoding.py:183): their fetch goes to the
+        // last actor level and is weighted 0 at the blend
+        const int lv = LPL * g + q, alv = lv < ad.La ? lv : ad.La - 1;
+        const Corners cs = hash_corners(p.x, p.y, p.z, ascal_lds[alv], amask);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Entry<F, false>::load(tb, ((uint32_t)alv << ad.log2T) + cs.idx[k], tf.fv[q][k]);
+      }
+    }
+  }
+  // the static scene: the lanes outside every box, i.e. all lanes of nearly every tile.  Issued LAST so that whatever
+  // bookkeeping the compiler attaches to the rare passes above (waits, copies) sits in front of these gathers, where
+  // nothing is in flight, and not between them and the MLPs.
+  if (slot < 0) {
+    const SamplePos p = contract_gaussian(gs.x, gs.y, gs.z, gs.std, fd.scale);
+    tf.x = p.x, tf.y = p.y, tf.z = p.z, tf.std = p.std;
+#pragma unroll
+    for (int q = 0; q < LPL; ++q) {
+      const Corners cs = hash_corners(p.x, p.y, p.z, scal_lds[q], mask);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        Entry<F, false>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs.idx[k], tf.fv[q][k]);
+    }
+  }
+}
+
+// ACT, tile with a hit: a sample inside an actor box sees the view direction in the box frame (neurad_encoding.py:203-208),
+// so the tile takes its SH inputs per sample.  -> this lane's B values of the four extra k-steps of feat layer 0: SH
+// components 4g..4g+3 of its sample's direction.  One wave-uniform pass per distinct winning actor (scalar loads of w2b).
+__device__ __forceinline__ void actor_tile_sh(int slot, uint32_t row, int g, float dx, float dy, float dz,
+                                              const float* __restrict__ cand_w2b, float (&shb)[4]) {
+  float bx = dx, by = dy, bz = dz;
+  unsigned long long todo = __ballot(slot >= 0);
+  while (todo) {
+    const int c = __builtin_amdgcn_readlane(slot, (int)__builtin_ctzll(todo));
+    const bool mine = slot == c;
+    todo &= ~__ballot(mine);
+    const float* w = cand_w2b + (row + (uint32_t)c) * 12u;
+    const float ddx = w[0] * dx + w[1] * dy + w[2] * dz;
+    const float ddy = w[4] * dx + w[5] * dy + w[6] * dz;
+    const float ddz = w[8] * dx + w[9] * dy + w[10] * dz;
+    const float nn = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) + 1e-7f;  // neurad_encoding.py:207
+    if (mine) bx = ddx / nn, by = ddy / nn, bz = ddz / nn;
+  }
+  float sh[16];
+  sh4((bx + 1.f) / 2.f, (by + 1.f) / 2.f, (bz + 1.f) / 2.f, sh);
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if ((c >> 2) == g) shb[c & 3] = sh[c];
+}
+
+template <int LPL, int F>
+__device__ __forceinline__ void blend_tile_actors(const TileFetch<LPL, F>& tf, int slot, int g, int La,
+                                                  const float* scal_lds, const float* ascal_lds, float (&feat)[8]) {
+  const bool in_box = slot >= 0;
+#pragma unroll
+  for (int q = 0; q < LPL; ++q) {
+    const int lv = LPL * g + q, alv = lv < La ? lv : La - 1;
+    const float sc = in_box ? ascal_lds[alv] : scal_lds[q];
+    Corners c;
+    const float sx = __fmul_rn(tf.x, sc), sy = __fmul_rn(tf.y, sc), sz = __fmul_rn(tf.z, sc);
+    c.ox = __fsub_rn(sx, floorf(sx)), c.oy = __fsub_rn(sy, floorf(sy)), c.oz = __fsub_rn(sz, floorf(sz));
+    float v[F];
+    lerp_corners<F>(c, tf.fv[q], v);
+    const float rw = (in_box && lv >= La) ? 0.f : rescale_weight(sc, tf.std);
+#pragma unroll
+    for (int f = 0; f < F; ++f) feat[q * F + f] = v[f] * rw;
+  }
+}
+
 template <int LPL, int F>
 __device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const float* scal_lds, float (&feat)[8]) {
   static_assert(LPL * F == 8, "8 features per lane");
@@ -251,15 +395,19 @@ __device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const fl
   }
 }
 
-// L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2.
-template <int L, int F, int H, bool HALF, bool COMPOSITE>
+// L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2, ACT = dynamic actors.
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(
     FieldDev fd, int64_t n_rays, int S, int stride, const int32_t* __restrict__ order, const float* __restrict__ ro,
     const float* __restrict__ rd, const float* __restrict__ rarea, const float* __restrict__ rstarts,
     const float* __restrict__ rends, float* __restrict__ out_feat, float* __restrict__ out_depth,
     float* __restrict__ out_acc, float* __restrict__ out_w, float* __restrict__ out_sdf, float* __restrict__ out_alpha,
-    SaveDev sv, float stop_eps) {
+    SaveDev sv, float stop_eps, const int32_t* __restrict__ range, ActorFieldDev ad,
+    const int32_t* __restrict__ cand_count,
+    const int32_t* __restrict__ cand_actor, const float* __restrict__ cand_w2b, const float* __restrict__ bounds,
+    const void* const* __restrict__ tables) {
   static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
+  static_assert(!ACT || (COMPOSITE && !HALF), "actors: composited eval kernel, fp32 tables");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
   using Ld = Lds<H>;
   constexpr int NB = H / 16;
@@ -269,6 +417,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
 
   // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
   stage_field_weights<H>(fd, lds);
+  if constexpr (ACT) {
+    for (int e = threadIdx.x; e < 16 * H; e += 256) lds[Ld::SHF + e] = frag_src<true, NB, 4>(fd.fw0 + 32, 48, 0, e);
+    if (threadIdx.x < ad.La) lds[Ld::ASCAL + threadIdx.x] = ad.scal[threadIdx.x];
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -281,8 +433,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
   const int xcd = (int)blockIdx.x % nx, lb = (int)blockIdx.x / nx;
   const int nblk = ((int)gridDim.x - xcd + nx - 1) / nx;  // workgroups that share this range
-  const int64_t lo = n_rays * xcd / nx;
-  const RayRange rr{n_rays * (xcd + 1) / nx, S, stride};
+  // `range` (device memory, optional): the slice [range[0], range[1]) of the processing order this launch renders -- a
+  // scene with actors is rendered as two launches over one order, split on the device (nrhip_render_fwd_actors)
+  const int64_t first = range ? range[0] : 0, count = range ? range[1] - range[0] : n_rays;
+  const int64_t lo = first + count * xcd / nx;
+  const RayRange rr{first + count * (xcd + 1) / nx, S, stride};
   const int64_t pos_step = (int64_t)nblk * 4;
 
   const float* scal_l = lds + Ld::SCAL + LPL * g;  // this lane's levels (re-read per tile: 1 ds_read, no VGPRs held)
@@ -294,13 +449,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   //   tf = gathered corners of the CURRENT tile | q = next tile (interval + ray constants loaded, gathers not yet
   //   issued) | the tile after q has its small loads requested at the end of the issue step
   TileFetch<LPL, F> tf;
+  int ta = -1;  // ACT: candidate slot of the actor containing this lane's sample of the tile in `tf` (-1: none)
+  const float* ascal_l = lds + Ld::ASCAL;
   PendingTile q;
-  load_pending(q, pos, 0, rr, j, order, ro, rd, rarea, rstarts, rends);
+  load_pending(q, pos, 0, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);
   int64_t ray = q.ray;
-  issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
+  if constexpr (ACT) issue_tile_actors<L, F>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
+  else issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
   {
     const bool wrap = ntile == 1;
-    load_pending(q, wrap ? pos + pos_step : pos, wrap ? 0 : 1, rr, j, order, ro, rd, rarea, rstarts, rends);
+    load_pending(q, wrap ? pos + pos_step : pos, wrap ? 0 : 1, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);
   }
 
   // per-ray state
@@ -354,7 +512,17 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
 
     // ---- blend the fetched corners (H1 + H4): the only wait on the gathers ---------------------------
     float feat[8];
-    blend_tile<LPL, F>(tf, scal_l, feat);
+    bool tile_hit = false;
+    float shb[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ACT) {
+      blend_tile_actors<LPL, F>(tf, ta, g, ad.La, scal_l, ascal_l, feat);
+      tile_hit = __ballot(ta >= 0) != 0ull;  // wave-uniform
+      if (tile_hit)  // here, where few registers are live -- not in the middle of the MLPs
+        actor_tile_sh(ta, (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)ray * (uint32_t)ad.K)), g, rd[3 * ray],
+                      rd[3 * ray + 1], rd[3 * ray + 2], cand_w2b, shb);
+    } else {
+      blend_tile<LPL, F>(tf, scal_l, feat);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- early ray termination (eval option): the transmittance ENTERING this tile is already below stop_eps, so
@@ -372,14 +540,17 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
 
     // ---- issue the next tile's gathers: they fly while this tile runs through the MLPs ---------------
     if (ray_done && q.valid && q.pos == pos)  // terminated early: q still points into this ray -> skip to the next ray
-      load_pending(q, pos + pos_step, 0, rr, j, order, ro, rd, rarea, rstarts, rends);  // (one exposed round trip)
+      load_pending(q, pos + pos_step, 0, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);  // (one exposed round trip)
     const bool have_next = q.valid;
     const int64_t npos = q.pos, nray = q.ray;
     const int nt = q.t;
-    issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);  // unconditional (see load_pending)
+    // unconditional (see load_pending)
+    if constexpr (ACT) issue_tile_actors<L, F>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
+    else issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
     {
       const bool wrap = nt + 1 == ntile;  // request the small loads of the tile after it
-      load_pending(q, wrap ? npos + pos_step : npos, wrap ? 0 : nt + 1, rr, j, order, ro, rd, rarea, rstarts, rends);
+      load_pending(q, wrap ? npos + pos_step : npos, wrap ? 0 : nt + 1, rr, j, order, ro, rd, rarea, rstarts, rends,
+                   cand_count);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -446,8 +617,15 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
         *reinterpret_cast<f32x4*>(xp + 32 + 4 * g) = shq;
       }
     }
+    if (!tile_hit) {
 #pragma unroll
-    for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::RB + wid * H + 16 * mb + 4 * g);
+      for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::RB + wid * H + 16 * mb + 4 * g);
+    } else {
+      // per-sample SH inputs (actor_tile_sh): four more k-steps instead of the per-ray bias row
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF0 + 16 * mb + 4 * g);
+      mfma_layer<NB, 4>(lw + Ld::SHF, lane, shb, h);
+    }
     mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb)
@@ -610,11 +788,23 @@ static FieldDev to_dev(const nrhip_field& f) {
   return d;
 }
 
-template <int L, int F, int H, bool HALF, bool COMPOSITE>
+// the candidate lists + actor tables an ACT launch reads (all device pointers)
+struct ActorLaunch {
+  const int32_t* range;  // [2] device: slice of the processing order (NULL = all rays)
+  ActorFieldDev ad;
+  const int32_t* cand_count;
+  const int32_t* cand_actor;
+  const float* cand_w2b;
+  const float* bounds;
+  const void* const* tables;
+};
+
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
-                         float* oal, const SaveDev& sv, float stop_eps, hipStream_t st) {
-  constexpr size_t lds = Lds<H>::TOTAL * sizeof(float);
-  auto kern = render_kernel<L, F, H, HALF, COMPOSITE>;
+                         float* oal, const SaveDev& sv, float stop_eps, hipStream_t st,
+                         const ActorLaunch& al = ActorLaunch()) {
+  constexpr size_t lds = (ACT ? Lds<H>::TOTAL_ACT : Lds<H>::TOTAL) * sizeof(float);
+  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT>;
   static int cap = 0;  // persistent grid: CUs x resident workgroups per CU, queried once per instantiation
   if (!cap) {
     if (lds > 64 * 1024)
@@ -628,13 +818,17 @@ static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float
   const int64_t want = (rd.R + 3) / 4;
   const int blocks = (int)(want < cap ? want : cap);
   kern<<<blocks, 256, lds, st>>>(fd, rd.R, rd.S, rd.stride, rd.order, rd.o, rd.d, rd.area, rd.starts, rd.ends, of, od, oa,
-                                 ow, os, oal, sv, stop_eps);
+                                 ow, os, oal, sv, stop_eps, al.range, al.ad, al.cand_count, al.cand_actor, al.cand_w2b,
+                                 al.bounds, al.tables);
   return check_launch("render/field fused kernel");
 }
 
 template <bool COMPOSITE>
 static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* of, float* od, float* oa, float* ow,
-                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{}, float stop_eps = 0.f) {
+                           float* os, float* oal, void* stream, const SaveDev& sv = SaveDev{}, float stop_eps = 0.f,
+                           const int32_t* range = nullptr) {
+  ActorLaunch al = ActorLaunch();
+  al.range = range;
   const FieldDev fd = to_dev(*f);
   const RaysDev rd = to_dev(*rays);
   const hipStream_t st = (hipStream_t)stream;
@@ -642,8 +836,8 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   const bool half = f->grid.param_dtype == 1;
 #define CASE(L_, F_, H_)                                                                                          \
   if (L == L_ && F == F_ && H == H_) {                                                                            \
-    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st)   \
-                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st); \
+    return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)   \
+                : launch_render<L_, F_, H_, false, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al); \
   }
   CASE(16, 2, 64)
   CASE(16, 2, 32)
@@ -653,6 +847,60 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   CASE(4, 8, 64)
 #undef CASE
   set_error("fused field kernel: no instantiation for L=%d F=%d H=%d", L, F, H);
+  return NRHIP_ERR_UNSUPPORTED;
+}
+
+// Stable partition of the processing order into [rays no actor can touch | rays with candidate actors] + the two slices
+// as device-side ranges {0, n0, n0, R}.  One workgroup: per-thread chunk counts -> block scan -> ordered writes, so each
+// half keeps the locality order it was given.
+constexpr int kPartThreads = 1024;
+__global__ __launch_bounds__(kPartThreads) void actor_partition_kernel(const int32_t* __restrict__ cand_count,
+                                                                       const int32_t* __restrict__ order_in, int64_t n,
+                                                                       int32_t* __restrict__ order_out,
+                                                                       int32_t* __restrict__ ranges) {
+  __shared__ uint32_t wave_tot[kPartThreads / 64];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + kPartThreads - 1) / kPartThreads, b = per * tid, e = b + per < n ? b + per : n;
+  uint32_t free_rays = 0;
+  for (int64_t i = b; i < e; ++i) free_rays += cand_count[order_in ? order_in[i] : i] == 0 ? 1u : 0u;
+  uint32_t incl = free_rays;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if ((tid & 63) >= off) incl += up;
+  }
+  if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t before = incl - free_rays, total = 0;
+  for (int w = 0; w < kPartThreads / 64; ++w) {
+    if (w < (tid >> 6)) before += wave_tot[w];
+    total += wave_tot[w];
+  }
+  // position i of the input is preceded by `before` free rays and (b - before) actor rays
+  int64_t pf = before, pa = (int64_t)total + (b < n ? b : n) - before;
+  for (int64_t i = b; i < e; ++i) {
+    const int32_t r = order_in ? order_in[i] : (int32_t)i;
+    if (cand_count[r] == 0) order_out[pf++] = r;
+    else order_out[pa++] = r;
+  }
+  if (tid == 0) ranges[0] = 0, ranges[1] = (int32_t)total, ranges[2] = (int32_t)total, ranges[3] = (int32_t)n;
+}
+
+// composited eval with dynamic actors: fp32 tables, the static shapes NeuRAD uses with actors
+static int dispatch_render_actors(const nrhip_field* f, const nrhip_rays* rays, const ActorLaunch& al, float* of, float* od,
+                                  float* oa, float* ow, float stop_eps, void* stream) {
+  const FieldDev fd = to_dev(*f);
+  const RaysDev rd = to_dev(*rays);
+  const hipStream_t st = (hipStream_t)stream;
+  const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
+#define CASE(L_, F_, H_)               \
+  if (L == L_ && F == F_ && H == H_)   \
+    return launch_render<L_, F_, H_, false, true, true>(fd, rd, of, od, oa, ow, nullptr, nullptr, SaveDev{}, stop_eps, st, al);
+  CASE(8, 4, 32)
+  CASE(8, 4, 64)
+  CASE(16, 2, 64)
+#undef CASE
+  set_error("fused field kernel with actors: no instantiation for L=%d F=%d H=%d", L, F, H);
   return NRHIP_ERR_UNSUPPORTED;
 }
 
@@ -700,4 +948,47 @@ extern "C" int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays,
 extern "C" int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,
                                 float* out_acc, float* out_weights, void* stream) {
   return nrhip_render_fwd_ex(f, rays, out_features, out_depth, out_acc, out_weights, 0.f, stream);
+}
+
+extern "C" int nrhip_render_fwd_actors(const nrhip_field* f, const nrhip_actors* a, const nrhip_rays* rays,
+                                       const int32_t* cand_count, const int32_t* cand_actor, const float* cand_w2b,
+                                       float* out_features, float* out_depth, float* out_acc, float* out_weights,
+                                       float early_stop_eps, int32_t* workspace, void* stream) {
+  if (int e = validate_field(f)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(a, NRHIP_ERR_INVALID_ARG, "render_fwd_actors: actors descriptor is NULL");
+  if (int e = validate_grid(&a->grid)) return e;
+  if (rays->n_rays == 0) return NRHIP_OK;
+  NR_REQUIRE(out_features && out_depth && out_acc && cand_count && cand_actor && cand_w2b && workspace && a->bounds &&
+                 a->tables && a->n_actors >= 1 && a->actor_scale > 0.f,
+             NRHIP_ERR_INVALID_ARG, "render_fwd_actors: NULL pointer / empty actor set");
+  NR_REQUIRE(rays->n_samples >= 1, NRHIP_ERR_INVALID_ARG, "render_fwd_actors: needs >= 1 sample per ray");
+  NR_REQUIRE(early_stop_eps >= 0.f && early_stop_eps < 1.f, NRHIP_ERR_INVALID_ARG,
+             "render_fwd_actors: early_stop_eps %g not in [0,1)", (double)early_stop_eps);
+  // per-sample table select keeps the gather shape: same features per level, no more levels than the static grid
+  NR_REQUIRE(f->grid.param_dtype == 0 && a->grid.param_dtype == 0, NRHIP_ERR_UNSUPPORTED,
+             "render_fwd_actors: fp32 tables only; use the unfused ops");
+  NR_REQUIRE(a->grid.n_features == f->grid.n_features && a->grid.num_levels <= f->grid.num_levels, NRHIP_ERR_UNSUPPORTED,
+             "render_fwd_actors: actor grid (L=%d F=%d) must have the static grid's features per level (F=%d) and at most "
+             "its levels (L=%d); use the unfused ops",
+             a->grid.num_levels, a->grid.n_features, f->grid.n_features, f->grid.num_levels);
+  ActorLaunch al;
+  al.ad.K = a->max_candidates > 0 ? a->max_candidates : NRHIP_DEFAULT_ACTOR_CANDIDATES;
+  al.ad.La = a->grid.num_levels, al.ad.log2T = a->grid.log2_table_size, al.ad.scale = a->actor_scale;
+  for (int l = 0; l < NRHIP_MAX_LEVELS; ++l) al.ad.scal[l] = a->grid.scalings[l];
+  al.cand_count = cand_count, al.cand_actor = cand_actor, al.cand_w2b = cand_w2b, al.bounds = a->bounds, al.tables = a->tables;
+  // Most rays of a street scene pass no actor at all.  The processing order is split on the device into those rays and
+  // the rays with candidates (no host round trip): the first slice runs through the plain static kernel at full speed,
+  // the second through the ACT instantiation, which pays for the candidate walk in registers and latency.
+  int32_t* order2 = workspace;
+  int32_t* ranges = workspace + rays->n_rays;
+  actor_partition_kernel<<<1, kPartThreads, 0, (hipStream_t)stream>>>(cand_count, rays->order, rays->n_rays, order2, ranges);
+  if (int e = check_launch("actor_partition")) return e;
+  nrhip_rays split = *rays;
+  split.order = order2;
+  if (int e = dispatch_render<true>(f, &split, out_features, out_depth, out_acc, out_weights, nullptr, nullptr, stream,
+                                    SaveDev{}, early_stop_eps, ranges))
+    return e;
+  al.range = ranges + 2;
+  return dispatch_render_actors(f, &split, al, out_features, out_depth, out_acc, out_weights, early_stop_eps, stream);
 }

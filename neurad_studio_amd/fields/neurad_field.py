@@ -115,10 +115,16 @@ class NeuRADField(nn.Module):
             param_groups["fields"] += list(self.sdf_to_density.parameters())
 
     # ---- fused path -----------------------------------------------------------------------------
-    def fused_supported(self) -> bool:
+    def fused_supported(self, with_actors: bool = False) -> bool:
+        """Can the fused kernels evaluate this field?  ``with_actors``: the composited eval kernel also covers scenes
+        with dynamic actors (per-sample table select, nrhip_render_fwd_actors) when the actor grids share the static
+        grid's features per level (the reference's defaults); the other fused kernels cover the static scene only."""
         c, g = self.config, self.hashgrid.static_grid
         if self.hashgrid.has_actors():
-            return False  # the fused kernels cover the static scene; actor scenes take the operator-level path
+            ag_ = self.hashgrid.actor_grids[0]
+            if not (with_actors and ag_.features_per_level == g.features_per_level and ag_.num_levels <= g.num_levels
+                    and g.hash_table.dtype == torch.float32 and (g.num_levels, c.geo_hidden_dim) in ((8, 32), (8, 64), (16, 64))):
+                return False
         return (g.get_out_dim() == 32 and g.num_levels % 4 == 0 and c.geo_num_layers == 2 and c.nff_num_layers == 3
                 and c.geo_hidden_dim == c.nff_hidden_dim and c.geo_hidden_dim in (32, 64) and c.nff_out_dim == 32)
 
@@ -143,11 +149,18 @@ class NeuRADField(nn.Module):
 
     @torch.no_grad()
     def render(self, origins, directions, pixel_area, starts, ends, return_weights=False, early_stop_eps: float = 0.0,
-               order: Optional[Tensor] = None):
+               order: Optional[Tensor] = None, times: Optional[Tensor] = None):
         """F1+C1+C2 in one kernel: -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S]).
-        early_stop_eps / order: see ops.render_fwd (eval-time ray termination; processing order from ops.ray_order)."""
-        if not self.fused_supported():
+        early_stop_eps / order: see ops.render_fwd (eval-time ray termination; processing order from ops.ray_order).
+        times [R]: needed when the scene has dynamic actors (their poses at the ray's time)."""
+        if not self.fused_supported(with_actors=True):
             raise NotImplementedError("fused render kernel: configuration not instantiated; use forward() + renderers")
+        if self.hashgrid.has_actors():
+            if times is None:
+                raise ValueError("dynamic actors need ray times")
+            spec, cand = self.hashgrid.prepare_actors(origins, directions, pixel_area, starts, ends, times)
+            return ops.render_fwd_actors(self.field_spec(), spec, cand, origins, directions, pixel_area, starts, ends,
+                                         return_weights, early_stop_eps=early_stop_eps, order=order)
         return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights,
                               early_stop_eps=early_stop_eps, order=order)
 

@@ -22,7 +22,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops
-from ..cameras.rays import RayBundle
+from ..cameras.rays import RayBundle, sample_times
 from ..field_components.field_heads import FieldHeadNames
 from ..fields.neurad_field import NeuRADField, NeuRADFieldConfig, NeuRADProposalField, NeuRADProposalFieldConfig
 from ..model_components.ray_samplers import PowerSampler, ProposalNetworkSampler
@@ -51,7 +51,7 @@ class FusedEvalMixin:
 
     def fused_eval_possible(self) -> bool:
         return (self.fused_eval and not torch.is_grad_enabled() and not self.training
-                and self.field.fused_supported() and not self.field.hashgrid.has_actors())
+                and self.field.fused_supported(with_actors=True))
 
     def fused_nff_outputs(self, ray_bundle) -> Dict[str, Tensor]:
         cfg = self.config
@@ -63,19 +63,28 @@ class FusedEvalMixin:
             ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
         if ray_bundle.nears is None:
             ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
-        pf = list(self.proposal_fields)
-        if self.reproduce_late_binding_quirk:
-            pf = [pf[-1]] * len(pf)
-        ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky)
-        fr = ray_samples.frustums
-        starts = fr.starts[..., 0]
-        ends = fr.ends[..., 0].clone()
-        ends[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
+        times = None
+        if self.field.hashgrid.has_actors():
+            # the proposal rounds of a scene with actors run as operator-level kernels (static density + the actor
+            # overlay); the field + compositing stay one kernel with per-sample table select
+            ray_samples, prop_ray_samples, prop_weights = self._get_ray_samples(ray_bundle)
+            fr = ray_samples.frustums
+            starts, ends = fr.starts[..., 0].contiguous(), fr.ends[..., 0].contiguous()
+            times = sample_times(ray_samples)
+        else:
+            pf = list(self.proposal_fields)
+            if self.reproduce_late_binding_quirk:
+                pf = [pf[-1]] * len(pf)
+            ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky)
+            fr = ray_samples.frustums
+            starts = fr.starts[..., 0]
+            ends = fr.ends[..., 0].clone()
+            ends[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
         o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
         order = ops.ray_order(o, d, self.field.hashgrid.static_scale) if self.order_rays else None
         want_w = bool(cfg.normalize_depth)
         out = self.field.render(o, d, ray_bundle.pixel_area, starts, ends, return_weights=want_w,
-                                early_stop_eps=self.early_stop_eps, order=order)
+                                early_stop_eps=self.early_stop_eps, order=order, times=times)
         features, depth, accumulation = out[:3]
         if want_w:  # DepthRenderer("expected") over the non-sky samples (renderers.py:398-416)
             w = out[3][:, :-1]

@@ -386,6 +386,27 @@ def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, ret
     return (feats, depth, acc, w) if return_weights else (feats, depth, acc)
 
 
+def render_fwd_actors(fs: FieldSpec, spec: "ActorSpec", cand, origins, directions, pixel_area, starts, ends,
+                      return_weights: bool = False, early_stop_eps: float = 0.0, order: Optional[Tensor] = None):
+    """``render_fwd`` for a scene with dynamic actors, still one kernel: samples inside an actor box read that actor's
+    grid (cand = ``actor_prepare``'s per-ray candidate lists).  Raises NrhipError(UNSUPPORTED) when the actor grid does
+    not share the static grid's features per level -- callers fall back to the operator-level path."""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends, order)
+    f, keep2 = fs.c_field()
+    a, keep3 = spec.c_actors()
+    cnt, act, w2b, _ = cand
+    R, S = r.n_rays, r.n_samples
+    dev = origins.device
+    feats = torch.empty((R, 32), device=dev, dtype=torch.float32)
+    depth = torch.empty((R, 1), device=dev, dtype=torch.float32)
+    acc = torch.empty((R, 1), device=dev, dtype=torch.float32)
+    w = torch.empty((R, S), device=dev, dtype=torch.float32) if return_weights else None
+    work = torch.empty((R + 4,), device=dev, dtype=torch.int32)
+    call("nrhip_render_fwd_actors", C.byref(f), C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(feats),
+         _ptr(depth), _ptr(acc), _ptr(w), float(early_stop_eps), _ptr(work), _stream())
+    return (feats, depth, acc, w) if return_weights else (feats, depth, acc)
+
+
 # ------------------------------------------------------------------------------------------------
 def render_weight_from_alpha(alphas: Tensor):
     a = _chk(alphas, "alphas")

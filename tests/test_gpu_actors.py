@@ -254,3 +254,89 @@ def test_many_actors_along_a_ray_no_candidate_cap():
                   for gr in fld.hashgrid.actor_grids)
     assert touched >= 12, touched
     assert actors.actor_positions.grad is not None and float(actors.actor_positions.grad.abs().sum()) > 0
+
+
+def _composite_reference(feature, alpha, starts, ends):
+    """C1 + C2 on per-sample outputs (oracle: nerfacc's exclusive cumprod + the sky residual of models/neurad.py:381)"""
+    w, _ = O.render_weight_from_alpha(alpha)
+    return O.composite(w, feature, starts, ends)
+
+
+def test_fused_render_with_actors_vs_reference_golden():
+    """nrhip_render_fwd_actors (device-side ray split + static kernel + per-sample table select kernel) against the
+    REFERENCE's per-sample field outputs for the actor scene (golden field_actors: feature, alpha), composited."""
+    g = load_golden("field_actors")
+    fld = make_field()
+    starts, ends = g["starts"], g["ends"]
+    with torch.no_grad():
+        feats, depth, acc, w = fld.render(dev(g["o"]), dev(g["d"]), dev(g["area"]), dev(starts), dev(ends), return_weights=True,
+                                          times=dev(g["times"]))
+    want_f, want_d, want_a = _composite_reference(g["feature"], g["alpha"], starts, ends)
+    assert want_f.shape == feats.shape
+    assert rel_l2(host(feats), want_f) < TOL
+    assert rel_l2(host(acc), want_a) < TOL
+    assert rel_l2(host(depth), want_d) < TOL
+    assert rel_l2(host(w), O.render_weight_from_alpha(g["alpha"])[0]) < TOL
+    # the scene really exercises both kernels: some rays have candidates, some do not
+    cnt = fld.hashgrid.prepare_actors(dev(g["o"]), dev(g["d"]), dev(g["area"]), dev(starts), dev(ends), dev(g["times"]))[1][0]
+    assert 0 < int((cnt > 0).sum()) and len(g["hit_ray"]) > 0
+
+
+@pytest.mark.parametrize("with_order", [False, True])
+def test_fused_render_many_actors_vs_oracle_and_operator_path(with_order):
+    """20 actors in a row (up to 20 candidates per ray, samples of one 16-sample tile inside different boxes), mixed with
+    rays that pass no actor: fused == oracle == operator-level path, with and without a locality order."""
+    from neurad_studio_amd import ops
+    from neurad_studio_amd.fields.neurad_field import NeuRADField, NeuRADFieldConfig
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+
+    A = 20
+    ts = torch.tensor([0.0, 1.0])
+    trajs = []
+    for a in range(A):
+        p = torch.eye(4).repeat(2, 1, 1)
+        p[:, :3, 3] = torch.tensor([6.0 + 5.0 * a, 0.3 * (a % 3 - 1), 0.4])
+        trajs.append({"timestamps": ts.clone(), "poses": p, "dims": torch.tensor([2.0, 4.6, 1.6]),
+                      "symmetric": torch.tensor(True), "deformable": torch.tensor(False)})
+    actors = DynamicActors(DynamicActorsConfig(), trajectories=trajs)
+    cfg = NeuRADFieldConfig()
+    cfg.grid.static.log2_hashmap_size = 11
+    cfg.grid.actor.log2_hashmap_size = 9
+    fld = NeuRADField(cfg, actors=actors, static_scale=100.0).cuda().eval()
+    fp = field_params()
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.copy_(dev(fp.grid.table))
+        tabs = [synth.hash_table(4 * 2**9, 4, seed=900 + i, scale=0.7) for i in range(A)]
+        for gr, t in zip(fld.hashgrid.actor_grids, tabs):
+            gr.hash_table.copy_(dev(t))
+        for layers, ws, bs in ((fld.mlp_geo.layers, fp.geo_w, fp.geo_b), (fld.mlp_feature.layers, fp.feat_w, fp.feat_b)):
+            for l, w, b in zip(layers, ws, bs):
+                l.weight.copy_(dev(w)), l.bias.copy_(dev(b))
+        fld.sdf_to_density.beta.fill_(fp.beta)
+    R, S = 301, 72  # ragged: not a multiple of the 4 rays per workgroup, last tile half full
+    o = (synth.normal((R, 3), 3) * np.array([0.5, 0.3, 0.1], np.float32)).astype(np.float32)
+    tgt = np.stack([np.full(R, 110.0), synth.uniform((R,), -0.6, 0.6, 4), synth.uniform((R,), 0.2, 0.6, 5)], -1)
+    tgt[::3] = np.stack([synth.uniform((R,), -50, 50, 7), np.full(R, 90.0), synth.uniform((R,), 5, 40, 8)], -1)[::3]  # away
+    d = (tgt - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    times = synth.uniform((R,), 0.0, 1.0, 6)
+    area = np.full((R,), 2.43e-6, np.float32)
+    edges = np.linspace(0.0, 108.0, S + 1, dtype=np.float32)[None].repeat(R, 0)
+    st, en = np.ascontiguousarray(edges[:, :-1]), np.ascontiguousarray(edges[:, 1:])
+    ap = O.ActorParams(host(actors.unique_timestamps), host(actors.actor_positions), host(actors.actor_rotations_6d),
+                       host(actors.actor_present_at_time), host(actors.actor_sizes), host(actors.actor_padding),
+                       [O.GridParams(t, 4, 64, 1024, 9) for t in tabs], actor_scale=10.0)
+    ref = O.field_fwd_actors(fp, ap, o, d, area, st, en, times)
+    want_f, want_d, want_a = _composite_reference(ref["feature"], ref["alpha"], st, en)
+    order = ops.ray_order(dev(o), dev(d), 100.0) if with_order else None
+    with torch.no_grad():
+        feats, depth, acc = fld.render(dev(o), dev(d), dev(area), dev(st), dev(en), times=dev(times), order=order)
+    cnt = fld.hashgrid.prepare_actors(dev(o), dev(d), dev(area), dev(st), dev(en), dev(times))[1][0]
+    assert int(cnt.max()) > 8 and int((cnt == 0).sum()) > 50
+    assert rel_l2(host(feats), want_f) < TOL
+    assert rel_l2(host(acc), want_a) < TOL
+    assert rel_l2(host(depth), want_d) < TOL
+    # early termination stays within its bound on the actor kernel too
+    with torch.no_grad():
+        f2, _, a2 = fld.render(dev(o), dev(d), dev(area), dev(st), dev(en), times=dev(times), early_stop_eps=1e-3)
+    assert float((a2 - acc).abs().max()) <= 1e-3 + 1e-6 and float((f2 - feats).abs().max()) < 5e-2
