@@ -41,3 +41,15 @@ class DepthRenderer(nn.Module):
         acc = nerfacc.accumulate_along_rays(weights[..., 0], values=None)
         depth = depth / (acc + eps)
         return torch.clip(depth, steps.min(), steps.max())
+
+
+class NormalsRenderer(nn.Module):
+    """Weighted sum of the per-sample normals, optionally renormalised (model_components/renderers.py:462-489; the
+    normalisation is safe_normalize, utils/math.py:455-468: v / (|v| + 1e-10))."""
+
+    @classmethod
+    def forward(cls, normals: Tensor, weights: Tensor, normalize: bool = True, ray_indices=None, num_rays=None) -> Tensor:
+        n = nerfacc.accumulate_along_rays(weights[..., 0], values=normals, ray_indices=ray_indices, n_rays=num_rays)
+        if normalize:
+            n = n / (torch.linalg.norm(n, dim=-1, keepdim=True) + 1e-10)
+        return n

@@ -98,6 +98,21 @@ class FusedEvalMixin:
         return nff
 
 
+def _slice_bundle(rb, a: int, b: int):
+    """rays [a, b) of a flat bundle: the reference's RayBundle slices itself (rays.py:293-311), this package's is a plain
+    dataclass of [R, C] tensors"""
+    if hasattr(rb, "get_row_major_sliced_ray_bundle"):
+        return rb.get_row_major_sliced_ray_bundle(a, b)
+
+    def sl(t):
+        return None if t is None else t[a:b]
+
+    return RayBundle(origins=sl(rb.origins), directions=sl(rb.directions), pixel_area=sl(rb.pixel_area),
+                     camera_indices=sl(rb.camera_indices), nears=sl(rb.nears), fars=sl(rb.fars),
+                     metadata={k: sl(v) for k, v in rb.metadata.items()}, times=sl(rb.times),
+                     termination_distances=sl(rb.termination_distances))
+
+
 @dataclass
 class SamplingSettings:  # models/neurad.py:96-117
     single_jitter: bool = True
@@ -182,6 +197,29 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
             features = features[is_lidar.reshape(-1)]
         intensity, ray_drop_logit = self.lidar_decoder(features).split(1, dim=-1)
         return intensity.sigmoid(), ray_drop_logit
+
+    # ---- chunked eval entry (models/neurad.py:623-675) ----------------------------------------------
+    @torch.no_grad()
+    def get_outputs_for_ray_bundle(self, ray_bundle, num_rays_per_chunk: int = 1 << 17,
+                                   is_lidar: bool = False) -> Dict[str, Tensor]:
+        """Render a whole image / lidar scan: flat bundle of N rays -> {features, depth, accumulation, prop_depth_i}
+        [N, C], plus the lidar head's outputs (intensity, ray_drop_logits, ray_drop_prob) for a lidar scan.  The
+        reference walks 2^15-ray chunks and concatenates (``get_outputs_for_camera_ray_bundle``); here the chunks are
+        large (the activations of 2^17 rays are a few hundred MB of 288 GB) and each writes its slice of buffers
+        allocated once.  Camera features go to neurad-studio's CNN decoder (decode_features, models/neurad.py:328-366)."""
+        n = len(ray_bundle)
+        out: Dict[str, Tensor] = {}
+        for a in range(0, n, num_rays_per_chunk):
+            b = min(a + num_rays_per_chunk, n)
+            chunk = self.get_nff_outputs(_slice_bundle(ray_bundle, a, b))
+            for k, v in chunk.items():
+                if k not in out:
+                    out[k] = torch.empty((n, *v.shape[1:]), dtype=v.dtype, device=v.device)
+                out[k][a:b] = v
+        if is_lidar and self.lidar_decoder is not None:
+            intensity, logit = self.decode_lidar(out["features"])
+            out["intensity"], out["ray_drop_logits"], out["ray_drop_prob"] = intensity, logit, logit.sigmoid()
+        return out
 
     # ---- M1 (models/neurad.py:443-459), operator-level path ---------------------------------------
     def _get_ray_samples(self, ray_bundle: RayBundle):

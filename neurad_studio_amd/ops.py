@@ -606,6 +606,9 @@ def proposal_sampler_fwd(props: Sequence[ProposalSpec], origins, directions, pix
     return ws, sps, eus
 
 
+_POINTER_TABLES: dict = {}
+
+
 @dataclass
 class ActorSpec:
     """Device-side view of DynamicActors + the per-actor grids."""
@@ -620,11 +623,19 @@ class ActorSpec:
     actor_scale: float = 10.0
 
     def c_actors(self):
+        present = self.present.contiguous()
+        present = present.view(torch.uint8) if present.dtype == torch.bool else present.to(torch.uint8)  # bool is 1 byte
         keep = [_chk(self.timestamps, "timestamps"), _chk(self.positions, "positions"),
-                _chk(self.rotations_6d, "rotations_6d"), self.present.to(torch.uint8).contiguous(),
-                _chk(self.bounds, "bounds")]
+                _chk(self.rotations_6d, "rotations_6d"), present, _chk(self.bounds, "bounds")]
         tabs = [_chk(t, "actor table") for t in self.tables]
-        ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=keep[0].device)
+        # device array of table pointers: uploaded once per set of tables, not once per call (a pageable H2D copy
+        # synchronises the host with the stream)
+        key = (keep[0].device, tuple(t.data_ptr() for t in tabs))
+        ptrs = _POINTER_TABLES.get(key)
+        if ptrs is None:
+            if len(_POINTER_TABLES) >= 16:
+                _POINTER_TABLES.clear()
+            ptrs = _POINTER_TABLES[key] = torch.tensor(key[1], dtype=torch.int64, device=key[0])
         a = _lib.Actors()
         a.n_times, a.n_actors = self.positions.shape[0], self.positions.shape[1]
         a.timestamps, a.positions, a.rotations_6d = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()

@@ -8,7 +8,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
@@ -78,6 +78,33 @@ def train():
 
 
 rs = sampler(rb)
+fr = rs.frustums
+starts, ends = fr.starts[..., 0].contiguous(), fr.ends[..., 0].contiguous()
+pa, tm = rb.pixel_area[:, 0].contiguous(), times[:, 0].contiguous()
+
+
+def fused():  # nrhip_actor_prepare + device-side ray split + static kernel + actor kernel
+    return fld.eval().render(o, d, pa, starts, ends, times=tm)
+
+
+def fused_static_only():  # the same rays through the static kernel alone (no actors): the floor
+    from neurad_studio_amd import ops
+    return ops.render_fwd(fld.field_spec(), o, d, pa, starts, ends)
+
+
 with torch.no_grad():
     out = fld.eval()(rs)
-print(f"{NA} actors, {R} rays x {S} samples: eval forward {timeit(fwd):.3f} ms, train forward+backward {timeit(train):.3f} ms")
+    cnt = fld.hashgrid.prepare_actors(o, d, pa, starts, ends, tm)[1][0]
+    from neurad_studio_amd import ops
+    from neurad_studio_amd.shims import nerfacc
+    w = nerfacc.render_weight_from_alpha(out[FieldHeadNames.ALPHA][..., 0])[0]
+    acc_ref = w.sum(-1, keepdim=True)
+    f, dep, acc = fused()
+    hit = ops.actor_hits(*fld.hashgrid.prepare_actors(o, d, pa, starts, ends, tm), o, d, pa, starts, ends)
+print(f"{NA} actors, {R} rays x {S} samples: {float((cnt > 0).float().mean()) * 100:.1f}% of the rays have candidate actors "
+      f"(max {int(cnt.max())}), {float((hit[:, 0] >= 0).float().mean()) * 100:.2f}% of the samples lie in a box")
+print(f"  fused vs operator path: accumulation max abs diff {float((acc - acc_ref).abs().max()):.2e}")
+print(f"  eval, operator-level path (per-sample outputs, no compositing) {timeit(fwd):.3f} ms")
+print(f"  eval, fused render with actors (prepare + split + 2 kernels)    {timeit(fused):.3f} ms")
+print(f"  eval, fused render of the static scene alone (floor)            {timeit(fused_static_only):.3f} ms")
+print(f"  train forward+backward (operator-level actor path)             {timeit(train):.3f} ms")

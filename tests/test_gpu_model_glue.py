@@ -209,3 +209,99 @@ def test_rgb_cnn_decoder_vs_reference():
     dec.eval()
     with torch.no_grad():
         assert rel_l2(host(decode_rgb(dec, feats, (8, 8))), g["rgb_eval"]) < TOL
+
+
+def test_chunked_eval_entry_and_lidar_head():
+    """get_outputs_for_ray_bundle (the chunked entry of models/neurad.py:623-675): chunks of any size give the outputs of
+    one call, the lidar head runs on the rendered features; also through the reference's own slicing protocol."""
+    g = load_golden("model_train_glue")
+    m = build_model(g).eval()
+    with torch.no_grad():
+        whole = m.get_nff_outputs(bundle(g))
+    out = m.get_outputs_for_ray_bundle(bundle(g), num_rays_per_chunk=32, is_lidar=True)  # 80 rays -> 32 + 32 + 16
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert torch.equal(out[k], whole[k]), k  # per-ray kernels: chunking changes nothing, bit for bit
+    intensity, logit = m.decode_lidar(whole["features"])
+    assert torch.equal(out["intensity"], intensity) and torch.equal(out["ray_drop_prob"], logit.sigmoid())
+    assert out["intensity"].shape == (80, 1) and float(out["intensity"].min()) >= 0 and float(out["intensity"].max()) <= 1
+
+    class RefLikeBundle:  # the reference RayBundle's protocol: __len__ + get_row_major_sliced_ray_bundle (rays.py:293-311)
+        def __init__(self, rb):
+            self.rb = rb
+
+        def __len__(self):
+            return len(self.rb)
+
+        def get_row_major_sliced_ray_bundle(self, a, b):
+            from neurad_studio_amd.models.neurad import _slice_bundle
+            return _slice_bundle(self.rb, a, b)
+
+    out2 = m.get_outputs_for_ray_bundle(RefLikeBundle(bundle(g)), num_rays_per_chunk=50)
+    assert torch.equal(out2["features"], whole["features"]) and "intensity" not in out2
+
+
+def test_normals_renderer_vs_reference_formula():
+    from neurad_studio_amd.model_components.renderers import NormalsRenderer
+
+    torch.manual_seed(3)
+    normals = torch.randn(37, 24, 3, device="cuda")
+    w = torch.rand(37, 24, 1, device="cuda") * 0.1
+    want = torch.sum(w * normals, dim=-2)  # renderers.py:481
+    assert rel_l2(host(NormalsRenderer.forward(normals, w, normalize=False)), host(want)) < 1e-6
+    want_n = want / (torch.norm(want, dim=-1, keepdim=True) + 1e-10)  # safe_normalize, utils/math.py:468
+    assert rel_l2(host(NormalsRenderer()(normals, w)), host(want_n)) < 1e-6
+
+
+def test_model_eval_with_actors_fused_render_matches_operator_path():
+    """A scene with dynamic actors through the model: eval under no_grad takes the fused render kernel with per-sample
+    table select (proposal rounds at operator level); the grad-enabled call of the same model takes the operator-level
+    path end to end (pinned to the reference by test_gpu_actors / proposal_actors goldens)."""
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+    from test_gpu_actors import trajectories
+
+    torch.manual_seed(1)
+    c = NeuRADHotPathConfig(appearance_dim=0)
+    c.field.grid.static.log2_hashmap_size = 12
+    c.field.grid.actor.log2_hashmap_size = 10
+    c.field.sdf_beta = 3.0
+    for pf in (c.sampling.proposal_field_1, c.sampling.proposal_field_2):
+        pf.grid.static.log2_hashmap_size = 11
+        pf.grid.actor.log2_hashmap_size = 9
+    actors = DynamicActors(DynamicActorsConfig(), trajectories=trajectories())
+    m = NeuRADHotPath(c, static_scale=100.0, actors=actors).cuda().eval()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(500.0)
+        for gr in m.field.hashgrid.actor_grids:
+            gr.hash_table.mul_(3000.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(500.0)
+            for gr in p.hashgrid.actor_grids:
+                gr.hash_table.mul_(2000.0)
+    R = 256
+    gen = torch.Generator().manual_seed(5)
+    times = 1.0 + torch.rand(R, 1, generator=gen)  # all three trajectories exist in [1, 2]
+    a = torch.arange(R) % 3  # look at actor a, where it is at the ray's time (test_gpu_actors.trajectories), from ~4 m:
+    tgt = torch.stack([12.0 + 2.0 * times[:, 0] + a, torch.tensor([8.0, -6.0, -5.0])[a], torch.full((R,), 0.5)], -1)
+    side = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.15]), dim=-1)
+    o = tgt + 4.0 * side  # the box fills the first metres of the ray, where the samplers put their samples
+    d = torch.nn.functional.normalize(tgt + 0.3 * torch.randn(R, 3, generator=gen) - o, dim=-1)
+    d[::4] = -d[::4]  # every fourth ray looks away
+
+    def rb():
+        return RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((R, 1), 2.7e-7, device="cuda"),
+                         times=times.cuda())
+
+    assert m.fused_eval_possible() is False  # (grad enabled here)
+    with torch.no_grad():
+        assert m.fused_eval_possible()
+        fused = m.get_nff_outputs(rb())
+    op = m.get_nff_outputs(rb())
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(host(fused[k]), host(op[k])) < 5e-5, k
+    # the actors matter in this scene: without them the rendering differs
+    m.field.hashgrid.config.disable_actors = True
+    with torch.no_grad():
+        static_only = m.get_nff_outputs(rb())
+    assert rel_l2(host(static_only["features"]), host(fused["features"])) > 1e-3
