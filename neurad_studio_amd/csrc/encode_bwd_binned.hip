@@ -6,6 +6,10 @@
 // training step.  The per-XCD L2s are not coherent with each other, so there is no cheaper scope to fall back to.
 //
 // This path gives every table entry exactly one owner instead -- a radix partition by table slice:
+// Samples whose incoming gradient is EXACTLY zero (samples behind an opaque surface: weight 0, transmittance 0) send no
+// records at all: `prep` drops them -- each 4096-sample chunk is compacted, in order, to its live samples -- and `count`
+// / `emit` walk only those.  Adding zeros changes nothing, so the result is bit-identical; on a uniformly sampled ray of
+// a converged scene the silent samples are the majority (bench config[1]: 76 %).
 //   count   : the table of a level is cut into slices of TS = 16384/F entries (128 KB of 64-bit accumulators).
 //             A workgroup takes 4096 consecutive samples, parks their contracted positions in LDS (and in the
 //             scratch, for `emit`), and for each of its levels histograms, in LDS, the records its samples send to
@@ -38,7 +42,7 @@ struct BinPlan {
   int log2TS, nb;        // entries per slice (log2), slices per level
   int chunks, lgroups;   // count/emit grid: sample chunks x level groups (levels dealt round-robin)
   int nmax;              // per-level partial maxima (one per emit wave)
-  size_t off_counts, off_totals, off_offsets, off_qmax, off_pos, off_rec, total_bytes;
+  size_t off_counts, off_totals, off_offsets, off_qmax, off_pos, off_idx, off_live, off_rec, total_bytes;
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -67,9 +71,36 @@ bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
   p->off_offsets = o, o += align256((cols + 1) * sizeof(uint32_t));
   p->off_qmax = o, o += align256((size_t)g.L * p->nmax * sizeof(float));
   p->off_pos = o, o += align256((size_t)p->chunks * kSamplesPerBlock * sizeof(float4));
+  p->off_idx = o, o += align256((size_t)p->chunks * kSamplesPerBlock * sizeof(uint16_t));
+  p->off_live = o, o += align256((size_t)p->chunks * sizeof(uint32_t));
   p->off_rec = o, o += (size_t)n * 8 * g.L * (g.F + 1) * sizeof(float);  // every corner term its own record: worst case
   p->total_bytes = o;
   return true;
+}
+
+// Is the gradient row of sample (w0 + lane) all +-0?  (NaN compares unequal to 0: a poisoned row stays alive and poisons,
+// as before.)  Called by whole waves, w0 wave-uniform; rows are `width` floats, [0, n_rows) are valid.  32-float rows --
+// every field grid -- are read the way they lie in memory: the wave's 64 rows are 8 KB in a row, lane l takes the
+// float4s l, l + 64, ... and a ballot per load tells which of its 8 rows saw a non-zero.
+__device__ __forceinline__ bool rows_are_zero(const float* __restrict__ g, int width, int64_t w0, int64_t n_rows) {
+  const int lane = threadIdx.x & 63;
+  if (width == 32 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    bool alive = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t row = w0 + 8 * k + (lane >> 3);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n_rows) v = reinterpret_cast<const float4*>(g + w0 * 32)[k * 64 + lane];
+      const unsigned long long nz = __ballot(!(v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f));
+      if ((lane >> 3) == k) alive = ((nz >> (8 * (lane & 7))) & 0xffull) != 0ull;
+    }
+    return !alive;
+  }
+  const int64_t row = w0 + lane;
+  bool z = true;
+  if (row < n_rows)
+    for (int k = 0; k < width; ++k) z = z && g[row * width + k] == 0.f;
+  return z;
 }
 
 // Where the samples and their feature gradients come from (pass A is otherwise identical):
@@ -93,6 +124,8 @@ struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray sample
 #pragma unroll
     for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k] * rw;
   }
+  int width;  // L * F
+  __device__ bool silent(int64_t w0, int64_t n_rows) const { return rows_are_zero(go, width, w0, n_rows); }
 };
 struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   const float* x;
@@ -104,6 +137,8 @@ struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
 #pragma unroll
     for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k];
   }
+  int width;  // L * F
+  __device__ bool silent(int64_t w0, int64_t n_rows) const { return rows_are_zero(go, width, w0, n_rows); }
 };
 struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(decoder . rescaled features), F = 1
   RaysDev r;
@@ -125,38 +160,78 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
     const float gx = gd[i] * expf(fminf(fmaxf(xlog, -15.f), 15.f));
     gv[0] = gx * dec[l] * rescale_weight(sc, std);
   }
+  __device__ bool silent(int64_t w0, int64_t n_rows) const {  // (exp(.) > 0: the chain factor cannot revive it)
+    const int64_t i = w0 + (threadIdx.x & 63);
+    return i < n_rows ? gd[i] == 0.f : true;
+  }
 };
 
-// ---- count ---------------------------------------------------------------------------------------------------
+// ---- prep ----------------------------------------------------------------------------------------------------
+// Positions of the round's LIVE samples, once, for `count` and `emit`: a sample that is out of range or whose incoming
+// gradient is exactly zero sends no records and is dropped here.  Each 4096-sample chunk is compacted in order (so that
+// consecutive samples of a ray stay neighbours and their equal entries still merge): gpos / gidx [chunk][slot] = position
+// / index inside the chunk of the slot-th live sample, nlive[chunk] = their number.
 template <class Src>
-__global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
-                                                          uint32_t* __restrict__ counts, float4* __restrict__ gpos) {
-  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
-  uint32_t* hist = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, int64_t n, int64_t n_total,
+                                                         float4* __restrict__ gpos, uint16_t* __restrict__ gidx,
+                                                         uint32_t* __restrict__ nlive) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
   const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;  // sample i of this round = sample i_off + i of the source
+  uint32_t base = 0;
 #pragma unroll
   for (int it = 0; it < nit; ++it) {
     const int64_t i0 = i_blk + it * nt + tid;
     const float4 p = src.position(i_off + (i0 < n ? i0 : n - 1));
-    pos[it * nt + tid] = p;
-    if (blockIdx.y == 0) gpos[i_blk + it * nt + tid] = p;
+    const bool live = !src.silent(i_off + i0 - lane, n_total) && i0 < n;
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t c = wave_tot[w];
+      before += w < wave ? c : 0u;
+      total += c;
+    }
+    if (live) {
+      const uint32_t slot = base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      gpos[i_blk + slot] = p;
+      gidx[i_blk + slot] = (uint16_t)(it * nt + tid);
+    }
+    base += total;
+    __syncthreads();  // wave_tot is reused by the next pass
   }
+  if (tid == 0) nlive[blockIdx.x] = base;
+}
+
+// ---- count ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, int nb, uint32_t* __restrict__ counts,
+                                                          const float4* __restrict__ gpos,
+                                                          const uint32_t* __restrict__ nlive) {
+  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
+  uint32_t* hist = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
+  const int tid = threadIdx.x;
+  constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
+  const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
+  const int nl = (int)nlive[blockIdx.x], nit_live = (nl + nt - 1) / nt;  // block-uniform
+  for (int it = 0; it < nit_live; ++it)
+    if (it * nt + tid < nl) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
   const uint32_t mask = (1u << g.log2T) - 1u;
   for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
     const float sc = g.scal[l];
     __syncthreads();  // pos[] written / previous level's histogram stored
     for (int b = tid; b < nb; b += nt) hist[b] = 0;
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < nit; ++it) {
-      const bool live = i_blk + it * nt + tid < n;
-      const float4 p = pos[it * nt + tid];
+    for (int it = 0; it < nit_live; ++it) {
+      const bool live = it * nt + tid < nl;
+      if (__ballot(live) == 0ull) continue;  // wave-uniform
+      const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t key = c.idx[k];
+        const uint32_t key = live ? c.idx[k] : 0xffffffffu;  // a silent sample never joins a run of equal entries
         const uint32_t prev = dpp_row_shr<1>(key, ~key);  // first lane of a 16-lane row always heads a run
         if (live && prev != key) atomicAdd(&hist[key >> log2TS], 1u);
       }
@@ -224,7 +299,9 @@ template <int F, class Src>
 __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
                                                          const uint32_t* __restrict__ bases,
                                                          const uint32_t* __restrict__ offsets,
-                                                         const float4* __restrict__ gpos, float* __restrict__ qrec,
+                                                         const float4* __restrict__ gpos,
+                                                         const uint16_t* __restrict__ gidx,
+                                                         const uint32_t* __restrict__ nlive, float* __restrict__ qrec,
                                                          float* __restrict__ qmax, int nmax) {
   extern __shared__ __attribute__((aligned(16))) float4 pos[];
   uint32_t* rank = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
@@ -232,8 +309,14 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
   const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
+  const int nl = (int)nlive[blockIdx.x], nit_live = (nl + nt - 1) / nt;  // block-uniform
+  int64_t src_i[nit];  // the source sample behind each of this thread's live slots
 #pragma unroll
-  for (int it = 0; it < nit; ++it) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
+  for (int it = 0; it < nit; ++it) {
+    const bool live = it * nt + tid < nl;
+    if (live) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
+    src_i[it] = i_off + i_blk + (live ? (int64_t)gidx[i_blk + it * nt + tid] : 0);
+  }
   const uint32_t mask = (1u << g.log2T) - 1u;
   const uint32_t tsmask = (1u << log2TS) - 1u;
   for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
@@ -247,22 +330,22 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
     float vmax = 0.f;
 #pragma unroll
     for (int it = 0; it < nit; ++it) {
-      const int64_t i0 = i_blk + it * nt + tid;
-      const bool live = i0 < n;
-      const int64_t i = live ? i0 : n - 1;
-      const float4 p = pos[it * nt + tid];
+      if (it >= nit_live) break;  // block-uniform
+      const bool live = it * nt + tid < nl;
+      if (__ballot(live) == 0ull) continue;
+      const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
       float w[8];
       corner_weights(c, w);
       float gv[F];
-      src.template grad<F>(i_off + i, l, sc, p.w, gv);
+      src.template grad<F>(live ? src_i[it] : i_off, l, sc, p.w, gv);
       if (!live) {
 #pragma unroll
         for (int k = 0; k < F; ++k) gv[k] = 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t key = c.idx[k];
+        const uint32_t key = live ? c.idx[k] : 0xffffffffu;
         const uint32_t prev = dpp_row_shr<1>(key, ~key);
         const bool head = prev != key;
         const unsigned long long hm = __ballot(head);
@@ -449,6 +532,8 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
   uint32_t* offsets = reinterpret_cast<uint32_t*>(ws + p.off_offsets);
   float* qmax = reinterpret_cast<float*>(ws + p.off_qmax);
   float4* gpos = reinterpret_cast<float4*>(ws + p.off_pos);
+  uint16_t* gidx = reinterpret_cast<uint16_t*>(ws + p.off_idx);
+  uint32_t* nlive = reinterpret_cast<uint32_t*>(ws + p.off_live);
   float* qrec = reinterpret_cast<float*>(ws + p.off_rec);
   const int cols = gd.L * p.nb;
   const int lds_a = kSamplesPerBlock * (int)sizeof(float4) + 2 * p.nb * (int)sizeof(uint32_t);
@@ -457,7 +542,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
   const size_t lds_b = (size_t)nacc * sizeof(unsigned long long) + (size_t)((nacc + 31) / 32) * sizeof(uint32_t);
   static thread_local bool count_configured = false;
   if (!count_configured) {
-    (void)hipFuncSetAttribute((const void*)bin_count_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
     count_configured = true;
   }
   for (int64_t i_off = 0; i_off < n; i_off += kRoundSamples) {
@@ -466,7 +551,8 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     const dim3 grid_a((unsigned)chunks, (unsigned)p.lgroups);
     // qmax slots of chunks this round does not have stay from an earlier round otherwise
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
-    bin_count_kernel<Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts, gpos);
+    bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive);
+    bin_count_kernel<<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     if (int e = check_launch(what)) return e;
     bin_scan_chunks_kernel<<<(cols + 255) / 256, 256, 0, st>>>(counts, chunks, cols, totals);
     bin_scan_totals_kernel<<<1, 1024, 0, st>>>(totals, cols, offsets);
@@ -482,7 +568,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
       configured = true;                                                                                            \
     }                                                                                                               \
     bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts, offsets, gpos, \
-                                                         qrec, qmax, p.nmax);                                       \
+                                                         gidx, nlive, qrec, qmax, p.nmax);                          \
     bin_reduce_kernel<F><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,      \
                                                     p.nmax, (overwrite && i_off == 0) ? 1 : 0);                     \
   } while (0)
@@ -504,7 +590,7 @@ extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, 
   const int64_t n = rays->n_rays * rays->n_samples;
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
-  const EncodeSrc src{to_dev(*rays), static_scale, grad_out, gd.L};
+  const EncodeSrc src{to_dev(*rays), static_scale, grad_out, gd.L, gd.L * gd.F};
   return run_binned("encode_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
                     (hipStream_t)stream);
 }
@@ -516,7 +602,7 @@ extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, co
   NR_REQUIRE(x && grad_out && grad_table && n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_binned: bad argument");
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(*g);
-  const GridSrc src{x, grad_out, gd.L};
+  const GridSrc src{x, grad_out, gd.L, gd.L * gd.F};
   return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
                     (hipStream_t)stream);
 }

@@ -426,6 +426,46 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("cfg", [(16, 2, 19, 2048, 64), (8, 4, 16, 257, 33), (6, 1, 14, 300, 48)])
+def test_table_gradient_skips_exactly_zero_samples_exactly(ops, cfg, monkeypatch):
+    """Samples whose incoming gradient is exactly zero (the tail of a ray behind an opaque surface; scattered ones; whole
+    rays) send no records.  The result must equal the atomic scatter-add of the same gradient, and -- integer
+    accumulation -- must not change by a single bit when the silent samples' rows hold -0.0 instead of +0.0 or when
+    silent samples sit between two samples of the same cell (they split a merged run, nothing else)."""
+    L, F, lg, R, S = cfg
+    spec = ops.GridSpec(L, F, lg, 16, 2048)
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=7)
+    do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
+    st, en = edges[:, :-1], edges[:, 1:]
+    g = synth.normal((R, S, L * F), 13)
+    cut = (synth.uniform((R,), 0, 1, 14) * S).astype(np.int64)  # the ray is opaque from sample cut[r] on
+    g[np.arange(S)[None, :] >= cut[:, None]] = 0.0
+    g[synth.uniform((R, S), 0, 1, 15) < 0.1] = 0.0  # scattered silent samples inside runs of equal cells
+    g[::7] = 0.0  # whole rays
+    go = dev(g.reshape(R * S, L * F))
+    assert 0.5 < float((go.abs().amax(-1) == 0).float().mean()) < 0.9
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
+    binned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    neg = torch.where(go == 0, -torch.zeros_like(go), go)
+    assert torch.equal(ops.encode_bwd(spec, 1.0, do, dd, da, st, en, neg), binned)
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+    atomic = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    assert rel_l2(host(binned), host(atomic)) < 2e-6
+    assert (binned - atomic).abs().max() <= 1e-5 * atomic.abs().max()
+    # an all-zero gradient gives an all-zero table gradient (every slice is "empty" and zero-filled)
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    assert float(ops.encode_bwd(spec, 1.0, do, dd, da, st, en, torch.zeros_like(go)).abs().max()) == 0.0
+    if F == 1:  # the proposal density backward flags by its own incoming gradient
+        ps = ops.ProposalSpec(spec, dev(synth.hash_table(L << lg, 1, seed=3, scale=0.5)), 1.0, dev(synth.normal((1, L), 5)))
+        dens = ops.proposal_density_fwd(ps, do, dd, da, st, en)
+        gd = dev(g[..., 0].copy())
+        gt, gdec = ops.proposal_density_bwd(ps, do, dd, da, st, en, dens, gd)
+        monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+        gt2, gdec2 = ops.proposal_density_bwd(ps, do, dd, da, st, en, dens, gd)
+        assert rel_l2(host(gt), host(gt2)) < 2e-6 and rel_l2(host(gdec), host(gdec2)) < 1e-5
+
+
 @pytest.mark.parametrize("dims", [(32, 2, 64, 33), (32, 2, 32, 33), (48, 3, 64, 32), (48, 3, 32, 32), (64, 3, 64, 32),
                                   (64, 3, 32, 32)])
 def test_mlp_register_chained_shapes_vs_oracle(ops, dims):
@@ -442,6 +482,10 @@ def test_mlp_register_chained_shapes_vs_oracle(ops, dims):
         for N in (1, 15, 16, 17, 1000, 70001):
             x = synth.normal((N, i), seed=N)
             go = synth.normal((N, o), seed=N + 1)
+            if N >= 1000:  # runs of exactly-zero gradient rows (samples behind a surface): whole 16-row tiles are
+                go[200:488] = 0.0  # skipped by the kernels, partially zero ones are not -- results must not change
+                go[N - 100:] = 0.0
+                go[3::5] = 0.0
             y, hidden = ops.mlp_fwd(dev(x), dws, dbs, save_hidden=True)
             ref_y, acts = O.mlp_fwd(x, ws, bs, return_hidden=True)
             assert rel_l2(host(y), ref_y) < TIGHT, (dims, N)
