@@ -174,34 +174,67 @@ struct SamplerDev {
   float* eu_out[3];
 };
 
-template <bool HALF>
+// S2 for one sample.  LT > 0: the grid has exactly LT levels and ALL 8*LT corner loads are issued before the first
+// blend -- one memory round trip per sample instead of one per level (the kernel is latency bound: 4-byte entries, a few
+// waves per SIMD).  LT == 0: any level count, level after level.  Same arithmetic and summation order either way.
+template <bool HALF, int LT>
 __device__ __forceinline__ float prop_density(const PropDev& p, float ox, float oy, float oz, float dx, float dy,
                                               float dz, float area, float t0, float t1) {
   const SamplePos q = sample_position(ox, oy, oz, dx, dy, dz, area, t0, t1, p.scale);
   const uint32_t mask = (1u << p.grid.log2T) - 1u;
   float acc = 0.f;
-  for (int l = 0; l < p.grid.L; ++l) {
-    float v[1];
-    hash_level<1, HALF>(p.table, (uint32_t)l << p.grid.log2T, q.x, q.y, q.z, p.grid.scal[l], mask, v);
-    acc += (v[0] * rescale_weight(p.grid.scal[l], q.std)) * p.dec[l];
+  if constexpr (LT > 0) {
+    float fv[LT][8][1];
+    float off[LT][3];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      const Corners cs = hash_corners(q.x, q.y, q.z, p.grid.scal[l], mask);
+      off[l][0] = cs.ox, off[l][1] = cs.oy, off[l][2] = cs.oz;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Entry<1, HALF>::load(p.table, ((uint32_t)l << p.grid.log2T) + cs.idx[k], fv[l][k]);
+    }
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      Corners cs;
+      cs.ox = off[l][0], cs.oy = off[l][1], cs.oz = off[l][2];
+      float v[1];
+      lerp_corners<1>(cs, fv[l], v);
+      acc += (v[0] * rescale_weight(p.grid.scal[l], q.std)) * p.dec[l];
+    }
+  } else {
+    for (int l = 0; l < p.grid.L; ++l) {
+      float v[1];
+      hash_level<1, HALF>(p.table, (uint32_t)l << p.grid.log2T, q.x, q.y, q.z, p.grid.scal[l], mask, v);
+      acc += (v[0] * rescale_weight(p.grid.scal[l], q.std)) * p.dec[l];
+    }
   }
   return expf(acc);
 }
 
+// HALF: fp16 tables; LT: level count of the proposal grids when both have the same, compile-time one (else 0).
+// slab_len = (largest sample count of any round) + 1: the per-wave LDS slabs are sized to what the launch needs, not to
+// kSMax, so that LDS does not cap the waves per CU (5 * 513 floats per wave allowed 12 of them).
+template <bool HALF, int LT>
 __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, const float* __restrict__ o,
                                                                 const float* __restrict__ d,
                                                                 const float* __restrict__ area,
                                                                 const float* __restrict__ nears,
-                                                                const float* __restrict__ fars, int64_t R) {
+                                                                const float* __restrict__ fars, int64_t R, int slab_len) {
   // per wave: spacing bins (2 buffers), euclid bins, weights, cdf
-  __shared__ float slab[4][5 * (kSMax + 1)];
+  extern __shared__ __attribute__((aligned(16))) float slab[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float* spA = slab[wid];
-  float* spB = spA + kSMax + 1;
-  float* eu = spB + kSMax + 1;
-  float* wl = eu + kSMax + 1;
-  float* cdf = wl + kSMax + 1;
-  for (int64_t ray = (int64_t)blockIdx.x * 4 + wid; ray < R; ray += (int64_t)gridDim.x * 4) {
+  float* spA = slab + (size_t)wid * 5 * slab_len;
+  float* spB = spA + slab_len;
+  float* eu = spB + slab_len;
+  float* wl = eu + slab_len;
+  float* cdf = wl + slab_len;
+  // each XCD (workgroup b runs on XCD b % 8) walks one contiguous eighth of the batch: neighbouring rays (a camera
+  // patch) share ONE L2 for the fine levels instead of leaving copies of their lines in all eight
+  const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = (int)blockIdx.x % nx, lb = (int)blockIdx.x / nx;
+  const int nblk = ((int)gridDim.x - xcd + nx - 1) / nx;
+  const int64_t r_end = R * (xcd + 1) / nx;
+  for (int64_t ray = R * xcd / nx + (int64_t)lb * 4 + wid; ray < r_end; ray += (int64_t)nblk * 4) {
     const float ox = o[3 * ray], oy = o[3 * ray + 1], oz = o[3 * ray + 2];
     const float dx = d[3 * ray], dy = d[3 * ray + 1], dz = d[3 * ray + 2];
     const float ar = area[ray];
@@ -228,9 +261,7 @@ __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, co
         const int k = k0 + lane;
         const bool live = k < S;
         const float t0 = eu[live ? k : 0], t1 = eu[live ? k + 1 : 1];
-        float dens = sd.prop[rd].grid.dtype == 1
-                         ? prop_density<true>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1)
-                         : prop_density<false>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
+        const float dens = prop_density<HALF, LT>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
         const float dd = live ? (t1 - t0) * dens : 0.f;
         const float incl = wscan_add(dd, lane);
         float w = (1.f - expf(-dd)) * expf(-(carry + incl - dd));
@@ -320,9 +351,31 @@ extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nr
     sd.w_out[i] = round_weights[i];
   }
   if (r == 0) return NRHIP_OK;
+  int smax = 0, lt = sd.prop[0].grid.L;
+  bool half = sd.prop[0].grid.dtype == 1;
+  for (int i = 0; i <= cfg->n_rounds; ++i) smax = cfg->n_samples[i] > smax ? cfg->n_samples[i] : smax;
+  for (int i = 1; i < cfg->n_rounds; ++i) {
+    if (sd.prop[i].grid.L != lt) lt = 0;
+    NR_REQUIRE((sd.prop[i].grid.dtype == 1) == half, NRHIP_ERR_UNSUPPORTED,
+               "proposal_sampler_fwd: the proposal tables must share one storage type");
+  }
+  const int slab_len = smax + 1;
+  const size_t lds = (size_t)4 * 5 * slab_len * sizeof(float);
   int64_t blocks = (r + 3) / 4;
-  if (blocks > 256 * 4) blocks = 256 * 4;
-  proposal_sampler_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(sd, origins, directions, pixel_area, nears,
-                                                                        fars, r);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(HALF_, LT_)                                                                                              \
+  proposal_sampler_kernel<HALF_, LT_><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars, r, \
+                                                                     slab_len)
+  if (half) {
+    if (lt == 6) LAUNCH(true, 6);
+    else LAUNCH(true, 0);
+  } else {
+    if (lt == 6) LAUNCH(false, 6);  // NeuRAD's proposal grids (fields/neurad_field.py:170-177)
+    else if (lt == 4) LAUNCH(false, 4);
+    else if (lt == 8) LAUNCH(false, 8);
+    else LAUNCH(false, 0);
+  }
+#undef LAUNCH
   return check_launch("proposal_sampler_fwd");
 }

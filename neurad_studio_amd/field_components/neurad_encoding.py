@@ -180,7 +180,7 @@ class NeuRADHashEncoding(nn.Module):
             mean = origins[ray] + directions[ray] * t[:, None]                       # cameras/rays.py:118-121
             std = (pixel_area.reshape(-1)[ray] * t.pow(2) * dist).pow(1 / 3)
             r_inv, t_inv = world2box_pairs(self.actors, times[ray], act)
-            pos = (r_inv @ mean[:, :, None])[..., 0] + t_inv                         # transform_points_pairwise
+            pos = (r_inv * mean[:, None, :]).sum(-1) + t_inv  # transform_points_pairwise (lidars.py:550-564), elementwise
             if flip is not None:
                 pos = torch.cat([pos[:, :1] * flip[ray, None], pos[:, 1:]], dim=-1)
             scale = self.config.actor.actor_scale                                    # ScaledSceneContraction(inf)

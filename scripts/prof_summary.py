@@ -17,6 +17,21 @@ for path in sys.argv[1:]:
     for name, calls, total, avg, pct in cur.execute(
             "select name,total_calls,total_duration,average,percentage from top_kernels limit 40"):
         print(f"{calls:6d} {total:12.1f} {avg:10.2f} {pct:6.2f}%  {short(name)}")
+    grp = {"nrhip": [0, 0.0], "other": [0, 0.0]}
+    others = []
+    for name, calls, total in cur.execute("select name,total_calls,total_duration from top_kernels"):
+        k = "nrhip" if "nrhip::" in name else "other"
+        grp[k][0] += calls
+        grp[k][1] += total
+        if k == "other":
+            others.append((total, calls, name))
+    tot = grp["nrhip"][1] + grp["other"][1]
+    if tot > 0:
+        print("-- by origin: hand-written kernels %d launches %.1f us (%.1f%%) | torch/rocm library kernels %d launches "
+              "%.1f us (%.1f%%)" % (grp["nrhip"][0], grp["nrhip"][1], 100 * grp["nrhip"][1] / tot, grp["other"][0],
+                                    grp["other"][1], 100 * grp["other"][1] / tot))
+        for total, calls, name in sorted(others, reverse=True)[:12]:
+            print(f"   other: {calls:6d} {total:10.1f} us  {short(name, 110)}")
     rows = list(cur.execute(
         "select substr(kernel_name,1,200), counter_name, count(*), avg(value), min(value), max(value), avg(duration)"
         " from counters_collection group by kernel_name, counter_name order by avg(value)*count(*) desc limit 10"))
