@@ -197,10 +197,12 @@ def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor,
     touches them: their optimizer state must not decay)."""
     x, grid_id, grad_out = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32), _chk(grad_out, "grad_out")
     present = torch.bincount(grid_id, minlength=n_grids).gt(0).tolist()  # one small device->host read per backward
-    gts = [torch.zeros((spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32) if p else None
-           for p in present]
     if not any(present):
-        return gts
+        return [None] * n_grids
+    # one zero-filled block for all touched grids (a scene has ~100 actor grids: one fill, not one per grid)
+    flat = torch.zeros((sum(present), spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
+    views = iter(flat.unbind(0))
+    gts = [next(views) if p else None for p in present]
     g = spec.c_grid(next(t for t in gts if t is not None))
     ptrs = torch.tensor([0 if t is None else t.data_ptr() for t in gts], dtype=torch.int64, device=x.device)
     call("nrhip_hashgrid_multi_bwd", C.byref(g), n_grids, _ptr(grid_id), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(ptrs),
