@@ -359,7 +359,7 @@ int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int
  * that actor's grid at its box-frame position and uses the box-frame view direction -- NeuRADHashEncoding.forward
  * (field_components/neurad_encoding.py:150-187, 203-208) + NeuRADField.forward (fields/neurad_field.py:128-152) +
  * compositing (models/neurad.py:373-395).  cand_*: the per-ray candidate lists of nrhip_actor_prepare (row length
- * a->max_candidates).  NRHIP_ERR_UNSUPPORTED unless both grids are fp32, the actor grid has the static grid's
+ * a->max_candidates).  NRHIP_ERR_UNSUPPORTED unless both grids share one storage type (fp32 or fp16), the actor grid has the static grid's
  * features per level and at most its number of levels (the reference's defaults: static 8x4, actors 4x4).
  * Three launches, no host round trip: a device-side split of the processing order into rays without / with candidate
  * actors, the plain static kernel over the first slice, the actor-aware instantiation over the second.

@@ -265,7 +265,7 @@ __device__ __forceinline__ void issue_tile(const FieldDev& fd, const PendingTile
 // distinct winner, so the table base stays in SGPRs and the loads keep the SGPR-base + 32-bit-offset form.  Vector loads
 // return in order: the later (actor) data is what the registers end up holding.  Nothing of (1)/(3) is live across the
 // gathers on the common path except one register (the winning slot).
-template <int L, int F>
+template <int L, int F, bool HALF>
 __device__ __forceinline__ void issue_tile_actors(const FieldDev& fd, const ActorFieldDev& ad, const PendingTile& pt, int g,
                                                   uint32_t mask, const float* scal_lds, const float* ascal_lds,
                                                   const int32_t* __restrict__ cand_actor,
@@ -314,7 +314,7 @@ __device__ __forceinline__ void issue_tile_actors(const FieldDev& fd, const Acto
         const int lv = LPL * g + q, alv = lv < ad.La ? lv : ad.La - 1;
         const Corners cs = hash_corners(p.x, p.y, p.z, ascal_lds[alv], amask);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) Entry<F, false>::load(tb, ((uint32_t)alv << ad.log2T) + cs.idx[k], tf.fv[q][k]);
+        for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(tb, ((uint32_t)alv << ad.log2T) + cs.idx[k], tf.fv[q][k]);
       }
     }
   }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void issue_tile_actors(const FieldDev& fd, const Acto
       const Corners cs = hash_corners(p.x, p.y, p.z, scal_lds[q], mask);
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        Entry<F, false>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs.idx[k], tf.fv[q][k]);
+        Entry<F, HALF>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs.idx[k], tf.fv[q][k]);
     }
   }
 }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     const int32_t* __restrict__ cand_actor, const float* __restrict__ cand_w2b, const float* __restrict__ bounds,
     const void* const* __restrict__ tables) {
   static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
-  static_assert(!ACT || (COMPOSITE && !HALF), "actors: composited eval kernel, fp32 tables");
+  static_assert(!ACT || COMPOSITE, "actors: composited eval kernel (static and actor tables share one storage type)");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
   using Ld = Lds<H>;
   constexpr int NB = H / 16;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   PendingTile q;
   load_pending(q, pos, 0, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);
   int64_t ray = q.ray;
-  if constexpr (ACT) issue_tile_actors<L, F>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
+  if constexpr (ACT) issue_tile_actors<L, F, HALF>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
   else issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
   {
     const bool wrap = ntile == 1;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     const int64_t npos = q.pos, nray = q.ray;
     const int nt = q.t;
     // unconditional (see load_pending)
-    if constexpr (ACT) issue_tile_actors<L, F>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
+    if constexpr (ACT) issue_tile_actors<L, F, HALF>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
     else issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
     {
       const bool wrap = nt + 1 == ntile;  // request the small loads of the tile after it
@@ -886,16 +886,20 @@ __global__ __launch_bounds__(kPartThreads) void actor_partition_kernel(const int
   if (tid == 0) ranges[0] = 0, ranges[1] = (int32_t)total, ranges[2] = (int32_t)total, ranges[3] = (int32_t)n;
 }
 
-// composited eval with dynamic actors: fp32 tables, the static shapes NeuRAD uses with actors
+// composited eval with dynamic actors: the static shapes NeuRAD uses with actors, fp32 or fp16 tables
 static int dispatch_render_actors(const nrhip_field* f, const nrhip_rays* rays, const ActorLaunch& al, float* of, float* od,
                                   float* oa, float* ow, float stop_eps, void* stream) {
   const FieldDev fd = to_dev(*f);
   const RaysDev rd = to_dev(*rays);
   const hipStream_t st = (hipStream_t)stream;
   const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
-#define CASE(L_, F_, H_)               \
-  if (L == L_ && F == F_ && H == H_)   \
-    return launch_render<L_, F_, H_, false, true, true>(fd, rd, of, od, oa, ow, nullptr, nullptr, SaveDev{}, stop_eps, st, al);
+  const bool half = f->grid.param_dtype == 1;
+#define CASE(L_, F_, H_)                                                                                                     \
+  if (L == L_ && F == F_ && H == H_)                                                                                         \
+    return half ? launch_render<L_, F_, H_, true, true, true>(fd, rd, of, od, oa, ow, nullptr, nullptr, SaveDev{}, stop_eps, \
+                                                              st, al)                                                        \
+                : launch_render<L_, F_, H_, false, true, true>(fd, rd, of, od, oa, ow, nullptr, nullptr, SaveDev{},          \
+                                                               stop_eps, st, al);
   CASE(8, 4, 32)
   CASE(8, 4, 64)
   CASE(16, 2, 64)
@@ -966,8 +970,8 @@ extern "C" int nrhip_render_fwd_actors(const nrhip_field* f, const nrhip_actors*
   NR_REQUIRE(early_stop_eps >= 0.f && early_stop_eps < 1.f, NRHIP_ERR_INVALID_ARG,
              "render_fwd_actors: early_stop_eps %g not in [0,1)", (double)early_stop_eps);
   // per-sample table select keeps the gather shape: same features per level, no more levels than the static grid
-  NR_REQUIRE(f->grid.param_dtype == 0 && a->grid.param_dtype == 0, NRHIP_ERR_UNSUPPORTED,
-             "render_fwd_actors: fp32 tables only; use the unfused ops");
+  NR_REQUIRE(f->grid.param_dtype == a->grid.param_dtype, NRHIP_ERR_UNSUPPORTED,
+             "render_fwd_actors: the static and the actor tables must share one storage type (fp32 or fp16)");
   NR_REQUIRE(a->grid.n_features == f->grid.n_features && a->grid.num_levels <= f->grid.num_levels, NRHIP_ERR_UNSUPPORTED,
              "render_fwd_actors: actor grid (L=%d F=%d) must have the static grid's features per level (F=%d) and at most "
              "its levels (L=%d); use the unfused ops",

@@ -123,7 +123,8 @@ class NeuRADField(nn.Module):
         if self.hashgrid.has_actors():
             ag_ = self.hashgrid.actor_grids[0]
             if not (with_actors and ag_.features_per_level == g.features_per_level and ag_.num_levels <= g.num_levels
-                    and g.hash_table.dtype == torch.float32 and (g.num_levels, c.geo_hidden_dim) in ((8, 32), (8, 64), (16, 64))):
+                    and all(a.hash_table.dtype == g.hash_table.dtype for a in self.hashgrid.actor_grids)
+                    and (g.num_levels, c.geo_hidden_dim) in ((8, 32), (8, 64), (16, 64))):
                 return False
         return (g.get_out_dim() == 32 and g.num_levels % 4 == 0 and c.geo_num_layers == 2 and c.nff_num_layers == 3
                 and c.geo_hidden_dim == c.nff_hidden_dim and c.geo_hidden_dim in (32, 64) and c.nff_out_dim == 32)

@@ -629,7 +629,7 @@ class ActorSpec:
         present = present.view(torch.uint8) if present.dtype == torch.bool else present.to(torch.uint8)  # bool is 1 byte
         keep = [_chk(self.timestamps, "timestamps"), _chk(self.positions, "positions"),
                 _chk(self.rotations_6d, "rotations_6d"), present, _chk(self.bounds, "bounds")]
-        tabs = [_chk(t, "actor table") for t in self.tables]
+        tabs = [_chk(t, "actor table", self.tables[0].dtype) for t in self.tables]  # one storage type (fp32 | fp16)
         # device array of table pointers: uploaded once per set of tables, not once per call (a pageable H2D copy
         # synchronises the host with the stream)
         key = (keep[0].device, tuple(t.data_ptr() for t in tabs))

@@ -340,3 +340,25 @@ def test_fused_render_many_actors_vs_oracle_and_operator_path(with_order):
     with torch.no_grad():
         f2, _, a2 = fld.render(dev(o), dev(d), dev(area), dev(st), dev(en), times=dev(times), early_stop_eps=1e-3)
     assert float((a2 - acc).abs().max()) <= 1e-3 + 1e-6 and float((f2 - feats).abs().max()) < 5e-2
+
+
+def test_fused_render_with_actors_fp16_tables_equal_rounded_fp32_tables():
+    """BASELINE config[4]'s storage: fp16 hash tables (static and actors).  The kernel converts entries on load, so the
+    result must equal, bit for bit, the fp32 run on tables holding the rounded values."""
+    g = load_golden("field_actors")
+    outs = []
+    for half in (False, True):
+        fld = make_field()
+        for grid in [fld.hashgrid.static_grid, *fld.hashgrid.actor_grids]:
+            rounded = grid.hash_table.data.half()
+            grid.hash_table.data = rounded if half else rounded.float()
+        assert fld.fused_supported(with_actors=True)
+        with torch.no_grad():
+            outs.append(fld.render(dev(g["o"]), dev(g["d"]), dev(g["area"]), dev(g["starts"]), dev(g["ends"]),
+                                   times=dev(g["times"])))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # mixed storage is refused, not silently converted
+    fld = make_field()
+    fld.hashgrid.static_grid.hash_table.data = fld.hashgrid.static_grid.hash_table.data.half()
+    assert not fld.fused_supported(with_actors=True)
