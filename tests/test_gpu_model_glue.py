@@ -305,3 +305,68 @@ def test_model_eval_with_actors_fused_render_matches_operator_path():
     with torch.no_grad():
         static_only = m.get_nff_outputs(rb())
     assert rel_l2(host(static_only["features"]), host(fused["features"])) > 1e-3
+
+
+def test_config4_shape_actors_fp16_field_tables_appearance_65536_rays_chunked():
+    """BASELINE config[4] at full size: NeuRAD-default grids with the main field's tables (static 8 x 2^22 x 4 and 24
+    actor grids) in fp16, appearance embedding, dynamic actors, a 65536-ray batch through the chunked eval entry.
+    Size-independent properties + a 2048-ray slice against the operator-level path of the same model with fp32 tables
+    holding the rounded values (that path is pinned to the reference by test_gpu_actors / the proposal_actors golden)."""
+    from neurad_studio_amd import ops
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig, _slice_bundle
+
+    A, R = 24, 65536
+    ts = torch.linspace(0.0, 4.0, 9)
+    gen = torch.Generator().manual_seed(21)
+    trajs = []
+    for a in range(A):
+        x0, y0 = 60 * torch.rand(2, generator=gen) - 30
+        yaw, v = 6.28 * float(torch.rand(1, generator=gen)), 4 * float(torch.rand(1, generator=gen))
+        poses = torch.eye(4).repeat(len(ts), 1, 1)
+        c, s = np.cos(yaw), np.sin(yaw)
+        poses[:, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        poses[:, 0, 3], poses[:, 1, 3], poses[:, 2, 3] = x0 + v * ts * c, y0 + v * ts * s, 0.8
+        trajs.append({"timestamps": ts.clone(), "poses": poses, "dims": torch.tensor([2.0, 4.6, 1.6]),
+                      "symmetric": torch.tensor(True), "deformable": torch.tensor(False)})
+
+    def build(half):
+        torch.manual_seed(2)
+        m = NeuRADHotPath(NeuRADHotPathConfig(), static_scale=100.0, num_sensors=6, duration=4.0,
+                          actors=DynamicActors(DynamicActorsConfig(), trajectories=trajs)).cuda().eval()
+        with torch.no_grad():
+            m.field.hashgrid.static_grid.hash_table.mul_(300.0)
+            for gr in m.field.hashgrid.actor_grids:
+                gr.hash_table.mul_(2000.0)
+            for p in m.proposal_fields:
+                p.hashgrid.static_grid.hash_table.mul_(500.0)
+            for gr in [m.field.hashgrid.static_grid, *m.field.hashgrid.actor_grids]:
+                gr.hash_table.data = gr.hash_table.data.half() if half else gr.hash_table.data.half().float()
+        return m
+
+    o = torch.randn(R, 3, generator=gen) * torch.tensor([20.0, 20.0, 0.3]) + torch.tensor([0.0, 0.0, 1.5])
+    d = torch.randn(R, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.1])
+    d = torch.nn.functional.normalize(d, dim=-1)
+    rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((R, 1), 2.7e-7, device="cuda"),
+                   times=(4 * torch.rand(R, 1, generator=gen)).cuda(),
+                   metadata={"sensor_idxs": torch.randint(0, 6, (R, 1), generator=gen).cuda()})
+    m16 = build(True)
+    calls = []
+    real = ops.render_fwd_actors
+    ops.render_fwd_actors = lambda *a, **k: (calls.append(a[3].shape[0]), real(*a, **k))[1]
+    try:
+        out = m16.get_outputs_for_ray_bundle(rb, num_rays_per_chunk=1 << 15)
+        out2 = m16.get_outputs_for_ray_bundle(rb, num_rays_per_chunk=24000)
+    finally:
+        ops.render_fwd_actors = real
+    assert calls[:2] == [1 << 15, 1 << 15] and len(calls) == 2 + 3  # the fused actor kernel rendered every chunk
+    assert out["features"].shape == (R, 48) and all(torch.isfinite(v).all() for v in out.values())
+    assert float(out["accumulation"].min()) >= -1e-6 and float(out["accumulation"].max()) <= 1 + 1e-5
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k  # chunking changes nothing
+    m32 = build(False)
+    sl = _slice_bundle(rb, 1000, 3048)
+    op = m32.get_nff_outputs(sl)  # grad enabled -> operator-level path, fp32 tables with the same (rounded) values
+    for k in ("features", "depth", "accumulation"):
+        assert rel_l2(host(out[k][1000:3048]), host(op[k])) < 5e-5, k
