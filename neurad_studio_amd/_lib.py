@@ -120,6 +120,8 @@ PROTOTYPES = {
     "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P, P],
     "nrhip_actor_hits": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],
+    "nrhip_actor_pair_positions_fwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P],
+    "nrhip_actor_pair_positions_bwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P, P, P],
     "nrhip_render_fwd_actors": [C.POINTER(Field), C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P, P, F32, P, P],
     "nrhip_occgrid_march": [C.POINTER(OccGrid), P, P, P, P, P, I64, F32, F32, F32, F32, I32, P, P, P, P, P, P],
     "nrhip_packed_visibility_from_alpha": [P, P, I64, F32, F32, P, P],

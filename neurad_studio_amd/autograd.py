@@ -34,6 +34,29 @@ class HashGridFn(torch.autograd.Function):
         return gx, _like_param(gt, ctx.table_dtype), None
 
 
+class ActorPairPositionsFn(torch.autograd.Function):
+    """Box-frame contracted positions of (sample, actor) pairs, differentiable w.r.t. the trajectory parameters
+    (interpolate_trajectories_6d -> rotation_6d_to_matrix -> pose inverse -> transform -> flip -> contraction, see
+    csrc/actors.hip).  args: actor_positions [Tn,A,3], actor_rotations_6d [Tn,A,6] (the tensors inside ``spec``, passed
+    so that autograd sees them), spec, origins, directions, pixel_area, starts, ends, times, sample_idx, actor_idx, flip.
+    -> x01 [P,3], cstd [P]"""
+
+    @staticmethod
+    def forward(ctx, positions, rotations_6d, spec, origins, directions, pixel_area, starts, ends, times, sample_idx,
+                actor_idx, flip):
+        ctx.spec, ctx.flip = spec, flip
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, times, sample_idx, actor_idx)
+        return ops.actor_pair_positions(spec, origins, directions, pixel_area, starts, ends, times, sample_idx, actor_idx,
+                                        flip)
+
+    @staticmethod
+    def backward(ctx, g_x01, g_cstd):
+        o, d, a, s, e, times, si, ai = ctx.saved_tensors
+        gp, gr = ops.actor_pair_positions_bwd(ctx.spec, o, d, a, s, e, times, si, ai, ctx.flip, g_x01.contiguous(),
+                                              g_cstd.contiguous())
+        return (gp, gr) + (None,) * 10
+
+
 class MultiHashGridFn(torch.autograd.Function):
     """HashEncoding.pytorch_fwd over several grids of one shape: row i looks into tables[grid_id[i]] -- the per-actor
     grids of NeuRADHashEncoding in one launch (`_get_actor_features_slow` loops over actor ids,

@@ -335,3 +335,202 @@ extern "C" int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays
                                                                          cand_w2b, decoder_weight, n_dec, density, hit);
   return check_launch("actor_density");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Training path of the in-box samples (B1): box-frame, contracted position of (sample, actor) PAIRS and its backward into
+// the trajectory parameters.  One thread per pair does what the reference spreads over ~50 torch ops (and their ~100
+// autograd kernels): interpolate_trajectories_6d (utils/poses.py:90-150: Gram-Schmidt of the stored 6-D rotations, lerp
+// between the two bracketing poses, Gram-Schmidt again) -> rotation_6d_to_matrix (cameras/camera_utils.py:422-443) ->
+// pose inverse (utils/poses.py:42-55) -> transform_points_pairwise (cameras/lidars.py:550-564) -> training flip
+// (neurad_encoding.py:212-219) -> ScaledSceneContraction(inf) of the gaussian (spatial_distortions.py:103-141).
+// Same arithmetic as actor_prepare_kernel / find_hit, so the forward kernels and this path agree on every position.
+namespace nrhip {
+
+struct PairFrame {
+  int left, right;
+  float frac;
+  float u1[3], u2[3], t[3];  // interpolated (normalised) pose: two rotation rows and the translation
+  float b1[3], b2[3], b3[3];
+  float n1, nc, dot;         // |u1|, |u2 - (b1.u2) b1|, b1.u2
+};
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// Gram-Schmidt with torch's F.normalize (eps 1e-12): a1 = r1/|r1|, a2 = c/|c|, c = r2 - (a1.r2) a1
+__device__ __forceinline__ void gram_schmidt(const float* r1, const float* r2, float* a1, float* a2, float& n1, float& nc,
+                                             float& dt) {
+  n1 = fmaxf(sqrtf(dot3(r1, r1)), 1e-12f);
+  for (int k = 0; k < 3; ++k) a1[k] = r1[k] / n1;
+  dt = dot3(a1, r2);
+  float c[3];
+  for (int k = 0; k < 3; ++k) c[k] = r2[k] - dt * a1[k];
+  nc = fmaxf(sqrtf(dot3(c, c)), 1e-12f);
+  for (int k = 0; k < 3; ++k) a2[k] = c[k] / nc;
+}
+
+// gradient of gram_schmidt: (g_a1, g_a2) -> (g_r1, g_r2)
+__device__ __forceinline__ void gram_schmidt_bwd(const float* r2, const float* a1, const float* a2, float n1, float nc,
+                                                 float dt, const float* g_a1_in, const float* g_a2, float* g_r1,
+                                                 float* g_r2) {
+  float gc[3], ga1[3];
+  const float s2 = dot3(g_a2, a2);
+  for (int k = 0; k < 3; ++k) gc[k] = (g_a2[k] - s2 * a2[k]) / nc;
+  const float s1 = dot3(gc, a1);
+  for (int k = 0; k < 3; ++k) {
+    g_r2[k] = gc[k] - s1 * a1[k];
+    ga1[k] = g_a1_in[k] - s1 * r2[k] - dt * gc[k];
+  }
+  const float s0 = dot3(ga1, a1);
+  for (int k = 0; k < 3; ++k) g_r1[k] = (ga1[k] - s0 * a1[k]) / n1;
+}
+
+__device__ __forceinline__ void pair_frame(const ActorsDev& a, int act, float q, PairFrame& f) {
+  int right = 0;
+  for (int i = 0; i < a.Tn; ++i) right += a.ts[i] < q ? 1 : 0;  // torch.searchsorted(side=left)
+  f.left = max(right - 1, 0);
+  f.right = min(right, a.Tn - 1);
+  const float lt = a.ts[f.left], rt = a.ts[f.right];
+  f.frac = fminf(fmaxf((q - lt) / (rt - lt + 1e-6f), 0.f), 1.f);
+  float pl[9], pr[9];
+  ortho6(a.rot6 + ((size_t)f.left * a.A + act) * 6, pl, a.pos + ((size_t)f.left * a.A + act) * 3);
+  ortho6(a.rot6 + ((size_t)f.right * a.A + act) * 6, pr, a.pos + ((size_t)f.right * a.A + act) * 3);
+  float ip[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ip[k] = pl[k] + (pr[k] - pl[k]) * f.frac;
+  for (int k = 0; k < 3; ++k) f.u1[k] = ip[k], f.u2[k] = ip[3 + k], f.t[k] = ip[6 + k];
+  gram_schmidt(f.u1, f.u2, f.b1, f.b2, f.n1, f.nc, f.dot);
+  f.b3[0] = f.b1[1] * f.b2[2] - f.b1[2] * f.b2[1];
+  f.b3[1] = f.b1[2] * f.b2[0] - f.b1[0] * f.b2[2];
+  f.b3[2] = f.b1[0] * f.b2[1] - f.b1[1] * f.b2[0];
+}
+
+// world -> box: rows of world2box are (b1x, b2x, b3x | -(.)t) ... exactly actor_prepare_kernel's w2b
+__device__ __forceinline__ void pair_box_position(const PairFrame& f, const SamplePos& g, float flip, float* pos) {
+  for (int i = 0; i < 3; ++i) {
+    const float tr = -(f.b1[i] * f.t[0] + f.b2[i] * f.t[1] + f.b3[i] * f.t[2]);
+    pos[i] = f.b1[i] * g.x + f.b2[i] * g.y + f.b3[i] * g.z + tr;
+  }
+  pos[0] *= flip;
+}
+
+__global__ __launch_bounds__(256) void actor_pair_positions_kernel(ActorsDev a, RaysDev r, const float* __restrict__ times,
+                                                                   const int64_t* __restrict__ sample_idx,
+                                                                   const int32_t* __restrict__ actor_idx,
+                                                                   const float* __restrict__ ray_flip, int64_t n_pairs,
+                                                                   float* __restrict__ x01, float* __restrict__ cstd) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int64_t i = sample_idx[p], ray = i / r.S;
+  const int s = (int)(i - ray * r.S);
+  PairFrame f;
+  pair_frame(a, actor_idx[p], times[ray], f);
+  const SamplePos g = sample_gaussian(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray], r.d[3 * ray + 1],
+                                      r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
+                                      r.ends[ray * r.stride + s]);
+  float pos[3];
+  pair_box_position(f, g, ray_flip ? ray_flip[ray] : 1.f, pos);
+  const SamplePos c = contract_gaussian(pos[0], pos[1], pos[2], g.std, a.scale);
+  x01[3 * p] = c.x, x01[3 * p + 1] = c.y, x01[3 * p + 2] = c.z;
+  cstd[p] = c.std;
+}
+
+__global__ __launch_bounds__(256) void actor_pair_positions_bwd_kernel(
+    ActorsDev a, RaysDev r, const float* __restrict__ times, const int64_t* __restrict__ sample_idx,
+    const int32_t* __restrict__ actor_idx, const float* __restrict__ ray_flip, int64_t n_pairs,
+    const float* __restrict__ g_x01, const float* __restrict__ g_cstd, float* __restrict__ g_positions,
+    float* __restrict__ g_rot6) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int64_t i = sample_idx[p], ray = i / r.S;
+  const int s = (int)(i - ray * r.S);
+  const int act = actor_idx[p];
+  PairFrame f;
+  pair_frame(a, act, times[ray], f);
+  const SamplePos g = sample_gaussian(r.o[3 * ray], r.o[3 * ray + 1], r.o[3 * ray + 2], r.d[3 * ray], r.d[3 * ray + 1],
+                                      r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + s],
+                                      r.ends[ray * r.stride + s]);
+  const float flip = ray_flip ? ray_flip[ray] : 1.f;
+  float pos[3];
+  pair_box_position(f, g, flip, pos);
+  // ---- contraction backward (spatial_distortions.py:126-141, order = inf): (g_x01, g_cstd) -> g_pos ----------------
+  float m[3] = {pos[0] / a.scale, pos[1] / a.scale, pos[2] / a.scale};
+  const float am[3] = {fabsf(m[0]), fabsf(m[1]), fabsf(m[2])};
+  const int kmax = am[0] >= am[1] ? (am[0] >= am[2] ? 0 : 2) : (am[1] >= am[2] ? 1 : 2);
+  const float mag = am[kmax];
+  float gm[3] = {g_x01[3 * p] / 4.f, g_x01[3 * p + 1] / 4.f, g_x01[3 * p + 2] / 4.f};  // x01 = (m' + 2) / 4
+  if (!(mag < 1.f)) {
+    // m' = k m, k = 2/mag - 1/mag^2;   cstd = (std/scale) q / 4, q = ((2 mag - 1)^(1/3) / mag)^2
+    const float k = 2.f / mag - 1.f / (mag * mag), dk = -2.f / (mag * mag) + 2.f / (mag * mag * mag);
+    const float cr = cbrtf(2.f * mag - 1.f), rr = cr / mag;
+    const float dq = 2.f * rr * ((2.f / 3.f) / (cr * cr * mag) - cr / (mag * mag));
+    const float g_mag = (gm[0] * m[0] + gm[1] * m[1] + gm[2] * m[2]) * dk + g_cstd[p] * (g.std / a.scale) * dq / 4.f;
+    for (int c = 0; c < 3; ++c) gm[c] *= k;
+    gm[kmax] += g_mag * (m[kmax] < 0.f ? -1.f : 1.f);
+  }
+  float gpos[3] = {gm[0] / a.scale * flip, gm[1] / a.scale, gm[2] / a.scale};
+  // ---- pos_i = b1_i v_0 + b2_i v_1 + b3_i v_2,  v = mean - t ---------------------------------------------------------
+  const float v[3] = {g.x - f.t[0], g.y - f.t[1], g.z - f.t[2]};
+  float gb1[3], gb2[3], gb3[3], gt[3];
+  for (int c = 0; c < 3; ++c) gb1[c] = v[0] * gpos[c], gb2[c] = v[1] * gpos[c], gb3[c] = v[2] * gpos[c];
+  gt[0] = -dot3(f.b1, gpos), gt[1] = -dot3(f.b2, gpos), gt[2] = -dot3(f.b3, gpos);
+  // b3 = b1 x b2:  g_b1 += b2 x g_b3,  g_b2 += g_b3 x b1
+  gb1[0] += f.b2[1] * gb3[2] - f.b2[2] * gb3[1];
+  gb1[1] += f.b2[2] * gb3[0] - f.b2[0] * gb3[2];
+  gb1[2] += f.b2[0] * gb3[1] - f.b2[1] * gb3[0];
+  gb2[0] += gb3[1] * f.b1[2] - gb3[2] * f.b1[1];
+  gb2[1] += gb3[2] * f.b1[0] - gb3[0] * f.b1[2];
+  gb2[2] += gb3[0] * f.b1[1] - gb3[1] * f.b1[0];
+  float gu1[3], gu2[3];
+  gram_schmidt_bwd(f.u2, f.b1, f.b2, f.n1, f.nc, f.dot, gb1, gb2, gu1, gu2);
+  // ---- lerp between the two stored poses, then each pose's own Gram-Schmidt -----------------------------------------
+  const float wgt[2] = {1.f - f.frac, f.frac};
+  const int tix[2] = {f.left, f.right};
+  for (int e = 0; e < 2; ++e) {
+    if (wgt[e] == 0.f) continue;
+    const float* raw = a.rot6 + ((size_t)tix[e] * a.A + act) * 6;
+    float a1[3], a2[3], n1, nc, dt, ga1[3], ga2[3], gr1[3], gr2[3];
+    gram_schmidt(raw, raw + 3, a1, a2, n1, nc, dt);
+    for (int c = 0; c < 3; ++c) ga1[c] = wgt[e] * gu1[c], ga2[c] = wgt[e] * gu2[c];
+    gram_schmidt_bwd(raw + 3, a1, a2, n1, nc, dt, ga1, ga2, gr1, gr2);
+    float* gr = g_rot6 + ((size_t)tix[e] * a.A + act) * 6;
+    float* gp = g_positions + ((size_t)tix[e] * a.A + act) * 3;
+    for (int c = 0; c < 3; ++c) {
+      atomicAdd(gr + c, gr1[c]);
+      atomicAdd(gr + 3 + c, gr2[c]);
+      atomicAdd(gp + c, wgt[e] * gt[c]);
+    }
+  }
+}
+
+}  // namespace nrhip
+
+extern "C" int nrhip_actor_pair_positions_fwd(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                              const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip,
+                                              int64_t n_pairs, float* x01, float* cstd, void* stream) {
+  ActorsDev d;
+  if (int e = to_dev(a, d)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(n_pairs >= 0 && a->actor_scale > 0.f, NRHIP_ERR_INVALID_ARG, "actor_pair_positions: bad argument");
+  if (n_pairs == 0) return NRHIP_OK;
+  NR_REQUIRE(times && sample_idx && actor_idx && x01 && cstd, NRHIP_ERR_INVALID_ARG, "actor_pair_positions: NULL pointer");
+  actor_pair_positions_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
+      d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, x01, cstd);
+  return check_launch("actor_pair_positions_fwd");
+}
+
+extern "C" int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                              const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip,
+                                              int64_t n_pairs, const float* grad_x01, const float* grad_cstd,
+                                              float* grad_positions, float* grad_rotations_6d, void* stream) {
+  ActorsDev d;
+  if (int e = to_dev(a, d)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(n_pairs >= 0 && a->actor_scale > 0.f, NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd: bad argument");
+  if (n_pairs == 0) return NRHIP_OK;
+  NR_REQUIRE(times && sample_idx && actor_idx && grad_x01 && grad_cstd && grad_positions && grad_rotations_6d,
+             NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd: NULL pointer");
+  actor_pair_positions_bwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
+      d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, grad_x01, grad_cstd, grad_positions,
+      grad_rotations_6d);
+  return check_launch("actor_pair_positions_bwd");
+}

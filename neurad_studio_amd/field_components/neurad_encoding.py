@@ -167,29 +167,17 @@ class NeuRADHashEncoding(nn.Module):
         pair = (hits >= 0).nonzero()                  # every (sample, candidate slot) containment
         if pair.shape[0] == 0:
             return None
-        from ..model_components.dynamic_actors import world2box_pairs
-
-        idx, act = pair[:, 0], hits[pair[:, 0], pair[:, 1]].long()
-        winner = act == hit[idx].long()               # the row the forward actually used (highest actor index)
-        S = starts.shape[1]
-        ray, smp = idx // S, idx % S
-        with torch.set_grad_enabled(torch.is_grad_enabled() and self.config.require_actor_grad):
-            t0, t1 = starts[ray, smp], ends[ray, smp]
-            dist = (t1 - t0) / 2
-            t = t0 + dist
-            mean = origins[ray] + directions[ray] * t[:, None]                       # cameras/rays.py:118-121
-            std = (pixel_area.reshape(-1)[ray] * t.pow(2) * dist).pow(1 / 3)
-            r_inv, t_inv = world2box_pairs(self.actors, times[ray], act)
-            pos = (r_inv * mean[:, None, :]).sum(-1) + t_inv  # transform_points_pairwise (lidars.py:550-564), elementwise
-            if flip is not None:
-                pos = torch.cat([pos[:, :1] * flip[ray, None], pos[:, 1:]], dim=-1)
-            scale = self.config.actor.actor_scale                                    # ScaledSceneContraction(inf)
-            m, s = pos / scale, std / scale
-            mag = m.abs().amax(dim=-1, keepdim=True)
-            cm = mag.clamp_min(1.0)
-            m = torch.where(mag < 1, m, (2 - 1 / cm) * (m / cm))
-            s = torch.where(mag[:, 0] < 1, s, s * (((2 * cm[:, 0] - 1).pow(1 / 3) / cm[:, 0]) ** 2))
-            x01, cstd = (m + 2.0) / 4.0, s / 4.0
+        idx, act = pair[:, 0], hits[pair[:, 0], pair[:, 1]]
+        winner = act == hit[idx]                      # the row the forward actually used (highest actor index)
+        # box-frame position + contraction of every pair in one kernel; its backward hands the trajectory parameters
+        # their gradient (require_actor_grad governs exactly that: neurad_encoding.py:174-176)
+        spec = self.actor_spec()
+        pose_grad = torch.is_grad_enabled() and self.config.require_actor_grad
+        with torch.set_grad_enabled(pose_grad):
+            x01, cstd = ag.ActorPairPositionsFn.apply(self.actors.actor_positions, self.actors.actor_rotations_6d, spec,
+                                                      origins, directions, pixel_area.reshape(-1), starts, ends, times, idx,
+                                                      act.int(), flip)
+        act = act.long()
         ids = self.actors.actor_to_id[act]
         # _get_actor_features_slow loops over the actor ids; all actor grids share one shape, so one multi-grid
         # lookup (row i -> actor_grids[ids[i]]) does the same without the per-id launches and host syncs

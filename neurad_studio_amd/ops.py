@@ -680,6 +680,37 @@ def actor_encode(spec: ActorSpec, cand, origins, directions, pixel_area, starts,
     return dirs, hit  # int32: actor index or -1
 
 
+def actor_pair_positions(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times, sample_idx: Tensor,
+                         actor_idx: Tensor, ray_flip: Optional[Tensor] = None):
+    """Box-frame, contracted position of (sample, actor) pairs.  sample_idx [P] int64 flat sample index, actor_idx [P]
+    int32.  -> (x01 [P,3] in [0,1]^3, cstd [P])"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    a, keep2 = spec.c_actors()
+    si, ai = _chk(sample_idx, "sample_idx", torch.int64), _chk(actor_idx, "actor_idx", torch.int32)
+    P_ = si.shape[0]
+    x01 = torch.empty((P_, 3), dtype=torch.float32, device=si.device)
+    cstd = torch.empty((P_,), dtype=torch.float32, device=si.device)
+    call("nrhip_actor_pair_positions_fwd", C.byref(a), C.byref(r), _ptr(_chk(times.reshape(-1), "times")), _ptr(si),
+         _ptr(ai), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), P_, _ptr(x01), _ptr(cstd),
+         _stream())
+    return x01, cstd
+
+
+def actor_pair_positions_bwd(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times, sample_idx, actor_idx,
+                             ray_flip, grad_x01: Tensor, grad_cstd: Tensor):
+    """-> (grad actor_positions [Tn,A,3], grad actor_rotations_6d [Tn,A,6])"""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    a, keep2 = spec.c_actors()
+    si, ai = _chk(sample_idx, "sample_idx", torch.int64), _chk(actor_idx, "actor_idx", torch.int32)
+    flat = torch.zeros((a.n_times * a.n_actors * 9,), dtype=torch.float32, device=si.device)
+    gp = flat[: a.n_times * a.n_actors * 3].view(a.n_times, a.n_actors, 3)
+    gr = flat[a.n_times * a.n_actors * 3:].view(a.n_times, a.n_actors, 6)
+    call("nrhip_actor_pair_positions_bwd", C.byref(a), C.byref(r), _ptr(_chk(times.reshape(-1), "times")), _ptr(si),
+         _ptr(ai), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), si.shape[0],
+         _ptr(_chk(grad_x01, "grad_x01")), _ptr(_chk(grad_cstd, "grad_cstd")), _ptr(gp), _ptr(gr), _stream())
+    return gp, gr
+
+
 def actor_hits(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends) -> Tensor:
     """-> hits [N,8] int32: the actors whose boxes contain the sample, ascending, padded with -1"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)

@@ -362,3 +362,60 @@ def test_fused_render_with_actors_fp16_tables_equal_rounded_fp32_tables():
     fld = make_field()
     fld.hashgrid.static_grid.hash_table.data = fld.hashgrid.static_grid.hash_table.data.half()
     assert not fld.fused_supported(with_actors=True)
+
+
+@pytest.mark.parametrize("scale", [10.0, 1.5])
+def test_actor_pair_positions_kernel_vs_torch_autograd(scale):
+    """nrhip_actor_pair_positions_fwd/bwd (pose interpolation -> 6-D rotation -> inverse -> transform -> flip ->
+    contraction, one thread per pair, hand-written backward) against the torch formulation of the same chain
+    (model_components/dynamic_actors.world2box_pairs + the contraction ops; that formulation matches the reference's
+    autograd, tests/golden/field_actors_grads).  scale 1.5 puts most pairs OUTSIDE the unit box of the contraction."""
+    from neurad_studio_amd import autograd as ag
+    from neurad_studio_amd.model_components.dynamic_actors import world2box_pairs
+
+    g = load_golden("field_actors")
+    fld = make_field()
+    fld.hashgrid.config.actor.actor_scale = scale
+    act = fld.hashgrid.actors
+    o, d, a = dev(g["o"]), dev(g["d"]), dev(g["area"])
+    st, en, times = dev(g["starts"]), dev(g["ends"]), dev(g["times"])
+    R, S = st.shape
+    torch.manual_seed(0)
+    P = 4000
+    idx = torch.randint(0, R * S, (P,), device="cuda")
+    aidx = torch.randint(0, 3, (P,), device="cuda")
+    flip = (torch.randint(0, 2, (R,), device="cuda") * 2 - 1).float()
+    gx, gs = torch.randn(P, 3, device="cuda"), torch.randn(P, device="cuda")
+
+    def torch_chain():
+        ray, smp = idx // S, idx % S
+        t0, t1 = st[ray, smp], en[ray, smp]
+        dist = (t1 - t0) / 2
+        t = t0 + dist
+        mean = o[ray] + d[ray] * t[:, None]
+        std = (a[ray] * t.pow(2) * dist).pow(1 / 3)
+        r_inv, t_inv = world2box_pairs(act, times[ray], aidx)
+        pos = (r_inv * mean[:, None, :]).sum(-1) + t_inv
+        pos = torch.cat([pos[:, :1] * flip[ray, None], pos[:, 1:]], dim=-1)
+        m, s = pos / scale, std / scale
+        mag = m.abs().amax(dim=-1, keepdim=True)
+        cm = mag.clamp_min(1.0)
+        m = torch.where(mag < 1, m, (2 - 1 / cm) * (m / cm))
+        s = torch.where(mag[:, 0] < 1, s, s * (((2 * cm[:, 0] - 1).pow(1 / 3) / cm[:, 0]) ** 2))
+        return (m + 2.0) / 4.0, s / 4.0
+
+    for p in (act.actor_positions, act.actor_rotations_6d):
+        p.requires_grad_(True)
+        p.grad = None
+    x_ref, s_ref = torch_chain()
+    ((x_ref * gx).sum() + (s_ref * gs).sum()).backward()
+    want = [act.actor_positions.grad.clone(), act.actor_rotations_6d.grad.clone()]
+    act.actor_positions.grad = act.actor_rotations_6d.grad = None
+    x, s = ag.ActorPairPositionsFn.apply(act.actor_positions, act.actor_rotations_6d, fld.hashgrid.actor_spec(), o, d, a, st,
+                                         en, times, idx, aidx.int(), flip)
+    assert float((x - x_ref).abs().max()) < 2e-6 and rel_l2(host(s), host(s_ref)) < 1e-5
+    if scale < 5:
+        assert float(((x_ref - 0.5).abs().amax(-1) > 0.25).float().mean()) > 0.5  # the contracted branch is exercised
+    ((x * gx).sum() + (s * gs).sum()).backward()
+    assert rel_l2(host(act.actor_positions.grad), host(want[0])) < 1e-4
+    assert rel_l2(host(act.actor_rotations_6d.grad), host(want[1])) < 1e-4
