@@ -355,6 +355,21 @@ int nrhip_actor_density(const nrhip_actors* a, const nrhip_rays* rays, const int
                         float* density /*[R,S] overwritten where hit*/, int32_t* hit /*actor index or -1*/, const float* ray_flip,
                         void* stream);
 
+/* Training path of the in-box samples: box-frame, contracted position of P (sample, actor) pairs -- the chain
+ * interpolate_trajectories_6d (utils/poses.py:90-150) -> rotation_6d_to_matrix (cameras/camera_utils.py:422-443) ->
+ * pose inverse (utils/poses.py:42-55) -> transform_points_pairwise (cameras/lidars.py:550-564) -> training x-flip
+ * (neurad_encoding.py:212-219) -> ScaledSceneContraction(inf) (spatial_distortions.py:103-141) -- and its backward into
+ * the trajectory parameters (what autograd does for `require_actor_grad`, neurad_encoding.py:174-176).
+ * sample_idx [P] int64 = flat sample index ray*S + s; actor_idx [P] int32; x01 [P,3] in [0,1]^3, cstd [P].
+ * bwd ACCUMULATES into grad_positions [Tn,A,3] and grad_rotations_6d [Tn,A,6] (caller zeroes).                    */
+int nrhip_actor_pair_positions_fwd(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                   const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip /*[R] or NULL*/,
+                                   int64_t n_pairs, float* x01, float* cstd, void* stream);
+int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                   const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip,
+                                   int64_t n_pairs, const float* grad_x01, const float* grad_cstd,
+                                   float* grad_positions, float* grad_rotations_6d, void* stream);
+
 /* F1+C1+C2 with dynamic actors in ONE kernel (eval): nrhip_render_fwd_ex where a sample inside an actor's box reads
  * that actor's grid at its box-frame position and uses the box-frame view direction -- NeuRADHashEncoding.forward
  * (field_components/neurad_encoding.py:150-187, 203-208) + NeuRADField.forward (fields/neurad_field.py:128-152) +

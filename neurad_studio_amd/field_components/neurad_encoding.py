@@ -69,6 +69,30 @@ class _MaskRowsFn(torch.autograd.Function):
         return g.masked_fill(hit[:, None], 0.0), None
 
 
+class _SpliceActorRowsFn(torch.autograd.Function):
+    """``features[ray_idx, sample_idx] = actor_rows`` with the reference's autograd (neurad_encoding.py:184-185) and no
+    sort / nonzero / host sync.  pairs: ``idx`` [P] flat sample index, ``winner`` [P] (exactly one per hit sample).
+    Value: the winner's row replaces the static row.  Gradient: the replaced static rows get none; EVERY pair -- the
+    shadowed actors of overlapping boxes too -- receives the gradient of its sample's row (index_put's backward hands it
+    to all duplicates)."""
+
+    @staticmethod
+    def forward(ctx, feats, rows, idx, winner):
+        n = feats.shape[0]
+        buf = torch.empty((n + 1, feats.shape[1]), dtype=feats.dtype, device=feats.device)
+        buf[:n] = feats
+        buf.index_copy_(0, torch.where(winner, idx, n), rows)  # the shadowed pairs land in the spare row n
+        ctx.save_for_backward(idx)
+        return buf[:n]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g_rows = g.index_select(0, idx) if ctx.needs_input_grad[1] else None
+        g_feats = g.index_fill(0, idx, 0.0) if ctx.needs_input_grad[0] else None
+        return g_feats, g_rows, None, None
+
+
 class NeuRADHashEncoding(nn.Module):
     def __init__(self, config: NeuRADHashEncodingConfig, dynamic_actors=None, static_scale: float = 1.0,
                  implementation: str = "hip") -> None:
@@ -108,9 +132,19 @@ class NeuRADHashEncoding(nn.Module):
             self._actor_ids = (key, act.actor_to_id.tolist())
         ids = self._actor_ids[1]
         g0 = self.actor_grids[0]
-        return ops.ActorSpec(act.unique_timestamps.float(), act.actor_positions.detach(),
-                             act.actor_rotations_6d.detach(), act.actor_present_at_time, act.actor_bounds(), g0.spec,
-                             [self.actor_grids[i].hash_table.detach() for i in ids], self.config.actor.actor_scale)
+        # The spec only holds POINTERS into the parameters: it stays valid across optimizer steps (in-place updates) and
+        # is rebuilt when a tensor is re-assigned or when the box sizes / padding (-> bounds, a derived tensor) change.
+        sizes, pad = act.actor_sizes, act.actor_padding
+        pad_key = (pad._version, pad.data_ptr()) if isinstance(pad, Tensor) else pad
+        skey = (act.actor_positions.data_ptr(), act.actor_rotations_6d.data_ptr(), act.unique_timestamps.data_ptr(),
+                act.actor_present_at_time.data_ptr(), sizes._version, sizes.data_ptr(), pad_key,
+                self.config.actor.actor_scale, tuple(self.actor_grids[i].hash_table.data_ptr() for i in ids))
+        if getattr(self, "_actor_spec", (None, None))[0] != skey:
+            self._actor_spec = (skey, ops.ActorSpec(
+                act.unique_timestamps.float(), act.actor_positions.detach(), act.actor_rotations_6d.detach(),
+                act.actor_present_at_time, act.actor_bounds().detach(), g0.spec,
+                [self.actor_grids[i].hash_table.detach() for i in ids], self.config.actor.actor_scale))
+        return self._actor_spec[1]
 
     def prepare_actors(self, origins, directions, pixel_area, starts, ends, times):
         """per-ray candidate lists (shared by every field evaluated on the same ray bundle)."""
@@ -193,13 +227,7 @@ class NeuRADHashEncoding(nn.Module):
             return feats
         idx, winner, f = pr
         rows = torch.nn.functional.pad(f, (0, self.scene_repr_dim - f.shape[1]))
-        out = feats.index_put((idx[winner],), rows[winner])
-        if not bool(winner.all()):
-            # overlapping actors: the reference's index_put backward hands the upstream gradient to EVERY duplicate
-            # (ray, sample) row (neurad_encoding.py:184-185) -> the shadowed actors get gradients too; zero in value
-            lose = ~winner
-            out = out.index_put((idx[lose],), rows[lose] - rows[lose].detach(), accumulate=True)
-        return out
+        return _SpliceActorRowsFn.apply(feats, rows, idx, winner)
 
     def forward(self, ray_samples, times=None, directions: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """Reference signature is forward(GaussiansStd, times, directions); here the frustums are passed directly

@@ -175,9 +175,19 @@ def hashgrid_bwd(spec: GridSpec, table_like: Tensor, x: Tensor, grad_out: Tensor
     return gt
 
 
+_POINTER_TABLES: dict = {}
+
+
 def _ptr_array(tensors: Sequence[Tensor]) -> Tensor:
-    """device array of data pointers (the multi-grid entry points take `void* const*` in device memory)"""
-    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=tensors[0].device)
+    """device array of data pointers (the multi-grid entry points take `void* const*` in device memory); uploaded once
+    per distinct set of tensors -- a pageable H2D copy per call synchronises the host with the stream"""
+    key = (tensors[0].device, tuple(t.data_ptr() for t in tensors))
+    ptrs = _POINTER_TABLES.get(key)
+    if ptrs is None:
+        if len(_POINTER_TABLES) >= 32:
+            _POINTER_TABLES.clear()
+        ptrs = _POINTER_TABLES[key] = torch.tensor(key[1], dtype=torch.int64, device=key[0])
+    return ptrs
 
 
 def hashgrid_multi_fwd(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor, x: Tensor) -> Tensor:
@@ -608,9 +618,6 @@ def proposal_sampler_fwd(props: Sequence[ProposalSpec], origins, directions, pix
     return ws, sps, eus
 
 
-_POINTER_TABLES: dict = {}
-
-
 @dataclass
 class ActorSpec:
     """Device-side view of DynamicActors + the per-actor grids."""
@@ -625,6 +632,9 @@ class ActorSpec:
     actor_scale: float = 10.0
 
     def c_actors(self):
+        cached = getattr(self, "_c_actors", None)  # plain pointers + sizes: valid for as long as this spec's tensors live
+        if cached is not None:
+            return cached
         present = self.present.contiguous()
         present = present.view(torch.uint8) if present.dtype == torch.bool else present.to(torch.uint8)  # bool is 1 byte
         keep = [_chk(self.timestamps, "timestamps"), _chk(self.positions, "positions"),
@@ -632,12 +642,7 @@ class ActorSpec:
         tabs = [_chk(t, "actor table", self.tables[0].dtype) for t in self.tables]  # one storage type (fp32 | fp16)
         # device array of table pointers: uploaded once per set of tables, not once per call (a pageable H2D copy
         # synchronises the host with the stream)
-        key = (keep[0].device, tuple(t.data_ptr() for t in tabs))
-        ptrs = _POINTER_TABLES.get(key)
-        if ptrs is None:
-            if len(_POINTER_TABLES) >= 16:
-                _POINTER_TABLES.clear()
-            ptrs = _POINTER_TABLES[key] = torch.tensor(key[1], dtype=torch.int64, device=key[0])
+        ptrs = _ptr_array(tabs)
         a = _lib.Actors()
         a.n_times, a.n_actors = self.positions.shape[0], self.positions.shape[1]
         a.timestamps, a.positions, a.rotations_6d = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
@@ -646,7 +651,8 @@ class ActorSpec:
         a.tables = ptrs.data_ptr()
         a.actor_scale = float(self.actor_scale)
         a.max_candidates = a.n_actors  # per-ray lists as long as the actor count: no ray can overflow, no host check
-        return a, (keep, tabs, ptrs)
+        self._c_actors = (a, (keep, tabs, ptrs))
+        return self._c_actors
 
 
 def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times):
