@@ -191,6 +191,30 @@ int nrhip_render_weight_from_density_bwd(const float* t_starts, const float* t_e
 /* values may be NULL (accumulation only, C=1) */
 int nrhip_accumulate_along_rays(const float* weights /*[R,S]*/, const float* values /*[R,S,C]*/, int64_t r,
                                 int32_t s, int32_t c, float* out /*[R,C]*/, void* stream);
+/* its autograd (values given): grad_weights [R,S] = sum_c g[r,c] v[r,s,c], grad_values [R,S,C] = w[r,s] g[r,c];
+ * either output may be NULL */
+int nrhip_accumulate_along_rays_bwd(const float* weights, const float* values, const float* g_out /*[R,C]*/, int64_t r,
+                                    int32_t s, int32_t c, float* grad_weights, float* grad_values, void* stream);
+
+/* ---- C4 / §8(f) row 2: lidar carving.  is_close [R,S] (uint8) = NeuRADModel._compute_is_close_to_lidar
+ * (models/neurad.py:677-700): lidar sample whose midpoint lies within carving_epsilon of the measured return, or -- no
+ * return -- anywhere closer than non_return_lidar_distance; with `weights` also the proposal carving term of
+ * models/neurad.py:399-408 per ray, loss_per_ray [R] = sum_s (w * (is_lidar & ~close))^2, and its gradient
+ * grad_weights [R,S] = 2 w (is_lidar & ~close).  is_lidar / did_return (may be NULL = all returned) are uint8 [R];
+ * any of the three outputs may be NULL.                                                                             */
+int nrhip_lidar_carving(const float* starts, const float* ends, int32_t sample_stride /*0 = S*/, const float* weights,
+                        const uint8_t* is_lidar, const uint8_t* did_return, const float* distance /*[R]*/,
+                        float carving_epsilon, float non_return_lidar_distance, int64_t r, int32_t s, uint8_t* is_close,
+                        float* loss_per_ray, float* grad_weights, void* stream);
+
+/* ---- C3: appearance embedding (models/neurad.py:423-441): out[r,:] = E[idx_lo[r]] * (1 - frac[r]) + E[idx_hi[r]] * frac[r]
+ * (idx_hi == frac == NULL: the plain lookup of use_temporal_appearance = False).  E [n_embed, dim], indices int64.
+ * bwd ACCUMULATES the table gradient into grad_weight [n_embed, dim] (caller zeroes): nn.Embedding's backward.     */
+int nrhip_embedding_lerp_fwd(const float* weight, const int64_t* idx_lo, const int64_t* idx_hi, const float* frac,
+                             int64_t r, int32_t n_embed, int32_t dim, float* out /*[R,dim]*/, void* stream);
+int nrhip_embedding_lerp_bwd(const float* g_out /*[R,dim]*/, const int64_t* idx_lo, const int64_t* idx_hi,
+                             const float* frac, int64_t r, int32_t n_embed, int32_t dim, float* grad_weight,
+                             void* stream);
 
 /* ---- C2: get_nff_outputs compositing (models/neurad.py:377-395,727-734) ------------------------
  * weights [R,S] come from C1; the residual 1-acc goes on the last (sky) sample; depth drops it.     */

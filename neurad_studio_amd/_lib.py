@@ -101,6 +101,10 @@ PROTOTYPES = {
     "nrhip_render_weight_from_density": [P, P, P, I64, I32, P, P, P, P],
     "nrhip_render_weight_from_density_bwd": [P, P, P, P, I64, I32, P, P],
     "nrhip_accumulate_along_rays": [P, P, I64, I32, I32, P, P],
+    "nrhip_lidar_carving": [P, P, I32, P, P, P, P, F32, F32, I64, I32, P, P, P, P],
+    "nrhip_embedding_lerp_fwd": [P, P, P, P, I64, I32, I32, P, P],
+    "nrhip_embedding_lerp_bwd": [P, P, P, P, I64, I32, I32, P, P],
+    "nrhip_accumulate_along_rays_bwd": [P, P, P, I64, I32, I32, P, P, P],
     "nrhip_composite_fwd": [P, P, P, P, I64, I32, I32, P, P, P, P],
     "nrhip_composite_bwd": [P, P, P, P, P, P, P, I64, I32, I32, P, P, P],
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],

@@ -244,9 +244,42 @@ class AccumulateFn(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, g):
         w, v = ctx.saved_tensors
-        gw = (g[:, None, :] * v).sum(-1) if v is not None else g.expand_as(w)
-        gv = w[..., None] * g[:, None, :] if (v is not None and ctx.needs_input_grad[1]) else None
-        return gw, gv
+        if v is None:
+            return g.expand_as(w), None
+        return ops.accumulate_along_rays_bwd(w, v, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+class CarvingLossFn(torch.autograd.Function):
+    """sum((w * (is_lidar & ~is_close))^2) over a level (models/neurad.py:399-408) -- value and gradient from ONE pass that
+    recomputes the mask from the sample edges.  args: weights [R,S], starts, ends [R,S], is_lidar, did_return, distance
+    (per ray), carving_epsilon, non_return_lidar_distance."""
+
+    @staticmethod
+    def forward(ctx, weights, starts, ends, is_lidar, did_return, distance, eps, non_return):
+        _, loss, gw = ops.lidar_carving(starts, ends, is_lidar, did_return, distance, eps, non_return,
+                                        weights=weights.contiguous(), want_mask=False)
+        ctx.save_for_backward(gw)
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gw,) = ctx.saved_tensors
+        return (gw * g,) + (None,) * 7
+
+
+class EmbeddingLerpFn(torch.autograd.Function):
+    """C3 (models/neurad.py:423-441): per-ray lerp of two embedding rows; gradient to the embedding table only."""
+
+    @staticmethod
+    def forward(ctx, weight, idx_lo, idx_hi, frac):
+        ctx.save_for_backward(idx_lo, idx_hi, frac)
+        ctx.n_embed = weight.shape[0]
+        return ops.embedding_lerp(weight, idx_lo, idx_hi, frac)
+
+    @staticmethod
+    def backward(ctx, g):
+        lo, hi, fr = ctx.saved_tensors
+        return ops.embedding_lerp_bwd(g.contiguous(), lo, hi, fr, ctx.n_embed), None, None, None
 
 
 class CompositeFn(torch.autograd.Function):

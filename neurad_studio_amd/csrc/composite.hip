@@ -179,6 +179,102 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void weights_bwd_kernel(const f
   }
 }
 
+// C3: appearance embedding (models/neurad.py:423-441): out[r] = E[lo[r]] (1 - f[r]) + E[hi[r]] f[r]  (hi == NULL: a plain
+// lookup).  Backward: a few dozen embedding rows receive all R gradients -- torch's embedding_dense_backward sorts the
+// indices for that (2 x 150 us per step at 57 344 rays); here every workgroup sums its rays into an LDS image of the
+// table and adds the image once (tables beyond 32 KB go straight to global atomics).
+constexpr int kEmbedLdsFloats = 8192;
+
+__global__ __launch_bounds__(256) void embedding_lerp_fwd_kernel(const float* __restrict__ wgt,
+                                                                 const int64_t* __restrict__ lo,
+                                                                 const int64_t* __restrict__ hi,
+                                                                 const float* __restrict__ frac, int64_t R, int D,
+                                                                 float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * D) return;
+  const int64_t r = i / D;
+  const int d = (int)(i - r * D);
+  const float a = wgt[lo[r] * D + d];
+  if (!hi) {
+    out[i] = a;
+    return;
+  }
+  const float f = frac[r];
+  out[i] = a * (1.f - f) + wgt[hi[r] * D + d] * f;  // the reference's e_lo * (1 - frac) + e_hi * frac
+}
+
+__global__ __launch_bounds__(256) void embedding_lerp_bwd_kernel(const float* __restrict__ g,
+                                                                 const int64_t* __restrict__ lo,
+                                                                 const int64_t* __restrict__ hi,
+                                                                 const float* __restrict__ frac, int64_t R, int E, int D,
+                                                                 int in_lds, float* __restrict__ gw) {
+  extern __shared__ __attribute__((aligned(16))) float img[];
+  const int cells = E * D;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < cells; k += 256) img[k] = 0.f;
+    __syncthreads();
+  }
+  float* acc = in_lds ? img : gw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < R * D; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    const float gv = g[i];
+    if (!hi) {
+      atomicAdd(acc + lo[r] * D + d, gv);
+    } else {
+      const float f = frac[r];
+      atomicAdd(acc + lo[r] * D + d, gv * (1.f - f));
+      atomicAdd(acc + hi[r] * D + d, gv * f);
+    }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < cells; k += 256)
+      if (img[k] != 0.f) atomicAdd(gw + k, img[k]);
+  }
+}
+
+// backward of accumulate_along_rays with values: gw[r,s] = Σ_c g[r,c] v[r,s,c];  gv[r,s,c] = w[r,s] g[r,c].  One wave per
+// ray walks the [S*C] row flat (coalesced); torch autograd materialises two [R,S,C] products for this.
+__global__ __launch_bounds__(64 * kRaysPerBlock) void accumulate_bwd_kernel(const float* __restrict__ w,
+                                                                            const float* __restrict__ v,
+                                                                            const float* __restrict__ g, int64_t R, int S,
+                                                                            int C, float* __restrict__ gw,
+                                                                            float* __restrict__ gv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const float* wr = w + ray * S;
+  const float* vr = v + ray * (int64_t)S * C;
+  const float* gr = g + ray * C;
+  if (C <= 64 && (64 % C) == 0) {
+    // a lane always sees the same channel; the C lanes of one sample are neighbours -> xor-reduce them for gw
+    const float gc = gr[lane % C];
+    const int total = S * C;
+    for (int i0 = 0; i0 < total; i0 += 64) {
+      const int i = i0 + lane;
+      const bool live = i < total;
+      const int s = live ? i / C : 0;
+      float part = live ? gc * vr[i] : 0.f;
+      if (gv && live) gv[ray * (int64_t)total + i] = wr[s] * gc;
+      if (gw) {
+        for (int off = C >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (live && (lane % C) == 0) gw[ray * S + s] = part;
+      }
+    }
+  } else {
+    for (int s = lane; s < S; s += 64) {
+      float acc = 0.f;
+      const float ws = wr[s];
+      for (int ch = 0; ch < C; ++ch) {
+        acc += gr[ch] * vr[(int64_t)s * C + ch];
+        if (gv) gv[(ray * S + s) * (int64_t)C + ch] = ws * gr[ch];
+      }
+      if (gw) gw[ray * S + s] = acc;
+    }
+  }
+}
+
 // accumulate_along_rays (dense): out[r,c] = Σ_s w[r,s] * v[r,s,c]   (values==NULL -> Σ_s w)
 __global__ __launch_bounds__(64 * kRaysPerBlock) void accumulate_kernel(const float* __restrict__ w,
                                                                         const float* __restrict__ v, int64_t R,
@@ -386,6 +482,42 @@ extern "C" int nrhip_accumulate_along_rays(const float* weights, const float* va
   if (r == 0) return NRHIP_OK;
   LAUNCH_RAYS(accumulate_kernel, r, stream, weights, values, r, s, c, out);
   return check_launch("accumulate_along_rays");
+}
+
+extern "C" int nrhip_embedding_lerp_fwd(const float* weight, const int64_t* idx_lo, const int64_t* idx_hi,
+                                        const float* frac, int64_t r, int32_t n_embed, int32_t dim, float* out,
+                                        void* stream) {
+  NR_REQUIRE(weight && idx_lo && out && r >= 0 && n_embed >= 1 && dim >= 1 && (!idx_hi || frac), NRHIP_ERR_INVALID_ARG,
+             "embedding_lerp_fwd: bad argument");
+  if (r == 0) return NRHIP_OK;
+  embedding_lerp_fwd_kernel<<<grid_for(r * dim, 256), 256, 0, (hipStream_t)stream>>>(weight, idx_lo, idx_hi, frac, r, dim,
+                                                                                    out);
+  return check_launch("embedding_lerp_fwd");
+}
+
+extern "C" int nrhip_embedding_lerp_bwd(const float* g_out, const int64_t* idx_lo, const int64_t* idx_hi,
+                                        const float* frac, int64_t r, int32_t n_embed, int32_t dim, float* grad_weight,
+                                        void* stream) {
+  NR_REQUIRE(g_out && idx_lo && grad_weight && r >= 0 && n_embed >= 1 && dim >= 1 && (!idx_hi || frac),
+             NRHIP_ERR_INVALID_ARG, "embedding_lerp_bwd: bad argument");
+  if (r == 0) return NRHIP_OK;
+  const int64_t cells = (int64_t)n_embed * dim;
+  const bool in_lds = cells <= kEmbedLdsFloats;
+  int blocks = (int)((r * dim + 256 * 16 - 1) / (256 * 16));  // >= 16 elements per thread before a table is flushed
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+  embedding_lerp_bwd_kernel<<<blocks, 256, in_lds ? cells * sizeof(float) : 0, (hipStream_t)stream>>>(
+      g_out, idx_lo, idx_hi, frac, r, n_embed, dim, in_lds ? 1 : 0, grad_weight);
+  return check_launch("embedding_lerp_bwd");
+}
+
+extern "C" int nrhip_accumulate_along_rays_bwd(const float* weights, const float* values, const float* g_out, int64_t r,
+                                               int32_t s, int32_t c, float* grad_weights, float* grad_values,
+                                               void* stream) {
+  NR_REQUIRE(weights && values && g_out && r >= 0 && s >= 0 && c >= 1 && (grad_weights || grad_values),
+             NRHIP_ERR_INVALID_ARG, "accumulate_along_rays_bwd: bad argument");
+  if (r == 0 || s == 0) return NRHIP_OK;
+  LAUNCH_RAYS(accumulate_bwd_kernel, r, stream, weights, values, g_out, r, s, c, grad_weights, grad_values);
+  return check_launch("accumulate_along_rays_bwd");
 }
 
 extern "C" int nrhip_composite_fwd(const float* weights, const float* features, const float* starts,

@@ -176,6 +176,43 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void distortion_loss_kernel(con
 }
 
 }  // namespace
+
+// ---- carving: NeuRADModel._compute_is_close_to_lidar (models/neurad.py:677-700) and the proposal
+// carving term sum((w * (is_lidar & ~close))^2) (models/neurad.py:399-408) ------------------------------------------------
+// The reference spends ~7 elementwise ops per sample level on the mask and ~6 more (with autograd) on each loss term; here
+// one pass per level writes the mask and, when weights are given, the per-ray loss and its gradient 2 w far.
+__global__ __launch_bounds__(256) void lidar_carving_kernel(const float* __restrict__ starts,
+                                                            const float* __restrict__ ends, int stride,
+                                                            const float* __restrict__ weights,
+                                                            const uint8_t* __restrict__ is_lidar,
+                                                            const uint8_t* __restrict__ did_return,
+                                                            const float* __restrict__ dist, float eps, float non_return,
+                                                            int64_t R, int S, uint8_t* __restrict__ is_close,
+                                                            float* __restrict__ loss_ray, float* __restrict__ grad_w) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const bool lidar = is_lidar[ray] != 0;
+  const bool returned = did_return ? did_return[ray] != 0 : true;
+  const float dr = dist[ray];
+  float acc = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float mid = (starts[ray * stride + s] + ends[ray * stride + s]) * 0.5f;
+    const bool close = lidar && (returned ? fabsf(dr - mid) < eps : mid < non_return);
+    if (is_close) is_close[ray * S + s] = close ? 1 : 0;
+    if (weights) {
+      const float wf = (lidar && !close) ? weights[ray * S + s] : 0.f;
+      acc += wf * wf;
+      if (grad_w) grad_w[ray * S + s] = 2.f * wf;
+    }
+  }
+  if (loss_ray) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) loss_ray[ray] = acc;
+  }
+}
+
 }  // namespace nrhip
 
 using namespace nrhip;
@@ -204,4 +241,18 @@ extern "C" int nrhip_distortion_loss(const float* c, const float* w, int32_t n_s
   distortion_loss_kernel<<<(unsigned)((r + kRaysPerBlock - 1) / kRaysPerBlock), 64 * kRaysPerBlock, 0,
                            (hipStream_t)stream>>>(c, w, n_samples, r, loss_per_ray, grad_w);
   return check_launch("distortion_loss");
+}
+
+extern "C" int nrhip_lidar_carving(const float* starts, const float* ends, int32_t sample_stride, const float* weights,
+                                   const uint8_t* is_lidar, const uint8_t* did_return, const float* distance,
+                                   float carving_epsilon, float non_return_lidar_distance, int64_t r, int32_t s,
+                                   uint8_t* is_close, float* loss_per_ray, float* grad_weights, void* stream) {
+  NR_REQUIRE(starts && ends && is_lidar && distance && r >= 0 && s >= 0 && (is_close || loss_per_ray || grad_weights),
+             NRHIP_ERR_INVALID_ARG, "lidar_carving: bad argument");
+  NR_REQUIRE(weights || (!loss_per_ray && !grad_weights), NRHIP_ERR_INVALID_ARG, "lidar_carving: the loss needs the weights");
+  if (r == 0) return NRHIP_OK;
+  nrhip::lidar_carving_kernel<<<(int)((r + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      starts, ends, sample_stride > 0 ? sample_stride : s, weights, is_lidar, did_return, distance, carving_epsilon,
+      non_return_lidar_distance, r, s, is_close, loss_per_ray, grad_weights);
+  return nrhip::check_launch("lidar_carving");
 }

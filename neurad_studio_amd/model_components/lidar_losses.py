@@ -42,18 +42,22 @@ def lidar_metrics(outputs: Dict[str, Tensor], is_lidar: Tensor, did_return: Tens
     """is_lidar [R] bool over the whole batch; did_return [n_lidar] bool, distance [n_lidar,1], intensity_target
     [n_lidar,1] for the lidar rays in batch order.  outputs: depth [R,1], prop_depth_i [R,1], prop_weights_loss_i,
     non_nearby_weights, and the lidar head's intensity / ray_drop_logits [n_lidar,1]."""
-    n_lidar = is_lidar.sum()
-    err = _depth_l1(outputs["depth"][is_lidar], distance, did_return, cfg)
+    # One compaction of the lidar rays for all three depth terms, and masked means instead of boolean indexing: every
+    # `x[mask]` is a nonzero + a device->host sync (its length) -- five of them per step in the reference formulation.
+    n_lidar = distance.shape[0]  # (== is_lidar.sum(): the lidar part of the batch comes with the batch)
+    lidar_rows = is_lidar.reshape(-1).nonzero().squeeze(-1)
+    err = _depth_l1(outputs["depth"].index_select(0, lidar_rows), distance, did_return, cfg)
     # robust mean: the worst (1 - quantile_threshold) of the rays are left out of the depth and intensity terms
     keep = (err < torch.quantile(err, cfg.quantile_threshold)).squeeze(-1)
-    m = {"depth_loss": err[keep].mean()}
+    m = {"depth_loss": (err.squeeze(-1) * keep).sum() / keep.sum()}
     sel = keep & did_return
-    m["intensity_loss"] = (intensity_target[sel] - outputs["intensity"][sel]).square().mean()
+    m["intensity_loss"] = ((intensity_target - outputs["intensity"]).square().squeeze(-1) * sel).sum() / sel.sum()
     logits = outputs["ray_drop_logits"]
     m["ray_drop_loss"] = binary_cross_entropy_with_logits(logits, (~did_return)[:, None].to(logits))
     m["carving_loss"] = outputs["non_nearby_weights"].square().sum() / n_lidar  # average per lidar ray
     for i in range(num_proposal_rounds):
-        m[f"depth_loss_{i}"] = _depth_l1(outputs[f"prop_depth_{i}"][is_lidar], distance, did_return, cfg).mean()
+        m[f"depth_loss_{i}"] = _depth_l1(outputs[f"prop_depth_{i}"].index_select(0, lidar_rows), distance, did_return,
+                                         cfg).mean()
         m[f"carving_loss_{i}"] = outputs[f"prop_weights_loss_{i}"] / n_lidar
     return m
 

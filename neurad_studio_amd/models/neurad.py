@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from .. import autograd as ag
 from .. import ops
 from ..cameras.rays import RayBundle, sample_times
 from ..field_components.field_heads import FieldHeadNames
@@ -264,28 +265,41 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
         if sensor is None:
             assert not self.training, "sensor_idxs must be present in metadata during training"
             sensor = torch.zeros_like(features[..., :1], dtype=torch.long)
+        table = self.appearance_embedding.weight
         if not self.config.use_temporal_appearance:
-            return self.appearance_embedding(sensor.squeeze(-1))
+            return ag.EmbeddingLerpFn.apply(table, sensor.reshape(-1).long(), None, None)
         n = self._num_embeds_per_sensor
         slot = ray_bundle.times / self._duration * n
         lo = slot.floor().clamp(0, n - 1)
         hi = (lo + 1).clamp(0, n - 1)
         frac = slot - lo
         base = sensor * n
-        e_lo = self.appearance_embedding((lo + base).squeeze(-1).long())
-        e_hi = self.appearance_embedding((hi + base).squeeze(-1).long())
-        return e_lo * (1 - frac) + e_hi * frac
+        # e_lo * (1 - frac) + e_hi * frac in one kernel; its backward sums the R gradient rows into the few embedding
+        # rows through LDS instead of torch's sort-based embedding_dense_backward (twice)
+        return ag.EmbeddingLerpFn.apply(table, (lo + base).reshape(-1).long(), (hi + base).reshape(-1).long(),
+                                        frac.reshape(-1))
 
     def _mark_close_to_lidar(self, rs) -> None:
         """metadata["is_close_to_lidar"] per sample (models/neurad.py:677-700): a lidar sample is "close" when it lies
         within carving_epsilon of the measured return, or -- for beams without a return -- anywhere inside the sensor's
         range; camera samples never are."""
+        close, _, _ = ops.lidar_carving(*self._carving_inputs(rs))  # one pass instead of ~7 elementwise ops per level
+        rs.metadata["is_close_to_lidar"] = close[..., None]
+
+    def _carving_inputs(self, rs):
+        """(starts, ends [R,S] views, per-ray is_lidar, did_return | None, measured distance, epsilon, non-return range)"""
         md, fr = rs.metadata, rs.frustums
-        mid = (fr.starts + fr.ends) * 0.5
-        close = (md["directions_norm"] - mid).abs() < self.config.carving_epsilon
-        if "did_return" in md:
-            close = torch.where(md["did_return"], close, mid < self.config.non_return_lidar_distance)
-        md["is_close_to_lidar"] = md["is_lidar"] & close
+
+        def edges(t):
+            t = t[..., 0]
+            return t if t.stride(-1) == 1 else t.contiguous()
+
+        starts, ends = edges(fr.starts), edges(fr.ends)
+        if starts.stride(0) != ends.stride(0):
+            starts, ends = starts.contiguous(), ends.contiguous()
+        ray = lambda t: t[:, 0, 0]  # noqa: E731  (per-ray metadata is broadcast over the samples)
+        return (starts, ends, ray(md["is_lidar"]), ray(md["did_return"]) if "did_return" in md else None,
+                ray(md["directions_norm"]), self.config.carving_epsilon, self.config.non_return_lidar_distance)
 
     # ---- get_nff_outputs (models/neurad.py:368-421) ------------------------------------------------
     def get_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool = False) -> Dict[str, Tensor]:
@@ -308,8 +322,7 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
         for i, (pw, prs) in enumerate(zip(proposal_weights, proposal_ray_samples)):
             nff[f"prop_depth_{i}"] = self.renderer_depth(pw, prs)
             if lidar_terms:  # carving: lidar weight away from the measured surface
-                far_from_hit = prs.metadata["is_lidar"] & ~prs.metadata["is_close_to_lidar"]
-                nff[f"prop_weights_loss_{i}"] = (pw * far_from_hit).square().sum()
+                nff[f"prop_weights_loss_{i}"] = ag.CarvingLossFn.apply(pw[..., 0], *self._carving_inputs(prs))
         if self.training:
             nff["weights_list"] = proposal_weights + [weights]
             nff["ray_samples_list"] = proposal_ray_samples + [ray_samples]

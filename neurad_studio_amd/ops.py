@@ -478,6 +478,60 @@ def composite_fwd(weights, features, starts, ends):
     return of, od, oa
 
 
+def lidar_carving(starts: Tensor, ends: Tensor, is_lidar: Tensor, did_return: Optional[Tensor], distance: Tensor,
+                  carving_epsilon: float, non_return_lidar_distance: float, weights: Optional[Tensor] = None,
+                  want_mask: bool = True, want_grad: bool = True):
+    """starts/ends [R,S] (any row stride), per-ray is_lidar / did_return (bool) / distance -> (is_close [R,S] bool or
+    None, loss_per_ray [R] or None, grad_weights [R,S] or None); the loss terms need ``weights`` [R,S]."""
+    R, S = starts.shape
+    assert starts.stride(1) == 1 and ends.stride(1) == 1 and starts.stride(0) == ends.stride(0)
+    for v, n in ((starts, "starts"), (ends, "ends")):
+        if not v.is_cuda or v.dtype != torch.float32:
+            raise _lib.NeuradHipError(f"{n}: expected a float32 GPU tensor")
+    u8 = lambda m: None if m is None else m.reshape(-1).contiguous().view(torch.uint8)  # noqa: E731  (bool is 1 byte)
+    lid, ret = u8(is_lidar), u8(did_return)
+    dist = _chk(distance.reshape(-1), "distance")
+    w = None if weights is None else _chk(weights, "weights")
+    dev = starts.device
+    close = torch.empty((R, S), dtype=torch.bool, device=dev) if want_mask else None
+    loss = torch.empty((R,), dtype=torch.float32, device=dev) if w is not None else None
+    gw = torch.empty((R, S), dtype=torch.float32, device=dev) if (w is not None and want_grad) else None
+    call("nrhip_lidar_carving", _ptr(starts), _ptr(ends), starts.stride(0), _ptr(w), _ptr(lid), _ptr(ret), _ptr(dist),
+         float(carving_epsilon), float(non_return_lidar_distance), R, S, _ptr(close), _ptr(loss), _ptr(gw), _stream())
+    return close, loss, gw
+
+
+def embedding_lerp(weight: Tensor, idx_lo: Tensor, idx_hi: Optional[Tensor] = None, frac: Optional[Tensor] = None) -> Tensor:
+    """out[r] = weight[idx_lo[r]] * (1 - frac[r]) + weight[idx_hi[r]] * frac[r]   (idx_hi None: weight[idx_lo])"""
+    w, lo = _chk(weight, "weight"), _chk(idx_lo.reshape(-1), "idx_lo", torch.int64)
+    hi = None if idx_hi is None else _chk(idx_hi.reshape(-1), "idx_hi", torch.int64)
+    fr = None if frac is None else _chk(frac.reshape(-1), "frac")
+    out = torch.empty((lo.shape[0], w.shape[1]), dtype=torch.float32, device=w.device)
+    call("nrhip_embedding_lerp_fwd", _ptr(w), _ptr(lo), _ptr(hi), _ptr(fr), lo.shape[0], w.shape[0], w.shape[1], _ptr(out),
+         _stream())
+    return out
+
+
+def embedding_lerp_bwd(g_out: Tensor, idx_lo, idx_hi, frac, n_embed: int) -> Tensor:
+    g, lo = _chk(g_out, "g_out"), _chk(idx_lo.reshape(-1), "idx_lo", torch.int64)
+    hi = None if idx_hi is None else _chk(idx_hi.reshape(-1), "idx_hi", torch.int64)
+    fr = None if frac is None else _chk(frac.reshape(-1), "frac")
+    gw = torch.zeros((n_embed, g.shape[1]), dtype=torch.float32, device=g.device)
+    call("nrhip_embedding_lerp_bwd", _ptr(g), _ptr(lo), _ptr(hi), _ptr(fr), lo.shape[0], n_embed, g.shape[1], _ptr(gw),
+         _stream())
+    return gw
+
+
+def accumulate_along_rays_bwd(weights, values, g_out, need_grad_weights=True, need_grad_values=True):
+    """-> (grad weights [R,S] or None, grad values [R,S,C] or None) of out[r,c] = sum_s w[r,s] v[r,s,c]"""
+    w, v, g = _chk(weights, "weights"), _chk(values, "values"), _chk(g_out, "g_out")
+    R, S, Cc = v.shape
+    gw = torch.empty_like(w) if need_grad_weights else None
+    gv = torch.empty_like(v) if need_grad_values else None
+    call("nrhip_accumulate_along_rays_bwd", _ptr(w), _ptr(v), _ptr(g), R, S, Cc, _ptr(gw), _ptr(gv), _stream())
+    return gw, gv
+
+
 def composite_bwd(weights, features, starts, ends, g_feat, g_depth=None, g_acc=None, need_grad_features=True):
     w, f, s, e, gf = (_chk(v, n) for v, n in ((weights, "weights"), (features, "features"), (starts, "starts"),
                                               (ends, "ends"), (g_feat, "g_feat")))

@@ -587,3 +587,40 @@ def test_power_sampler_sky_stretch_folded(ops):
     sp1, eu1 = ops.power_sampler(None, fars, 37, last_edge=20000.0)
     eu0[:, -1] = 20000.0
     assert torch.equal(sp0, sp1) and torch.equal(eu0, eu1)
+
+
+@pytest.mark.parametrize("shape", [(301, 32, 32), (17, 129, 3), (64, 31, 48), (5, 1, 1)])
+def test_accumulate_along_rays_backward_kernel_vs_torch(ops, shape):
+    """nrhip_accumulate_along_rays_bwd == autograd of sum_s w[r,s] v[r,s,c] (torch fp32), flat-walk and generic channel
+    counts, with either gradient switched off."""
+    R, S, Cc = shape
+    w, v, g = dev(synth.uniform((R, S), 0, 1, 1)), dev(synth.normal((R, S, Cc), 2)), dev(synth.normal((R, Cc), 3))
+    wt, vt = w.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    (wt[..., None] * vt).sum(1).backward(g)
+    gw, gv = ops.accumulate_along_rays_bwd(w, v, g)
+    assert rel_l2(host(gw), host(wt.grad)) < 1e-6 and rel_l2(host(gv), host(vt.grad)) < 1e-6
+    assert ops.accumulate_along_rays_bwd(w, v, g, need_grad_values=False)[1] is None
+    assert torch.equal(ops.accumulate_along_rays_bwd(w, v, g, need_grad_weights=False)[1], gv)
+
+
+@pytest.mark.parametrize("cfg", [(40000, 42, 16, True), (1000, 7, 16, False), (5000, 3000, 8, True)])
+def test_embedding_lerp_kernels_vs_torch_embedding(cfg):
+    """C3 (models/neurad.py:423-441): e_lo (1 - frac) + e_hi frac, forward bit for bit the torch expression, table gradient
+    against nn.Embedding's autograd -- LDS-image path (small tables) and the global-atomic path (3000 x 8 > 32 KB)."""
+    from neurad_studio_amd import autograd as ag
+
+    R, E, D, temporal = cfg
+    torch.manual_seed(4)
+    emb = torch.nn.Embedding(E, D).cuda()
+    lo = torch.randint(0, E, (R,), device="cuda")
+    hi = (lo + 1).clamp_max(E - 1)
+    frac = torch.rand(R, device="cuda")
+    g = torch.randn(R, D, device="cuda")
+    ref = emb(lo) * (1 - frac[:, None]) + emb(hi) * frac[:, None] if temporal else emb(lo)
+    ref.backward(g)
+    want = emb.weight.grad.clone()
+    emb.weight.grad = None
+    out = ag.EmbeddingLerpFn.apply(emb.weight, lo, hi if temporal else None, frac if temporal else None)
+    assert torch.equal(out, ref.detach())
+    out.backward(g)
+    assert rel_l2(host(emb.weight.grad), host(want)) < 2e-6
