@@ -30,6 +30,8 @@ ka = steps["prof"].key_averages(group_by_input_shape=True)
 rows = sorted(ka, key=lambda e: -getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)))
 print("op | calls/step | device us/step | shapes")
 tot = 0.0
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+rows = [e for e in rows if e.key.startswith(only)] if only else rows
 for e in rows[:45]:
     t = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)) / 3
     tot += t
