@@ -347,11 +347,28 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ wf, int lan
 #pragma unroll
     for (int mb = 0; mb < NBLK; ++mb)
       a[mb] = *reinterpret_cast<const f32x4*>(wf + ((mb * (NS / 4) + s4) * 64 + lane) * 4);
+#ifdef NRHIP_EXP_BF16_PROXY
+    // experiment (scripts/build_variant.sh): the matrix-pipe load of a split-bf16 formulation -- six 8-cycle bf16 MFMAs per
+    // (16 outputs x 16 inputs) block on whatever bits the fp32 operands hold: WRONG results, realistic timing
+    using s16x4 = __attribute__((ext_vector_type(4))) short;
+    const s16x4 bb0 = __builtin_bit_cast(s16x4, float2{b[4 * s4], b[4 * s4 + 1]});
+    const s16x4 bb1 = __builtin_bit_cast(s16x4, float2{b[4 * s4 + 2], b[4 * s4 + 3]});
+#pragma unroll
+    for (int rep = 0; rep < 3; ++rep)
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb) {
+        const s16x4 aa0 = __builtin_bit_cast(s16x4, float2{a[mb][0], a[mb][1]});
+        const s16x4 aa1 = __builtin_bit_cast(s16x4, float2{a[mb][2], a[mb][3]});
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aa0, bb0, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aa1, bb1, acc[mb], 0, 0, 0);
+      }
+#else
 #pragma unroll
     for (int s3 = 0; s3 < 4; ++s3)
 #pragma unroll
       for (int mb = 0; mb < NBLK; ++mb)
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][s3], b[4 * s4 + s3], acc[mb], 0, 0, 0);
+#endif
   }
 }
 
