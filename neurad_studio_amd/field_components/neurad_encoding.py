@@ -106,8 +106,12 @@ class NeuRADHashEncoding(nn.Module):
                                         implementation=implementation)
         n_actors = 0 if dynamic_actors is None else int(getattr(dynamic_actors, "n_actors", 0))
         if n_actors and a.use_4d_hashgrid:
-            raise NotImplementedError("use_4d_hashgrid=True exists only in tiny-cuda-nn; the torch path (and this one) "
-                                      "uses one 3-D grid per actor (neurad_encoding.py:110-131)")
+            # the reference's torch branch does exactly this (neurad_encoding.py:110-111: "4D hashgrid is not supported
+            # with torch implementation, falling back multiple grids"); the 4-D grid exists only inside tiny-cuda-nn
+            import warnings
+
+            warnings.warn("use_4d_hashgrid=True is a tiny-cuda-nn feature; using one 3-D grid per actor like the "
+                          "reference's torch implementation", stacklevel=2)
         self.actor_grids = nn.ModuleList([
             HashEncoding(num_levels=a.num_levels, min_res=a.base_res, max_res=a.max_res,
                          log2_hashmap_size=a.log2_hashmap_size, features_per_level=a.hashgrid_dim,
