@@ -66,14 +66,16 @@ struct SaveDev {
 
 // LDS carve (floats), H = hidden width.  Fragment-ordered weights use [mb][s/4][lane][s%4] so that one
 // ds_read_b128 fetches the A fragments of 4 consecutive k-steps.
-template <int H>
+// SPLIT: the four per-tile matrices are stored as 3-way bf16 splits (6 bytes per weight instead of 4, see mfma_layer_split).
+template <int H, bool SPLIT = false>
 struct Lds {
   static constexpr int NB = H / 16;        // 16-neuron blocks of a hidden layer
+  static constexpr int WS(int n) { return SPLIT ? n + n / 2 : n; }
   static constexpr int G0 = 0;             // geo L0 : NB blocks x 8 steps
-  static constexpr int G1 = G0 + H * 32;   // geo L1 (rows 1..32): 2 blocks x H/4 steps
-  static constexpr int F0 = G1 + 32 * H;   // feat L0 (geo part): NB blocks x 8 steps
-  static constexpr int F1 = F0 + H * 32;   // feat L1: NB blocks x H/4 steps
-  static constexpr int F2 = F1 + H * H;    // feat L2: 2 blocks x H/4 steps
+  static constexpr int G1 = G0 + WS(H * 32);   // geo L1 (rows 1..32): 2 blocks x H/4 steps
+  static constexpr int F0 = G1 + WS(32 * H);   // feat L0 (geo part): NB blocks x 8 steps
+  static constexpr int F1 = F0 + WS(H * 32);   // feat L1: NB blocks x H/4 steps
+  static constexpr int F2 = F1 + WS(H * H);    // feat L2: 2 blocks x H/4 steps (always fp32: applied once per ray)
   static constexpr int SHW = F2 + 32 * H;  // feat L0 SH part: [16 c][NB][4 g][4 r]
   static constexpr int SDFW = SHW + 16 * H;  // geo L1 row 0: [NB][4 g][4 r]
   static constexpr int BG0 = SDFW + H;     // biases, [blk][g][r] == natural order
@@ -112,12 +114,122 @@ __device__ __forceinline__ float frag_src(const float* __restrict__ W, int ldw, 
   return W[(size_t)(row_off + 16 * mb + i) * ldw + col];
 }
 
+// ---- the matrix work on the matrix cores: 3-way split bf16 ------------------------------------------------------------
+// On gfx950 v_mfma_f32_16x16x4_f32 executes at the fp32 VECTOR rate on the vector ALU and overlaps with no other VALU work
+// (profiles/r02_mfma_overlap_probe.txt); v_mfma_f32_16x16x16_bf16 is a real second pipe (8 cycles, hides behind VALU
+// work).  x = h + m + l with h, m, l bf16 obtained by TRUNCATION (each remainder is exact in fp32), likewise w; the six
+// products h.h, h.m, m.h, h.l, l.h, m.m carry every term above 2^-24 of the full product and each is exact in the MFMA's
+// fp32 accumulation -- an fp32-equivalent dot product (measured 6e-8 representational error vs 1.4e-7 rounding error of an
+// fp32 GEMM), unlike plain bf16 (4e-3) or a 2-way split (3e-5).
+using bf16x4 = __attribute__((ext_vector_type(4))) short;
+
+struct Split4 {  // four consecutive k values of one lane, as the three bf16 operands
+  bf16x4 h, m, l;
+};
+
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t lo_src, uint32_t hi_src) {  // {hi_src[31:16], lo_src[31:16]}
+  return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u);
+}
+
+__device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3) {
+  const float x[4] = {x0, x1, x2, x3};
+  uint32_t h[4], m[4], l[4];
+#ifdef NRHIP_EXP_CHEAP_SPLIT  // experiment: no splitting arithmetic (wrong results) -- what does the VALU work of the split cost?
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h[k] = m[k] = l[k] = __float_as_uint(x[k]);
+#else
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = __float_as_uint(x[k]) & 0xffff0000u;
+    const float r1 = x[k] - __uint_as_float(h[k]);  // exact
+    m[k] = __float_as_uint(r1) & 0xffff0000u;
+    l[k] = __float_as_uint(r1 - __uint_as_float(m[k]));  // exact; its upper half is taken at the packing
+  }
+#endif
+  Split4 s;
+  s.h = __builtin_bit_cast(bf16x4, uint2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])});
+  s.m = __builtin_bit_cast(bf16x4, uint2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])});
+  s.l = __builtin_bit_cast(bf16x4, uint2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])});
+  return s;
+}
+
+// One layer on a 16-sample tile: acc[mb] += W[16 mb .. +15][:] . x, K = 16 KB inputs.  Weights: LDS image
+// [mb][kb][split h|m|l][lane] of 8-byte A fragments (lane (i, g): row 16 mb + i, k = 16 kb + 4 g + 0..3 in the layer's own
+// input order, see stage_split_matrix; stored as a (h | m) 16-byte image followed by an l 8-byte image); activations
+// b[4 kb + v]: this lane's inputs of k-block kb.
+template <int NBLK, int KB>
+__device__ __forceinline__ void mfma_layer_split(const float* __restrict__ wf, int lane, const float (&b)[4 * KB],
+                                                 f32x4 (&acc)[NBLK]) {
+  const uint2* w2 = reinterpret_cast<const uint2*>(wf);
+  // Consecutive MFMAs go to DIFFERENT accumulators: a dependent bf16 MFMA waits ~3 issue slots for its predecessor, so the
+  // six terms of one block issued back to back run no faster than the fp32 MFMA they replace.  Two-block layers get a second
+  // accumulator set for that (terms 0-2 | 3-5), summed at the end.
+  constexpr bool kTwoSets = NBLK < 4;
+  f32x4 acc2[kTwoSets ? NBLK : 1];
+  if constexpr (kTwoSets) {
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb) acc2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const Split4 x = split4(b[4 * kb], b[4 * kb + 1], b[4 * kb + 2], b[4 * kb + 3]);
+    bf16x4 ah[NBLK], am[NBLK], al[NBLK];
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb) {  // one 16-byte read (h | m) + one 8-byte read (l) per block
+      const uint4 hm = reinterpret_cast<const uint4*>(wf)[(mb * KB + kb) * 64 + lane];
+      ah[mb] = __builtin_bit_cast(bf16x4, uint2{hm.x, hm.y});
+      am[mb] = __builtin_bit_cast(bf16x4, uint2{hm.z, hm.w});
+      al[mb] = __builtin_bit_cast(bf16x4, w2[NBLK * KB * 128 + (mb * KB + kb) * 64 + lane]);
+    }
+#define NR_TERM(ACC, A_, X_)                                                                          \
+  _Pragma("unroll") for (int mb = 0; mb < NBLK; ++mb) ACC[mb] =                                        \
+      __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A_[mb], X_, ACC[mb], 0, 0, 0);
+    if constexpr (kTwoSets) {
+      NR_TERM(acc2, al, x.h) NR_TERM(acc, ah, x.h) NR_TERM(acc2, ah, x.l) NR_TERM(acc, ah, x.m)
+      NR_TERM(acc2, am, x.m) NR_TERM(acc, am, x.h)
+    } else {  // small terms first
+      NR_TERM(acc, al, x.h) NR_TERM(acc, ah, x.l) NR_TERM(acc, am, x.m) NR_TERM(acc, am, x.h) NR_TERM(acc, ah, x.m)
+      NR_TERM(acc, ah, x.h)
+    }
+#undef NR_TERM
+  }
+  if constexpr (kTwoSets) {
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb) acc[mb] += acc2[mb];
+  }
+}
+
+// W[row_off + 16 mb + i][col] -> the split image above.  CHAIN: the layer's input is the previous layer's D tile (lane (j,g)
+// holds neurons 16 kb + 4 g + v of block kb): col = 16 kb + 4 g + v; else the gathered features (lane holds 8 g .. 8 g + 7,
+// k-block kb takes its features 4 kb .. 4 kb + 3): col = 8 g + 4 kb + v.
+template <bool CHAIN, int NBLK, int KB>
+__device__ __forceinline__ void stage_split_matrix(float* __restrict__ dst, const float* __restrict__ W, int ldw,
+                                                   int row_off) {
+  unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+  for (int e = threadIdx.x; e < NBLK * KB * 64 * 4; e += 256) {
+    const int v = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+    const int kb = rest % KB, mb = rest / KB;
+    const int i = lane & 15, g = lane >> 4;
+    const int col = CHAIN ? (16 * kb + 4 * g + v) : (8 * g + 4 * kb + v);
+    const float w = W[(size_t)(row_off + 16 * mb + i) * ldw + col];
+    const uint32_t h = __float_as_uint(w) & 0xffff0000u;
+    const float r1 = w - __uint_as_float(h);
+    const uint32_t m = __float_as_uint(r1) & 0xffff0000u;
+    const uint32_t l = __float_as_uint(r1 - __uint_as_float(m));
+    // in bf16 units: [mb][kb][lane][h0..h3 m0..m3] (16 bytes per lane), then [mb][kb][lane][l0..l3] (8 bytes per lane)
+    const int blk = (mb * KB + kb) * 64 + lane;
+    d16[blk * 8 + v] = (unsigned short)(h >> 16);
+    d16[blk * 8 + 4 + v] = (unsigned short)(m >> 16);
+    d16[NBLK * KB * 64 * 8 + blk * 4 + v] = (unsigned short)(l >> 16);
+  }
+}
+
 // Stage all weights of the field into LDS (256-thread workgroup; caller barriers afterwards).  Every thread first
 // ISSUES all of its global loads (one register each, ~60 in flight), then stores: one memory round trip for the whole
 // 54 KB image instead of one per loop iteration.
-template <int H>
+template <int H, bool SPLIT = false>
 __device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* __restrict__ lds) {
-  using Ld = Lds<H>;
+  using Ld = Lds<H, SPLIT>;
   constexpr int NB = H / 16;
   constexpr int T = 256;  // == blockDim.x
   constexpr int N_G0 = H * 32 / T, N_G1 = 32 * H / T, N_F0 = H * 32 / T, N_F1 = H * H / T, N_F2 = 32 * H / T,
@@ -125,14 +237,21 @@ __device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* _
   static_assert((H * 32) % T == 0 && (H * H) % T == 0 && (16 * H) % T == 0, "regions are whole passes of the block");
   const int tid = threadIdx.x;
   float vg0[N_G0], vg1[N_G1], vf0[N_F0], vf1[N_F1], vf2[N_F2], vsh[N_SH], vs[7];
+  if constexpr (SPLIT) {
+    stage_split_matrix<false, NB, 2>(lds + Ld::G0, fd.gw0, 32, 0);
+    stage_split_matrix<true, 2, NB>(lds + Ld::G1, fd.gw1, H, 1);
+    stage_split_matrix<true, NB, 2>(lds + Ld::F0, fd.fw0, 48, 0);
+    stage_split_matrix<true, NB, NB>(lds + Ld::F1, fd.fw1, H, 0);
+  } else {
 #pragma unroll
-  for (int it = 0; it < N_G0; ++it) vg0[it] = frag_src<false, NB, 8>(fd.gw0, 32, 0, it * T + tid);
+    for (int it = 0; it < N_G0; ++it) vg0[it] = frag_src<false, NB, 8>(fd.gw0, 32, 0, it * T + tid);
 #pragma unroll
-  for (int it = 0; it < N_G1; ++it) vg1[it] = frag_src<true, 2, H / 4>(fd.gw1, H, 1, it * T + tid);
+    for (int it = 0; it < N_G1; ++it) vg1[it] = frag_src<true, 2, H / 4>(fd.gw1, H, 1, it * T + tid);
 #pragma unroll
-  for (int it = 0; it < N_F0; ++it) vf0[it] = frag_src<true, NB, 8>(fd.fw0, 48, 0, it * T + tid);
+    for (int it = 0; it < N_F0; ++it) vf0[it] = frag_src<true, NB, 8>(fd.fw0, 48, 0, it * T + tid);
 #pragma unroll
-  for (int it = 0; it < N_F1; ++it) vf1[it] = frag_src<true, NB, H / 4>(fd.fw1, H, 0, it * T + tid);
+    for (int it = 0; it < N_F1; ++it) vf1[it] = frag_src<true, NB, H / 4>(fd.fw1, H, 0, it * T + tid);
+  }
 #pragma unroll
   for (int it = 0; it < N_F2; ++it) vf2[it] = frag_src<true, 2, H / 4>(fd.fw2, H, 0, it * T + tid);
 #pragma unroll
@@ -148,14 +267,16 @@ __device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* _
   vs[4] = fd.gb1 ? fd.gb1[t33] : 0.f;
   vs[5] = fd.fb2 ? fd.fb2[t32] : 0.f;
   vs[6] = fd.grid.scal[t32];
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int it = 0; it < N_G0; ++it) lds[Ld::G0 + it * T + tid] = vg0[it];
+    for (int it = 0; it < N_G0; ++it) lds[Ld::G0 + it * T + tid] = vg0[it];
 #pragma unroll
-  for (int it = 0; it < N_G1; ++it) lds[Ld::G1 + it * T + tid] = vg1[it];
+    for (int it = 0; it < N_G1; ++it) lds[Ld::G1 + it * T + tid] = vg1[it];
 #pragma unroll
-  for (int it = 0; it < N_F0; ++it) lds[Ld::F0 + it * T + tid] = vf0[it];
+    for (int it = 0; it < N_F0; ++it) lds[Ld::F0 + it * T + tid] = vf0[it];
 #pragma unroll
-  for (int it = 0; it < N_F1; ++it) lds[Ld::F1 + it * T + tid] = vf1[it];
+    for (int it = 0; it < N_F1; ++it) lds[Ld::F1 + it * T + tid] = vf1[it];
+  }
 #pragma unroll
   for (int it = 0; it < N_F2; ++it) lds[Ld::F2 + it * T + tid] = vf2[it];
 #pragma unroll
@@ -396,7 +517,7 @@ __device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const fl
 }
 
 // L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2, ACT = dynamic actors.
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false>
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(
     FieldDev fd, int64_t n_rays, int S, int stride, const int32_t* __restrict__ order, const float* __restrict__ ro,
     const float* __restrict__ rd, const float* __restrict__ rarea, const float* __restrict__ rstarts,
@@ -409,14 +530,15 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
   static_assert(!ACT || COMPOSITE, "actors: composited eval kernel (static and actor tables share one storage type)");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
-  using Ld = Lds<H>;
+  static_assert(!SPLIT || (COMPOSITE && !ACT), "split-bf16 matrix products: the composited static-scene kernel");
+  using Ld = Lds<H, SPLIT>;
   constexpr int NB = H / 16;
   constexpr int LPL = L / 4;         // levels per lane
   constexpr bool DEFER = COMPOSITE;  // last feature layer applied once per ray
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
-  stage_field_weights<H>(fd, lds);
+  stage_field_weights<H, SPLIT>(fd, lds);
   if constexpr (ACT) {
     for (int e = threadIdx.x; e < 16 * H; e += 256) lds[Ld::SHF + e] = frag_src<true, NB, 4>(fd.fw0 + 32, 48, 0, e);
     if (threadIdx.x < ad.La) lds[Ld::ASCAL + threadIdx.x] = ad.scal[threadIdx.x];
@@ -570,7 +692,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     f32x4 h[NB];
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BG0 + 16 * mb + 4 * g);
-    mfma_layer<NB, 8>(lw + Ld::G0, lane, feat, h);
+    if constexpr (SPLIT) mfma_layer_split<NB, 2>(lw + Ld::G0, lane, feat, h);
+    else mfma_layer<NB, 8>(lw + Ld::G0, lane, feat, h);
     float hb[H / 4];
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb)
@@ -603,7 +726,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       const float* bp = lw + Ld::BG1 + 1 + 16 * mb + 4 * g;
       e[mb] = f32x4{bp[0], bp[1], bp[2], bp[3]};
     }
-    mfma_layer<2, H / 4>(lw + Ld::G1, lane, hb, e);
+    if constexpr (SPLIT) mfma_layer_split<2, NB>(lw + Ld::G1, lane, hb, e);
+    else mfma_layer<2, H / 4>(lw + Ld::G1, lane, hb, e);
     float eb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) eb[k] = e[k >> 2][k & 3];
@@ -626,7 +750,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF0 + 16 * mb + 4 * g);
       mfma_layer<NB, 4>(lw + Ld::SHF, lane, shb, h);
     }
-    mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
+    if constexpr (SPLIT) mfma_layer_split<NB, 2>(lw + Ld::F0, lane, eb, h);
+    else mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
@@ -641,7 +766,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     }
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF1 + 16 * mb + 4 * g);
-    mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
+    if constexpr (SPLIT) mfma_layer_split<NB, NB>(lw + Ld::F1, lane, hb, h);
+    else mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
@@ -799,12 +925,12 @@ struct ActorLaunch {
   const void* const* tables;
 };
 
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false>
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
                          float* oal, const SaveDev& sv, float stop_eps, hipStream_t st,
                          const ActorLaunch& al = ActorLaunch()) {
-  constexpr size_t lds = (ACT ? Lds<H>::TOTAL_ACT : Lds<H>::TOTAL) * sizeof(float);
-  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT>;
+  constexpr size_t lds = (ACT ? Lds<H, SPLIT>::TOTAL_ACT : Lds<H, SPLIT>::TOTAL) * sizeof(float);
+  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT, SPLIT>;
   static int cap = 0;  // persistent grid: CUs x resident workgroups per CU, queried once per instantiation
   if (!cap) {
     if (lds > 64 * 1024)
@@ -834,6 +960,23 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   const hipStream_t st = (hipStream_t)stream;
   const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
   const bool half = f->grid.param_dtype == 1;
+  // NRHIP_MLP_SPLIT_BF16=1 (read per call; 64-wide MLPs, composited output): the per-tile matrix products run as 3-way
+  // split bf16 on the matrix cores (mfma_layer_split) instead of the fp32 MFMA.  Same results to fp32 accuracy; NOT the
+  // default because it measured no faster (163 vs 163 us on config[1]: the splitting costs the vector ALU what the matrix
+  // pipe saves -- DESIGN.md §9).
+  const bool split_bf16 = getenv("NRHIP_MLP_SPLIT_BF16") != nullptr;
+  if constexpr (COMPOSITE) {
+    if (H == 64 && split_bf16) {
+#define SCASE(L_, F_)                                                                                                  \
+  if (L == L_ && F == F_)                                                                                              \
+    return half ? launch_render<L_, F_, 64, true, true, false, true>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)   \
+                : launch_render<L_, F_, 64, false, true, false, true>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+      SCASE(16, 2)
+      SCASE(8, 4)
+      SCASE(4, 8)
+#undef SCASE
+    }
+  }
 #define CASE(L_, F_, H_)                                                                                          \
   if (L == L_ && F == F_ && H == H_) {                                                                            \
     return half ? launch_render<L_, F_, H_, true, COMPOSITE>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)   \

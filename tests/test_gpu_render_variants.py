@@ -137,3 +137,26 @@ def test_early_ray_termination_bounded(ops, use_sdf):
 
     with pytest.raises(NeuradHipError):
         ops.render_fwd(*args, early_stop_eps=1.5)
+
+
+def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
+    """NRHIP_MLP_SPLIT_BF16: the fused render kernel's MLP layers as 3-way split bf16 on the matrix cores (six bf16 MFMAs
+    per 16 x 16 block keep every product term above 2^-24).  Same outputs as the fp32-MFMA kernel to fp32 rounding, and the
+    same parity against the oracle -- on config[1]'s shape (16 levels, 64-wide) and on 8 x 4 levels."""
+    from neurad_studio_amd import ops
+
+    for L, F, mn, mx in ((16, 2, 16, 1024), (8, 4, 32, 8192)):
+        p = field_params(L=L, F=F, lg=12, H=64, mn=mn, mx=mx)
+        fs = to_spec(ops, p)
+        R, S = 300, 72
+        o, d, area, s, e, _ = _sample_rays(R, S, seed=11)
+        args = (fs, dev(o), dev(d), dev(area), dev(s), dev(e))
+        monkeypatch.delenv("NRHIP_MLP_SPLIT_BF16", raising=False)
+        f32 = ops.render_fwd(*args, return_weights=True)
+        monkeypatch.setenv("NRHIP_MLP_SPLIT_BF16", "1")
+        spl = ops.render_fwd(*args, return_weights=True)
+        for a, b in zip(f32, spl):
+            assert rel_l2(host(b), host(a)) < 1e-6
+        assert not torch.equal(spl[0], f32[0])  # (a different kernel did run)
+        ref = O.render_rays(p, o[:32], d[:32], area[:32], s[:32], e[:32])
+        assert rel_l2(host(spl[0][:32]), ref["features"]) < 1e-5
