@@ -337,7 +337,12 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
       const f32x4 hv = *reinterpret_cast<const f32x4*>(hidden + rc * HID_LD + (NL - 2) * H + 16 * mb + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) db[4 * mb + r] = d[mb][r] = hv[r] > 0.f ? d[mb][r] : 0.f;
-      if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + (NL - 2) * H + 16 * mb + 4 * g) = d[mb];
+      // dZ goes to memory only for a layer whose weight gradient is NOT formed in here (the separate kernel reads it).
+      // (48 -> 64 -> 64 -> 32 keeps the store: without it the allocator needs 12 more VGPRs, 152 + 116 AGPRs > 256, and
+      //  the kernel drops to one wave per SIMD: 277 -> 304 us.)
+      constexpr bool kStoreFirstDz = !WFIRST || (IN == 48 && H == 64);
+      if constexpr (kStoreFirstDz)
+        if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + (NL - 2) * H + 16 * mb + 4 * g) = d[mb];
       if constexpr (WFIRST) {
         *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];  // zero for dead rows (gb was zeroed)
         if constexpr (NL == 3) bs1[mb] += d[mb]; else bs0[mb] += d[mb];
@@ -371,7 +376,8 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
         const f32x4 hv = *reinterpret_cast<const f32x4*>(hidden + rc * HID_LD + 16 * mb + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) db[4 * mb + r] = d[mb][r] = hv[r] > 0.f ? d[mb][r] : 0.f;
-        if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + 16 * mb + 4 * g) = d[mb];
+        if constexpr (!WL0)
+          if (live) *reinterpret_cast<f32x4*>(dz + row * HID_LD + 16 * mb + 4 * g) = d[mb];
         if constexpr (WL0) {
           *reinterpret_cast<f32x4*>(tz + j * W::LD + 16 * mb + 4 * g) = d[mb];
           bs0[mb] += d[mb];
