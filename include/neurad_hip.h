@@ -450,6 +450,18 @@ int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposa
                                float* const* round_spacing /*host array[n_rounds+1] of [R,S_i+1]*/,
                                float* const* round_euclid  /*host array[n_rounds+1] of [R,S_i+1]*/,
                                void* stream);
+/* The same for a scene with dynamic actors: a proposal sample inside an actor's box takes its density from that actor's
+ * grid of the proposal field (fields/neurad_field.py:208-213 over neurad_encoding.py:150-187).  actors[i] = the actor
+ * grids of props[i] (host array[n_rounds]; all rounds share the actor set: bounds, max_candidates); cand_* = the per-ray
+ * candidate lists of nrhip_actor_prepare -- they depend on the ray's line only, so one call on any two samples of the
+ * ray serves every round and the field.  NRHIP_ERR_UNSUPPORTED unless the actor grids have 1 feature per level, fp32
+ * tables and at most the static grid's levels (the reference's proposal defaults).                                  */
+int nrhip_proposal_sampler_fwd_actors(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props,
+                                      const nrhip_actors* actors /*host array[n_rounds]*/, const int32_t* cand_count,
+                                      const int32_t* cand_actor, const float* cand_w2b, const float* origins,
+                                      const float* directions, const float* pixel_area, const float* nears,
+                                      const float* fars, int64_t r, float* const* round_weights,
+                                      float* const* round_spacing, float* const* round_euclid, void* stream);
 
 /* ---- losses on the sampler outputs (model_components/losses.py) ---------------
  * One wavefront per ray; spacing-space bin edges c [R,S+1] in [0,1], weights [R,S].

@@ -131,6 +131,8 @@ PROTOTYPES = {
     "nrhip_packed_visibility_from_alpha": [P, P, I64, F32, F32, P, P],
     "nrhip_proposal_sampler_fwd": [C.POINTER(SamplerCfg), C.POINTER(Proposal), P, P, P, P, P, I64, C.POINTER(P),
                                    C.POINTER(P), C.POINTER(P), P],
+    "nrhip_proposal_sampler_fwd_actors": [C.POINTER(SamplerCfg), C.POINTER(Proposal), C.POINTER(Actors), P, P, P, P, P, P, P,
+                                          P, I64, C.POINTER(P), C.POINTER(P), C.POINTER(P), P],
     "nrhip_interlevel_loss": [P, P, I32, P, P, I32, F32, I64, P, P, P],
     "nrhip_distortion_loss": [P, P, I32, I64, P, P, P],
 }

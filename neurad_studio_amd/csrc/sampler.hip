@@ -164,6 +164,11 @@ struct PropDev {
   float scale;
   const float* dec;
 };
+struct PropActorDev {  // the proposal field's per-actor grids (F = 1), ACT launches only
+  const void* const* tables;
+  GridDev grid;
+  float scale;
+};
 struct SamplerDev {
   int n_rounds;
   int ns[3];
@@ -172,7 +177,56 @@ struct SamplerDev {
   float* w_out[2];
   float* sp_out[3];
   float* eu_out[3];
+  PropActorDev pact[2];
+  int K;  // row length of the per-ray candidate lists
 };
+
+// S2 with dynamic actors (fields/neurad_field.py:208-213 over neurad_encoding.py:150-187): a sample inside an actor's box
+// takes its density from THAT actor's grid at the box-frame position, density = exp(sum_{l < La} f_l w_l dec[l]) (the
+// actor features are zero-padded to the static width, so only the decoder's first La weights see them).  Called by the
+// whole wave after the static densities; `ncand` (wave-uniform) > 0.  Candidate walk over scalar loads, then one
+// wave-uniform pass per distinct winning actor so that the table base stays in SGPRs (as in render.hip).
+__device__ __forceinline__ float actor_density_override(const PropDev& p, const PropActorDev& pa, int K, int64_t ray,
+                                                        int ncand, float dens, bool live, float ox, float oy, float oz,
+                                                        float dx, float dy, float dz, float area, float t0, float t1,
+                                                        const int32_t* __restrict__ cand_actor,
+                                                        const float* __restrict__ cand_w2b,
+                                                        const float* __restrict__ bounds) {
+  const SamplePos gs = sample_gaussian(ox, oy, oz, dx, dy, dz, area, t0, t1);
+  const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)ray * (uint32_t)K));
+  int slot = -1;
+  for (int c = 0; c < ncand; ++c) {  // ascending actor index: the last containing box wins (neurad_encoding.py:184-185)
+    const float* w = cand_w2b + (row + (uint32_t)c) * 12u;
+    const int act = cand_actor[row + (uint32_t)c];
+    const float bx = w[0] * gs.x + w[1] * gs.y + w[2] * gs.z + w[3];
+    const float by = w[4] * gs.x + w[5] * gs.y + w[6] * gs.z + w[7];
+    const float bz = w[8] * gs.x + w[9] * gs.y + w[10] * gs.z + w[11];
+    if (fabsf(bx) < bounds[3 * act] && fabsf(by) < bounds[3 * act + 1] && fabsf(bz) < bounds[3 * act + 2]) slot = c;
+  }
+  unsigned long long todo = __ballot(live && slot >= 0);
+  const uint32_t amask = (1u << pa.grid.log2T) - 1u;
+  while (todo) {
+    const int c = __builtin_amdgcn_readlane(slot, (int)__builtin_ctzll(todo));
+    const bool mine = live && slot == c;
+    todo &= ~__ballot(mine);
+    const float* w = cand_w2b + (row + (uint32_t)c) * 12u;
+    const void* tb = pa.tables[cand_actor[row + (uint32_t)c]];
+    if (mine) {
+      const float bx = w[0] * gs.x + w[1] * gs.y + w[2] * gs.z + w[3];
+      const float by = w[4] * gs.x + w[5] * gs.y + w[6] * gs.z + w[7];
+      const float bz = w[8] * gs.x + w[9] * gs.y + w[10] * gs.z + w[11];
+      const SamplePos q = contract_gaussian(bx, by, bz, gs.std, pa.scale);
+      float acc = 0.f;
+      for (int l = 0; l < pa.grid.L; ++l) {
+        float v[1];
+        hash_level<1, false>(tb, (uint32_t)l << pa.grid.log2T, q.x, q.y, q.z, pa.grid.scal[l], amask, v);
+        acc += (v[0] * rescale_weight(pa.grid.scal[l], q.std)) * p.dec[l];
+      }
+      dens = expf(acc);
+    }
+  }
+  return dens;
+}
 
 // S2 for one sample.  LT > 0: the grid has exactly LT levels and ALL 8*LT corner loads are issued before the first
 // blend -- one memory round trip per sample instead of one per level (the kernel is latency bound: 4-byte entries, a few
@@ -214,12 +268,16 @@ __device__ __forceinline__ float prop_density(const PropDev& p, float ox, float 
 // HALF: fp16 tables; LT: level count of the proposal grids when both have the same, compile-time one (else 0).
 // slab_len = (largest sample count of any round) + 1: the per-wave LDS slabs are sized to what the launch needs, not to
 // kSMax, so that LDS does not cap the waves per CU (5 * 513 floats per wave allowed 12 of them).
-template <bool HALF, int LT>
+template <bool HALF, int LT, bool ACT = false>
 __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, const float* __restrict__ o,
                                                                 const float* __restrict__ d,
                                                                 const float* __restrict__ area,
                                                                 const float* __restrict__ nears,
-                                                                const float* __restrict__ fars, int64_t R, int slab_len) {
+                                                                const float* __restrict__ fars, int64_t R, int slab_len,
+                                                                const int32_t* __restrict__ cand_count,
+                                                                const int32_t* __restrict__ cand_actor,
+                                                                const float* __restrict__ cand_w2b,
+                                                                const float* __restrict__ bounds) {
   // per wave: spacing bins (2 buffers), euclid bins, weights, cdf
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -261,7 +319,13 @@ __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, co
         const int k = k0 + lane;
         const bool live = k < S;
         const float t0 = eu[live ? k : 0], t1 = eu[live ? k + 1 : 1];
-        const float dens = prop_density<HALF, LT>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
+        float dens = prop_density<HALF, LT>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
+        if constexpr (ACT) {
+          const int ncand = __builtin_amdgcn_readfirstlane(cand_count[ray]);
+          if (ncand > 0)
+            dens = actor_density_override(sd.prop[rd], sd.pact[rd], sd.K, ray, ncand, dens, live, ox, oy, oz, dx, dy, dz, ar,
+                                          t0, t1, cand_actor, cand_w2b, bounds);
+        }
         const float dd = live ? (t1 - t0) * dens : 0.f;
         const float incl = wscan_add(dd, lane);
         float w = (1.f - expf(-dd)) * expf(-(carry + incl - dd));
@@ -322,11 +386,10 @@ extern "C" int nrhip_pdf_sample(const float* weights, const float* spacing_bins,
   return check_launch("pdf_sample");
 }
 
-extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props,
-                                          const float* origins, const float* directions, const float* pixel_area,
-                                          const float* nears, const float* fars, int64_t r,
-                                          float* const* round_weights, float* const* round_spacing,
-                                          float* const* round_euclid, void* stream) {
+static int sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props, const nrhip_actors* actors,
+                       const int32_t* cand_count, const int32_t* cand_actor, const float* cand_w2b, const float* origins,
+                       const float* directions, const float* pixel_area, const float* nears, const float* fars, int64_t r,
+                       float* const* round_weights, float* const* round_spacing, float* const* round_euclid, void* stream) {
   NR_REQUIRE(cfg && props && origins && directions && pixel_area && round_weights && round_spacing && round_euclid,
              NRHIP_ERR_INVALID_ARG, "proposal_sampler_fwd: null pointer");
   NR_REQUIRE(cfg->n_rounds >= 1 && cfg->n_rounds <= 2, NRHIP_ERR_UNSUPPORTED,
@@ -350,6 +413,27 @@ extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nr
     sd.prop[i] = PropDev{to_dev(props[i].grid), props[i].table, props[i].static_scale, props[i].decoder_weight};
     sd.w_out[i] = round_weights[i];
   }
+  const float* bounds = nullptr;
+  sd.K = 0;
+  if (actors) {
+    NR_REQUIRE(cand_count && cand_actor && cand_w2b, NRHIP_ERR_INVALID_ARG, "proposal_sampler_fwd_actors: NULL candidate lists");
+    for (int i = 0; i < cfg->n_rounds; ++i) {
+      const nrhip_actors& a = actors[i];
+      if (int e = validate_grid(&a.grid)) return e;
+      NR_REQUIRE(a.tables && a.bounds && a.actor_scale > 0.f && a.n_actors >= 1, NRHIP_ERR_INVALID_ARG,
+                 "proposal_sampler_fwd_actors: bad actor descriptor %d", i);
+      NR_REQUIRE(a.grid.n_features == 1 && a.grid.param_dtype == 0 && props[i].grid.param_dtype == 0 &&
+                     a.grid.num_levels <= props[i].grid.num_levels,
+                 NRHIP_ERR_UNSUPPORTED,
+                 "proposal_sampler_fwd_actors: actor grids need 1 feature per level, fp32 tables and at most the static "
+                 "grid's levels; use the unfused ops");
+      const int k = a.max_candidates > 0 ? a.max_candidates : NRHIP_DEFAULT_ACTOR_CANDIDATES;
+      NR_REQUIRE(i == 0 || (k == sd.K && a.bounds == bounds), NRHIP_ERR_INVALID_ARG,
+                 "proposal_sampler_fwd_actors: the rounds must share one actor set (candidate lists, bounds)");
+      sd.K = k, bounds = a.bounds;
+      sd.pact[i] = PropActorDev{a.tables, to_dev(a.grid), a.actor_scale};
+    }
+  }
   if (r == 0) return NRHIP_OK;
   int smax = 0, lt = sd.prop[0].grid.L;
   bool half = sd.prop[0].grid.dtype == 1;
@@ -366,8 +450,17 @@ extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nr
   const hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(HALF_, LT_)                                                                                              \
   proposal_sampler_kernel<HALF_, LT_><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars, r, \
-                                                                     slab_len)
-  if (half) {
+                                                                     slab_len, nullptr, nullptr, nullptr, nullptr)
+  if (actors) {
+    if (lt == 6)
+      proposal_sampler_kernel<false, 6, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
+                                                                            r, slab_len, cand_count, cand_actor, cand_w2b,
+                                                                            bounds);
+    else
+      proposal_sampler_kernel<false, 0, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
+                                                                            r, slab_len, cand_count, cand_actor, cand_w2b,
+                                                                            bounds);
+  } else if (half) {
     if (lt == 6) LAUNCH(true, 6);
     else LAUNCH(true, 0);
   } else {
@@ -378,4 +471,24 @@ extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nr
   }
 #undef LAUNCH
   return check_launch("proposal_sampler_fwd");
+}
+
+extern "C" int nrhip_proposal_sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props,
+                                          const float* origins, const float* directions, const float* pixel_area,
+                                          const float* nears, const float* fars, int64_t r,
+                                          float* const* round_weights, float* const* round_spacing,
+                                          float* const* round_euclid, void* stream) {
+  return sampler_fwd(cfg, props, nullptr, nullptr, nullptr, nullptr, origins, directions, pixel_area, nears, fars, r,
+                     round_weights, round_spacing, round_euclid, stream);
+}
+
+extern "C" int nrhip_proposal_sampler_fwd_actors(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props,
+                                                 const nrhip_actors* actors, const int32_t* cand_count,
+                                                 const int32_t* cand_actor, const float* cand_w2b, const float* origins,
+                                                 const float* directions, const float* pixel_area, const float* nears,
+                                                 const float* fars, int64_t r, float* const* round_weights,
+                                                 float* const* round_spacing, float* const* round_euclid, void* stream) {
+  NR_REQUIRE(actors, NRHIP_ERR_INVALID_ARG, "proposal_sampler_fwd_actors: actors is NULL");
+  return sampler_fwd(cfg, props, actors, cand_count, cand_actor, cand_w2b, origins, directions, pixel_area, nears, fars, r,
+                     round_weights, round_spacing, round_euclid, stream);
 }

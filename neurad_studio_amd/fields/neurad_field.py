@@ -150,16 +150,20 @@ class NeuRADField(nn.Module):
 
     @torch.no_grad()
     def render(self, origins, directions, pixel_area, starts, ends, return_weights=False, early_stop_eps: float = 0.0,
-               order: Optional[Tensor] = None, times: Optional[Tensor] = None):
+               order: Optional[Tensor] = None, times: Optional[Tensor] = None, actor_cand=None):
         """F1+C1+C2 in one kernel: -> features [R,32], depth [R,1], accumulation [R,1] (, weights [R,S]).
         early_stop_eps / order: see ops.render_fwd (eval-time ray termination; processing order from ops.ray_order).
-        times [R]: needed when the scene has dynamic actors (their poses at the ray's time)."""
+        times [R]: needed when the scene has dynamic actors (their poses at the ray's time); actor_cand: candidate lists
+        already computed for these rays (they depend on the ray's line only), else they are computed here."""
         if not self.fused_supported(with_actors=True):
             raise NotImplementedError("fused render kernel: configuration not instantiated; use forward() + renderers")
         if self.hashgrid.has_actors():
-            if times is None:
+            if actor_cand is not None:
+                spec, cand = self.hashgrid.actor_spec(), actor_cand
+            elif times is None:
                 raise ValueError("dynamic actors need ray times")
-            spec, cand = self.hashgrid.prepare_actors(origins, directions, pixel_area, starts, ends, times)
+            else:
+                spec, cand = self.hashgrid.prepare_actors(origins, directions, pixel_area, starts, ends, times)
             return ops.render_fwd_actors(self.field_spec(), spec, cand, origins, directions, pixel_area, starts, ends,
                                          return_weights, early_stop_eps=early_stop_eps, order=order)
         return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights,
@@ -243,6 +247,16 @@ class NeuRADProposalField(nn.Module):
     def get_param_groups(self, param_groups: Dict):
         self.hashgrid.get_param_groups(param_groups)
         param_groups["fields"] += list(self.density_decoder.parameters())
+
+    def fused_sampler_supported(self) -> bool:
+        """Can the fused proposal sampler evaluate this field?  Always for the static scene; with dynamic actors when their
+        grids have one feature per level, fp32 tables and at most the static grid's levels (the reference's defaults)."""
+        hg = self.hashgrid
+        if not hg.has_actors():
+            return True
+        g, a = hg.static_grid, hg.actor_grids[0]
+        return (a.features_per_level == 1 and a.num_levels <= g.num_levels and g.hash_table.dtype == torch.float32
+                and all(t.hash_table.dtype == torch.float32 for t in hg.actor_grids))
 
     def proposal_spec(self) -> ops.ProposalSpec:
         g = self.hashgrid.static_grid

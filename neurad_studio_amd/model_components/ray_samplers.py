@@ -164,18 +164,21 @@ class ProposalNetworkSampler(Sampler):
         return ray_samples, weights_list, ray_samples_list
 
     @torch.no_grad()
-    def generate_fused(self, ray_bundle: RayBundle, proposal_fields: Sequence, sky_distance: float = 20000.0):
+    def generate_fused(self, ray_bundle: RayBundle, proposal_fields: Sequence, sky_distance: float = 20000.0,
+                       actor_cand=None):
         """Eval-mode fast path: proposal_fields[i] is the field evaluated in round i (pass the SAME field twice to
-        reproduce the reference's late-binding quirk, models/neurad.py:248)."""
+        reproduce the reference's late-binding quirk, models/neurad.py:248).  actor_cand: per-ray candidate lists
+        (ops.actor_prepare) of a scene with dynamic actors -- the proposal fields' actor grids then take part."""
         if not isinstance(self.initial_sampler, PowerSampler):
             raise NotImplementedError("fused sampler needs PowerSampler bins")
         ns = tuple(self.num_proposal_samples_per_ray[: self.num_proposal_network_iterations]) + (
             self.num_nerf_samples_per_ray,)
         specs = [f.proposal_spec() for f in proposal_fields]
         lam, scaling = self.initial_sampler.lambda_, self.initial_sampler.scaling
+        actor_specs = None if actor_cand is None else [f.hashgrid.actor_spec() for f in proposal_fields]
         ws, sps, eus = ops.proposal_sampler_fwd(specs, ray_bundle.origins, ray_bundle.directions, ray_bundle.pixel_area,
                                                 ray_bundle.nears, ray_bundle.fars, ns, lam, scaling,
-                                                self.pdf_sampler.histogram_padding, sky_distance)
+                                                self.pdf_sampler.histogram_padding, sky_distance, actor_specs, actor_cand)
         fars = ray_bundle.fars if ray_bundle.fars is not None else torch.full_like(ray_bundle.pixel_area, sky_distance)
         fn = PowerSpacing(ray_bundle.nears if ray_bundle.nears is not None else torch.zeros_like(fars),
                           fars.clamp_max(sky_distance), lam, scaling)

@@ -64,28 +64,39 @@ class FusedEvalMixin:
             ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
         if ray_bundle.nears is None:
             ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
-        times = None
-        if self.field.hashgrid.has_actors():
-            # the proposal rounds of a scene with actors run as operator-level kernels (static density + the actor
-            # overlay); the field + compositing stay one kernel with per-sample table select
+        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        pf = list(self.proposal_fields)
+        if self.reproduce_late_binding_quirk:
+            pf = [pf[-1]] * len(pf)
+        times, cand = None, None
+        actors = self.field.hashgrid.has_actors()
+        if actors and not all(f.fused_sampler_supported() for f in pf):
+            # actor grids the fused sampler is not instantiated for: the proposal rounds run as operator-level kernels
+            # (static density + the actor overlay); the field + compositing stay one kernel with per-sample table select
             ray_samples, prop_ray_samples, prop_weights = self._get_ray_samples(ray_bundle)
             fr = ray_samples.frustums
             starts, ends = fr.starts[..., 0].contiguous(), fr.ends[..., 0].contiguous()
             times = sample_times(ray_samples)
         else:
-            pf = list(self.proposal_fields)
-            if self.reproduce_late_binding_quirk:
-                pf = [pf[-1]] * len(pf)
-            ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky)
+            if actors:
+                # Which actors a ray can meet depends on its LINE only (bounding-sphere cull, neurad_encoding.py:225-247):
+                # one candidate list per ray, from any two samples on it, serves both proposal rounds and the field.
+                if ray_bundle.times is None:
+                    raise ValueError("dynamic actors need ray times")
+                times = ray_bundle.times.reshape(-1)
+                n = ray_bundle.nears.reshape(-1)  # two one-metre samples at the start of the ray: a well-conditioned line
+                _, cand = self.field.hashgrid.prepare_actors(o, d, ray_bundle.pixel_area.reshape(-1),
+                                                             torch.stack([n, n + 1], -1), torch.stack([n + 1, n + 2], -1),
+                                                             times)
+            ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky, actor_cand=cand)
             fr = ray_samples.frustums
             starts = fr.starts[..., 0]
             ends = fr.ends[..., 0].clone()
             ends[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
-        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
         order = ops.ray_order(o, d, self.field.hashgrid.static_scale) if self.order_rays else None
         want_w = bool(cfg.normalize_depth)
         out = self.field.render(o, d, ray_bundle.pixel_area, starts, ends, return_weights=want_w,
-                                early_stop_eps=self.early_stop_eps, order=order, times=times)
+                                early_stop_eps=self.early_stop_eps, order=order, times=times, actor_cand=cand)
         features, depth, accumulation = out[:3]
         if want_w:  # DepthRenderer("expected") over the non-sky samples (renderers.py:398-416)
             w = out[3][:, :-1]

@@ -639,8 +639,10 @@ def pdf_sample(weights, spacing_bins, nears, fars, num_samples, lam=-1.0, scalin
 
 def proposal_sampler_fwd(props: Sequence[ProposalSpec], origins, directions, pixel_area, nears, fars,
                          num_samples=(128, 64, 32), lam=-1.0, scaling=0.1, histogram_padding=0.01,
-                         sky_distance=20000.0):
-    """Fused S5 (+ the far clamp of M1).  -> (weights per round, spacing bins per round+1, euclid bins per round+1)"""
+                         sky_distance=20000.0, actor_specs: Optional[Sequence["ActorSpec"]] = None, cand=None):
+    """Fused S5 (+ the far clamp of M1).  -> (weights per round, spacing bins per round+1, euclid bins per round+1).
+    actor_specs[i] (+ cand, the per-ray candidate lists of ``actor_prepare``): the actor grids of props[i] -- proposal
+    samples inside an actor box take their density from them (nrhip_proposal_sampler_fwd_actors)."""
     n_rounds = len(props)
     if len(num_samples) != n_rounds + 1:
         raise ValueError("num_samples needs one entry per proposal round plus the final count")
@@ -666,6 +668,17 @@ def proposal_sampler_fwd(props: Sequence[ProposalSpec], origins, directions, pix
     pw = (C.c_void_p * n_rounds)(*[t.data_ptr() for t in ws])
     psp = (C.c_void_p * (n_rounds + 1))(*[t.data_ptr() for t in sps])
     peu = (C.c_void_p * (n_rounds + 1))(*[t.data_ptr() for t in eus])
+    if actor_specs is not None:
+        cacts = (_lib.Actors * n_rounds)()
+        for i, s in enumerate(actor_specs):
+            ca, k = s.c_actors()
+            cacts[i] = ca
+            keep.append(k)
+        cnt, act, w2b, _ = cand
+        call("nrhip_proposal_sampler_fwd_actors", C.byref(cfg), cprops, cacts, _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(o),
+             _ptr(d), _ptr(a), _ptr(n), _ptr(f), R, C.cast(pw, C.POINTER(C.c_void_p)), C.cast(psp, C.POINTER(C.c_void_p)),
+             C.cast(peu, C.POINTER(C.c_void_p)), _stream())
+        return ws, sps, eus
     call("nrhip_proposal_sampler_fwd", C.byref(cfg), cprops, _ptr(o), _ptr(d), _ptr(a), _ptr(n), _ptr(f), R,
          C.cast(pw, C.POINTER(C.c_void_p)), C.cast(psp, C.POINTER(C.c_void_p)), C.cast(peu, C.POINTER(C.c_void_p)),
          _stream())

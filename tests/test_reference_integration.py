@@ -142,7 +142,9 @@ class OracleOps:
         return T(O.proposal_density(p, N(origins), N(directions), N(pixel_area), N(starts), N(ends)))
 
     def proposal_sampler_fwd(self, props, origins, directions, pixel_area, nears, fars, num_samples=(128, 64, 32),
-                             lam=-1.0, scaling=0.1, histogram_padding=0.01, sky_distance=20000.0):
+                             lam=-1.0, scaling=0.1, histogram_padding=0.01, sky_distance=20000.0, actor_specs=None,
+                             cand=None):
+        assert actor_specs is None and cand is None, "the stub covers the static scene"
         self.calls.append(("proposal_sampler_fwd", tuple(origins.shape), tuple(num_samples)))
         pp = [O.ProposalParams(O.GridParams(N(p.table), p.grid.num_levels, p.grid.min_res, p.grid.max_res,
                                             p.grid.log2_hashmap_size), p.static_scale, N(p.decoder_weight)) for p in props]
