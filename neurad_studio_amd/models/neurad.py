@@ -69,26 +69,29 @@ class FusedEvalMixin:
         if self.reproduce_late_binding_quirk:
             pf = [pf[-1]] * len(pf)
         times, cand = None, None
-        actors = self.field.hashgrid.has_actors()
-        if actors and not all(f.fused_sampler_supported() for f in pf):
-            # actor grids the fused sampler is not instantiated for: the proposal rounds run as operator-level kernels
-            # (static density + the actor overlay); the field + compositing stay one kernel with per-sample table select
+        field_actors = self.field.hashgrid.has_actors()
+        prop_actors = [f.hashgrid.has_actors() for f in pf]
+        if any(prop_actors) and not (all(prop_actors) and all(f.fused_sampler_supported() for f in pf)):
+            # actor grids the fused sampler is not instantiated for (or actors in only some of the proposal fields): the
+            # proposal rounds run as operator-level kernels (static density + the actor overlay); the field + compositing
+            # stay one kernel with per-sample table select
             ray_samples, prop_ray_samples, prop_weights = self._get_ray_samples(ray_bundle)
             fr = ray_samples.frustums
             starts, ends = fr.starts[..., 0].contiguous(), fr.ends[..., 0].contiguous()
             times = sample_times(ray_samples)
         else:
-            if actors:
+            if field_actors or any(prop_actors):
                 # Which actors a ray can meet depends on its LINE only (bounding-sphere cull, neurad_encoding.py:225-247):
                 # one candidate list per ray, from any two samples on it, serves both proposal rounds and the field.
                 if ray_bundle.times is None:
                     raise ValueError("dynamic actors need ray times")
                 times = ray_bundle.times.reshape(-1)
                 n = ray_bundle.nears.reshape(-1)  # two one-metre samples at the start of the ray: a well-conditioned line
-                _, cand = self.field.hashgrid.prepare_actors(o, d, ray_bundle.pixel_area.reshape(-1),
-                                                             torch.stack([n, n + 1], -1), torch.stack([n + 1, n + 2], -1),
-                                                             times)
-            ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(ray_bundle, pf, sky, actor_cand=cand)
+                hg = self.field.hashgrid if field_actors else pf[0].hashgrid
+                _, cand = hg.prepare_actors(o, d, ray_bundle.pixel_area.reshape(-1), torch.stack([n, n + 1], -1),
+                                            torch.stack([n + 1, n + 2], -1), times)
+            ray_samples, prop_weights, prop_ray_samples = self.sampler.generate_fused(
+                ray_bundle, pf, sky, actor_cand=cand if any(prop_actors) else None)
             fr = ray_samples.frustums
             starts = fr.starts[..., 0]
             ends = fr.ends[..., 0].clone()

@@ -300,6 +300,24 @@ def test_model_eval_with_actors_fused_render_matches_operator_path():
     op = m.get_nff_outputs(rb())
     for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
         assert rel_l2(host(fused[k]), host(op[k])) < 5e-5, k
+    # the proposal rounds see the actors too (fused sampler with per-sample table select): switching the proposal
+    # fields' actors off changes the proposal depths; with actors in only ONE of the two fields the model falls back to
+    # the operator-level sampler and still agrees with the grad-enabled path
+    for p in m.proposal_fields:
+        p.hashgrid.config.disable_actors = True
+    with torch.no_grad():
+        no_prop_actors = m.get_nff_outputs(rb())
+    assert rel_l2(host(no_prop_actors["prop_depth_1"]), host(fused["prop_depth_1"])) > 1e-4
+    m.proposal_fields[1].hashgrid.config.disable_actors = False
+    m.reproduce_late_binding_quirk = False  # round 0 -> field 0 (no actors), round 1 -> field 1 (actors)
+    quirk_fns, m.density_fns = m.density_fns, [lambda x, f=f: f.get_density(x)[0] for f in m.proposal_fields]
+    with torch.no_grad():
+        mixed = m.get_nff_outputs(rb())
+    mixed_op = m.get_nff_outputs(rb())
+    for k in ("features", "depth", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(host(mixed[k]), host(mixed_op[k])) < 5e-5, k
+    m.proposal_fields[0].hashgrid.config.disable_actors = False
+    m.reproduce_late_binding_quirk, m.density_fns = True, quirk_fns
     # the actors matter in this scene: without them the rendering differs
     m.field.hashgrid.config.disable_actors = True
     with torch.no_grad():
