@@ -4,9 +4,11 @@
 Static path: contraction (H3), gaussian (H2), lookup (H1) and rescale (H4) are ONE HIP kernel (nrhip_encode_fwd)
 consuming per-ray origin/direction and per-sample [start,end]; nothing of shape [R,S,3] is materialised.
 Actor path (H5): nrhip_actor_prepare (pose interpolation + line cull per ray) then nrhip_actor_encode (in-box test,
-actor-grid lookup, overwrite) -- torch-path semantics (one 3-D grid per actor, use_4d_hashgrid=False).  Training:
-the hit rows are recomputed differentiably (``_actor_rows_with_grad``) so actor grids and trajectories get the
-reference's gradients; rows overwritten by actors give the static table no gradient."""
+actor-grid lookup, overwrite) -- torch-path semantics (one 3-D grid per actor, use_4d_hashgrid=False).  Eval renders
+actor scenes through the fused kernels instead (fields/neurad_field.py:render, models/neurad.py).  Training: the hit rows
+are recomputed differentiably (``_actor_rows_with_grad``: pair positions + multi-grid lookup kernels with hand-written
+backward) so actor grids and trajectories get the reference's gradients; rows overwritten by actors give the static
+table no gradient."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -198,8 +200,8 @@ class NeuRADHashEncoding(nn.Module):
 
     def actor_pair_rows(self, hit, hits, origins, directions, pixel_area, starts, ends, times, flip):
         """Training path of the actor rows (B1): the kernels found WHICH samples lie in WHICH actor; the few hit rows
-        are recomputed differentiably -- box-frame position through torch (gradient to the trajectories when
-        ``require_actor_grad``), the actor grids through MultiHashGridFn (table scatter-add, and
+        are recomputed differentiably -- box-frame position through nrhip_actor_pair_positions_fwd/bwd (gradient to the
+        trajectories when ``require_actor_grad``), the actor grids through MultiHashGridFn (table scatter-add, and
         nrhip_hashgrid_bwd_input for dL/dx).  -> None, or (idx [P] flat sample index, winner [P] bool: the actor the
         forward kernels used for that sample (highest index), rows [P, La*Fa] rescaled actor features)."""
         pair = (hits >= 0).nonzero()                  # every (sample, candidate slot) containment

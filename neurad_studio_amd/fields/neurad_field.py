@@ -6,7 +6,8 @@ Same constructor arguments, ``forward(ray_samples) -> Dict[FieldHeadNames, Tenso
 
 Two execution paths, both pure HIP:
   * no-grad (eval / render): ONE fused kernel -- nrhip_field_fwd per-sample, or nrhip_render_fwd when the
-    caller wants composited rays (``render``);
+    caller wants composited rays (``render``; scenes with dynamic actors: nrhip_render_fwd_actors, per-sample
+    table select in the same kernel);
   * grad-enabled (training), static scene: the same fused field kernel storing its activations, with the
     hand-written backward chained behind it in one autograd node (autograd.FieldTrainFn: feature-MLP and
     geometry-MLP data + weight gradients on the matrix cores, table gradient without memory-side atomics);

@@ -30,7 +30,10 @@ def world2box_pairs(actors, query_times: Tensor, actor_idx: Tensor) -> Tuple[Ten
     model_components/dynamic_actors.py:153-170).  Differentiable (w.r.t. actor_positions / actor_rotations_6d) world->box transform of ``actor_idx[m]`` at
     ``query_times[m]``: interpolate_trajectories_6d (utils/poses.py:90-150) + rotation_6d_to_matrix
     (cameras/camera_utils.py:422-443) + pose inverse (utils/poses.py:42-55), evaluated only for the (few)
-    sample/actor pairs the HIP kernels reported as hits.  -> (R_inv [M,3,3], t_inv [M,3])"""
+    sample/actor pairs the HIP kernels reported as hits.  -> (R_inv [M,3,3], t_inv [M,3])
+
+    The torch formulation of what csrc/actors.hip:actor_pair_positions_kernel and its hand-derived backward compute; the
+    product path calls the kernels (autograd.ActorPairPositionsFn), the tests use this function to pin them."""
     F = torch.nn.functional
     poses = torch.cat([actors.actor_rotations_6d, actors.actor_positions], dim=-1)
     a1 = F.normalize(poses[..., :3], dim=-1)
