@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void proposal_levels_lp_kernel(GridDev g, cons
   const uint32_t mask = (1u << g.log2T) - 1u;
   float v[1];
   hash_level<1, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
-  lf[(size_t)l * n + i] = v[0] * rescale_weight(g.scal[l], p.std);
+  // streaming store: the feature stream must not push this XCD's level (exactly one L2) out of the L2
+  __builtin_nontemporal_store(v[0] * rescale_weight(g.scal[l], p.std), lf + (size_t)l * n + i);
 }
 
 __global__ __launch_bounds__(256) void proposal_density_from_levels_kernel(const float* __restrict__ lf,
