@@ -274,7 +274,33 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     el = timed(step, steps, warmup, world, device)
     assert torch.isfinite(state["loss"]), "non-finite loss"
     s = m.config.sampling
-    return {"iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
+    # roofline of the step's largest single kernel, the fused training forward of the main field (render_kernel storing its
+    # activations): timed standalone, after the timed region, on this batch's rays and 32 PowerSampler samples per ray
+    from neurad_studio_amd import ops
+
+    S = s.num_nerf_samples
+    eu = ops.power_sampler(None, torch.full((R,), s.sky_distance, device=device), S, last_edge=s.sky_distance)[1]
+    fspec, a1 = m.field.field_spec(), area.reshape(-1).contiguous()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+    for k in range(10):
+        if k >= 2:
+            ev[k - 2][0].record()
+        ops.field_fwd_train(fspec, o, d, a1, eu[:, :-1], eu[:, 1:])
+        if k >= 2:
+            ev[k - 2][1].record()
+    torch.cuda.synchronize()
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    g = m.field.hashgrid.static_grid
+    H = m.config.field.geo_hidden_dim
+    per_sample = algorithmic_bytes_per_sample(g.num_levels, g.features_per_level, 4, S) + 4 * (32 + H + 48 + 2 * H) + 4 * 34
+    roof = {"kernel": f"nrhip::render_kernel<{g.num_levels},{g.features_per_level},{H},fp32,train> (fused field forward that "
+                      "stores its activations; timed standalone after the step loop)",
+            "bound": "hbm", "achieved": R * S * per_sample / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": R * S * per_sample / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": R * S * per_sample, "kernel_ms": k_ms,
+            "bytes_per_sample": "table reads L*8*F*4 + 8 B interval + per-ray I/O / S + saved activations "
+                                "(32 + H + 48 + 2H floats) + per-sample outputs (34 floats)"}
+    return {"roofline": roof, "iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
             "grad_exchange_bytes_per_rank": state["bytes"], "optimizer": opt_name,
@@ -475,7 +501,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": tf["what"], "rays_per_gpu": tf["rays_per_gpu"],
                           "parallelism": f"dp{world}: rays sharded, table gradients reduce-scatter + all-gather"},
-               "iters_per_sec": tf["iters_per_sec"], "train_full": tf}
+               "iters_per_sec": tf["iters_per_sec"], "roofline": tf.pop("roofline"), "train_full": tf}
     else:
         out, (fs, origins, dirs, area, edges, feats) = bench_c1(args, device, rank, world)
         train = train_full = None
@@ -487,6 +513,7 @@ def main():
             if train is not None:
                 out["train"] = train
             if train_full is not None:
+                train_full["field_forward_roofline"] = train_full.pop("roofline")
                 out["train_full"] = train_full
             if world == 1 and not args.no_cpu_baseline:
                 cb, (n, ref) = cpu_baseline(fs, origins, dirs, area, edges)

@@ -138,7 +138,7 @@ class NeuRADField(nn.Module):
         b = self.sdf_to_density.beta
         key = (b._version, b.data_ptr())
         if getattr(self, "_beta_cache", (None, 0.0))[0] != key:
-            self._beta_cache = (key, float(self.sdf_to_density.get_beta()))
+            self._beta_cache = (key, float(self.sdf_to_density.get_beta().detach()))
         return self._beta_cache[1]
 
     def field_spec(self) -> ops.FieldSpec:
