@@ -62,7 +62,10 @@ bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
   p->nb = (int)nb;
   p->chunks = (int)((n + kSamplesPerBlock - 1) / kSamplesPerBlock);
   int lg = (1024 + p->chunks - 1) / p->chunks;  // ~4 workgroups of 1024 threads per CU
-  p->lgroups = lg < 1 ? 1 : (lg > g.L ? g.L : lg);
+  lg = lg < 1 ? 1 : (lg > g.L ? g.L : lg);
+  while (g.L % lg != 0) ++lg;  // every level group the same number of levels: 6 proposal levels over 4 groups left a
+                               // third of the workgroups with twice the work of the others
+  p->lgroups = lg;
   p->nmax = p->chunks * (kSamplesPerBlock / 4 / 64);
   const size_t cols = (size_t)g.L * nb;
   size_t o = 0;
