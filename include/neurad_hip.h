@@ -276,6 +276,33 @@ int nrhip_lidar_rays(const nrhip_lidar_table* lidars, const int64_t* lidar_indic
                      int32_t point_dim, int64_t n_rays, float* origins, float* directions, float* pixel_area,
                      float* distance, uint8_t* did_return, float* times, void* stream);
 
+/* == ScaledPatchSampler.collate_image_dataset_batch (data/pixel_samplers.py:618-742) on a device-resident image batch
+ * images [n_images, height, width, channels] (image_dtype 0 = fp32, 1 = uint8; may be NULL together with patches):
+ * patch centres -> ray_indices [P * patch_size^2, 3] int64 = (image_idx[c] (or c when image_idx is NULL), y, x), the
+ * ground-truth patches [P, K, K, channels] with K = patch_size * patch_scale, and (optional, may be NULL) coords
+ * [P * patch_size^2, 2] = (y + 0.5, x + 0.5), the image_coords[y, x] row RayGenerator.forward feeds to
+ * nrhip_camera_rays (model_components/ray_generators.py:41-55).  Exactly one of
+ *   uniforms [P,3] fp32  -- the torch.rand((P,3)) draws of PixelSampler.sample_method (:100-103); centre =
+ *                           (u * float(n_images, H-K+1, W-K+1)).long() + (0, K/2, K/2)  (:722-726), and
+ *   centers  [P,3] int64 -- (image, y, x) given directly (the sampling-weights branch, :728-742, clips them itself)
+ * is non-NULL.  Integer results are bit-identical to the reference's; patches are copies.  Image reads are clamped into
+ * the image (a centre closer than K/2 to the border would raise in the reference). */
+int nrhip_patch_sample(const float* uniforms, const int64_t* centers, int64_t n_patches, int32_t n_images, int32_t height,
+                       int32_t width, int32_t channels, int32_t patch_size, int32_t patch_scale, const int64_t* image_idx,
+                       const void* images, int32_t image_dtype, int64_t* ray_indices, float* coords, void* patches,
+                       void* stream);
+
+/* == LidarPointSampler.collate_image_dataset_batch (data/pixel_samplers.py:538-583) on packed point clouds
+ * lidar [sum(points_per_lidar), point_dim] fp32 (lidar_packed_collate, image_lidar_datamanager.py:60-74).  The caller
+ * hands over torch's own draws -- shuffle [n_lidars] int64 = torch.randperm (:540) and draws [n_lidars, rays_per_lidar]
+ * fp64 = torch.rand(..., dtype=float64) (:552), rays_per_lidar = ceil(n_rays / n_lidars) (:542).  Output row r < n_rays
+ * belongs to scan l = shuffle[r / rays_per_lidar] and is its point p = floor(draws[l, r % rays_per_lidar] *
+ * points_per_lidar[l]): indices [n_rays,2] = (lidar_idx[l] (or l when NULL), p), points [n_rays, point_dim] = the
+ * gathered rows -- exactly what LidarRayGenerator / nrhip_lidar_rays consume.  n_lidars <= 2048. */
+int nrhip_lidar_point_sample(const int64_t* shuffle, const double* draws, const int64_t* points_per_lidar,
+                             const int64_t* lidar_idx, const float* lidar, int32_t n_lidars, int32_t rays_per_lidar,
+                             int32_t point_dim, int64_t n_rays, int64_t* indices, float* points, void* stream);
+
 /* ---- optimizer step of a hash table == torch.optim.Adam / AdamW on one fp32 tensor
  * (engine/optimizers.py:168-181; hashgrids group: lr 1e-2, eps 1e-15, configs/method_configs.py:423-426).  In place on
  * param / exp_avg / exp_avg_sq [n], 16-byte aligned; step = 1 for the first update; weight_decay is decoupled (AdamW),

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "nrhip_ray_order": [P, P, I64, F32, F32, I32, P, P],
     "nrhip_camera_rays": [C.POINTER(CameraTable), P, P, I64, P, P, P, P, P, P],
     "nrhip_lidar_rays": [C.POINTER(LidarTable), P, P, I32, I64, P, P, P, P, P, P, P],
+    "nrhip_patch_sample": [P, P, I64, I32, I32, I32, I32, I32, I32, P, P, I32, P, P, P, P],
+    "nrhip_lidar_point_sample": [P, P, P, P, P, I32, I32, I32, I64, P, P, P],
     "nrhip_adam_step": [P, P, P, P, I64, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],

@@ -129,6 +129,93 @@ __global__ __launch_bounds__(256) void lidar_rays_kernel(LidarTable t, const int
   if (times) times[i] = (t.times ? t.times[l] : 0.f) + dt;
 }
 
+// ---- ScaledPatchSampler (data/pixel_samplers.py:618-742): patch centres -> ray indices + ground-truth RGB patches ------
+// One workgroup per patch.  The centre is either handed over (the sampling-weights branch draws it with
+// torch.multinomial and clips it, :728-742) or derived from the three uniform draws of PixelSampler.sample_method
+// (:100-103): (u * float(dim)).long() over (n_images, H - K + 1, W - K + 1), then + K/2 on the pixel axes (:722-726).
+// Integer work downstream of that one fp32 product; the image gather is a row-wise copy, K*C contiguous elements per row.
+template <typename Pix>
+__global__ __launch_bounds__(256) void patch_sample_kernel(const float* __restrict__ uniforms,
+                                                           const int64_t* __restrict__ centers, int n_images, int H, int W,
+                                                           int C, int Kf, int sc, const int64_t* __restrict__ image_idx,
+                                                           const Pix* __restrict__ images, int64_t* __restrict__ ray_indices,
+                                                           float* __restrict__ coords, Pix* __restrict__ patches) {
+#pragma clang fp contract(off)
+  const int64_t p = blockIdx.x;
+  const int K = Kf * sc, half = K / 2;
+  int64_t c, cy, cx;
+  if (centers) {
+    c = centers[3 * p], cy = centers[3 * p + 1], cx = centers[3 * p + 2];
+  } else {
+    c = (int64_t)(uniforms[3 * p] * (float)n_images);
+    cy = (int64_t)(uniforms[3 * p + 1] * (float)(H - K + 1)) + half;
+    cx = (int64_t)(uniforms[3 * p + 2] * (float)(W - K + 1)) + half;
+  }
+  const int64_t y0 = cy - half, x0 = cx - half;  // offsets = arange(-(K//2), K//2 + K%2)  (:703)
+  const int64_t global_c = image_idx ? image_idx[min(max(c, (int64_t)0), (int64_t)n_images - 1)] : c;
+  for (int r = threadIdx.x; r < Kf * Kf; r += 256) {  // ray_indices = rgb_indices[:, sc//2::sc, sc//2::sc]  (:709-712)
+    const int64_t y = y0 + sc / 2 + (r / Kf) * sc, x = x0 + sc / 2 + (r % Kf) * sc;
+    int64_t* o = ray_indices + 3 * (p * Kf * Kf + r);
+    o[0] = global_c, o[1] = y, o[2] = x;
+    if (coords) {  // RayGenerator.forward's image_coords[y, x] = pixel centres (ray_generators.py:49, cameras.py:get_image_coords)
+      coords[2 * (p * Kf * Kf + r)] = (float)y + 0.5f;
+      coords[2 * (p * Kf * Kf + r) + 1] = (float)x + 0.5f;
+    }
+  }
+  if (!patches) return;
+  // reads are clamped into the image: a centre the caller placed too close to the border must not fault (the reference's
+  // advanced indexing would raise / wrap there)
+  const int64_t cc = min(max(c, (int64_t)0), (int64_t)n_images - 1);
+  const int row_len = K * C;
+  Pix* dst = patches + p * (int64_t)K * row_len;
+  for (int e = threadIdx.x; e < K * row_len; e += 256) {
+    const int r = e / row_len, q = e - r * row_len;
+    const int64_t y = min(max(y0 + r, (int64_t)0), (int64_t)H - 1);
+    const int64_t x = min(max(x0 + q / C, (int64_t)0), (int64_t)W - 1);
+    dst[e] = images[((cc * H + y) * W + x) * C + q % C];
+  }
+}
+
+// ---- LidarPointSampler.collate_image_dataset_batch (data/pixel_samplers.py:538-583), packed point clouds ----------------
+// Output row r belongs to scan l = shuffle[r / rays_per_lidar] and takes its point floor(draw[l, r % rays_per_lidar] *
+// points_per_lidar[l]) (fp64 product, as torch computes it): one thread per row copies the point and writes the
+// (lidar_idx[l], point) index pair.  The exclusive prefix sum of the scan sizes (:549-551) is rebuilt per workgroup in LDS.
+constexpr int kMaxScans = 2048;
+
+__global__ __launch_bounds__(256) void lidar_point_sample_kernel(const int64_t* __restrict__ shuffle,
+                                                                 const double* __restrict__ draws,
+                                                                 const int64_t* __restrict__ points_per_lidar,
+                                                                 const int64_t* __restrict__ lidar_idx,
+                                                                 const float* __restrict__ lidar, int n_lidars,
+                                                                 int rays_per_lidar, int D, int64_t n_rays,
+                                                                 int64_t* __restrict__ indices, float* __restrict__ points) {
+#pragma clang fp contract(off)
+  __shared__ int64_t first_point[kMaxScans];
+  if (threadIdx.x < 64) {  // one wave: chunked serial scan, n_lidars is tens to hundreds
+    int64_t run = 0;
+    for (int base = 0; base < n_lidars; base += 64) {
+      const int i = base + threadIdx.x;
+      int64_t v = i < n_lidars ? points_per_lidar[i] : 0, incl = v;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int64_t up = __shfl_up(incl, d, 64);
+        if ((int)threadIdx.x >= d) incl += up;
+      }
+      if (i < n_lidars) first_point[i] = run + incl - v;
+      run += __shfl(incl, 63, 64);
+    }
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rays) return;
+  const int64_t l = shuffle[r / rays_per_lidar];
+  const int64_t k = r % rays_per_lidar;
+  const int64_t p = (int64_t)floor(draws[l * rays_per_lidar + k] * (double)points_per_lidar[l]);
+  indices[2 * r] = lidar_idx ? lidar_idx[l] : l;
+  indices[2 * r + 1] = p;
+  const float* src = lidar + (first_point[l] + p) * D;
+  for (int d = 0; d < D; ++d) points[r * D + d] = src[d];
+}
+
 }  // namespace nrhip
 
 using namespace nrhip;
@@ -166,4 +253,46 @@ extern "C" int nrhip_lidar_rays(const nrhip_lidar_table* lidars, const int64_t* 
                                                                            origins, directions, pixel_area, distance,
                                                                            did_return, times);
   return check_launch("lidar_rays");
+}
+
+extern "C" int nrhip_patch_sample(const float* uniforms, const int64_t* centers, int64_t n_patches, int32_t n_images,
+                                  int32_t height, int32_t width, int32_t channels, int32_t patch_size, int32_t patch_scale,
+                                  const int64_t* image_idx, const void* images, int32_t image_dtype, int64_t* ray_indices,
+                                  float* coords, void* patches, void* stream) {
+  NR_REQUIRE(n_patches >= 0 && n_images > 0 && channels > 0 && patch_size > 0 && patch_scale > 0, NRHIP_ERR_INVALID_ARG,
+             "patch_sample: bad argument");
+  const int64_t K = (int64_t)patch_size * patch_scale;
+  NR_REQUIRE(K <= height && K <= width, NRHIP_ERR_INVALID_ARG, "patch_sample: the rgb patch (patch_size * patch_scale) exceeds the image");
+  NR_REQUIRE(image_dtype == 0 || image_dtype == 1, NRHIP_ERR_UNSUPPORTED, "patch_sample: image_dtype 0 (fp32) or 1 (uint8)");
+  if (n_patches == 0) return NRHIP_OK;
+  NR_REQUIRE((uniforms != nullptr) != (centers != nullptr), NRHIP_ERR_INVALID_ARG,
+             "patch_sample: exactly one of uniforms / centers");
+  NR_REQUIRE(ray_indices && (!patches || images), NRHIP_ERR_INVALID_ARG, "patch_sample: NULL pointer");
+  NR_REQUIRE(n_patches <= 0x7fffffff, NRHIP_ERR_INVALID_ARG, "patch_sample: too many patches for one launch");
+  if (image_dtype == 0)
+    patch_sample_kernel<float><<<(int)n_patches, 256, 0, (hipStream_t)stream>>>(
+        uniforms, centers, n_images, height, width, channels, patch_size, patch_scale, image_idx, (const float*)images,
+        ray_indices, coords, (float*)patches);
+  else
+    patch_sample_kernel<uint8_t><<<(int)n_patches, 256, 0, (hipStream_t)stream>>>(
+        uniforms, centers, n_images, height, width, channels, patch_size, patch_scale, image_idx, (const uint8_t*)images,
+        ray_indices, coords, (uint8_t*)patches);
+  return check_launch("patch_sample");
+}
+
+extern "C" int nrhip_lidar_point_sample(const int64_t* shuffle, const double* draws, const int64_t* points_per_lidar,
+                                        const int64_t* lidar_idx, const float* lidar, int32_t n_lidars,
+                                        int32_t rays_per_lidar, int32_t point_dim, int64_t n_rays, int64_t* indices,
+                                        float* points, void* stream) {
+  NR_REQUIRE(n_rays >= 0 && n_lidars > 0 && rays_per_lidar > 0 && point_dim > 0, NRHIP_ERR_INVALID_ARG,
+             "lidar_point_sample: bad argument");
+  NR_REQUIRE(n_lidars <= kMaxScans, NRHIP_ERR_UNSUPPORTED, "lidar_point_sample: at most 2048 scans per batch");
+  NR_REQUIRE(n_rays <= (int64_t)n_lidars * rays_per_lidar, NRHIP_ERR_INVALID_ARG,
+             "lidar_point_sample: n_rays exceeds n_lidars * rays_per_lidar draws");
+  if (n_rays == 0) return NRHIP_OK;
+  NR_REQUIRE(shuffle && draws && points_per_lidar && lidar && indices && points, NRHIP_ERR_INVALID_ARG,
+             "lidar_point_sample: NULL pointer");
+  lidar_point_sample_kernel<<<grid_for(n_rays, 256), 256, 0, (hipStream_t)stream>>>(
+      shuffle, draws, points_per_lidar, lidar_idx, lidar, n_lidars, rays_per_lidar, point_dim, n_rays, indices, points);
+  return check_launch("lidar_point_sample");
 }

@@ -728,3 +728,54 @@ def distortion_loss_rays(c, w):
     loss = (w * inner).sum(-1, dtype=f32) + (w * w * delta).sum(-1, dtype=f32) / f32(3)
     grad = f32(2) * inner + f32(2) / f32(3) * w * delta
     return loss.astype(f32), grad.astype(f32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ScaledPatchSampler: patch centres -> ray indices + rgb patches (nerfstudio/data/pixel_samplers.py:618-742)
+# ------------------------------------------------------------------------------------------------------------------
+def patch_centers_from_uniforms(uniforms, n_images: int, height: int, width: int, rgb_size: int):
+    """PixelSampler.sample_method on the cropped extent (pixel_samplers.py:100-103) + the crop shift of
+    ScaledPatchSampler.sample_method (:722-726): (u * float(dims)).long(), then + rgb_size // 2 on (y, x)."""
+    dims = np.array([n_images, height - rgb_size + 1, width - rgb_size + 1], dtype=np.float32)
+    c = (np.asarray(uniforms, dtype=np.float32) * dims).astype(np.int64)  # fp32 product, truncation
+    c[:, 1:] += rgb_size // 2
+    return c
+
+
+def patches_from_centers(images, centers, patch_size: int, patch_scale: int, image_idx=None):
+    """ScaledPatchSampler._patches_from_centers (pixel_samplers.py:696-714) + the global image index (:652).
+    images [N,H,W,C]; centers [P,3] int64 (image, y, x).  Returns (ray_indices [P*patch_size^2, 3] int64,
+    coords [P*patch_size^2, 2] fp32 = RayGenerator's image_coords[y, x] (ray_generators.py:49), patches [P,K,K,C])."""
+    K = patch_size * patch_scale
+    off = np.arange(-(K // 2), K // 2 + K % 2)
+    yy, xx = np.meshgrid(off, off, indexing="ij")
+    centers = np.asarray(centers, dtype=np.int64)
+    img = np.broadcast_to(centers[:, None, None, 0], (centers.shape[0], K, K))
+    ys = centers[:, None, None, 1] + yy[None]
+    xs = centers[:, None, None, 2] + xx[None]
+    sl = slice(patch_scale // 2, None, patch_scale)
+    rays = np.stack([img[:, sl, sl], ys[:, sl, sl], xs[:, sl, sl]], -1).reshape(-1, 3)
+    patches = None if images is None else np.asarray(images)[img, ys, xs]
+    coords = np.stack([rays[:, 1].astype(np.float32) + 0.5, rays[:, 2].astype(np.float32) + 0.5], -1)
+    if image_idx is not None:
+        rays = rays.copy()
+        rays[:, 0] = np.asarray(image_idx, dtype=np.int64)[rays[:, 0]]
+    return rays, coords, patches
+
+
+def lidar_point_sample(lidar, points_per_lidar, num_rays: int, shuffle, draws, lidar_idx=None):
+    """LidarPointSampler.collate_image_dataset_batch (pixel_samplers.py:538-583) given torch's draws: shuffle =
+    randperm(n) (:540), draws = rand((n, ceil(num_rays / n)), float64) (:552).  Returns (indices [num_rays,2], points)."""
+    npl = np.asarray(points_per_lidar, dtype=np.int64)
+    n = npl.shape[0]
+    first = np.zeros(n, dtype=np.int64)
+    first[1:] = np.cumsum(npl)[:-1]
+    point = np.floor(np.asarray(draws, dtype=np.float64) * npl[:, None].astype(np.float64)).astype(np.int64)
+    scan = np.repeat(np.arange(n)[:, None], point.shape[1], 1)
+    shuffle = np.asarray(shuffle)
+    scan, point, first = scan[shuffle], point[shuffle], first[shuffle]
+    flat = (point + first[:, None]).reshape(-1)[:num_rays]
+    idx = np.stack([scan.reshape(-1), point.reshape(-1)], -1)[:num_rays]
+    if lidar_idx is not None:
+        idx[:, 0] = np.asarray(lidar_idx, dtype=np.int64)[idx[:, 0]]
+    return idx, np.asarray(lidar)[flat]

@@ -190,3 +190,35 @@ def test_sampler_losses_vs_reference_autograd():
     assert abs(total - g["interlevel"]) / g["interlevel"] < 1e-5
     loss, grad = O.distortion_loss_rays(g["sdf"], g["wf"])
     assert abs(loss.mean() - g["distortion"]) / g["distortion"] < 1e-5 and rel_l2(grad / R, g["g_wf"]) < 1e-5
+
+
+PATCH_CASES = ["neurad", "odd", "even", "single"]
+
+
+@pytest.mark.parametrize("tag", PATCH_CASES)
+def test_patch_sampler_restatement_vs_reference(tag):
+    """oracle patch sampler == the reference's ScaledPatchSampler on the recorded torch.rand draws: integer work, bit-exact"""
+    g = load_golden("patch_sampler")
+    n, h, w, ps, sc = (int(v) for v in g[f"{tag}_shape"])
+    c = O.patch_centers_from_uniforms(g[f"{tag}_uniforms"], n, h, w, ps * sc)
+    rays, coords, patches = O.patches_from_centers(g[f"{tag}_image"], c, ps, sc, image_idx=g[f"{tag}_image_idx"])
+    np.testing.assert_array_equal(rays, g[f"{tag}_indices"])
+    np.testing.assert_array_equal(patches, g[f"{tag}_patches"])
+    np.testing.assert_array_equal(coords, g[f"{tag}_coords"])
+
+
+def test_patch_sampler_restatement_given_centers():
+    g = load_golden("patch_sampler")
+    n, h, w, ps, sc = (int(v) for v in g["centers_shape"])
+    rays, _, patches = O.patches_from_centers(g["centers_image"], g["centers_centers"], ps, sc)
+    np.testing.assert_array_equal(rays, g["centers_indices"])
+    np.testing.assert_array_equal(patches, g["centers_patches"])
+
+
+@pytest.mark.parametrize("tag,rays", [("lidar", 203), ("lidar_one", 16)])
+def test_lidar_point_sampler_restatement_vs_reference(tag, rays):
+    g = load_golden("patch_sampler")
+    idx, pts = O.lidar_point_sample(g[f"{tag}_cloud"], g[f"{tag}_points_per_lidar"], rays, g[f"{tag}_shuffle"],
+                                    g[f"{tag}_draws"], lidar_idx=g[f"{tag}_lidar_idx"])
+    np.testing.assert_array_equal(idx, g[f"{tag}_indices"])
+    np.testing.assert_array_equal(pts, g[f"{tag}_points"])
