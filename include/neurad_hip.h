@@ -165,6 +165,16 @@ int nrhip_mlp_bwd_workspace(const nrhip_mlp* m, int64_t n, int64_t* floats);
 int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_y, int64_t n,
                   float* grad_x, float* const* grad_weight /*host array*/, float* const* grad_bias /*host array*/,
                   float* workspace, int64_t workspace_floats, void* stream);
+/* Backward of NeuRADField's feature head, feature = geo[:, 1:] + mlp_feature([geo[:, 1:] | sh]) (neurad_field.py:146-152),
+ * in one pass: the feature MLP's weight / bias gradients as nrhip_mlp_bwd forms them (x [N,48] = (embedding | sh), hidden,
+ * workspace as there, sized by nrhip_mlp_bwd_workspace), and -- instead of grad_x -- the geometry MLP's complete output
+ * gradient grad_geo [N,33]: column 0 = grad_geo0[n] (the sdf / density logit's gradient), columns 1..32 = grad_feature +
+ * the embedding columns of grad_x (the residual connection).  The sh columns' gradient has no consumer and is not formed.
+ * Covers the feature head's shapes 48 -> {32,64} -> {32,64} -> 32; pointers 16-byte aligned. */
+int nrhip_field_feature_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_feature /*[N,32]*/,
+                            const float* grad_geo0 /*[N]*/, int64_t n, float* grad_geo /*[N,33]*/,
+                            float* const* grad_weight, float* const* grad_bias, float* workspace, int64_t workspace_floats,
+                            void* stream);
 
 /* ---- F1+F4: NeuRADField.forward, per-sample outputs (neurad_field.py:128-152) ------------------
  * feature [R,S,C], sdf_or_raw [R,S] (sdf when use_sdf else the pre-exp geo output), alpha_or_density [R,S] */

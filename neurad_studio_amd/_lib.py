@@ -94,6 +94,7 @@ PROTOTYPES = {
     "nrhip_mlp_fwd": [C.POINTER(Mlp), P, I64, P, P, P],
     "nrhip_mlp_bwd_workspace": [C.POINTER(Mlp), I64, C.POINTER(I64)],
     "nrhip_mlp_bwd": [C.POINTER(Mlp), P, P, P, I64, P, C.POINTER(P), C.POINTER(P), P, I64, P],
+    "nrhip_field_feature_bwd": [C.POINTER(Mlp), P, P, P, P, I64, P, C.POINTER(P), C.POINTER(P), P, I64, P],
     "nrhip_field_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P],
     "nrhip_field_fwd_train": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P, P, P, P],
     "nrhip_render_weight_from_alpha": [P, I64, I32, P, P, P],

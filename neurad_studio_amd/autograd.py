@@ -127,10 +127,14 @@ class FieldTrainFn(torch.autograd.Function):
         gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
         g_feature = g_feature.contiguous()
         # feature = embedding + mlp_feature([embedding | sh])
-        gxf, gfw, gfb = ops.mlp_bwd(xf, hf, g_feature, fw, fb)
-        g_geo = torch.empty((g_feature.shape[0], 33), device=g_feature.device, dtype=torch.float32)
-        g_geo[:, 0] = g_geo_out.reshape(-1)
-        torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
+        if ops.field_feature_bwd_supported(fw, fb):
+            # one kernel: weight gradients + the geometry MLP's output gradient (residual add and column 0 included)
+            g_geo, gfw, gfb = ops.field_feature_bwd(xf, hf, g_feature, g_geo_out, fw, fb)
+        else:
+            gxf, gfw, gfb = ops.mlp_bwd(xf, hf, g_feature, fw, fb)
+            g_geo = torch.empty((g_feature.shape[0], 33), device=g_feature.device, dtype=torch.float32)
+            g_geo[:, 0] = g_geo_out.reshape(-1)
+            torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
         genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
         gt = _like_param(ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc), ctx.table_dtype) \
             if ctx.needs_input_grad[0] else None

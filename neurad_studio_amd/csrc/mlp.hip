@@ -337,6 +337,9 @@ int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float
 int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, int64_t n, float* gx,
                   float* dz, float* part, int64_t part_floats, float* const* gw, float* const* gbias, int* done_mask,
                   void* stream);
+int mlp_chain_bwd_residual(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, const float* col0,
+                           int64_t n, float* g_geo, float* dz, float* part, int64_t part_floats, float* const* gw,
+                           float* const* gbias, int* done_mask, void* stream);
 int64_t mlp_chain_part_floats(const nrhip_mlp* m);
 static bool use_chain() {
   static const bool off = getenv("NRHIP_MLP_GENERIC") != nullptr;  // A/B switch (tests run both paths)
@@ -425,6 +428,38 @@ extern "C" int nrhip_mlp_bwd_workspace(const nrhip_mlp* m, int64_t n, int64_t* f
   return NRHIP_OK;
 }
 
+namespace {
+// weight / bias gradients of the layers the chained kernel did not cover (bit l of wgrad_done = layer l is done)
+int run_wgrad(const MlpDev& d, const float* x, const float* hidden, const float* grad_y, const float* workspace,
+              float* const* grad_weight, float* const* grad_bias, int wgrad_done, int64_t n, hipStream_t st) {
+  const int hid_ld = (d.nl - 1) * d.hidden;
+  WgradArgs wa{};
+  int nsub = 0;
+  for (int l = 0; l < d.nl; ++l) {
+    if (!grad_weight[l] || ((wgrad_done >> l) & 1)) continue;
+    const int in = layer_in(d, l), out = layer_out(d, l);
+    WgradLayer& L = wa.layer[wa.nl++];
+    L.dz = (l == d.nl - 1) ? grad_y : workspace + (size_t)l * d.hidden;
+    L.dz_ld = (l == d.nl - 1) ? d.out_dim : hid_ld;
+    L.h = (l == 0) ? x : hidden + (size_t)(l - 1) * d.hidden;
+    L.h_ld = (l == 0) ? d.in_dim : hid_ld;
+    L.dW = grad_weight[l];
+    L.db = grad_bias ? grad_bias[l] : nullptr;
+    L.out = out, L.in = in, L.nb_in = (in + 63) / 64;
+    L.sub0 = nsub;
+    nsub += ((out + 63) / 64) * L.nb_in;
+  }
+  if (wa.nl > 0) {
+    int64_t bx = ((n + 3) / 4 + 4 * 64 - 1) / (4 * 64);  // >= 64 sample-quads per wave
+    if (bx > 256) bx = 256;  // every workgroup ends in out*in memory-side atomics: measured optimum on 524 288 samples
+    if (bx < 1) bx = 1;
+    mlp_wgrad_kernel<<<dim3((unsigned)bx, (unsigned)nsub), 256, 0, st>>>(wa, n);
+    if (int e = check_launch("mlp_wgrad")) return e;
+  }
+  return NRHIP_OK;
+}
+}  // namespace
+
 extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_y, int64_t n,
                              float* grad_x, float* const* grad_weight, float* const* grad_bias, float* workspace,
                              int64_t workspace_floats, void* stream) {
@@ -461,29 +496,29 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
     mlp_bwd_data_kernel<<<blocks_for_tiles(n, waves), 64 * waves, lds, st>>>(d, hidden, grad_y, n, grad_x, workspace);
     if (int e = check_launch("mlp_bwd_data")) return e;
   }
-  const int hid_ld = (d.nl - 1) * d.hidden;
-  WgradArgs wa{};
-  int nsub = 0;
-  for (int l = 0; l < d.nl; ++l) {
-    if (!grad_weight[l] || ((wgrad_done >> l) & 1)) continue;
-    const int in = layer_in(d, l), out = layer_out(d, l);
-    WgradLayer& L = wa.layer[wa.nl++];
-    L.dz = (l == d.nl - 1) ? grad_y : workspace + (size_t)l * d.hidden;
-    L.dz_ld = (l == d.nl - 1) ? d.out_dim : hid_ld;
-    L.h = (l == 0) ? x : hidden + (size_t)(l - 1) * d.hidden;
-    L.h_ld = (l == 0) ? d.in_dim : hid_ld;
-    L.dW = grad_weight[l];
-    L.db = grad_bias ? grad_bias[l] : nullptr;
-    L.out = out, L.in = in, L.nb_in = (in + 63) / 64;
-    L.sub0 = nsub;
-    nsub += ((out + 63) / 64) * L.nb_in;
-  }
-  if (wa.nl > 0) {
-    int64_t bx = ((n + 3) / 4 + 4 * 64 - 1) / (4 * 64);  // >= 64 sample-quads per wave
-    if (bx > 256) bx = 256;  // every workgroup ends in out*in memory-side atomics: measured optimum on 524 288 samples
-    if (bx < 1) bx = 1;
-    mlp_wgrad_kernel<<<dim3((unsigned)bx, (unsigned)nsub), 256, 0, st>>>(wa, n);
-    if (int e = check_launch("mlp_wgrad")) return e;
-  }
-  return NRHIP_OK;
+  return run_wgrad(d, x, hidden, grad_y, workspace, grad_weight, grad_bias, wgrad_done, n, st);
+}
+
+extern "C" int nrhip_field_feature_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const float* grad_feature,
+                                       const float* grad_geo0, int64_t n, float* grad_geo, float* const* grad_weight,
+                                       float* const* grad_bias, float* workspace, int64_t workspace_floats, void* stream) {
+  if (int e = validate_mlp(m)) return e;
+  NR_REQUIRE(n >= 0 && grad_weight, NRHIP_ERR_INVALID_ARG, "field_feature_bwd: bad argument");
+  NR_REQUIRE(m->in_dim == 48 && m->out_dim == 32 && m->num_layers == 3 && (m->hidden_dim == 32 || m->hidden_dim == 64),
+             NRHIP_ERR_UNSUPPORTED, "field_feature_bwd: covers the feature head 48 -> {32,64} -> {32,64} -> 32");
+  if (n == 0) return NRHIP_OK;
+  NR_REQUIRE(x && hidden && grad_feature && grad_geo0 && grad_geo && workspace, NRHIP_ERR_INVALID_ARG,
+             "field_feature_bwd: null pointer");
+  for (int l = 0; l < 3; ++l)
+    NR_REQUIRE(grad_weight[l], NRHIP_ERR_INVALID_ARG, "field_feature_bwd: every layer's weight gradient is formed here");
+  const int64_t part_off = (dz_floats(m, n) + 3) & ~(int64_t)3;
+  NR_REQUIRE(workspace_floats > part_off, NRHIP_ERR_INVALID_ARG,
+             "field_feature_bwd: workspace smaller than nrhip_mlp_bwd_workspace asks for");
+  int wgrad_done = 0;
+  const int rc = mlp_chain_bwd_residual(m, x, hidden, grad_feature, grad_geo0, n, grad_geo, workspace, workspace + part_off,
+                                        workspace_floats - part_off, grad_weight, grad_bias, &wgrad_done, stream);
+  NR_REQUIRE(rc != NRHIP_ERR_UNSUPPORTED, NRHIP_ERR_UNSUPPORTED,
+             "field_feature_bwd: pointers must be 16-byte aligned and the workspace sized by nrhip_mlp_bwd_workspace");
+  if (rc != NRHIP_OK) return rc;
+  return run_wgrad(to_dev(*m), x, hidden, grad_feature, workspace, grad_weight, grad_bias, wgrad_done, n, (hipStream_t)stream);
 }

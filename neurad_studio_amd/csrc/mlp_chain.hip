@@ -251,12 +251,18 @@ struct WgShape {
   static constexpr int TILE = 16 * LD;
 };
 
-template <int IN, int H, int OUT, int NL>
+// RES (the feature head of NeuRADField, feature = geo[:, 1:] + mlp([geo[:, 1:] | sh]), neurad_field.py:146-152): instead
+// of grad_x the kernel writes the geometry MLP's whole output gradient, gx[n][0] = col0[n] (the sdf / density logit's
+// gradient) and gx[n][1 + c] = gy[n][c] + grad_x[n][c] for the OUT embedding columns -- rows of OUT + 1 floats, a tile's 16
+// rows gathered in the wave's LDS tile and written as one contiguous run.  The gradient of the SH columns has no consumer.
+template <int IN, int H, int OUT, int NL, bool RES = false>
 __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, const float* __restrict__ x,
                                                                 const float* __restrict__ hidden,
                                                                 const float* __restrict__ gy, int64_t n,
                                                                 float* __restrict__ gx, float* __restrict__ dz,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part,
+                                                                const float* __restrict__ col0 = nullptr) {
+  static_assert(!RES || (OUT % 16 == 0 && OUT <= IN && OUT + 1 <= H + 16), "residual head: whole blocks, fits the LDS tile");
   using S = Shape<IN, H, OUT, NL>;
   using W = WgShape<IN, H, OUT, NL>;
   constexpr int NB = S::NB, IB = S::IB, OB = S::OB, KP = S::KP, KS = W::KS;
@@ -400,11 +406,39 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
       }
     }
     if (gx) {
-      f32x4 dx[IB];
+      constexpr int XB = RES ? OUT / 16 : IB;  // RES: the SH blocks of grad_x are never formed (block-major weight image)
+      f32x4 dx[XB];
 #pragma unroll
-      for (int mb = 0; mb < IB; ++mb) dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mfma_layer<IB, H / 4>(lw + S::B_T0, lane, db, dx);
-      if (live) {
+      for (int mb = 0; mb < XB; ++mb) dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mfma_layer<XB, H / 4>(lw + S::B_T0, lane, db, dx);
+      if constexpr (RES) {
+        constexpr int RL = OUT + 1;  // row length of the geometry MLP's output gradient
+        // (the MFMA chain leaves no register to spare at H = 64: every step below is fenced so that its few temporaries
+        //  die before the next step's are born, and grad_y / col0 are added on the way out, in the output layout)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < XB; ++mb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tz[j * W::LD + 1 + 16 * mb + 4 * g + r] = dx[mb][r];
+        }
+        const int64_t left = n - row0;
+        const int total = (left < 16 ? (int)left : 16) * RL;  // floats of this tile's run (dead rows are not written)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // the nine tile offsets below depend on the lane only: recomputed per tile, or the
+                                      // compiler keeps them in nine registers across the whole loop (one wave per SIMD)
+        float* dst = gx + row0 * RL + ln;
+        int rr = ln / RL, cc = ln - rr * RL;                   // element e = lane + 64 k of the run sits at tile (rr, cc)
+#pragma unroll
+        for (int k = 0; k < (16 * RL + 63) / 64; ++k) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (ln + 64 * k < total) {
+            const float add = cc ? gy[(row0 + rr) * OUT + cc - 1] : col0[row0 + rr];
+            dst[64 * k] = (cc ? tz[rr * W::LD + cc] : 0.f) + add;
+          }
+          rr += 64 / RL, cc += 64 % RL;
+          if (cc >= RL) cc -= RL, ++rr;
+        }
+      } else if (live) {
 #pragma unroll
         for (int mb = 0; mb < IB; ++mb) *reinterpret_cast<f32x4*>(gx + row * IN + 16 * mb + 4 * g) = dx[mb];
       }
@@ -604,10 +638,10 @@ int mlp_chain_fwd(const nrhip_mlp* m, const float* x, int64_t n, float* y, float
 
 namespace {
 
-template <int IN, int H, int OUT, int NL>
+template <int IN, int H, int OUT, int NL, bool RES = false>
 int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const float* hidden, const float* gy,
                   int64_t n, float* gx, float* dz, float* part, int64_t part_floats, float* const* gw,
-                  float* const* gbias, int* done_mask, hipStream_t st) {
+                  float* const* gbias, int* done_mask, hipStream_t st, const float* col0 = nullptr) {
   using S = Shape<IN, H, OUT, NL>;
   using W = WgShape<IN, H, OUT, NL>;
   // (all 36 accumulator tiles of 48|64 -> 64 -> 64 -> 32 in registers leave one wave per SIMD and measured slower
@@ -615,7 +649,7 @@ int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const 
   if (W::MASK == 0) return NRHIP_ERR_UNSUPPORTED;
   const int64_t fit = part_floats / W::PART_FLOATS;
   if (fit < 1) return NRHIP_ERR_UNSUPPORTED;
-  auto kern = mlp_chain_bwd_wg_kernel<IN, H, OUT, NL>;
+  auto kern = mlp_chain_bwd_wg_kernel<IN, H, OUT, NL, RES>;
   constexpr int lds = (S::B_TOTAL + 4 * W::TILE > W::PART_FLOATS ? S::B_TOTAL + 4 * W::TILE : W::PART_FLOATS) *
                       (int)sizeof(float);
   static thread_local int resident = 0;  // workgroups per CU the accumulators + LDS admit: one partial per resident one
@@ -627,7 +661,7 @@ int launch_bwd_wg(const nrhip_mlp* m, const ChainArgs& a, const float* x, const 
   }
   int blocks = grid_blocks(n, resident);
   if (blocks > fit) blocks = (int)fit;
-  kern<<<blocks, 256, lds, st>>>(a, x, hidden, gy, n, gx, dz, part);
+  kern<<<blocks, 256, lds, st>>>(a, x, hidden, gy, n, gx, dz, part, col0);
   if (int e = check_launch("mlp_chain_bwd_wg")) return e;
   MergeArgs ma{};
   ma.nacc = W::NACC, ma.nslot = W::NSLOT;
@@ -678,6 +712,24 @@ int mlp_chain_bwd(const nrhip_mlp* m, const float* x, const float* hidden, const
   if (m->in_dim == IN_ && m->hidden_dim == H_ && m->out_dim == OUT_ && m->num_layers == NL_)         \
     return launch_bwd<IN_, H_, OUT_, NL_>(a, hidden, gy, n, gx, dz, (hipStream_t)stream);
   NR_CHAIN_SHAPES(X)
+#undef X
+  return NRHIP_ERR_UNSUPPORTED;
+}
+
+// Feature head backward (see RES above): x [n,48] = (embedding | sh), gy [n,32], col0 [n] -> g_geo [n,33] + all three
+// weight / bias gradients; done_mask as in mlp_chain_bwd.  Covers the 48 -> H -> H -> 32 shapes only.
+int mlp_chain_bwd_residual(const nrhip_mlp* m, const float* x, const float* hidden, const float* gy, const float* col0,
+                           int64_t n, float* g_geo, float* dz, float* part, int64_t part_floats, float* const* gw,
+                           float* const* gbias, int* done_mask, void* stream) {
+  *done_mask = 0;
+  if (!aligned16(hidden) || !aligned16(dz) || !aligned16(g_geo) || !aligned16(gy) || !part) return NRHIP_ERR_UNSUPPORTED;
+  ChainArgs a{};
+  for (int l = 0; l < m->num_layers && l < 3; ++l) a.w[l] = m->weight[l], a.b[l] = m->bias[l];
+#define X(H_)                                                                                                     \
+  if (m->in_dim == 48 && m->hidden_dim == H_ && m->out_dim == 32 && m->num_layers == 3)                             \
+    return launch_bwd_wg<48, H_, 32, 3, true>(m, a, x, hidden, gy, n, g_geo, dz, part, part_floats, gw, gbias, done_mask, \
+                                              (hipStream_t)stream, col0);
+  X(64) X(32)
 #undef X
   return NRHIP_ERR_UNSUPPORTED;
 }

@@ -320,6 +320,36 @@ def mlp_bwd(x: Tensor, hidden: Optional[Tensor], grad_y: Tensor, weights, biases
     return gx, gws, gbs
 
 
+def field_feature_bwd_supported(weights, biases) -> bool:
+    """shapes nrhip_field_feature_bwd covers: NeuRADField's feature head 48 -> {32,64} -> {32,64} -> 32 with biases"""
+    return (len(weights) == 3 and weights[0].shape[1] == 48 and weights[2].shape[0] == 32 and weights[0].shape[0] in (32, 64)
+            and all(b is not None for b in biases))
+
+
+def field_feature_bwd(x: Tensor, hidden: Tensor, grad_feature: Tensor, grad_geo0: Tensor, weights, biases):
+    """Backward of feature = geo[:, 1:] + mlp_feature([geo[:, 1:] | sh]) (neurad_field.py:146-152) in one pass: returns
+    (grad_geo [N,33] = (grad_geo0 | grad_feature + grad_x[:, :32]), weight gradients, bias gradients)."""
+    x, grad_feature, grad_geo0 = _chk(x, "x"), _chk(grad_feature, "grad_feature"), _chk(grad_geo0.reshape(-1), "grad_geo0")
+    m, keep = _c_mlp(weights, biases)
+    n = x.shape[0]
+    if grad_geo0.shape[0] != n or grad_feature.shape != (n, 32):
+        raise ValueError("field_feature_bwd: grad_feature [N,32] and grad_geo0 [N] expected")
+    g_geo = torch.empty((n, 33), device=x.device, dtype=torch.float32)
+    sizes = [w.numel() for w in weights] + [b.numel() for b in biases]
+    flat = torch.zeros((sum(sizes),), device=x.device, dtype=torch.float32)
+    views = torch.split(flat, sizes)
+    gws = [v.view_as(w) for v, w in zip(views[:len(weights)], weights)]
+    gbs = [v.view_as(b) for v, b in zip(views[len(weights):], biases)]
+    need = C.c_int64(0)
+    call("nrhip_mlp_bwd_workspace", C.byref(m), n, C.byref(need))
+    ws = torch.empty((max(need.value, 1),), device=x.device, dtype=torch.float32)
+    pw = (C.c_void_p * _lib.MAX_LAYERS)(*[g.data_ptr() for g in gws])
+    pb = (C.c_void_p * _lib.MAX_LAYERS)(*[g.data_ptr() for g in gbs])
+    call("nrhip_field_feature_bwd", C.byref(m), _ptr(x), _ptr(hidden), _ptr(grad_feature), _ptr(grad_geo0), n, _ptr(g_geo),
+         C.cast(pw, C.POINTER(C.c_void_p)), C.cast(pb, C.POINTER(C.c_void_p)), _ptr(ws), need.value, _stream())
+    return g_geo, gws, gbs
+
+
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class FieldSpec:

@@ -504,6 +504,39 @@ def test_mlp_register_chained_shapes_vs_oracle(ops, dims):
                     assert rel_l2(host(gbs[k]), rbs[k]) < TIGHT, (dims, N, k)
 
 
+@pytest.mark.parametrize("width", [32, 64])
+def test_field_feature_head_backward_one_pass_vs_composed(ops, width):
+    """nrhip_field_feature_bwd == nrhip_mlp_bwd + the residual add + column 0 (the composition it replaces), and the
+    oracle's MLP backward, on ragged batch sizes (partial tiles, a single row, many workgroups)"""
+    ws, bs = [], []
+    dd = [48, width, width, 32]
+    for k in range(3):
+        wk, bk = synth.linear(dd[k + 1], dd[k], 700 + k)
+        ws.append(wk), bs.append(bk)
+    dws, dbs = [dev(a) for a in ws], [dev(b) for b in bs]
+    assert ops.field_feature_bwd_supported(dws, dbs)
+    for N in (1, 15, 16, 17, 1000, 70001):
+        x = synth.normal((N, 48), seed=N)
+        gf = synth.normal((N, 32), seed=N + 1)
+        g0 = synth.normal((N,), seed=N + 2)
+        if N >= 1000:
+            gf[200:488] = 0.0
+            gf[3::5] = 0.0
+        y, hidden = ops.mlp_fwd(dev(x), dws, dbs, save_hidden=True)
+        g_geo, gws, gbs = ops.field_feature_bwd(dev(x), hidden, dev(gf), dev(g0), dws, dbs)
+        gx, rws, rbs = ops.mlp_bwd(dev(x), hidden, dev(gf), dws, dbs)
+        ref = np.concatenate([g0[:, None], gf + host(gx)[:, :32]], 1)
+        assert g_geo.shape == (N, 33)
+        np.testing.assert_array_equal(host(g_geo)[:, 0], g0)
+        assert rel_l2(host(g_geo), ref) < 1e-6, (width, N)
+        for k in range(3):  # same kernel body for the weight gradients: identical sums
+            assert rel_l2(host(gws[k]), host(rws[k])) < 1e-6 and rel_l2(host(gbs[k]), host(rbs[k])) < 1e-6, (width, N, k)
+        hh = host(hidden)
+        acts_dev = [x] + [hh[:, k * width:(k + 1) * width] for k in range(2)] + [host(y)]
+        ox, ows, _ = O.mlp_bwd(acts_dev, ws, gf)
+        assert rel_l2(host(g_geo)[:, 1:], gf + ox[:, :32]) < TIGHT and rel_l2(host(gws[0]), ows[0]) < TIGHT, (width, N)
+
+
 def test_encode_bwd_binned_degenerate_distribution(ops, monkeypatch):
     """Every ray identical (one line of cells), half of the samples at one point: a handful of table entries receive
     almost all records.  The radix partition sizes its queues exactly, so this is slow-ish but exact."""
