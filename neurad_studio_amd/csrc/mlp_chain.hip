@@ -253,8 +253,8 @@ struct WgShape {
 
 // RES (the feature head of NeuRADField, feature = geo[:, 1:] + mlp([geo[:, 1:] | sh]), neurad_field.py:146-152): instead
 // of grad_x the kernel writes the geometry MLP's whole output gradient, gx[n][0] = col0[n] (the sdf / density logit's
-// gradient) and gx[n][1 + c] = gy[n][c] + grad_x[n][c] for the OUT embedding columns -- rows of OUT + 1 floats, a tile's 16
-// rows gathered in the wave's LDS tile and written as one contiguous run.  The gradient of the SH columns has no consumer.
+// gradient) and gx[n][1 + c] = gy[n][c] + grad_x[n][c] for the OUT embedding columns -- rows of OUT + 1 floats.  The
+// gradient of the SH columns has no consumer and is not formed.
 template <int IN, int H, int OUT, int NL, bool RES = false>
 __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, const float* __restrict__ x,
                                                                 const float* __restrict__ hidden,
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
                                                                 float* __restrict__ gx, float* __restrict__ dz,
                                                                 float* __restrict__ part,
                                                                 const float* __restrict__ col0 = nullptr) {
-  static_assert(!RES || (OUT % 16 == 0 && OUT <= IN && OUT + 1 <= H + 16), "residual head: whole blocks, fits the LDS tile");
+  static_assert(!RES || (OUT % 16 == 0 && OUT <= IN), "residual head: whole blocks of embedding columns");
   using S = Shape<IN, H, OUT, NL>;
   using W = WgShape<IN, H, OUT, NL>;
   constexpr int NB = S::NB, IB = S::IB, OB = S::OB, KP = S::KP, KS = W::KS;
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
   const int64_t ntiles = (n + 15) / 16;
   constexpr int HID_LD = (NL - 1) * H;
   float* tz = lds + S::B_TOTAL + wid * W::TILE;  // wave-private dZ tile [16 samples][LD]
+  constexpr int RL = OUT + 1;                     // RES: row length of the geometry MLP's output gradient
 
   constexpr bool WL0 = W::L0, WL1 = W::L1, WLL = W::LL;
   // the weight gradient of the layer whose dZ is produced first / second in the chain (layer NL-2 / layer 0 of 3)
@@ -412,32 +413,22 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, cons
       for (int mb = 0; mb < XB; ++mb) dx[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       mfma_layer<XB, H / 4>(lw + S::B_T0, lane, db, dx);
       if constexpr (RES) {
-        constexpr int RL = OUT + 1;  // row length of the geometry MLP's output gradient
-        // (the MFMA chain leaves no register to spare at H = 64: every step below is fenced so that its few temporaries
-        //  die before the next step's are born, and grad_y / col0 are added on the way out, in the output layout)
+        // Straight from the registers: each lane owns 4 consecutive columns per block of its row; the odd row stride makes
+        // them four 4-byte stores.  (Gathering the tile's 16 x RL run in LDS first -- residual parked there at tile start,
+        // grad_x added with ds_add_f32, 16-byte stores -- measured SLOWER: 734 vs 536 us at the c3 size, 426 vs 378 us at
+        // c1; this kernel is latency-bound at two waves per SIMD, and the LDS round trip is one more dependent chain.)
+        // The MFMA chain leaves no register to spare at H = 64 (140 + 116 AGPRs): one block's grad_y at a time.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < XB; ++mb) {
+          const f32x4 gf = *reinterpret_cast<const f32x4*>(gy + rc * OUT + 16 * mb + 4 * g);
+          if (live) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tz[j * W::LD + 1 + 16 * mb + 4 * g + r] = dx[mb][r];
-        }
-        const int64_t left = n - row0;
-        const int total = (left < 16 ? (int)left : 16) * RL;  // floats of this tile's run (dead rows are not written)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));  // the nine tile offsets below depend on the lane only: recomputed per tile, or the
-                                      // compiler keeps them in nine registers across the whole loop (one wave per SIMD)
-        float* dst = gx + row0 * RL + ln;
-        int rr = ln / RL, cc = ln - rr * RL;                   // element e = lane + 64 k of the run sits at tile (rr, cc)
-#pragma unroll
-        for (int k = 0; k < (16 * RL + 63) / 64; ++k) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (ln + 64 * k < total) {
-            const float add = cc ? gy[(row0 + rr) * OUT + cc - 1] : col0[row0 + rr];
-            dst[64 * k] = (cc ? tz[rr * W::LD + cc] : 0.f) + add;
+            for (int r = 0; r < 4; ++r) gx[row * RL + 1 + 16 * mb + 4 * g + r] = dx[mb][r] + gf[r];
           }
-          rr += 64 / RL, cc += 64 % RL;
-          if (cc >= RL) cc -= RL, ++rr;
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (g == 0 && live) gx[row * RL] = col0[rc];
       } else if (live) {
 #pragma unroll
         for (int mb = 0; mb < IB; ++mb) *reinterpret_cast<f32x4*>(gx + row * IN + 16 * mb + 4 * g) = dx[mb];
