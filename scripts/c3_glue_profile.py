@@ -32,7 +32,7 @@ print("op | calls/step | device us/step | shapes")
 tot = 0.0
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 rows = [e for e in rows if e.key.startswith(only)] if only else rows
-for e in rows[:45]:
+for e in rows[:int(os.environ.get("GLUE_ROWS", "45"))]:
     t = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0)) / 3
     tot += t
     print(f"{e.key[:38]:38s} {e.count / 3:6.1f} {t:9.1f}  {str(e.input_shapes)[:110]}")
