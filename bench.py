@@ -73,6 +73,13 @@ def make_workload(device, seed):
     return fs, origins.contiguous(), dirs.contiguous(), area, fars
 
 
+def recorded_traffic(name):
+    """HBM bytes per launch of a kernel from the committed PMC summary profiles/traffic_<name>.json (FETCH_SIZE / WRITE_SIZE
+    passes, corrected as MI355X_MICROARCH.md prescribes); None when the file is missing"""
+    tf = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
+    return json.load(open(tf)).get("hbm_bytes_per_launch") if os.path.exists(tf) else None
+
+
 def timed(step, steps, warmup, world, device):
     """the contract's timing: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks"""
     import torch.distributed as dist
@@ -296,7 +303,8 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     roof = {"kernel": f"nrhip::render_kernel<{g.num_levels},{g.features_per_level},{H},fp32,train> (fused field forward that "
                       "stores its activations; timed standalone after the step loop)",
             "bound": "hbm", "achieved": R * S * per_sample / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": R * S * per_sample / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": R * S * per_sample / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": recorded_traffic("field_fwd_train") if (n_cam, n_lidar) == (C3_CAMERA_RAYS, C3_LIDAR_RAYS) else None,
             "algorithmic_bytes_per_launch": R * S * per_sample, "kernel_ms": k_ms,
             "bytes_per_sample": "table reads L*8*F*4 + 8 B interval + per-ray I/O / S + saved activations "
                                 "(32 + H + 48 + 2H floats) + per-sample outputs (34 floats)"}
@@ -382,10 +390,7 @@ def bench_c1(args, device, rank, world):
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
         bytes_per = algorithmic_bytes_per_sample(GRID["num_levels"], GRID["features_per_level"], 4, S)
         achieved = n_samples * bytes_per / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_render_kernel.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        traffic = recorded_traffic("render_kernel")
         out = {
             "metric": "ray-samples/sec (4096 rays x 128 samples)", "value": world * n_samples * args.steps / elapsed,
             "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -463,7 +468,8 @@ def bench_c2(args, device, rank, world):
         "rays_per_sec": world * R * args.steps / elapsed, "proposal_evals_per_sec": world * n_prop * args.steps / elapsed,
         "roofline": {"kernel": "nrhip::proposal_sampler_kernel (all rounds on chip, one wave per ray)", "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": prop_bytes, "kernel_ms": t_samp},
+                     "traffic": recorded_traffic("proposal_sampler"), "algorithmic_bytes_per_launch": prop_bytes,
+                     "kernel_ms": t_samp},
         "render_kernel_ms": t_rend,
     }
 
