@@ -256,7 +256,7 @@ struct WgShape {
 // gradient) and gx[n][1 + c] = gy[n][c] + grad_x[n][c] for the OUT embedding columns -- rows of OUT + 1 floats.  The
 // gradient of the SH columns has no consumer and is not formed.
 template <int IN, int H, int OUT, int NL, bool RES = false>
-__global__ __launch_bounds__(256) void mlp_chain_bwd_wg_kernel(ChainArgs a, const float* __restrict__ x,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 32 ? 3 : 2, H == 32 ? 3 : 2))) void mlp_chain_bwd_wg_kernel(ChainArgs a, const float* __restrict__ x,
                                                                 const float* __restrict__ hidden,
                                                                 const float* __restrict__ gy, int64_t n,
                                                                 float* __restrict__ gx, float* __restrict__ dz,
