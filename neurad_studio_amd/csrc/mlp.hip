@@ -299,26 +299,21 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(WgradArgs a, int64_t n) 
         for (int r = 0; r < 4; ++r) red[wid - 1][(x * 4 + y) * 4 + r][lane] = acc[x][y][r];
   }
   __syncthreads();
-  if (wid == 0) {
+  // D[o][i]: lane holds rows o = 4g + r, col i = lane&15.  One 16 x 16 block at a time (fenced: read all at once the three
+  // other waves' 192 partials per lane set the kernel's register count -- 256 + 64, one wave per SIMD)
+  if (wid == 0)
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
+      for (int y = 0; y < 4; ++y) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[x][y][r] += red[0][(x * 4 + y) * 4 + r][lane] + red[1][(x * 4 + y) * 4 + r][lane] +
-                          red[2][(x * 4 + y) * 4 + r][lane];
-  }
-  // D[o][i]: lane holds rows o = 4g + r, col i = lane&15
-  if (wid == 0)
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = ob * 64 + 16 * x + 4 * g + r, i = ib * 64 + 16 * y + i16;
-        if (o < out && i < in) unsafeAtomicAdd(dW + (size_t)o * in + i, acc[x][y][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int e = (x * 4 + y) * 4 + r;
+          const float v = acc[x][y][r] + red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
+          const int o = ob * 64 + 16 * x + 4 * g + r, i = ib * 64 + 16 * y + i16;
+          if (o < out && i < in) unsafeAtomicAdd(dW + (size_t)o * in + i, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
   if (db && ib == 0) {
 #pragma unroll
@@ -451,7 +446,9 @@ int run_wgrad(const MlpDev& d, const float* x, const float* hidden, const float*
   }
   if (wa.nl > 0) {
     int64_t bx = ((n + 3) / 4 + 4 * 64 - 1) / (4 * 64);  // >= 64 sample-quads per wave
-    if (bx > 256) bx = 256;  // every workgroup ends in out*in memory-side atomics: measured optimum on 524 288 samples
+    // every workgroup ends in out*in memory-side atomics: measured optimum on 524 288 samples (re-measured once the kernel fit
+    // three waves per SIMD: 512 .. 1024 workgroups are 18 us slower)
+    if (bx > 256) bx = 256;
     if (bx < 1) bx = 1;
     mlp_wgrad_kernel<<<dim3((unsigned)bx, (unsigned)nsub), 256, 0, st>>>(wa, n);
     if (int e = check_launch("mlp_wgrad")) return e;
