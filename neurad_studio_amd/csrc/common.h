@@ -147,23 +147,6 @@ __device__ __forceinline__ Corners hash_corners(float x, float y, float z, float
   return c;
 }
 
-// trilinear blend of 8 loaded corner entries, reference lerp tree (encodings.py:454-464)
-template <int F>
-__device__ __forceinline__ void hash_lerp(const float (&f)[8][F], float ox, float oy, float oz, float (&out)[F]) {
-  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-#pragma unroll
-  for (int i = 0; i < F; ++i) {
-    // a*o + b*(1-o) as fma(a, o, b*(1-o)): 2 VALU ops per lerp; one rounding fewer than torch's mul,mul,add
-    const float f03 = fmaf(f[0][i], ox, f[3][i] * mx);
-    const float f12 = fmaf(f[1][i], ox, f[2][i] * mx);
-    const float f56 = fmaf(f[5][i], ox, f[6][i] * mx);
-    const float f47 = fmaf(f[4][i], ox, f[7][i] * mx);
-    const float f0312 = fmaf(f03, oy, f12 * my);
-    const float f4756 = fmaf(f47, oy, f56 * my);
-    out[i] = fmaf(f0312, oz, f4756 * mz);
-  }
-}
-
 // trilinear blend of the 8 corner entries, reference order of operations (encodings.py:446-464)
 template <int F>
 __device__ __forceinline__ void lerp_corners(const Corners& c, const float (&f)[8][F], float (&out)[F]) {
@@ -182,13 +165,49 @@ __device__ __forceinline__ void lerp_corners(const Corners& c, const float (&f)[
   }
 }
 
-template <int F, bool HALF>
+// F = 1: the (floor x, ceil x) corners of one (y, z) differ only through ifx ^ icx -- the same value for all four such pairs
+// of a sample.  When it is 0 or 1 (x integral, or floor(x) even: half of the samples) both entries lie in one aligned
+// 2-entry pair and ONE 8-byte (fp16: 4-byte) load serves both; the other lanes fetch their ceil corners with a second,
+// exec-masked load.  Same bytes, same results; the L1 sees 6 line accesses per (sample, level) on average instead of 8,
+// and the level-partitioned F = 1 kernels (every access an L2 hit) run against exactly that rate.  row0 must be even.
+template <bool HALF>
+__device__ __forceinline__ void load_corners_f1(const void* table, uint32_t row0, const Corners& c, float (&f)[8][1]) {
+  constexpr int kF[4] = {3, 2, 7, 6}, kC[4] = {0, 1, 4, 5};  // (f, c) corner of the pairs (y, z) = cc, fc, cf, ff
+  const bool same = ((c.idx[3] ^ c.idx[0]) >> 1) == 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t rf = row0 + c.idx[kF[p]], rc = row0 + c.idx[kC[p]];
+    float lo, hi;
+    if constexpr (HALF) {
+      const float2 t = __half22float2(*reinterpret_cast<const __half2*>(reinterpret_cast<const char*>(table) + (rf & ~1u) * 2u));
+      lo = t.x, hi = t.y;
+    } else {
+      const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(table) + (rf & ~1u) * 4u);
+      lo = t.x, hi = t.y;
+    }
+    f[kF[p]][0] = (rf & 1u) ? hi : lo;
+    f[kC[p]][0] = (rc & 1u) ? hi : lo;  // meaningful where `same`
+  }
+  if (!same) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Entry<1, HALF>::load(table, row0 + c.idx[kC[p]], f[kC[p]]);
+  }
+}
+
+// PAIRED (F = 1 only): load_corners_f1.  For kernels whose threads do ONE level each (proposal_levels_lp: 286 -> 265 us on
+// 2.1 M samples x 6 levels); where a thread walks all levels the exec-masked second load turns one memory round trip
+// into one per level and loses (409 -> 492 us), so it is opt-in.
+template <int F, bool HALF, bool PAIRED = false>
 __device__ __forceinline__ void hash_level(const void* table, uint32_t level_row0, float x, float y, float z,
                                            float scale, uint32_t mask, float (&out)[F]) {
   const Corners c = hash_corners(x, y, z, scale, mask);
   float f[8][F];
+  if constexpr (F == 1 && PAIRED) {
+    load_corners_f1<HALF>(table, level_row0, c, f);
+  } else {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(table, level_row0 + c.idx[k], f[k]);
+    for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(table, level_row0 + c.idx[k], f[k]);
+  }
   lerp_corners<F>(c, f, out);
 }
 

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(GridDev g, const void
   const int l = (int)(t - i * g.L);
   const uint32_t mask = (1u << g.log2T) - 1u;
   float v[F];
-  hash_level<F, HALF>(table, (uint32_t)l << g.log2T, x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask, v);
+  hash_level<F, HALF, true>(table, (uint32_t)l << g.log2T, x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask, v);
   float* o = out + t * F;
 #pragma unroll
   for (int k = 0; k < F; ++k) o[k] = v[k];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(GridDev g, const void* 
                                       r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
   const uint32_t mask = (1u << g.log2T) - 1u;
   float v[F];
-  hash_level<F, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
+  hash_level<F, HALF, true>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
   const float w = rescale_weight(g.scal[l], p.std);
   float* o = out + t * F;
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void proposal_levels_lp_kernel(GridDev g, cons
                                       r.d[3 * ray + 1], r.d[3 * ray + 2], r.area[ray], r.starts[ray * r.stride + (i - ray * r.S)], r.ends[ray * r.stride + (i - ray * r.S)], scale);
   const uint32_t mask = (1u << g.log2T) - 1u;
   float v[1];
-  hash_level<1, HALF>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
+  hash_level<1, HALF, true>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
   // streaming store: the feature stream must not push this XCD's level (exactly one L2) out of the L2
   __builtin_nontemporal_store(v[0] * rescale_weight(g.scal[l], p.std), lf + (size_t)l * n + i);
 }
