@@ -5,6 +5,7 @@ Randomness (training-mode jitter) is drawn with torch on the device exactly wher
 and INJECTED into the kernels, so a seeded reference run can be reproduced sample for sample."""
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -131,37 +132,35 @@ class ProposalNetworkSampler(Sampler):
         self._step = step
         self._steps_since_update += 1
 
+    def _proposals_train_this_step(self) -> bool:
+        """the update schedule of the proposal networks (ray_samplers.py:630): every step for the first ten, then
+        whenever more than update_sched(step) steps have passed since the last one"""
+        return self._step < 10 or self._steps_since_update > self.update_sched(self._step)
+
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fns: Optional[List[Callable]] = None,
                              pass_ray_samples: bool = False) -> Tuple[RaySamples, List, List]:
-        assert ray_bundle is not None and density_fns is not None
-        if not pass_ray_samples:
-            density_fns = [lambda rs, f=f: f(rs.frustums.get_positions()) for f in density_fns]
-        weights_list, ray_samples_list = [], []
-        n = self.num_proposal_network_iterations
-        weights, ray_samples = None, None
-        updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
-        for i_level in range(n + 1):
-            is_prop = i_level < n
-            num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
-            if i_level == 0:
-                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples)
-            else:
-                assert weights is not None
-                annealed = weights if self._anneal == 1.0 else torch.pow(weights, self._anneal)
-                ray_samples = self.pdf_sampler(ray_bundle, ray_samples, annealed, num_samples=num_samples)
-            if is_prop:
-                if updated:
-                    density = density_fns[i_level](ray_samples)
-                else:
-                    with torch.no_grad():
-                        density = density_fns[i_level](ray_samples)
-                weights = ray_samples.get_weights(density)
-                weights_list.append(weights)
-                ray_samples_list.append(ray_samples)
-        if updated:
+        """Operator-level orchestration with the reference's contract (ray_samplers.py:614-666): round k evaluates
+        density_fns[k] on its samples, turns the densities into weights and resamples the next round's bins from them
+        (annealed); returns the field's samples plus every proposal round's (weights, samples)."""
+        if ray_bundle is None or density_fns is None:
+            raise ValueError("ray_bundle and density_fns must be provided")
+        fns = list(density_fns) if pass_ray_samples else [
+            (lambda rs, f=f: f(rs.frustums.get_positions())) for f in density_fns]
+        rounds, train_props = self.num_proposal_network_iterations, self._proposals_train_this_step()
+        counts = tuple(self.num_proposal_samples_per_ray[:rounds]) + (self.num_nerf_samples_per_ray,)
+        samples = self.initial_sampler(ray_bundle, num_samples=counts[0])
+        round_weights, round_samples = [], []
+        for k in range(rounds):
+            with contextlib.nullcontext() if train_props else torch.no_grad():  # frozen between scheduled updates
+                density = fns[k](samples)
+            w = samples.get_weights(density)
+            round_weights.append(w)
+            round_samples.append(samples)
+            samples = self.pdf_sampler(ray_bundle, samples, w if self._anneal == 1.0 else w.pow(self._anneal),
+                                       num_samples=counts[k + 1])
+        if train_props:
             self._steps_since_update = 0
-        assert ray_samples is not None
-        return ray_samples, weights_list, ray_samples_list
+        return samples, round_weights, round_samples
 
     @torch.no_grad()
     def generate_fused(self, ray_bundle: RayBundle, proposal_fields: Sequence, sky_distance: float = 20000.0,
