@@ -130,3 +130,54 @@ def test_mlp_backward_workspace_query(lib):
     assert need(13, 24, 3, 4, n) == (n * 3 * 24 + 3) // 4 * 4           # generic shape: dZ of the hidden layers only
     assert need(32, 64, 33, 2, n) > n * 64                              # NeuRAD's geometry MLP: + weight-gradient partials
     assert need(48, 64, 32, 3, n) > n * 128
+
+
+def test_host_side_argument_validation_of_the_batch_samplers_and_feature_head(lib):
+    """argument checks that run on the host before any launch: C entry points return INVALID_ARG / UNSUPPORTED with a
+    message, the Python mirrors refuse CPU batches (no fallback)"""
+    import torch
+
+    from neurad_studio_amd import _lib
+    from neurad_studio_amd.data.pixel_samplers import (LidarPointSamplerConfig, ScaledPatchSamplerConfig, lidar_point_sample,
+                                                       patch_sample)
+
+    I32, I64 = ctypes.c_int32, ctypes.c_int64
+    lib.nrhip_patch_sample.restype = ctypes.c_int
+    # rgb patch (4 * 3 = 12) larger than the 8 x 8 image
+    rc = lib.nrhip_patch_sample(None, None, I64(2), I32(1), I32(8), I32(8), I32(3), I32(4), I32(3), None, None, I32(0), None,
+                                None, None, None)
+    assert rc != 0 and b"exceeds the image" in lib.nrhip_last_error()
+    rc = lib.nrhip_patch_sample(None, None, I64(0), I32(1), I32(8), I32(8), I32(3), I32(2), I32(1), None, None, I32(0), None,
+                                None, None, None)
+    assert rc == 0  # empty batch: nothing to do, no pointer is touched
+    rc = lib.nrhip_patch_sample(None, None, I64(2), I32(1), I32(8), I32(8), I32(3), I32(2), I32(1), None, None, I32(7), None,
+                                None, None, None)
+    assert rc != 0 and b"image_dtype" in lib.nrhip_last_error()
+    lib.nrhip_lidar_point_sample.restype = ctypes.c_int
+    rc = lib.nrhip_lidar_point_sample(None, None, None, None, None, I32(3000), I32(4), I32(5), I64(16), None, None, None)
+    assert rc != 0 and b"2048" in lib.nrhip_last_error()
+    rc = lib.nrhip_lidar_point_sample(None, None, None, None, None, I32(3), I32(4), I32(5), I64(13), None, None, None)
+    assert rc != 0 and b"exceeds" in lib.nrhip_last_error()  # 13 rays from 3 x 4 draws
+    # feature head backward: only the 48 -> H -> H -> 32 shapes
+    m = _lib.Mlp()
+    m.in_dim, m.hidden_dim, m.out_dim, m.num_layers = 64, 64, 32, 3
+    for k in range(3):
+        m.weight[k] = 1
+    pw = (ctypes.c_void_p * _lib.MAX_LAYERS)()
+    lib.nrhip_field_feature_bwd.restype = ctypes.c_int
+    rc = lib.nrhip_field_feature_bwd(ctypes.byref(m), None, None, None, None, I64(16), None, pw, pw, None, I64(0), None)
+    assert rc != 0 and b"feature head" in lib.nrhip_last_error()
+    # Python mirrors: CPU batches are refused, malformed draws are caught before the call
+    with pytest.raises(RuntimeError, match="GPU"):
+        ScaledPatchSamplerConfig(patch_size=2, patch_scale=1).setup(num_rays_per_batch=8).sample(
+            {"image": torch.rand(1, 8, 8, 3), "image_idx": torch.tensor([0])})
+    with pytest.raises(RuntimeError, match="GPU"):
+        LidarPointSamplerConfig().setup(num_rays_per_batch=8).sample(
+            {"lidar": torch.rand(20, 5), "lidar_idx": torch.tensor([0, 1]), "points_per_lidar": torch.tensor([12, 8])})
+    with pytest.raises(ValueError):
+        patch_sample(torch.rand(1, 8, 8, 3), 2, 1)  # neither uniforms nor centers
+    with pytest.raises(ValueError):
+        lidar_point_sample(torch.rand(20, 5), torch.tensor([12, 8]), 8, shuffle=torch.tensor([0, 1]),
+                           draws=torch.rand(2, 3, dtype=torch.float64))  # draws must be [2, ceil(8 / 2)]
+    with pytest.raises(NotImplementedError):
+        LidarPointSamplerConfig().setup(num_rays_per_batch=8).sample({"lidar": [torch.rand(20, 5)], "lidar_idx": torch.tensor([0])})
