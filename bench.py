@@ -366,20 +366,26 @@ def bench_c1(args, device, rank, world):
     depth = torch.empty((R_RAYS, 1), device=device)
     acc = torch.empty((R_RAYS, 1), device=device)
     state = {}
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events around the render kernel on every 4th timed step (each record is a marker packet in the queue: on every
+    # step they cost ~1.5 % of it)
+    ev_every = 4
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range((args.steps + ev_every - 1) // ev_every)]
 
     def step(i=None):
         # M1 sky stretch (models/neurad.py:451-455) folded into the sampler launch; far == sky_distance here anyway
-        sp, eu = ops.power_sampler(None, fars, S, lam=-1.0, scaling=0.1, last_edge=20000.0)
-        # the processing order of this batch (cache-locality hint, csrc/rayorder.hip): part of the step, recomputed every
-        # time.  (Running it on a second stream next to the sampler measured SLOWER: 0.206 vs 0.190 ms per step -- the two
-        # event waits cost more than the 9 us kernel.)
-        order = ops.ray_order(origins, dirs, STATIC_SCALE)
-        if i is not None:
-            events[i][0].record()
+        # bins + the processing order of this batch (cache-locality hint, csrc/rayorder.h): part of the step, recomputed
+        # every time, ONE launch (workgroup 0 sorts while the others fill bins).  (As two launches the step was 9 us
+        # longer; the ordering pass on a second stream next to the sampler was slower still: 0.206 vs 0.190 ms per step --
+        # the two event waits cost more than the kernel.)
+        sp, eu, order = ops.power_sampler_ordered(None, fars, S, origins, dirs, STATIC_SCALE, lam=-1.0, scaling=0.1,
+                                                  last_edge=20000.0)
+        timed_kernel = i is not None and i % ev_every == 0
+        if timed_kernel:
+            events[i // ev_every][0].record()
         ops.render_fwd(fs, origins, dirs, area, eu[:, :-1], eu[:, 1:], out=(feats, depth, acc), order=order)
-        if i is not None:
-            events[i][1].record()
+        if timed_kernel:
+            events[i // ev_every][1].record()
         state["edges"] = eu
 
     elapsed = timed(step, args.steps, args.warmup, world, device)

@@ -358,6 +358,13 @@ int nrhip_weights_from_density_bwd(const float* deltas, const float* densities, 
 int nrhip_power_sampler(const float* nears /*[R]*/, const float* fars /*[R]*/, int64_t r, int32_t s, float lam,
                         float scaling, const float* t_rand, float last_edge, float* spacing_bins /*[R,S+1]*/,
                         float* euclid_bins /*[R,S+1]*/, void* stream);
+/* nrhip_power_sampler + nrhip_ray_order in ONE launch (same arguments, same results as the two calls): workgroup 0 runs the
+ * single-workgroup ordering pass while the others fill bins, so that the processing order of an eval chunk costs no launch
+ * of its own in front of the render kernel. */
+int nrhip_power_sampler_ordered(const float* nears, const float* fars, int64_t r, int32_t s, float lam, float scaling,
+                                const float* t_rand, float last_edge, float* spacing_bins, float* euclid_bins,
+                                const float* origins /*[R,3]*/, const float* directions /*[R,3]*/, float t_ref,
+                                float static_scale, int32_t key_bits, int32_t* order /*[R]*/, void* stream);
 
 /* ---- S4: PDFSampler (ray_samplers.py:280-376), include_original=False -------------------------
  * rand: NULL (eval) or [R] (single_jitter) / [R,S_new+1] (rand_stride = 1 / S_new+1)               */

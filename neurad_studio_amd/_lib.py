@@ -122,6 +122,7 @@ PROTOTYPES = {
     "nrhip_weights_from_density": [P, P, I64, I32, P, P],
     "nrhip_weights_from_density_bwd": [P, P, P, I64, I32, P, P],
     "nrhip_power_sampler": [P, P, I64, I32, F32, F32, P, F32, P, P, P],
+    "nrhip_power_sampler_ordered": [P, P, I64, I32, F32, F32, P, F32, P, P, P, P, F32, F32, I32, P, P],
     "nrhip_pdf_sample": [P, P, P, P, I64, I32, I32, F32, F32, F32, P, I32, P, P, P],
     "nrhip_actor_prepare": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P],
     "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P, P],

@@ -2,7 +2,7 @@
 // One wavefront marches one ray; bin edges, the CDF and the weights of a round live in a per-wave LDS
 // slab, the exclusive sum scans are wave shuffles, the inverse-CDF lookups are per-lane binary searches
 // in LDS (the 65 / 33 query points of a round fit one / two passes of the 64 lanes).
-#include "common.h"
+#include "rayorder.h"
 
 namespace nrhip {
 
@@ -51,13 +51,11 @@ __device__ __forceinline__ float power_bin(int k, int S, const float* t_rand_row
   return b;
 }
 
-__global__ __launch_bounds__(256) void power_sampler_kernel(const float* __restrict__ nears,
-                                                             const float* __restrict__ fars, int64_t R, int S,
-                                                             float lam, float scaling,
-                                                             const float* __restrict__ t_rand, float last_edge,
-                                                             float* __restrict__ sp, float* __restrict__ eu) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= R * (S + 1)) return;
+// bin edge t of the flattened [R, S+1] arrays
+__device__ __forceinline__ void power_sampler_bin(const float* __restrict__ nears, const float* __restrict__ fars,
+                                                  int64_t t, int S, float lam, float scaling,
+                                                  const float* __restrict__ t_rand, float last_edge,
+                                                  float* __restrict__ sp, float* __restrict__ eu) {
   const int64_t ray = t / (S + 1);
   const int k = (int)(t - ray * (S + 1));
   const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
@@ -65,6 +63,31 @@ __global__ __launch_bounds__(256) void power_sampler_kernel(const float* __restr
   sp[t] = b;
   // last_edge > 0: the model's sky stretch (models/neurad.py:451-455, frustums.ends[:, -1] = sky_distance) folded in
   eu[t] = (k == S && last_edge > 0.f) ? last_edge : spc.to_euclid(b);
+}
+
+__global__ __launch_bounds__(256) void power_sampler_kernel(const float* __restrict__ nears,
+                                                             const float* __restrict__ fars, int64_t R, int S,
+                                                             float lam, float scaling,
+                                                             const float* __restrict__ t_rand, float last_edge,
+                                                             float* __restrict__ sp, float* __restrict__ eu) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < R * (S + 1)) power_sampler_bin(nears, fars, t, S, lam, scaling, t_rand, last_edge, sp, eu);
+}
+
+// The same bins plus the processing order of the rays (rayorder.h) in ONE launch: workgroup 0 runs the single-workgroup
+// counting sort while all the others fill bins -- the ordering pass is a 9 us latency chain on one CU and costs nothing
+// next to a chip-wide kernel, but as a launch of its own it sits in front of the render kernel.
+template <int BITS>
+__global__ __launch_bounds__(kOrderThreads) void power_sampler_order_kernel(
+    const float* __restrict__ nears, const float* __restrict__ fars, int64_t R, int S, float lam, float scaling,
+    const float* __restrict__ t_rand, float last_edge, float* __restrict__ sp, float* __restrict__ eu,
+    const float* __restrict__ o, const float* __restrict__ d, float t_ref, float scale, int32_t* __restrict__ order) {
+  if (blockIdx.x == 0) {
+    ray_order_body<BITS>(o, d, R, t_ref, scale, order);
+    return;
+  }
+  const int64_t t = ((int64_t)blockIdx.x - 1) * kOrderThreads + threadIdx.x;
+  if (t < R * (S + 1)) power_sampler_bin(nears, fars, t, S, lam, scaling, t_rand, last_edge, sp, eu);
 }
 
 __device__ __forceinline__ float wsum(float v) {
@@ -367,6 +390,30 @@ extern "C" int nrhip_power_sampler(const float* nears, const float* fars, int64_
   power_sampler_kernel<<<grid_for(r * (s + 1), 256), 256, 0, (hipStream_t)stream>>>(
       nears, fars, r, s, lam, scaling, t_rand, last_edge, spacing_bins, euclid_bins);
   return check_launch("power_sampler");
+}
+
+extern "C" int nrhip_power_sampler_ordered(const float* nears, const float* fars, int64_t r, int32_t s, float lam,
+                                           float scaling, const float* t_rand, float last_edge, float* spacing_bins,
+                                           float* euclid_bins, const float* origins, const float* directions, float t_ref,
+                                           float static_scale, int32_t key_bits, int32_t* order, void* stream) {
+  NR_REQUIRE(r >= 0 && r < (INT64_C(1) << 31) && s >= 1, NRHIP_ERR_INVALID_ARG, "power_sampler_ordered: bad argument");
+  if (r == 0) return NRHIP_OK;
+  NR_REQUIRE(fars && spacing_bins && euclid_bins && origins && directions && order, NRHIP_ERR_INVALID_ARG,
+             "power_sampler_ordered: NULL pointer");
+  NR_REQUIRE(static_scale > 0.f && t_ref >= 0.f, NRHIP_ERR_INVALID_ARG,
+             "power_sampler_ordered: scale must be > 0 and t_ref >= 0");
+  NR_REQUIRE(key_bits == 0 || key_bits == 4 || key_bits == 5, NRHIP_ERR_INVALID_ARG,
+             "power_sampler_ordered: key_bits %d not in {0 (default = 4), 4, 5}", key_bits);
+  const int blocks = 1 + grid_for(r * (s + 1), kOrderThreads);
+  if (key_bits == 5)
+    power_sampler_order_kernel<5><<<blocks, kOrderThreads, 0, (hipStream_t)stream>>>(
+        nears, fars, r, s, lam, scaling, t_rand, last_edge, spacing_bins, euclid_bins, origins, directions, t_ref,
+        static_scale, order);
+  else
+    power_sampler_order_kernel<4><<<blocks, kOrderThreads, 0, (hipStream_t)stream>>>(
+        nears, fars, r, s, lam, scaling, t_rand, last_edge, spacing_bins, euclid_bins, origins, directions, t_ref,
+        static_scale, order);
+  return check_launch("power_sampler_ordered");
 }
 
 extern "C" int nrhip_pdf_sample(const float* weights, const float* spacing_bins, const float* nears, const float* fars,

@@ -650,6 +650,26 @@ def power_sampler(nears: Optional[Tensor], fars: Tensor, num_samples: int, lam: 
     return sp, eu
 
 
+def power_sampler_ordered(nears: Optional[Tensor], fars: Tensor, num_samples: int, origins: Tensor, directions: Tensor,
+                          static_scale: float, lam: float = -1.0, scaling: float = 0.1, t_rand: Optional[Tensor] = None,
+                          last_edge: float = 0.0, t_ref: Optional[float] = None, key_bits: int = 0):
+    """``power_sampler`` and ``ray_order`` as one launch -> (spacing bins, euclidean bins [R,S+1], order int32 [R])"""
+    f = _chk(fars.reshape(-1), "fars")
+    n = None if nears is None else _chk(nears.reshape(-1), "nears")
+    o, d = _chk(origins, "origins"), _chk(directions, "directions")
+    R = f.shape[0]
+    if o.shape != (R, 3) or d.shape != (R, 3):
+        raise ValueError(f"origins / directions must be [R={R},3]")
+    tr = None if t_rand is None else _chk(t_rand, "t_rand")
+    sp = torch.empty((R, num_samples + 1), device=f.device, dtype=torch.float32)
+    eu = torch.empty_like(sp)
+    order = torch.empty((R,), device=f.device, dtype=torch.int32)
+    call("nrhip_power_sampler_ordered", _ptr(n), _ptr(f), R, num_samples, float(lam), float(scaling), _ptr(tr),
+         float(last_edge), _ptr(sp), _ptr(eu), _ptr(o), _ptr(d), float(static_scale if t_ref is None else t_ref),
+         float(static_scale), int(key_bits), _ptr(order), _stream())
+    return sp, eu, order
+
+
 def pdf_sample(weights, spacing_bins, nears, fars, num_samples, lam=-1.0, scaling=0.1, histogram_padding=0.01,
                rand: Optional[Tensor] = None):
     w, b = _chk(weights, "weights"), _chk(spacing_bins, "spacing_bins")

@@ -40,6 +40,30 @@ def test_ray_order_is_a_permutation_grouped_by_region(ops):
     assert torch.equal(torch.sort(ops.ray_order(nan, d, 100.0).long()).values, torch.arange(R, device="cuda"))
 
 
+def test_power_sampler_and_ordering_pass_in_one_launch(ops):
+    """nrhip_power_sampler_ordered == nrhip_power_sampler + nrhip_ray_order: identical bins (eval and injected jitter), and an
+    order that is a permutation with the same grouping quality (the order inside a bucket is unspecified in both)"""
+    R, S = 4099, 128
+    g = torch.Generator(device="cuda").manual_seed(8)
+    o = torch.randn((R, 3), device="cuda", generator=g) * 5
+    d = torch.randn((R, 3), device="cuda", generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    fars = torch.rand((R,), device="cuda", generator=g) * 1000 + 50
+    nears = torch.rand((R,), device="cuda", generator=g)
+    for t_rand in (None, torch.rand((R, S + 1), device="cuda", generator=g)):
+        sp0, eu0 = ops.power_sampler(nears, fars, S, t_rand=t_rand, last_edge=20000.0)
+        sp1, eu1, order = ops.power_sampler_ordered(nears, fars, S, o, d, 100.0, t_rand=t_rand, last_edge=20000.0, t_ref=20.0)
+        assert torch.equal(sp0, sp1) and torch.equal(eu0, eu1)
+        assert order.dtype == torch.int32 and torch.equal(torch.sort(order.long()).values, torch.arange(R, device="cuda"))
+        sep = ops.ray_order(o, d, static_scale=100.0, t_ref=20.0)
+        key_pts = o + 20.0 * d
+        spread = lambda od: float((key_pts[od.long()][1:] - key_pts[od.long()][:-1]).norm(dim=-1).mean())  # noqa: E731
+        assert abs(spread(order) / spread(sep) - 1) < 0.05
+    sp, eu, order = ops.power_sampler_ordered(None, fars[:3], 7, o[:3], d[:3], 100.0)  # fewer rays than one workgroup
+    assert sp.shape == (3, 8) and sorted(order.tolist()) == [0, 1, 2]
+    assert ops.power_sampler_ordered(None, fars[:0], 7, o[:0], d[:0], 100.0)[2].shape == (0,)
+
+
 @pytest.mark.parametrize("ordered", [False, True])
 @pytest.mark.parametrize("cfg", RENDER_CFGS)
 def test_render_with_processing_order_vs_oracle(ops, cfg, ordered):
