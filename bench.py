@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 --config c1 (default, the headline: BASELINE config[1], the configuration `metric` is quoted on).  One step = one pass of
-  the hot path over a batch of synthetic rays resident in HBM: PowerSampler bins (S1) -> ray ordering pass
+  the hot path over a batch of synthetic rays resident in HBM: PowerSampler bins (S1) + ray ordering pass (one launch)
   -> fused hash-grid lookup + tiny MLPs (fp32 MFMA) + transmittance/alpha compositing (F1+C1+C2, nrhip_render_fwd_ex).
   4096 rays x 128 samples, HashEncoding(16 levels, T=2^19, F=2) + 64-wide MLPs, fp32 table.  Rays shard across ranks
   with no data-path collective (inference needs none) -> weak scaling.  The same JSON line carries
@@ -26,8 +26,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this host driver needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the
+# environment exports it already -- kept here for launches that build their own
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
