@@ -132,3 +132,72 @@ def test_model_replicas_stay_identical_world2_gloo(overlap):
         ret = mgr.dict()
         mp.spawn(_worker_model, args=(world, _free_port(), ret, overlap), nprocs=world, join=True)
         assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _torch_adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, grad_scale):
+    """torch.optim.Adam's single-tensor arithmetic on a slice (stands in for nrhip_adam_step, which has no CPU path)"""
+    g = grad * grad_scale
+    if weight_decay:
+        param.mul_(1 - lr * weight_decay)
+    exp_avg.lerp_(g, 1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = (exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(eps)
+    param.addcdiv_(exp_avg, denom, value=-lr / bc1)
+
+
+def _sharded_adam_worker(rank, world, port, ret):
+    from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    tables = [torch.nn.Parameter(torch.randn(1024, 4) * 0.1), torch.nn.Parameter(torch.randn(512, 2) * 0.1)]
+    ref_tables = [torch.nn.Parameter(t.detach().clone()) for t in tables]
+    ref_opt = torch.optim.Adam(ref_tables, lr=1e-2, eps=1e-15)  # one process on the MEAN gradient
+    opt = ShardedTableAdam(tables, lr=1e-2, eps=1e-15, update_fn=_torch_adam_update)
+    nbytes = 0
+    for it in range(3):
+        grads = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(1000 * it + r)
+            grads.append([torch.randn(t.shape, generator=g) for t in tables])
+        for t, gr in zip(tables, grads[rank]):
+            t.grad = gr.clone()
+        if it == 1:  # rank 1 has no gradient for table 1 this step: it contributes zeros
+            grads[1][1] = torch.zeros_like(grads[1][1])
+            if rank == 1:
+                tables[1].grad = None
+        nbytes = opt.step()
+        for i, t in enumerate(ref_tables):
+            t.grad = sum(g[i] for g in grads) / world
+        ref_opt.step()
+    ok = all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(tables, ref_tables))
+    ok = ok and nbytes == sum(2 * t.numel() * 4 * (world - 1) // world for t in tables)
+    sd = opt.state_dict()  # full-size moments in torch.optim.Adam's layout
+    rsd = ref_opt.state_dict()
+    for i in range(2):
+        ok = ok and sd["state"][i]["exp_avg"].shape == tables[i].shape
+        ok = ok and torch.allclose(sd["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"], atol=1e-7)
+        ok = ok and torch.allclose(sd["state"][i]["exp_avg_sq"], rsd["state"][i]["exp_avg_sq"], atol=1e-9)
+        ok = ok and float(sd["state"][i]["step"]) == float(rsd["state"][i]["step"]) == 3.0
+    # a fresh optimizer resumes from the gathered state (the reference's checkpoint layout) and keeps in step
+    opt2 = ShardedTableAdam(tables, lr=1.0, update_fn=_torch_adam_update)
+    opt2.load_state_dict(sd)
+    for t, rt in zip(tables, ref_tables):
+        g = torch.Generator().manual_seed(77)
+        t.grad = torch.randn(t.shape, generator=g)
+        rt.grad = t.grad.clone()  # identical on both ranks: the mean is the gradient itself
+    opt2.step()
+    ref_opt.step()
+    ok = ok and all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(tables, ref_tables))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_table_adam_world2_matches_one_process_on_the_mean_gradient():
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_sharded_adam_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)

@@ -109,3 +109,26 @@ def test_fp16_storage_table_trains_through_the_fused_field_and_master_weights():
     st = opt.state[table]
     assert st["master"].dtype == torch.float32 and table.dtype == torch.float16
     assert torch.equal(table, st["master"].half()) and float((table.float() - before.float()).abs().max()) > 1e-3
+
+
+def test_sharded_table_adam_single_process_equals_torch_adam():
+    """parallel/sharded_adam.py with one rank: the HIP kernel on the (whole-table) shard == torch.optim.Adam, and its
+    state_dict loads into torch.optim.Adam (the N > 1 exchange around it is covered by the gloo world-2 test)"""
+    from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
+
+    torch.manual_seed(4)
+    t = torch.nn.Parameter(torch.randn((1 << 16, 4), device="cuda") * 0.1)
+    r = torch.nn.Parameter(t.detach().clone())
+    opt, ref = ShardedTableAdam([t], lr=1e-2, eps=1e-15), torch.optim.Adam([r], lr=1e-2, eps=1e-15)
+    for it in range(4):
+        g = torch.randn_like(t)
+        g[torch.rand((t.shape[0],), device="cuda") < 0.7] = 0.0  # untouched rows
+        t.grad, r.grad = g.clone(), g.clone()
+        assert opt.step() == 0  # nothing on the wire with one rank
+        ref.step()
+    assert torch.allclose(t, r, rtol=2e-6, atol=3e-8)
+    sd = opt.state_dict()
+    assert torch.allclose(sd["state"][0]["exp_avg_sq"], ref.state_dict()["state"][0]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    other = torch.optim.Adam([torch.nn.Parameter(t.detach().clone())], lr=1e-2, eps=1e-15)
+    other.load_state_dict(sd)
+    assert float(other.state_dict()["state"][0]["step"]) == 4.0
