@@ -11,7 +11,6 @@ pixel-centre coordinates for nrhip_camera_rays, the ground-truth patch gather --
 ``cameras.raygen.camera_rays`` without another gather."""
 from __future__ import annotations
 
-import ctypes as C
 from dataclasses import dataclass
 from typing import Dict, Optional
 
