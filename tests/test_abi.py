@@ -181,3 +181,16 @@ def test_host_side_argument_validation_of_the_batch_samplers_and_feature_head(li
                            draws=torch.rand(2, 3, dtype=torch.float64))  # draws must be [2, ceil(8 / 2)]
     with pytest.raises(NotImplementedError):
         LidarPointSamplerConfig().setup(num_rays_per_batch=8).sample({"lidar": [torch.rand(20, 5)], "lidar_idx": torch.tensor([0])})
+
+
+def test_power_sampler_ordered_host_checks(lib):
+    """nrhip_power_sampler_ordered validates on the host: empty batch is a no-op, bad sizes / NULL buffers are errors"""
+    I32, I64, F32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    fn = lib.nrhip_power_sampler_ordered
+    fn.restype = ctypes.c_int
+    args = lambda r, s: (None, None, I64(r), I32(s), F32(-1.0), F32(0.1), None, F32(0.0), None, None, None, None, F32(1.0),  # noqa: E731
+                         F32(100.0), I32(0), None, None)
+    assert fn(*args(0, 8)) == 0
+    assert fn(*args(-1, 8)) != 0 and b"bad argument" in lib.nrhip_last_error()
+    assert fn(*args(4, 0)) != 0
+    assert fn(*args(4, 8)) != 0 and b"NULL" in lib.nrhip_last_error()
