@@ -40,6 +40,26 @@ def test_ray_order_is_a_permutation_grouped_by_region(ops):
     assert torch.equal(torch.sort(ops.ray_order(nan, d, 100.0).long()).values, torch.arange(R, device="cuda"))
 
 
+def test_ray_order_five_bit_keys(ops):
+    """key_bits = 5: 32 768 buckets (128 KB LDS histogram), both entry points"""
+    R = 6000
+    g = torch.Generator(device="cuda").manual_seed(6)
+    o = torch.randn((R, 3), device="cuda", generator=g) * 5
+    d = torch.randn((R, 3), device="cuda", generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    key_pts = o + 20.0 * d
+    spread = lambda od: float((key_pts[od.long()][1:] - key_pts[od.long()][:-1]).norm(dim=-1).mean())  # noqa: E731
+    o4 = ops.ray_order(o, d, static_scale=100.0, t_ref=20.0)
+    o5 = ops.ray_order(o, d, static_scale=100.0, t_ref=20.0, key_bits=5)
+    fars = torch.full((R,), 1000.0, device="cuda")
+    sp, eu, o5f = ops.power_sampler_ordered(None, fars, 16, o, d, 100.0, t_ref=20.0, key_bits=5)
+    for od in (o5, o5f):
+        assert torch.equal(torch.sort(od.long()).values, torch.arange(R, device="cuda"))
+        assert spread(od) <= spread(o4) * 1.05  # finer cells group at least as tightly
+    sp0, eu0 = ops.power_sampler(None, fars, 16)
+    assert torch.equal(sp, sp0) and torch.equal(eu, eu0)
+
+
 def test_power_sampler_and_ordering_pass_in_one_launch(ops):
     """nrhip_power_sampler_ordered == nrhip_power_sampler + nrhip_ray_order: identical bins (eval and injected jitter), and an
     order that is a permutation with the same grouping quality (the order inside a bucket is unspecified in both)"""
