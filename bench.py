@@ -133,7 +133,30 @@ class _Optimizers:
             o.step()
 
 
-def make_optimizer(params):
+class _ShardedOptimizers(_Optimizers):
+    """--sharded-adam at N > 1: the hash tables on parallel/sharded_adam.py (their reduce-scatter IS the gradient exchange,
+    Adam runs on 1/N of each table, the updated parameters are all-gathered); the GradientSynchronizer skips them"""
+
+    def __init__(self, params):
+        from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
+
+        params = list(params)
+        self.tables = [p for p in params if p.numel() >= 1 << 16]
+        small = [p for p in params if p.numel() < 1 << 16]
+        self.sharded = ShardedTableAdam(self.tables, lr=1e-3, eps=1e-15, usage="static")
+        self.opts = [self.sharded]
+        if small:
+            self.opts.append(torch.optim.Adam(small, lr=1e-3, eps=1e-15, fused=True))
+
+    def owned_params(self):
+        return self.tables
+
+
+def make_optimizer(params, sharded=False):
+    if sharded:
+        return _ShardedOptimizers(params), ("Adam: hash tables on ShardedTableAdam (reduce-scatter of the gradient, Adam on the "
+                                            "rank's shard via nrhip_adam_step, all-gather of the parameters), MLPs on torch "
+                                            "fused Adam")
     return _Optimizers(params), "Adam: hash tables on nrhip_adam_step (dense, torch.optim.Adam arithmetic), MLPs on torch fused Adam"
 
 
@@ -228,40 +251,57 @@ def joint_batch(device, rank, n_cam, n_lidar):
     return o, d, area, times, md
 
 
-def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS):
-    """The whole hot-path training step at the reference's default sizes (models/neurad.py defaults: static grid L=8, F=4,
-    T=2^22; proposal grids L=6, F=1, T=2^20; 128+64 proposal samples, 32 field samples; 32-wide MLPs; 16-d appearance
-    embedding; lidar head) on a camera+lidar joint batch: get_nff_outputs (training mode, jitter, lidar metadata) ->
-    lidar head -> lidar depth / intensity / ray-drop / carving losses + interlevel + distortion (reference multipliers)
-    + a feature regression standing in for the CNN decoder's rgb loss (the CNN is outside the path) -> backward ->
-    gradient exchange -> Adam."""
+def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, rgb_decoder=True,
+                       cfg_edit=None, sharded_adam=False):
+    """The whole training step at the reference's default sizes (models/neurad.py defaults: static grid L=8, F=4, T=2^22;
+    proposal grids L=6, F=1, T=2^20; 128+64 proposal samples, 32 field samples; 32-wide MLPs; 16-d appearance embedding;
+    lidar head; RGB CNN decoder) on a camera+lidar joint batch: get_nff_outputs (training mode, jitter, lidar metadata) ->
+    lidar head + RGB CNN decoder (32x32 feature patches -> 96x96 rgb, models/neurad.py:198-216,359-366; under fp16 autocast
+    like the reference's mixed_precision=True trainer, configs/method_configs.py:401) -> rgb MSE + lidar depth / intensity /
+    ray-drop / carving losses + interlevel + distortion (reference multipliers, models/neurad.py:65-94,534-560) -> backward
+    -> gradient exchange -> Adam.  rgb_decoder=False: a feature regression stands in for the decoder + rgb loss (round 2's
+    step, kept as the `hot path only` variant)."""
     from neurad_studio_amd.cameras.rays import RayBundle
-    from neurad_studio_amd.model_components.lidar_losses import LidarLossSettings, lidar_loss_dict, lidar_metrics
+    from neurad_studio_amd.model_components.cnns import decode_rgb, make_rgb_decoder
+    from neurad_studio_amd.model_components.lidar_losses import (LidarLossSettings, WeightedLossSum, lidar_loss_multipliers,
+                                                                 lidar_metrics, lidar_rows)
     from neurad_studio_amd.model_components.losses import distortion_loss, zipnerf_interlevel_loss
     from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
     from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
 
     torch.manual_seed(11)  # identical replicas
-    m = NeuRADHotPath(NeuRADHotPathConfig(), static_scale=STATIC_SCALE, num_sensors=7, duration=8.0).to(device).train()
+    mcfg = NeuRADHotPathConfig()
+    if cfg_edit is not None:
+        cfg_edit(mcfg)
+    m = NeuRADHotPath(mcfg, static_scale=STATIC_SCALE, num_sensors=7, duration=8.0).to(device).train()
+    dec = make_rgb_decoder(mcfg.field.nff_out_dim + mcfg.appearance_dim, 32, mcfg.rgb_upsample_factor).to(device).train() \
+        if rgb_decoder else None
     with torch.no_grad():  # O(1) features so that densities / alphas are not degenerate
         m.field.hashgrid.static_grid.hash_table.mul_(1000.0)
         for p in m.proposal_fields:
             p.hashgrid.static_grid.hash_table.mul_(2000.0)
-    params = [p for p in m.parameters() if p.requires_grad]
-    opt, opt_name = make_optimizer(params)
+    params = [p for p in m.parameters() if p.requires_grad] + ([] if dec is None else list(dec.parameters()))
+    opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1)
     # static scene: the used-parameter set is agreed once (no per-step host read); the proposal tables' exchange starts
     # from their gradient hooks, under the field backward
-    sync = GradientSynchronizer(params, average=True, usage="static", overlap=world > 1)
+    sync = GradientSynchronizer(params, average=True, usage="static", overlap=world > 1,
+                                skip=opt.owned_params() if hasattr(opt, "owned_params") else ())
     o, d, area, times, md = joint_batch(device, rank, n_cam, n_lidar)
     R = n_cam + n_lidar
     g = torch.Generator(device=device)
     g.manual_seed(5 + rank)
-    target = torch.rand((n_cam, 48), device=device, generator=g)
+    up = mcfg.rgb_upsample_factor
+    image = torch.rand((n_cam // 1024, 32 * up, 32 * up, 3), device=device, generator=g)  # the batch's rgb patches
+    target = torch.rand((n_cam, 32 + mcfg.appearance_dim), device=device, generator=g)
     is_lidar = md["is_lidar"][:, 0]
     did_return = md["did_return"][is_lidar][:, 0]
     distance = md["directions_norm"][is_lidar]
     intensity_t = torch.rand((n_lidar, 1), device=device, generator=g)
     lcfg = LidarLossSettings()
+    mults = lidar_loss_multipliers(lcfg)
+    mults.update(interlevel=0.001, distortion=0.002)  # models/neurad.py:84-85
+    mults["rgb" if rgb_decoder else "feature"] = 5.0  # rgb_mult (models/neurad.py:70)
+    total_loss = WeightedLossSum(mults, device)
     nears = torch.zeros((R, 1), device=device)
     state = {}
 
@@ -269,12 +309,18 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
         rb = RayBundle(origins=o, directions=d, pixel_area=area.clone(), nears=nears, fars=None, times=times,
                        metadata=dict(md))
         out = m.get_nff_outputs(rb, calc_lidar_losses=True)
-        out["intensity"], out["ray_drop_logits"] = m.decode_lidar(out["features"], is_lidar)
-        losses = lidar_loss_dict(lidar_metrics(out, is_lidar, did_return, distance, intensity_t, lcfg), lcfg)
-        losses["interlevel"] = 0.001 * zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
-        losses["distortion"] = 0.002 * distortion_loss(out["weights_list"], out["ray_samples_list"])
-        losses["feature"] = 5.0 * (out["features"][:n_cam] - target).square().mean()
-        loss = sum(losses.values())
+        rows = lidar_rows(is_lidar, n_lidar)  # positions of the lidar rays, no host sync
+        out["intensity"], out["ray_drop_logits"] = m.decode_lidar(out["features"], rows=rows[0])
+        terms = lidar_metrics(out, is_lidar, did_return, distance, intensity_t, lcfg, rows=rows)
+        terms["interlevel"] = zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
+        terms["distortion"] = distortion_loss(out["weights_list"], out["ray_samples_list"])
+        if dec is not None:
+            with torch.autocast("cuda", dtype=torch.float16):
+                rgb = decode_rgb(dec, out["features"][:n_cam], (32, 32))
+            terms["rgb"] = torch.nn.functional.mse_loss(rgb.float(), image)
+        else:
+            terms["feature"] = (out["features"][:n_cam] - target).square().mean()
+        loss = total_loss(terms)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         state["bytes"] = sync.sync()
@@ -301,23 +347,45 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             ev[k - 2][1].record()
     torch.cuda.synchronize()
     k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    dec_ms = None
+    if dec is not None:  # the decoder's own share: forward + backward of decode_rgb on this batch's patches, standalone
+        f48 = torch.randn((n_cam, 32 + mcfg.appearance_dim), device=device, requires_grad=True)
+        evd = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for k in range(7):
+            if k >= 2:
+                evd[k - 2][0].record()
+            with torch.autocast("cuda", dtype=torch.float16):
+                rgb = decode_rgb(dec, f48, (32, 32))
+            torch.nn.functional.mse_loss(rgb.float(), image).backward()
+            if k >= 2:
+                evd[k - 2][1].record()
+        torch.cuda.synchronize()
+        dec_ms = float(np.mean([a.elapsed_time(b) for a, b in evd]))
+        opt.zero_grad(set_to_none=True)
     g = m.field.hashgrid.static_grid
     H = m.config.field.geo_hidden_dim
-    per_sample = algorithmic_bytes_per_sample(g.num_levels, g.features_per_level, 4, S) + 4 * (32 + H + 48 + 2 * H) + 4 * 34
-    roof = {"kernel": f"nrhip::render_kernel<{g.num_levels},{g.features_per_level},{H},fp32,train> (fused field forward that "
-                      "stores its activations; timed standalone after the step loop)",
+    tb = 2 if g.hash_table.dtype == torch.float16 else 4
+    per_sample = algorithmic_bytes_per_sample(g.num_levels, g.features_per_level, tb, S) + 4 * (32 + H + 48 + 2 * H) + 4 * 34
+    roof = {"kernel": f"nrhip::render_kernel<{g.num_levels},{g.features_per_level},{H},{'fp16' if tb == 2 else 'fp32'},train> "
+                      "(fused field forward that stores its activations; timed standalone after the step loop)",
             "bound": "hbm", "achieved": R * S * per_sample / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": R * S * per_sample / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": recorded_traffic("field_fwd_train") if (n_cam, n_lidar) == (C3_CAMERA_RAYS, C3_LIDAR_RAYS) else None,
+            "traffic": recorded_traffic("field_fwd_train") if (n_cam, n_lidar, tb) == (C3_CAMERA_RAYS, C3_LIDAR_RAYS, 4)
+            else None,
             "algorithmic_bytes_per_launch": R * S * per_sample, "kernel_ms": k_ms,
-            "bytes_per_sample": "table reads L*8*F*4 + 8 B interval + per-ray I/O / S + saved activations "
+            "bytes_per_sample": "table reads L*8*F*sizeof(entry) + 8 B interval + per-ray I/O / S + saved activations "
                                 "(32 + H + 48 + 2H floats) + per-sample outputs (34 floats)"}
     return {"roofline": roof, "iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
             "grad_exchange_bytes_per_rank": state["bytes"], "optimizer": opt_name,
+            "rgb_decoder": ("CNN decoder (4 BasicBlocks of 7x7 convs + 3x transposed conv, MIOpen under fp16 autocast) + rgb "
+                            f"MSE in the step; standalone forward+backward {dec_ms:.2f} ms") if dec is not None
+            else "not in this step (feature regression stands in)",
+            "rgb_decoder_fwd_bwd_ms": dec_ms,
             "what": "BASELINE config[3] shape per GPU: NeuRAD-default grids, sampler (2 rounds) + field + compositing + "
-                    "appearance + lidar head + lidar/interlevel/distortion losses, backward, gradient exchange, Adam"}
+                    "appearance + lidar head" + (" + RGB CNN decoder" if dec is not None else "") +
+                    " + rgb/lidar/interlevel/distortion losses, backward, gradient exchange, Adam"}
 
 
 def cpu_baseline(fs, origins, dirs, area, edges, budget_s=12.0):

@@ -520,6 +520,74 @@ int nrhip_interlevel_loss(const float* c, const float* w, int32_t n_fine, const 
 int nrhip_distortion_loss(const float* c, const float* w, int32_t n_samples, int64_t r, float* loss_per_ray,
                           float* grad_w, void* stream);
 
+/* ---- the training step's glue as kernels (csrc/train_fused.hip) ---------------------------------------------------
+ * What the reference spreads over dozens of elementwise torch ops per step between the field / sampler kernels.
+ * `edges` is a bin-edge tensor e[R, >= S+1] with row stride edge_stride (floats): sample s of a ray spans
+ * [e[s], e[s+1]] -- the [R,S,1] starts / ends / deltas views of cameras/rays.py:313-357 are never materialised.   */
+
+/* RaySamples.get_weights (cameras/rays.py:188-210) + render_depth_simple of the round (models/neurad.py:396,727-734):
+ * weights [R,S] = nan_to_num((1 - exp(-delta*dens)) * exp(-exclusive_cumsum(delta*dens))), depth [R] (may be NULL)
+ * = sum_s weights * (e[s] + e[s+1]) / 2.                                                                            */
+int nrhip_prop_weights_fwd(const float* edges, int32_t edge_stride, const float* densities /*[R,S]*/, int64_t r,
+                           int32_t s, float* weights, float* depth, void* stream);
+/* its autograd: grad_densities [R,S] from grad_weights [R,S] and / or grad_depth [R] (either may be NULL) */
+int nrhip_prop_weights_bwd(const float* edges, int32_t edge_stride, const float* densities, const float* grad_weights,
+                           const float* grad_depth, int64_t r, int32_t s, float* grad_densities, void* stream);
+
+/* SigmoidDensity (model_components/utils.py:21-41; `beta` = DEVICE pointer to the raw learnable parameter, the kernel
+ * applies |beta| + beta_min) -> nerfacc.render_weight_from_alpha -> accumulation -> sky residual on the last sample ->
+ * features over all S samples, depth over the first S-1 (models/neurad.py:377-395).  alpha [R,S] (saved for the
+ * backward), weights_ns [R,S-1] = the weights of the non-sky samples (`weights[..., :-1, :]` of models/neurad.py:388),
+ * out_features rows of out_stride floats (>= C: room for the appearance embedding beside them), depth / acc [R].   */
+int nrhip_sdf_render_fwd(const float* sdf /*[R,S]*/, const float* beta, float beta_min, const float* features /*[R,S,C]*/,
+                         const float* edges, int32_t edge_stride, int64_t r, int32_t s, int32_t c, float* alpha,
+                         float* weights_ns, float* out_features, int32_t out_stride, float* out_depth, float* out_acc,
+                         void* stream);
+/* floats of scratch nrhip_sdf_render_bwd needs (host out-pointer) */
+int nrhip_sdf_render_bwd_workspace(int64_t r, int64_t* floats);
+/* backward of the above: g_features rows of g_stride floats, g_depth / g_acc [R] and g_weights_ns [R,S-1] may be NULL;
+ * -> grad_features [R,S,C], grad_sdf [R,S], grad_beta [1] (w.r.t. the raw parameter, sign(beta) applied; summed in a
+ * fixed order: reproducible)                                                                                          */
+int nrhip_sdf_render_bwd(const float* sdf, const float* beta, float beta_min, const float* alpha, const float* features,
+                         const float* edges, int32_t edge_stride, const float* g_features, int32_t g_stride,
+                         const float* g_depth, const float* g_acc, const float* g_weights_ns, int64_t r, int32_t s,
+                         int32_t c, float* grad_features, float* grad_sdf, float* grad_beta, float* workspace,
+                         void* stream);
+
+/* NeuRADModel._get_appearance_embedding (models/neurad.py:423-441) with the slot arithmetic in the kernel:
+ * t = times / duration * n_per_sensor, lo = clamp(floor(t)), hi = clamp(lo + 1), out = E[lo + sensor*n] (1 - (t - lo))
+ * + E[hi + sensor*n] (t - lo); temporal = 0 (or times NULL): out = E[sensor].  sensor_idx may be NULL (= 0).  Rows of
+ * `out` are out_stride floats apart.  Indices are clamped into the table.                                            */
+int nrhip_appearance_fwd(const float* weight /*[E,D]*/, const int64_t* sensor_idx /*[R]*/, const float* times /*[R]*/,
+                         float duration, int32_t n_per_sensor, int32_t temporal, int64_t r, int32_t n_embed, int32_t dim,
+                         float* out, int32_t out_stride, void* stream);
+/* gradient to the embedding table [E,D] (written, not accumulated) */
+int nrhip_appearance_bwd(const float* g_out, int32_t g_stride, const int64_t* sensor_idx, const float* times,
+                         float duration, int32_t n_per_sensor, int32_t temporal, int64_t r, int32_t n_embed, int32_t dim,
+                         float* grad_weight, void* stream);
+
+/* rows [n_out] (in order; the first n_out set positions) of a uint8 ray mask [R] + inverse [R] (slot of the row or -1)
+ * + count [1] (all may be NULL): what `x[mask]` needs a nonzero + a device->host read for (models/neurad.py:478,485). */
+int nrhip_mask_compact(const uint8_t* mask, int64_t r, int64_t* rows, int64_t n_out, int32_t* inverse, int32_t* count,
+                       void* stream);
+
+/* The lidar terms of NeuRADModel.get_metrics_dict (models/neurad.py:485-521) over the n lidar rays of a batch:
+ * depths: HOST array of n_levels DEVICE pointers [R] (level 0 = the field's depth, 1.. = prop_depth_i), read at
+ * lidar_rows [n].  metrics [2 + n_levels] = depth_loss (mean over the rays below the `quantile` of the per-ray error,
+ * torch.quantile's linear interpolation), intensity_loss (same rays & returned), ray_drop_loss (BCE with logits, target
+ * = no return), depth_loss_0, ...  unit_grads [(n_levels + 2), n] = d metric / d prediction per lidar ray (depth levels,
+ * intensity, logits); scratch [n].  One workgroup; the quantile is a radix select, nothing is sorted.                */
+int nrhip_lidar_losses(const float* const* depths, int32_t n_levels, const int64_t* lidar_rows, const float* distance,
+                       const uint8_t* did_return, const float* intensity, const float* intensity_target,
+                       const float* ray_drop_logits, int64_t n, float non_return_distance, float non_return_mult,
+                       float quantile, float* metrics, float* unit_grads, float* scratch, void* stream);
+/* unit gradients x upstream [2 + n_levels] (device) scattered to the batch: grad_depths = HOST array of n_levels DEVICE
+ * pointers [R] (0 for camera rays; entries may be NULL), grad_intensity / grad_logits [n] (may be NULL);
+ * inverse [R] from nrhip_mask_compact                                                                               */
+int nrhip_lidar_losses_bwd(const float* unit_grads, const int32_t* inverse, const float* upstream, int32_t n_levels,
+                           int64_t r, int64_t n, float* const* grad_depths, float* grad_intensity, float* grad_logits,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,16 @@ PROTOTYPES = {
                                           P, I64, C.POINTER(P), C.POINTER(P), C.POINTER(P), P],
     "nrhip_interlevel_loss": [P, P, I32, P, P, I32, F32, I64, P, P, P],
     "nrhip_distortion_loss": [P, P, I32, I64, P, P, P],
+    "nrhip_prop_weights_fwd": [P, I32, P, I64, I32, P, P, P],
+    "nrhip_prop_weights_bwd": [P, I32, P, P, P, I64, I32, P, P],
+    "nrhip_sdf_render_fwd": [P, P, F32, P, P, I32, I64, I32, I32, P, P, P, I32, P, P, P],
+    "nrhip_sdf_render_bwd_workspace": [I64, C.POINTER(I64)],
+    "nrhip_sdf_render_bwd": [P, P, F32, P, P, P, I32, P, I32, P, P, P, I64, I32, I32, P, P, P, P, P],
+    "nrhip_appearance_fwd": [P, P, P, F32, I32, I32, I64, I32, I32, P, I32, P],
+    "nrhip_appearance_bwd": [P, I32, P, P, F32, I32, I32, I64, I32, I32, P, P],
+    "nrhip_mask_compact": [P, I64, P, I64, P, P, P],
+    "nrhip_lidar_losses": [C.POINTER(P), I32, P, P, P, P, P, P, I64, F32, F32, F32, P, P, P, P],
+    "nrhip_lidar_losses_bwd": [P, P, P, I32, I64, I64, C.POINTER(P), P, P, P],
 }
 
 _lib = None

@@ -124,22 +124,27 @@ class FieldTrainFn(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, g_feature, g_geo_out):
         o, d, a, s, e, enc, hg, xf, hf, *params = ctx.saved_tensors
-        gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
-        g_feature = g_feature.contiguous()
-        # feature = embedding + mlp_feature([embedding | sh])
-        if ops.field_feature_bwd_supported(fw, fb):
-            # one kernel: weight gradients + the geometry MLP's output gradient (residual add and column 0 included)
-            g_geo, gfw, gfb = ops.field_feature_bwd(xf, hf, g_feature, g_geo_out, fw, fb)
-        else:
-            gxf, gfw, gfb = ops.mlp_bwd(xf, hf, g_feature, fw, fb)
-            g_geo = torch.empty((g_feature.shape[0], 33), device=g_feature.device, dtype=torch.float32)
-            g_geo[:, 0] = g_geo_out.reshape(-1)
-            torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
-        genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
-        gt = _like_param(ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, genc), ctx.table_dtype) \
-            if ctx.needs_input_grad[0] else None
-        grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
+        gt, grads = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, s, e, enc, hg, xf,
+                                    hf, params, g_feature.contiguous(), g_geo_out)
         return (gt, None, None, None, None, None, None, None, None, None, *grads, *([None] if ctx.has_order else []))
+
+
+def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends, enc, hg, xf, hf, params, g_feature, g_geo_out):
+    """Backward of the fused field forward from (dL/dfeature [N,32], dL/dgeo_out [N]): feature-MLP gradients -> residual ->
+    geometry-MLP gradients -> table gradient.  -> (grad table or None, the ten MLP parameter gradients in argument order)"""
+    gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
+    # feature = embedding + mlp_feature([embedding | sh])
+    if ops.field_feature_bwd_supported(fw, fb):
+        # one kernel: weight gradients + the geometry MLP's output gradient (residual add and column 0 included)
+        g_geo, gfw, gfb = ops.field_feature_bwd(xf, hf, g_feature, g_geo_out, fw, fb)
+    else:
+        gxf, gfw, gfb = ops.mlp_bwd(xf, hf, g_feature, fw, fb)
+        g_geo = torch.empty((g_feature.shape[0], 33), device=g_feature.device, dtype=torch.float32)
+        g_geo[:, 0] = g_geo_out.reshape(-1)
+        torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
+    genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
+    gt = _like_param(ops.encode_bwd(spec, scale, o, d, a, starts, ends, genc), table_dtype) if need_table else None
+    return gt, [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
 
 
 class MLPFn(torch.autograd.Function):
@@ -360,3 +365,131 @@ class DistortionLossFn(torch.autograd.Function):
     def backward(ctx, go):
         (g,) = ctx.saved_tensors
         return None, g * (go / ctx.n_rays)
+
+
+# ------------------------------------------------------------------------------------------------
+# The training step as a handful of nodes (csrc/train_fused.hip): what the reference's orchestration spreads over
+# RaySamples views, cats and elementwise ops between the kernels stays inside them.
+class ProposalRoundFn(torch.autograd.Function):
+    """One round of the training-mode proposal sampler as ONE node (ray_samplers.py:640-652 + models/neurad.py:396):
+    density of the round's samples (S2) -> RaySamples.get_weights (S3) -> render_depth_simple of the round, all from the
+    round's bin EDGES [R,S+1].  args: table, decoder_weight, spec, static_scale, origins, directions, pixel_area, edges
+    -> weights [R,S], prop_depth [R,1]."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, table, decoder_weight, spec, static_scale, origins, directions, pixel_area, edges):
+        ctx.set_materialize_grads(False)
+        ps = ops.ProposalSpec(spec, table, static_scale, decoder_weight)
+        starts, ends = edges[:, :-1], edges[:, 1:]
+        if table.requires_grad or decoder_weight.requires_grad:
+            dens, lf = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends, save_features=True)
+            ctx.ps = ps
+            ctx.save_for_backward(origins, directions, pixel_area, edges, dens, lf)
+        else:  # frozen between scheduled updates / eval: nothing to save
+            dens = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends)
+        return ops.prop_weights_fwd(edges, dens)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gw, gdepth):
+        o, d, a, edges, dens, lf = ctx.saved_tensors
+        if gw is None and gdepth is None:
+            return (None,) * 8
+        gdens = ops.prop_weights_bwd(edges, dens, None if gw is None else gw.contiguous(), gdepth)
+        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, edges[:, :-1], edges[:, 1:], dens, gdens, level_features=lf)
+        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None
+
+
+class NffRenderTrainFn(torch.autograd.Function):
+    """get_nff_outputs behind the sampler (models/neurad.py:373-395) for the static scene as ONE node: fused field forward
+    (NeuRADField.forward) -> SigmoidDensity with the learnable beta -> render_weight_from_alpha -> accumulation, sky
+    residual, features, depth -> appearance embedding written beside the features.
+
+    args: table, spec, static_scale, beta (raw parameter), beta_min, origins, directions, pixel_area, edges [R,S+1] (last
+    edge = sky distance), emb_weight | None, sensor_idx | None, times | None, (duration, n_per_sensor, temporal), order |
+    None, gw0, gb0, gw1, gb1, fw0, fb0, fw1, fb1, fw2, fb2
+    -> features [R, 32 + A], depth [R,1], accumulation [R,1], weights of the non-sky samples [R,S-1]"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, table, spec, static_scale, beta, beta_min, origins, directions, pixel_area, edges, emb_weight,
+                sensor_idx, times, emb_cfg, order, *params):
+        ctx.set_materialize_grads(False)
+        gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
+        fs = ops.FieldSpec(spec, table, static_scale, gw, gb, fw, fb, use_sdf=True, beta=1.0)  # (kernel head unused)
+        (feature, sdf, _head), (enc, hg, xf, hf) = ops.field_fwd_train(fs, origins, directions, pixel_area, edges[:, :-1],
+                                                                      edges[:, 1:], order=order)
+        R, S = edges.shape[0], edges.shape[1] - 1
+        A = 0 if emb_weight is None else emb_weight.shape[1]
+        alpha, w_ns, out, depth, acc = ops.sdf_render_fwd(sdf.view(R, S), beta, beta_min, feature.view(R, S, -1), edges,
+                                                          extra_cols=A)
+        if A:
+            ops.appearance_fwd(emb_weight, sensor_idx, times, emb_cfg[0], emb_cfg[1], emb_cfg[2], R, out=out[:, out.shape[1] - A:])
+        ctx.spec, ctx.scale, ctx.table_dtype, ctx.beta_min, ctx.emb_cfg = spec, static_scale, table.dtype, beta_min, emb_cfg
+        ctx.n_embed, ctx.A = (0 if emb_weight is None else emb_weight.shape[0]), A
+        ctx.has = (sensor_idx is not None, times is not None)
+        opt = [t for t in (sensor_idx, times) if t is not None]
+        ctx.save_for_backward(origins, directions, pixel_area, edges, enc, hg, xf, hf, feature, sdf, alpha, beta, *params, *opt)
+        return out, depth, acc, w_ns
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_out, g_depth, g_acc, g_wns):
+        o, d, a, edges, enc, hg, xf, hf, feature, sdf, alpha, beta, *rest = ctx.saved_tensors
+        params, opt = rest[:10], list(rest[10:])
+        sensor_idx = opt.pop(0) if ctx.has[0] else None
+        times = opt.pop(0) if ctx.has[1] else None
+        R, S = edges.shape[0], edges.shape[1] - 1
+        C_ = feature.shape[-1]
+        if g_out is None:
+            g_out = torch.zeros((R, C_ + ctx.A), device=o.device, dtype=torch.float32)
+        gfeat, gsdf, gbeta = ops.sdf_render_bwd(sdf.view(R, S), beta, ctx.beta_min, alpha, feature.view(R, S, C_), edges,
+                                                g_out[:, :C_], g_depth, g_acc, g_wns)
+        g_emb = None
+        if ctx.A and ctx.needs_input_grad[9]:
+            g_emb = ops.appearance_bwd(g_out[:, C_:], sensor_idx, times, ctx.emb_cfg[0], ctx.emb_cfg[1], ctx.emb_cfg[2],
+                                       ctx.n_embed)
+        gt, grads = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, edges[:, :-1],
+                                    edges[:, 1:], enc, hg, xf, hf, params, gfeat.view(R * S, C_), gsdf.view(-1))
+        g_beta = gbeta.reshape(beta.shape) if ctx.needs_input_grad[3] else None
+        return (gt, None, None, g_beta, None, None, None, None, None, g_emb, None, None, None, None, *grads)
+
+
+class LidarLossFn(torch.autograd.Function):
+    """The lidar terms of get_metrics_dict (models/neurad.py:485-521) in one launch each way.
+    args: (non_return_distance, non_return_mult, quantile), lidar_rows int64 [n], inverse int32 [R] (ops.mask_compact),
+    distance [n,1], did_return [n] bool, intensity_target [n,1], intensity [n,1], ray_drop_logits [n,1], depth [R,1],
+    prop_depth_0 [R,1], ...  -> metrics [2 + n_levels]: depth_loss, intensity_loss, ray_drop_loss, depth_loss_0, ..."""
+
+    @staticmethod
+    def forward(ctx, cfg, lidar_rows, inverse, distance, did_return, intensity_target, intensity, logits, *depths):
+        metrics, unit = ops.lidar_losses(depths, lidar_rows, distance, did_return, intensity, intensity_target, logits,
+                                         cfg[0], cfg[1], cfg[2])
+        ctx.save_for_backward(unit, inverse)
+        ctx.n_levels, ctx.n_rays = len(depths), depths[0].shape[0]
+        return metrics
+
+    @staticmethod
+    def backward(ctx, g):
+        unit, inverse = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gds, gi, gl = ops.lidar_losses_bwd(unit, inverse, g.contiguous(), ctx.n_levels, ctx.n_rays, need[8:], need[6], need[7])
+        return (None,) * 6 + (gi, gl, *gds)
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """sum_i mult_i * term_i over 0-dim loss terms: the trainer's `functools.reduce(torch.add, loss_dict.values())` over
+    `mult * metric` entries (engine/trainer.py:551) is two launches per term; this is one stack + one dot each way."""
+
+    @staticmethod
+    def forward(ctx, mults, *terms):
+        ctx.save_for_backward(mults)
+        return torch.dot(torch.stack([t.reshape(()) for t in terms]), mults)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mults,) = ctx.saved_tensors
+        gs = (mults * g).unbind(0)
+        return (None, *gs)
+

@@ -74,6 +74,9 @@ class RaySamples:
     spacing_to_euclidean_fn: Optional[Callable] = None
     metadata: Optional[Dict[str, Tensor]] = None
     times: Optional[Tensor] = None
+    sdist: Optional[Tensor] = None
+    """spacing-space bin edges [R, S+1] when the producer has them as ONE tensor (the fused training path): what
+    losses.ray_samples_to_sdist would otherwise cat together from spacing_starts / spacing_ends"""
 
     @property
     def shape(self):
@@ -94,7 +97,7 @@ class RaySamples:
         return replace(self, frustums=Frustums(sl(fr.origins), sl(fr.directions), sl(fr.starts), sl(fr.ends),
                                                sl(fr.pixel_area), sl(fr.offsets)),
                        camera_indices=sl(self.camera_indices), deltas=sl(self.deltas), spacing_starts=sl(self.spacing_starts),
-                       spacing_ends=sl(self.spacing_ends), times=sl(self.times),
+                       spacing_ends=sl(self.spacing_ends), times=sl(self.times), sdist=None,
                        metadata=None if self.metadata is None else {k: sl(v) for k, v in self.metadata.items()})
 
 

@@ -28,6 +28,8 @@
 //             quantum is below 2^-40 of the level's largest term -- finer than the fp32 rounding of the atomic path
 //             for anything that matters -- and integer addition is associative: the result is bit-reproducible.
 //             Inf/NaN values poison their entry (NaN out), as an atomic add of them would.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace nrhip {
@@ -36,20 +38,36 @@ namespace {
 constexpr int kSamplesPerBlock = 4096;      // count/emit: 1024 threads x 4 samples
 constexpr int kMaxSlices = 2048;            // per level (LDS histogram + base table = 16 KB)
 constexpr int kTileBytes = 128 * 1024;      // slice image in LDS
-constexpr int64_t kRoundSamples = 1 << 20;  // samples per count/scan/emit/reduce round: bounds the scratch
+constexpr int kSegChunks = 64;              // the chunk-prefix scan runs per segment of 64 chunks, then over the segments
+
+// Samples per count/scan/emit/reduce round: bounds the scratch (one record slot per corner term).  Round 2 used 2^20
+// (400 MB for the proposal grid); the c3 step then ran 11 rounds of seven launches each for its two proposal calls.  With
+// 288 GB of HBM a round of 2^23 samples (3.4 GB for that grid) covers every call of the step in one: the fixed cost per
+// round (memset, two scan launches, the tails of five kernels) is paid once, and with >= 1024 chunks a count / emit
+// workgroup walks all levels of its samples instead of one (positions and per-sample factors loaded once).
+// NRHIP_BIN_ROUND_LOG2 (15..24) overrides, for A/B runs.
+int64_t round_samples() {  // (read per call: a getenv is nothing next to seven launches, and tests flip it)
+  int lg = 23;
+  if (const char* e = getenv("NRHIP_BIN_ROUND_LOG2")) {
+    const int x = atoi(e);
+    if (x >= 15 && x <= 24) lg = x;
+  }
+  return (int64_t)1 << lg;
+}
 
 struct BinPlan {
   int log2TS, nb;        // entries per slice (log2), slices per level
   int chunks, lgroups;   // count/emit grid: sample chunks x level groups (levels dealt round-robin)
   int nmax;              // per-level partial maxima (one per emit wave)
-  size_t off_counts, off_totals, off_offsets, off_qmax, off_pos, off_idx, off_live, off_rec, total_bytes;
+  int nseg;              // segments of kSegChunks chunks (two-level prefix over the chunks)
+  size_t off_counts, off_seg, off_totals, off_offsets, off_qmax, off_pos, off_idx, off_live, off_rec, total_bytes;
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Returns false when the grid can not be binned (too many slices per level).
 bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
-  const int64_t n = n_total < kRoundSamples ? n_total : kRoundSamples;  // larger batches go through in rounds
+  const int64_t n = n_total < round_samples() ? n_total : round_samples();  // larger batches go through in rounds
   int log2F = 0;
   while ((1 << log2F) < g.F) ++log2F;
   int log2TS = 14 - log2F;  // 8-byte accumulators: 16384 / F entries fill the 128 KB image
@@ -67,9 +85,11 @@ bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
                                // third of the workgroups with twice the work of the others
   p->lgroups = lg;
   p->nmax = p->chunks * (kSamplesPerBlock / 4 / 64);
+  p->nseg = (p->chunks + kSegChunks - 1) / kSegChunks;
   const size_t cols = (size_t)g.L * nb;
   size_t o = 0;
   p->off_counts = o, o += align256((size_t)p->chunks * cols * sizeof(uint32_t));
+  p->off_seg = o, o += align256((size_t)p->nseg * cols * sizeof(uint32_t));
   p->off_totals = o, o += align256(cols * sizeof(uint32_t));
   p->off_offsets = o, o += align256((cols + 1) * sizeof(uint32_t));
   p->off_qmax = o, o += align256((size_t)g.L * p->nmax * sizeof(float));
@@ -121,8 +141,9 @@ struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray sample
                                         r.ends[ray * r.stride + s], scale);
     return make_float4(p.x, p.y, p.z, p.std);
   }
+  __device__ float pre(int64_t) const { return 0.f; }
   template <int F>
-  __device__ void grad(int64_t i, int l, float sc, float std, float (&gv)[F]) const {
+  __device__ void grad(int64_t i, int l, float sc, float std, float, float (&gv)[F]) const {
     const float rw = rescale_weight(sc, std);
 #pragma unroll
     for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k] * rw;
@@ -135,8 +156,9 @@ struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   const float* go;
   int L;
   __device__ float4 position(int64_t i) const { return make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f); }
+  __device__ float pre(int64_t) const { return 0.f; }
   template <int F>
-  __device__ void grad(int64_t i, int l, float, float, float (&gv)[F]) const {
+  __device__ void grad(int64_t i, int l, float, float, float, float (&gv)[F]) const {
 #pragma unroll
     for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k];
   }
@@ -157,10 +179,13 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
                                         r.ends[ray * r.stride + s], scale);
     return make_float4(p.x, p.y, p.z, p.std);
   }
-  template <int F>
-  __device__ void grad(int64_t i, int l, float sc, float std, float (&gv)[F]) const {
+  // the level-independent factor of a sample's gradient, once per sample (a workgroup may walk all levels)
+  __device__ float pre(int64_t i) const {
     const float xlog = logf(dens[i]);  // activations.py:37-41: g * exp(clamp(x, -15, 15))
-    const float gx = gd[i] * expf(fminf(fmaxf(xlog, -15.f), 15.f));
+    return gd[i] * expf(fminf(fmaxf(xlog, -15.f), 15.f));
+  }
+  template <int F>
+  __device__ void grad(int64_t, int l, float sc, float std, float gx, float (&gv)[F]) const {
     gv[0] = gx * dec[l] * rescale_weight(sc, std);
   }
   __device__ bool silent(int64_t w0, int64_t n_rows) const {  // (exp(.) > 0: the chain factor cannot revive it)
@@ -246,15 +271,19 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, 
 }
 
 // ---- scan ----------------------------------------------------------------------------------------------------
-// counts[chunk][col] -> exclusive prefix over the chunks (in place), totals[col] = column sum.  The loads of a
-// column do not depend on the running sum, so they are issued 8 at a time.
+// counts[chunk][col] -> exclusive prefix over the chunks OF ONE SEGMENT (in place), segtot[seg][col] = the segment's sum.
+// The loads of a column do not depend on the running sum, so they are issued 8 at a time.  (One thread per column over
+// ALL chunks was the round-2 form: with 2^23-sample rounds that is a serial walk over up to 2048 rows by a few hundred
+// threads; segments give the walk chunks / 64 times the parallelism.)
 __global__ __launch_bounds__(256) void bin_scan_chunks_kernel(uint32_t* __restrict__ counts, int chunks, int cols,
-                                                               uint32_t* __restrict__ totals) {
+                                                               uint32_t* __restrict__ segtot) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
+  const int k0 = blockIdx.y * kSegChunks;
+  const int k1 = k0 + kSegChunks < chunks ? k0 + kSegChunks : chunks;
   uint32_t run = 0;
-  int k = 0;
-  for (; k + 8 <= chunks; k += 8) {
+  int k = k0;
+  for (; k + 8 <= k1; k += 8) {
     uint32_t v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = counts[(size_t)(k + u) * cols + c];
@@ -264,9 +293,23 @@ __global__ __launch_bounds__(256) void bin_scan_chunks_kernel(uint32_t* __restri
       run += v[u];
     }
   }
-  for (; k < chunks; ++k) {
+  for (; k < k1; ++k) {
     const uint32_t v = counts[(size_t)k * cols + c];
     counts[(size_t)k * cols + c] = run;
+    run += v;
+  }
+  segtot[(size_t)blockIdx.y * cols + c] = run;
+}
+
+// segtot[seg][col] -> exclusive prefix over the segments (in place), totals[col] = column sum
+__global__ __launch_bounds__(256) void bin_scan_segments_kernel(uint32_t* __restrict__ segtot, int nseg, int cols,
+                                                                 uint32_t* __restrict__ totals) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  uint32_t run = 0;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const uint32_t v = segtot[(size_t)sg * cols + c];
+    segtot[(size_t)sg * cols + c] = run;
     run += v;
   }
   totals[c] = run;
@@ -301,6 +344,7 @@ __global__ __launch_bounds__(1024) void bin_scan_totals_kernel(const uint32_t* _
 template <int F, class Src>
 __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
                                                          const uint32_t* __restrict__ bases,
+                                                         const uint32_t* __restrict__ segbase,
                                                          const uint32_t* __restrict__ offsets,
                                                          const float4* __restrict__ gpos,
                                                          const uint16_t* __restrict__ gidx,
@@ -314,12 +358,15 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
   const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
   const int nl = (int)nlive[blockIdx.x], nit_live = (nl + nt - 1) / nt;  // block-uniform
   int64_t src_i[nit];  // the source sample behind each of this thread's live slots
+  float pre[nit];      // its level-independent gradient factor
 #pragma unroll
   for (int it = 0; it < nit; ++it) {
     const bool live = it * nt + tid < nl;
     if (live) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
     src_i[it] = i_off + i_blk + (live ? (int64_t)gidx[i_blk + it * nt + tid] : 0);
+    pre[it] = live ? src.pre(src_i[it]) : 0.f;
   }
+  const uint32_t* seg = segbase ? segbase + (size_t)(blockIdx.x / kSegChunks) * g.L * nb : nullptr;
   const uint32_t mask = (1u << g.log2T) - 1u;
   const uint32_t tsmask = (1u << log2TS) - 1u;
   for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
@@ -327,7 +374,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
     __syncthreads();  // pos[] loaded / previous level's ranks consumed
     for (int b = tid; b < nb; b += nt) {
       rank[b] = 0;
-      base[b] = offsets[l * nb + b] + bases[((size_t)blockIdx.x * g.L + l) * nb + b];
+      base[b] = offsets[l * nb + b] + bases[((size_t)blockIdx.x * g.L + l) * nb + b] + (seg ? seg[l * nb + b] : 0u);
     }
     __syncthreads();
     float vmax = 0.f;
@@ -341,7 +388,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
       float w[8];
       corner_weights(c, w);
       float gv[F];
-      src.template grad<F>(live ? src_i[it] : i_off, l, sc, p.w, gv);
+      src.template grad<F>(live ? src_i[it] : i_off, l, sc, p.w, pre[it], gv);
       if (!live) {
 #pragma unroll
         for (int k = 0; k < F; ++k) gv[k] = 0.f;
@@ -517,7 +564,7 @@ extern "C" int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_
 
 namespace {
 
-// All four passes for one source of samples, in rounds of kRoundSamples.  `what` names the entry point in errors.
+// All four passes for one source of samples, in rounds of round_samples().  `what` names the entry point in errors.
 template <class Src>
 int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, bool overwrite,
                void* workspace, int64_t workspace_bytes, hipStream_t st) {
@@ -531,6 +578,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
              NRHIP_ERR_INVALID_ARG, "%s: workspace and grad_table must be 16-byte aligned", what);
   char* ws = static_cast<char*>(workspace);
   uint32_t* counts = reinterpret_cast<uint32_t*>(ws + p.off_counts);
+  uint32_t* segtot = reinterpret_cast<uint32_t*>(ws + p.off_seg);
   uint32_t* totals = reinterpret_cast<uint32_t*>(ws + p.off_totals);
   uint32_t* offsets = reinterpret_cast<uint32_t*>(ws + p.off_offsets);
   float* qmax = reinterpret_cast<float*>(ws + p.off_qmax);
@@ -548,16 +596,20 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
     count_configured = true;
   }
-  for (int64_t i_off = 0; i_off < n; i_off += kRoundSamples) {
-    const int64_t cnt = n - i_off < kRoundSamples ? n - i_off : kRoundSamples;
+  const int64_t round = round_samples();
+  for (int64_t i_off = 0; i_off < n; i_off += round) {
+    const int64_t cnt = n - i_off < round ? n - i_off : round;
     const int chunks = (int)((cnt + kSamplesPerBlock - 1) / kSamplesPerBlock);
+    const int nseg = (chunks + kSegChunks - 1) / kSegChunks;
     const dim3 grid_a((unsigned)chunks, (unsigned)p.lgroups);
     // qmax slots of chunks this round does not have stay from an earlier round otherwise
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
     bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive);
     bin_count_kernel<<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     if (int e = check_launch(what)) return e;
-    bin_scan_chunks_kernel<<<(cols + 255) / 256, 256, 0, st>>>(counts, chunks, cols, totals);
+    // one segment: its sums ARE the column totals and there is no second level
+    bin_scan_chunks_kernel<<<dim3((cols + 255) / 256, nseg), 256, 0, st>>>(counts, chunks, cols, nseg > 1 ? segtot : totals);
+    if (nseg > 1) bin_scan_segments_kernel<<<(cols + 255) / 256, 256, 0, st>>>(segtot, nseg, cols, totals);
     bin_scan_totals_kernel<<<1, 1024, 0, st>>>(totals, cols, offsets);
     if (int e = check_launch(what)) return e;
 #define CALL(F)                                                                                                     \
@@ -570,7 +622,8 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
                                 kTileBytes + 4096);                                                                 \
       configured = true;                                                                                            \
     }                                                                                                               \
-    bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts, offsets, gpos, \
+    bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,                \
+                                                         nseg > 1 ? segtot : nullptr, offsets, gpos,                \
                                                          gidx, nlive, qrec, qmax, p.nmax);                          \
     bin_reduce_kernel<F><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,      \
                                                     p.nmax, (overwrite && i_off == 0) ? 1 : 0);                     \

@@ -19,6 +19,9 @@ PULSE_WIDTHS = (0.03, 0.003)  # losses.py:677
 
 def ray_samples_to_sdist(ray_samples: RaySamples) -> Tensor:
     """spacing-space bin edges [R, S+1] (losses.py:107-112)"""
+    sdist = getattr(ray_samples, "sdist", None)
+    if sdist is not None:  # the fused training path carries the edges as one tensor
+        return sdist
     return torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
 
 

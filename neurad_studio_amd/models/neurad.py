@@ -14,6 +14,7 @@ eval / no-grad -> 2 kernels per ray batch (+ the optional ray-ordering pass);
 training       -> operator-level HIP ops with hand-written backward (fields: one autograd node each)."""
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -23,10 +24,10 @@ from torch import Tensor, nn
 
 from .. import autograd as ag
 from .. import ops
-from ..cameras.rays import RayBundle, sample_times
+from ..cameras.rays import Frustums, RayBundle, RaySamples, sample_times
 from ..field_components.field_heads import FieldHeadNames
 from ..fields.neurad_field import NeuRADField, NeuRADFieldConfig, NeuRADProposalField, NeuRADProposalFieldConfig
-from ..model_components.ray_samplers import PowerSampler, ProposalNetworkSampler
+from ..model_components.ray_samplers import PowerSampler, PowerSpacing, ProposalNetworkSampler
 from ..model_components.renderers import AccumulationRenderer, DepthRenderer, FeatureRenderer, render_depth_simple
 from ..shims import nerfacc
 
@@ -111,6 +112,19 @@ class FusedEvalMixin:
         for i, (pw, prs) in enumerate(zip(prop_weights, prop_ray_samples)):
             nff[f"prop_depth_{i}"] = self.renderer_depth(pw, prs)
         return nff
+
+
+def _light_samples(rb: RayBundle, sp: Tensor, eu: Tensor, fn) -> RaySamples:
+    """RaySamples of the fused training path: S samples from S+1 edges, every field a VIEW (per-ray fields stride-0 like
+    rays.py:336-355, starts / ends two views of the edge tensor); no deltas, no metadata -- nothing is launched"""
+    S = eu.shape[1] - 1
+
+    def ex(t):
+        return None if t is None else t[..., None, :].expand(*t.shape[:-1], S, t.shape[-1])
+
+    fr = Frustums(ex(rb.origins), ex(rb.directions), eu[:, :-1, None], eu[:, 1:, None], ex(rb.pixel_area))
+    return RaySamples(frustums=fr, spacing_starts=sp[:, :-1, None], spacing_ends=sp[:, 1:, None],
+                      spacing_to_euclidean_fn=fn, times=ex(rb.times), sdist=sp)
 
 
 def _slice_bundle(rb, a: int, b: int):
@@ -205,10 +219,14 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
             groups["fields"] += list(self.appearance_embedding.parameters())
         return groups
 
-    def decode_lidar(self, features: Tensor, is_lidar: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    def decode_lidar(self, features: Tensor, is_lidar: Optional[Tensor] = None, rows: Optional[Tensor] = None
+                     ) -> Tuple[Tensor, Tensor]:
         """lidar head of decode_features (models/neurad.py:341-348): rendered features of the lidar rays ->
-        (intensity in [0,1], ray-drop logit), each [n_lidar, 1]"""
-        if is_lidar is not None:
+        (intensity in [0,1], ray-drop logit), each [n_lidar, 1].  rows (int64 [n_lidar], lidar_losses.lidar_rows): the
+        lidar rays' positions in the batch -- `features[is_lidar]` costs a nonzero and a host sync for the same thing"""
+        if rows is not None:
+            features = features.index_select(0, rows)
+        elif is_lidar is not None:
             features = features[is_lidar.reshape(-1)]
         intensity, ray_drop_logit = self.lidar_decoder(features).split(1, dim=-1)
         return intensity.sigmoid(), ray_drop_logit
@@ -315,10 +333,110 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
         return (starts, ends, ray(md["is_lidar"]), ray(md["did_return"]) if "did_return" in md else None,
                 ray(md["directions_norm"]), self.config.carving_epsilon, self.config.non_return_lidar_distance)
 
+    # ---- training step on the fused nodes ---------------------------------------------------------
+    fused_training: bool = True
+    """Static scenes, grad enabled: get_nff_outputs as a handful of autograd nodes (autograd.ProposalRoundFn per sampler
+    round, autograd.NffRenderTrainFn for field + head + compositing + appearance) instead of the reference's orchestration
+    over RaySamples views -- same outputs, ~1/4 of the launches.  False keeps the operator-level path (A/B, debugging)."""
+
+    def fused_training_possible(self) -> bool:
+        f = self.field
+        return (self.fused_training and self.training and torch.is_grad_enabled() and f.fused_training and f.config.use_sdf
+                and not f.hashgrid.has_actors() and f.fused_supported() and f._fused_train_ok()
+                and not any(p.hashgrid.has_actors() for p in self.proposal_fields)
+                and isinstance(self.sampler.initial_sampler, PowerSampler) and not self.config.normalize_depth)
+
+    def _fused_train_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool) -> Dict[str, Tensor]:
+        """get_nff_outputs (models/neurad.py:368-421) without the RaySamples plumbing: bin edges [R,S+1] go from kernel to
+        kernel.  ``ray_samples_list`` holds light RaySamples (edges as views, no deltas / metadata: the carving terms
+        recompute their masks from the edges)."""
+        cfg, smp = self.config, self.sampler
+        sky = cfg.sampling.sky_distance
+        self._scale_pixel_area(ray_bundle)
+        if ray_bundle.fars is None:
+            ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
+        else:
+            ray_bundle.fars.clamp_max_(sky)
+        if ray_bundle.nears is None:
+            ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
+        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        a = ray_bundle.pixel_area.reshape(-1)
+        R, dev = o.shape[0], o.device
+        init, pdf = smp.initial_sampler, smp.pdf_sampler
+        rounds = smp.num_proposal_network_iterations
+        counts = tuple(smp.num_proposal_samples_per_ray[:rounds]) + (smp.num_nerf_samples_per_ray,)
+        fn = PowerSpacing(ray_bundle.nears, ray_bundle.fars, init.lambda_, init.scaling)
+        t_rand = None
+        if init.train_stratified and init.training:
+            t_rand = (torch.rand((R, 1), device=dev).expand(R, counts[0] + 1).contiguous() if init.single_jitter
+                      else torch.rand((R, counts[0] + 1), device=dev))
+        sp, eu = ops.power_sampler(ray_bundle.nears, ray_bundle.fars, counts[0], init.lambda_, init.scaling, t_rand)
+        pfs = list(self.proposal_fields)
+        if self.reproduce_late_binding_quirk:
+            pfs = [pfs[-1]] * len(pfs)
+        train_props = smp._proposals_train_this_step()
+        nff: Dict[str, Tensor] = {}
+        weights_list, samples_list = [], []
+        lidar_terms = self.training and calc_lidar_losses
+        if lidar_terms:
+            md = ray_bundle.metadata
+            carve = (md["is_lidar"], md.get("did_return"), md["directions_norm"], cfg.carving_epsilon,
+                     cfg.non_return_lidar_distance)
+        for k in range(rounds):
+            pf = pfs[k]
+            g = pf.hashgrid.static_grid
+            with contextlib.nullcontext() if train_props else torch.no_grad():  # frozen between scheduled updates
+                w, pdepth = ag.ProposalRoundFn.apply(g.hash_table, pf.density_decoder.weight, g.spec, pf.hashgrid.static_scale,
+                                                     o, d, a, eu)
+            weights_list.append(w[..., None])
+            samples_list.append(_light_samples(ray_bundle, sp, eu, fn))
+            nff[f"prop_depth_{k}"] = pdepth
+            if lidar_terms:
+                nff[f"prop_weights_loss_{k}"] = ag.CarvingLossFn.apply(w, eu[:, :-1], eu[:, 1:], *carve)
+            rand = None
+            if pdf.train_stratified and pdf.training:
+                rand = torch.rand((R,) if pdf.single_jitter else (R, counts[k + 1] + 1), device=dev)
+            wd = w.detach()
+            sp, eu = ops.pdf_sample(wd if smp._anneal == 1.0 else wd.pow(smp._anneal), sp, fn.nears, fn.fars, counts[k + 1],
+                                    fn.lam, fn.scaling, pdf.histogram_padding, rand)
+        if train_props:
+            smp._steps_since_update = 0
+        eu[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
+        sp[:, -1] = 1 - EPS
+        f = self.field
+        g = f.hashgrid.static_grid
+        emb = sensor = times = None
+        emb_cfg = (1.0, 1, False)
+        if cfg.appearance_dim > 0:
+            emb = self.appearance_embedding.weight
+            sensor = ray_bundle.metadata.get("sensor_idxs")
+            assert sensor is not None, "sensor_idxs must be present in metadata during training"
+            times = ray_bundle.times if cfg.use_temporal_appearance else None
+            emb_cfg = (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance))
+        order = ops.ray_order(o, d, f.hashgrid.static_scale) if f.order_rays else None
+        sd = f.sdf_to_density
+        features, depth, accumulation, w_ns = ag.NffRenderTrainFn.apply(
+            g.hash_table, g.spec, f.hashgrid.static_scale, sd.beta, float(sd.beta_min), o, d, a, eu, emb, sensor, times,
+            emb_cfg, order, *[t for l in f.mlp_geo.layers for t in (l.weight, l.bias)],
+            *[t for l in f.mlp_feature.layers for t in (l.weight, l.bias)])
+        nff.update(features=features, depth=depth, accumulation=accumulation)
+        S = counts[-1]
+        if self.training:
+            nff["weights_list"] = weights_list + [w_ns[..., None]]
+            # the sky sample plays no further role: the first S-1 samples = the first S edges
+            nff["ray_samples_list"] = samples_list + [_light_samples(ray_bundle, sp[:, :S], eu[:, :S], fn)]
+        if lidar_terms:
+            # sum((w * (is_lidar & ~is_close))^2) of the final samples: what the reference forms from `non_nearby_weights`
+            # (models/neurad.py:410-419,508-509) -- selecting them needs a nonzero + a host sync
+            nff["non_nearby_weights_loss"] = ag.CarvingLossFn.apply(w_ns, eu[:, :S - 1], eu[:, 1:S], *carve)
+        return nff
+
     # ---- get_nff_outputs (models/neurad.py:368-421) ------------------------------------------------
     def get_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool = False) -> Dict[str, Tensor]:
         if self.fused_eval_possible():
             return self.fused_nff_outputs(ray_bundle)
+        if self.fused_training_possible():
+            return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         self._scale_pixel_area(ray_bundle)
         ray_samples, proposal_ray_samples, proposal_weights = self._get_ray_samples(ray_bundle)
         outputs = self.field(ray_samples)

@@ -951,3 +951,178 @@ def distortion_loss_rays(c: Tensor, w: Tensor, need_grad: bool = True):
     g = torch.empty_like(w) if need_grad else None
     call("nrhip_distortion_loss", _ptr(c), _ptr(w), s, R, _ptr(loss), _ptr(g), _stream())
     return loss, g
+
+
+# ------------------------------------------------------------------------------------------------
+# The training step's glue as kernels (csrc/train_fused.hip): bin EDGES [R,S+1] in, no [R,S,1] views
+def _edges(e: Tensor, S: int, name: str = "edges"):
+    if not (isinstance(e, Tensor) and e.is_cuda and e.dtype == torch.float32 and e.dim() == 2):
+        raise _lib.NeuradHipError(f"{name}: expected a 2-D float32 GPU tensor")
+    if e.shape[1] < S + 1:
+        raise ValueError(f"{name}: {tuple(e.shape)} holds fewer than S+1 = {S + 1} edges per ray")
+    if e.stride(1) != 1:
+        e = e.contiguous()
+    return e, (e.stride(0) if e.shape[0] > 1 else e.shape[1])
+
+
+def prop_weights_fwd(edges: Tensor, densities: Tensor, want_depth: bool = True):
+    """RaySamples.get_weights + render_depth_simple of one proposal round -> (weights [R,S], depth [R,1] or None)"""
+    dens = _chk(densities, "densities")
+    R, S = dens.shape
+    e, es = _edges(edges, S)
+    w = torch.empty_like(dens)
+    depth = torch.empty((R, 1), device=dens.device, dtype=torch.float32) if want_depth else None
+    call("nrhip_prop_weights_fwd", _ptr(e), es, _ptr(dens), R, S, _ptr(w), _ptr(depth), _stream())
+    return w, depth
+
+
+def prop_weights_bwd(edges: Tensor, densities: Tensor, grad_w: Optional[Tensor], grad_depth: Optional[Tensor]) -> Tensor:
+    dens = _chk(densities, "densities")
+    R, S = dens.shape
+    e, es = _edges(edges, S)
+    gw = None if grad_w is None else _chk(grad_w, "grad_w")
+    gd = None if grad_depth is None else _chk(grad_depth.reshape(-1), "grad_depth")
+    gdens = torch.empty_like(dens)
+    call("nrhip_prop_weights_bwd", _ptr(e), es, _ptr(dens), _ptr(gw), _ptr(gd), R, S, _ptr(gdens), _stream())
+    return gdens
+
+
+def sdf_render_fwd(sdf: Tensor, beta: Tensor, beta_min: float, features: Tensor, edges: Tensor, extra_cols: int = 0):
+    """SDF head + weights + compositing.  sdf [R,S], beta = the raw learnable parameter (device, 1 element), features
+    [R,S,C], edges [R,S+1] (last edge = sky distance).  -> alpha [R,S], weights_ns [R,S-1], out [R,C+extra_cols] (the
+    first C columns written), depth [R,1], acc [R,1]"""
+    sdf, feat, b = _chk(sdf, "sdf"), _chk(features, "features"), _chk(beta.reshape(-1), "beta")
+    R, S = sdf.shape
+    C_ = feat.shape[-1]
+    if feat.numel() != R * S * C_ or b.numel() != 1:
+        raise ValueError("sdf_render_fwd: features must be [R,S,C], beta one element")
+    e, es = _edges(edges, S)
+    dev = sdf.device
+    alpha = torch.empty_like(sdf)
+    w_ns = torch.empty((R, S - 1), device=dev, dtype=torch.float32)
+    out = torch.empty((R, C_ + extra_cols), device=dev, dtype=torch.float32)
+    depth = torch.empty((R, 1), device=dev, dtype=torch.float32)
+    acc = torch.empty((R, 1), device=dev, dtype=torch.float32)
+    call("nrhip_sdf_render_fwd", _ptr(sdf), _ptr(b), float(beta_min), _ptr(feat), _ptr(e), es, R, S, C_, _ptr(alpha),
+         _ptr(w_ns), _ptr(out), C_ + extra_cols, _ptr(depth), _ptr(acc), _stream())
+    return alpha, w_ns, out, depth, acc
+
+
+def _strided_rows(t: Tensor, name: str):
+    """[R, C] float32 GPU view with unit inner stride -> (tensor, row stride); copies only when it has to"""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise _lib.NeuradHipError(f"{name}: expected a 2-D float32 GPU tensor")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def sdf_render_bwd(sdf, beta, beta_min, alpha, features, edges, g_out: Tensor, g_depth: Optional[Tensor],
+                   g_acc: Optional[Tensor], g_weights_ns: Optional[Tensor]):
+    """-> grad_features [R,S,C], grad_sdf [R,S], grad_beta [1].  g_out: [R,C] view (row stride free) of the gradient of
+    the composited features."""
+    sdf, feat, b, alpha = _chk(sdf, "sdf"), _chk(features, "features"), _chk(beta.reshape(-1), "beta"), _chk(alpha, "alpha")
+    R, S = sdf.shape
+    C_ = feat.shape[-1]
+    e, es = _edges(edges, S)
+    g, gs = _strided_rows(g_out, "g_out")
+    if g.shape != (R, C_):
+        raise ValueError(f"sdf_render_bwd: g_out {tuple(g.shape)} != {(R, C_)}")
+    if g.data_ptr() % 16 or (gs * 4) % 16:
+        g, gs = g.contiguous(), C_
+    gd = None if g_depth is None else _chk(g_depth.reshape(-1), "g_depth")
+    ga = None if g_acc is None else _chk(g_acc.reshape(-1), "g_acc")
+    gw = None if g_weights_ns is None else _chk(g_weights_ns.reshape(R, S - 1), "g_weights_ns")
+    dev = sdf.device
+    gfeat = torch.empty_like(feat)
+    gsdf = torch.empty_like(sdf)
+    gbeta = torch.empty((1,), device=dev, dtype=torch.float32)
+    need = C.c_int64(0)
+    call("nrhip_sdf_render_bwd_workspace", R, C.byref(need))
+    ws = torch.empty((max(need.value, 1),), device=dev, dtype=torch.float32)
+    call("nrhip_sdf_render_bwd", _ptr(sdf), _ptr(b), float(beta_min), _ptr(alpha), _ptr(feat), _ptr(e), es, _ptr(g), gs,
+         _ptr(gd), _ptr(ga), _ptr(gw), R, S, C_, _ptr(gfeat), _ptr(gsdf), _ptr(gbeta), _ptr(ws), _stream())
+    return gfeat, gsdf, gbeta
+
+
+def appearance_fwd(weight: Tensor, sensor_idx: Optional[Tensor], times: Optional[Tensor], duration: float,
+                   n_per_sensor: int, temporal: bool, n_rays: int, out: Optional[Tensor] = None) -> Tensor:
+    """appearance embedding rows (models/neurad.py:423-441) written into ``out`` ([R,D] view, row stride free)"""
+    w = _chk(weight, "weight")
+    E, D = w.shape
+    s = None if sensor_idx is None else _chk(sensor_idx.reshape(-1), "sensor_idx", torch.int64)
+    t = None if times is None else _chk(times.reshape(-1), "times")
+    if out is None:
+        out = torch.empty((n_rays, D), device=w.device, dtype=torch.float32)
+    if not (out.is_cuda and out.dtype == torch.float32 and out.shape == (n_rays, D) and out.stride(1) == 1):
+        raise ValueError("appearance_fwd: out must be a float32 [R,D] GPU view with unit inner stride")
+    call("nrhip_appearance_fwd", _ptr(w), _ptr(s), _ptr(t), float(duration), int(n_per_sensor), 1 if temporal else 0,
+         n_rays, E, D, _ptr(out), out.stride(0) if n_rays > 1 else D, _stream())
+    return out
+
+
+def appearance_bwd(g_out: Tensor, sensor_idx, times, duration: float, n_per_sensor: int, temporal: bool,
+                   n_embed: int) -> Tensor:
+    g, gs = _strided_rows(g_out, "g_out")
+    R, D = g.shape
+    s = None if sensor_idx is None else _chk(sensor_idx.reshape(-1), "sensor_idx", torch.int64)
+    t = None if times is None else _chk(times.reshape(-1), "times")
+    gw = torch.empty((n_embed, D), device=g.device, dtype=torch.float32)  # the entry point zero-fills it
+    call("nrhip_appearance_bwd", _ptr(g), gs, _ptr(s), _ptr(t), float(duration), int(n_per_sensor), 1 if temporal else 0,
+         R, n_embed, D, _ptr(gw), _stream())
+    return gw
+
+
+def mask_compact(mask: Tensor, n_out: int):
+    """rows (int64 [n_out], ascending) where ``mask`` [R] is set + inverse (int32 [R]: slot or -1), without the host sync of
+    ``mask.nonzero()`` -- the caller knows n_out (the lidar part of a batch comes with the batch)"""
+    m = mask.reshape(-1)
+    if not m.is_cuda:
+        raise _lib.NeuradHipError("mask_compact: mask is on the CPU (no CPU fallback)")
+    m = (m if m.dtype == torch.uint8 else (m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.ne(0).view(torch.uint8)))
+    m = m.contiguous()
+    rows = torch.empty((n_out,), device=m.device, dtype=torch.int64)
+    inverse = torch.empty((m.shape[0],), device=m.device, dtype=torch.int32)
+    call("nrhip_mask_compact", _ptr(m), m.shape[0], _ptr(rows), n_out, _ptr(inverse), _ptr(None), _stream())
+    return rows, inverse
+
+
+def lidar_losses(depths: Sequence[Tensor], lidar_rows: Tensor, distance: Tensor, did_return: Tensor, intensity: Tensor,
+                 intensity_target: Tensor, ray_drop_logits: Tensor, non_return_distance: float, non_return_mult: float,
+                 quantile: float):
+    """-> metrics [2 + n_levels] (depth_loss, intensity_loss, ray_drop_loss, depth_loss_0, ...), unit gradients
+    [(n_levels + 2), n]"""
+    nl = len(depths)
+    ds = [_chk(d.reshape(-1), f"depth[{i}]") for i, d in enumerate(depths)]
+    rows = _chk(lidar_rows, "lidar_rows", torch.int64)
+    n = rows.shape[0]
+    dist, inten = _chk(distance.reshape(-1), "distance"), _chk(intensity.reshape(-1), "intensity")
+    tgt, lg = _chk(intensity_target.reshape(-1), "intensity_target"), _chk(ray_drop_logits.reshape(-1), "ray_drop_logits")
+    ret = did_return.reshape(-1).contiguous()
+    ret = ret.view(torch.uint8) if ret.dtype == torch.bool else ret.to(torch.uint8)
+    for v, nm in ((dist, "distance"), (inten, "intensity"), (tgt, "intensity_target"), (lg, "ray_drop_logits"), (ret, "did_return")):
+        if v.shape[0] != n:
+            raise ValueError(f"lidar_losses: {nm} has {v.shape[0]} rows, expected {n}")
+    dev = rows.device
+    metrics = torch.empty((2 + nl,), device=dev, dtype=torch.float32)
+    unit = torch.empty((nl + 2, n), device=dev, dtype=torch.float32)
+    scratch = torch.empty((n,), device=dev, dtype=torch.float32)
+    pd = (C.c_void_p * nl)(*[d.data_ptr() for d in ds])
+    call("nrhip_lidar_losses", C.cast(pd, C.POINTER(C.c_void_p)), nl, _ptr(rows), _ptr(dist), _ptr(ret), _ptr(inten),
+         _ptr(tgt), _ptr(lg), n, float(non_return_distance), float(non_return_mult), float(quantile), _ptr(metrics),
+         _ptr(unit), _ptr(scratch), _stream())
+    return metrics, unit
+
+
+def lidar_losses_bwd(unit: Tensor, inverse: Tensor, upstream: Tensor, n_levels: int, n_rays: int, need_depth: Sequence[bool],
+                     need_intensity: bool = True, need_logits: bool = True):
+    """-> ([grad depth [R,1] or None per level], grad intensity [n,1] or None, grad logits [n,1] or None)"""
+    unit, inv, up = _chk(unit, "unit"), _chk(inverse, "inverse", torch.int32), _chk(upstream.reshape(-1), "upstream")
+    n, dev = unit.shape[1], unit.device
+    gds = [torch.empty((n_rays, 1), device=dev, dtype=torch.float32) if nd else None for nd in need_depth]
+    gi = torch.empty((n, 1), device=dev, dtype=torch.float32) if need_intensity else None
+    gl = torch.empty((n, 1), device=dev, dtype=torch.float32) if need_logits else None
+    pg = (C.c_void_p * n_levels)(*[(0 if g is None else g.data_ptr()) for g in gds])
+    call("nrhip_lidar_losses_bwd", _ptr(unit), _ptr(inv), _ptr(up), n_levels, n_rays, n, C.cast(pg, C.POINTER(C.c_void_p)),
+         _ptr(gi), _ptr(gl), _stream())
+    return gds, gi, gl

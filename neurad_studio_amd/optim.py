@@ -49,13 +49,33 @@ class HashGridAdam(torch.optim.Optimizer):
                 target, grad = p, p.grad
                 if p.dtype != torch.float32:
                     # fp16-storage table (BASELINE config 5): the update runs on an fp32 master copy kept in the
-                    # optimizer state (what tiny-cuda-nn does for its fp16 parameters); the table is its rounded image
-                    if "master" not in st:
+                    # optimizer state (what tiny-cuda-nn does for its fp16 parameters); the table is its rounded image.
+                    # Checked by DTYPE, not by key presence: a state that went through a generic load_state_dict may
+                    # hold these tensors cast to the parameter's dtype (torch does that to floating-point state).
+                    if "master" not in st or st["master"].dtype != torch.float32:
                         st["master"] = p.detach().float()
-                        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].float(), st["exp_avg_sq"].float()
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if st[k].dtype != torch.float32:
+                            st[k] = st[k].float()
                     target, grad = st["master"], p.grad.float()
                 ops.adam_step(target, grad, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), group["lr"], b1, b2,
                               group["eps"], group["weight_decay"], 1.0 if grad_scale is None else grad_scale)
                 if target is not p:
                     p.copy_(target)
         return loss
+
+    def load_state_dict(self, state_dict) -> None:
+        """torch.optim.Optimizer.load_state_dict casts every floating-point state tensor to its parameter's dtype; for an
+        fp16-storage table that would round the fp32 master copy and both moments to fp16.  They are restored from the
+        tensors of ``state_dict`` itself, in fp32."""
+        super().load_state_dict(state_dict)
+        saved = state_dict["state"]
+        ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        params = [p for g in self.param_groups for p in g["params"]]
+        for i, p in zip(ids, params):
+            if p.dtype == torch.float32 or i not in saved:
+                continue
+            for k in ("master", "exp_avg", "exp_avg_sq"):
+                if k in saved[i]:
+                    self.state[p][k] = saved[i][k].detach().to(device=p.device, dtype=torch.float32).clone()
+

@@ -38,18 +38,21 @@ class GradientSynchronizer:
     """Averages (or sums) ``param.grad`` across ranks with large flat collectives."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, average: bool = True,
-                 large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False) -> None:
+                 large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False,
+                 skip: Iterable[torch.nn.Parameter] = ()) -> None:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         if overlap and usage != "static":
             raise ValueError("overlap=True needs usage='static': a hook cannot wait for the other ranks' usage bitmap")
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        skipped = {id(p) for p in skip}  # exchanged by someone else (parallel/sharded_adam.py reduces its own tables)
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and id(p) not in skipped]
         self.group = process_group
         self.average = average
         self.large_threshold = large_threshold_bytes
         self.usage = usage
         self.overlap = overlap
         self._agreed: Optional[List[bool]] = None      # usage == "static": the set agreed at the first sync
+        self._agreed_all: Optional[List[bool]] = None  # ... and the parameters EVERY rank holds a local gradient for
         self._local_at_agreement: Optional[List[bool]] = None
         self._inflight: Dict[int, Tuple[object, Tensor, Tensor]] = {}  # param index -> (work, flat grad, shard)
         self._hooks = []
@@ -70,19 +73,21 @@ class GradientSynchronizer:
     def _local_pattern(self) -> List[bool]:
         return [p.grad is not None for p in self.params]
 
-    def _agree(self, local: List[bool]) -> List[bool]:
+    def _agree(self, local: List[bool]) -> Tuple[List[bool], List[bool]]:
+        """-> (has a gradient on ANY rank, has a gradient on EVERY rank): one tiny MAX all-reduce over (flag, 1 - flag)"""
         dev = self.params[0].device
-        m = torch.tensor([int(u) for u in local], device=dev, dtype=torch.int32)
+        m = torch.tensor([int(u) for u in local] + [int(not u) for u in local], device=dev, dtype=torch.int32)
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
-        return [bool(v) for v in m.tolist()]
+        v, n = m.tolist(), len(local)
+        return [bool(x) for x in v[:n]], [not bool(x) for x in v[n:]]
 
     def _used_mask(self) -> List[bool]:
         """Which parameters have a gradient on ANY rank (missing ones are treated as zeros)."""
         local = self._local_pattern()
         if self.usage == "dynamic":
-            return self._agree(local)
+            return self._agree(local)[0]
         if self._agreed is None:
-            self._agreed, self._local_at_agreement = self._agree(local), local
+            (self._agreed, self._agreed_all), self._local_at_agreement = self._agree(local), local
         elif local != self._local_at_agreement:
             raise RuntimeError("GradientSynchronizer(usage='static'): the set of parameters with a gradient changed on "
                                "this rank; use usage='dynamic' for models whose used parameters vary (actor grids)")
@@ -108,9 +113,14 @@ class GradientSynchronizer:
     def _on_grad_ready(self, i: int) -> None:
         """post-accumulate-grad hook (overlap): autograd is done with this gradient -> its reduce-scatter starts now, on
         the backend's own stream, while the rest of the backward keeps the compute stream busy.  Only after the usage
-        set has been agreed (first step runs without overlap) and only for parameters in it."""
-        if self._agreed is None or not self._agreed[i] or self.world_size() == 1:
+        set has been agreed (first step runs without overlap) and only for parameters EVERY rank holds a local gradient
+        for: a rank without one never fires this hook and would issue the collective later, from sync(), in index order --
+        the ranks' collective sequences would differ (a hang, or a silent mix-up of equal-sized tables)."""
+        if self._agreed is None or not self._agreed_all[i] or self.world_size() == 1:
             return
+        if i in self._inflight:
+            raise RuntimeError("GradientSynchronizer(overlap=True): a second backward reached parameter "
+                               f"{i} before sync(); call sync() after every backward (gradient accumulation: overlap=False)")
         self._start_large(i, async_op=True)
 
     @torch.no_grad()

@@ -11,7 +11,7 @@ have computed from the mean gradient.
 ``state_dict()`` gathers the moment shards back into full tensors in torch.optim.Adam's layout (the reference's
 checkpoints, engine/trainer.py:499-533, engine/optimizers.py:168-181, stay loadable); ``load_state_dict`` scatters them.
 Backend-agnostic like data_parallel.py ("nccl" == RCCL; "gloo" in the CPU tests, which inject a torch ``update_fn`` because
-the product kernel has no CPU path).  Not wired into bench.py: it has not run on a multi-GPU box yet."""
+the product kernel has no CPU path).  bench.py --sharded-adam uses it for the tables at N > 1."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Iterable, List, Optional, Tuple
@@ -30,39 +30,63 @@ def _hip_update(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
 
 class ShardedTableAdam:
     """Adam / AdamW for large fp32 tables whose element count divides by the world size.  Every rank calls ``step()`` after
-    backward with its LOCAL ``table.grad``; tables without a gradient on this rank contribute zeros (all ranks must hold
-    the same list of tables)."""
+    backward with its LOCAL ``table.grad``; a table without a gradient on this rank contributes zeros, a table without a
+    gradient on ANY rank is skipped -- no moment decay, no step count, like torch.optim.Adam on ``grad is None`` (an actor
+    grid no ray hit; all ranks must hold the same list of tables).  usage="dynamic" agrees on that set every step (a tiny
+    MAX all-reduce + a host read), "static" once (afterwards only a host-side check that the local pattern is unchanged)."""
 
     def __init__(self, tables: Iterable[torch.nn.Parameter], lr: float = 1e-2, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-15, weight_decay: float = 0.0, process_group=None, average: bool = True,
-                 update_fn: Optional[Callable] = None) -> None:
+                 update_fn: Optional[Callable] = None, usage: str = "dynamic") -> None:
+        if usage not in ("dynamic", "static"):
+            raise ValueError("usage must be 'dynamic' or 'static'")
+        self.usage = usage
+        self._agreed: Optional[List[bool]] = None
+        self._local_at_agreement: Optional[List[bool]] = None
         self.tables: List[torch.nn.Parameter] = list(tables)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.group, self.average = process_group, average
         self.update_fn = update_fn if update_fn is not None else _hip_update
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
-        self.steps = 0
-        self.state: List[Dict[str, Tensor]] = []
+        self.state: List[Dict] = []  # per table: its own step count (tables may be skipped) + the moment shards
         for p in self.tables:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise ValueError("ShardedTableAdam: contiguous fp32 tables only (fp16-storage tables keep HashGridAdam)")
             if p.numel() % self.world or (p.numel() // self.world) % 4:
                 raise ValueError(f"ShardedTableAdam: {p.numel()} elements do not split into {self.world} 16-byte aligned shards")
             m = p.numel() // self.world
-            self.state.append({"exp_avg": torch.zeros((m,), device=p.device), "exp_avg_sq": torch.zeros((m,), device=p.device)})
+            self.state.append({"step": 0, "exp_avg": torch.zeros((m,), device=p.device),
+                               "exp_avg_sq": torch.zeros((m,), device=p.device)})
 
     def _shard(self, flat: Tensor) -> Tensor:
         m = flat.numel() // self.world
         return flat[self.rank * m:(self.rank + 1) * m]
 
+    def _used(self) -> List[bool]:
+        local = [p.grad is not None for p in self.tables]
+        if self.world == 1:
+            return local
+        if self.usage == "static" and self._agreed is not None:
+            if local != self._local_at_agreement:
+                raise RuntimeError("ShardedTableAdam(usage='static'): the set of tables with a gradient changed on this rank")
+            return self._agreed
+        m = torch.tensor([int(u) for u in local], device=self.tables[0].device, dtype=torch.int32)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        used = [bool(v) for v in m.tolist()]
+        if self.usage == "static":
+            self._agreed, self._local_at_agreement = used, local
+        return used
+
     @torch.no_grad()
     def step(self) -> int:
         """-> payload bytes this rank exchanged (reduce-scatter + all-gather)"""
-        self.steps += 1
         nbytes = 0
         b1, b2 = self.betas
-        for p, st in zip(self.tables, self.state):
+        for p, st, used in zip(self.tables, self.state, self._used()):
+            if not used:
+                continue  # no gradient anywhere: parameters, moments and the step count stay as they are
+            st["step"] += 1
             flat_p = p.data.view(-1)
             grad = p.grad if p.grad is not None else torch.zeros_like(p)
             flat_g = grad.contiguous().view(-1)
@@ -73,7 +97,7 @@ class ShardedTableAdam:
             else:
                 g_shard = flat_g
             p_shard = self._shard(flat_p)  # a view: the update lands in the table itself
-            self.update_fn(p_shard, g_shard, st["exp_avg"], st["exp_avg_sq"], self.steps, self.lr, b1, b2, self.eps,
+            self.update_fn(p_shard, g_shard, st["exp_avg"], st["exp_avg_sq"], st["step"], self.lr, b1, b2, self.eps,
                            self.weight_decay, 1.0 / self.world if (self.average and self.world > 1) else 1.0)
             if self.world > 1:
                 # in place (send buffer = this rank's slot of the receive buffer) where the backend supports it
@@ -99,7 +123,7 @@ class ShardedTableAdam:
     def state_dict(self) -> Dict:
         """collective: every rank must call it.  {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}
         with FULL-size moments, as torch.optim.Adam over the same tables would write it"""
-        state = {i: {"step": torch.tensor(float(self.steps)), "exp_avg": self._gather(st["exp_avg"], p),
+        state = {i: {"step": torch.tensor(float(st["step"])), "exp_avg": self._gather(st["exp_avg"], p),
                      "exp_avg_sq": self._gather(st["exp_avg_sq"], p)}
                  for i, (p, st) in enumerate(zip(self.tables, self.state))}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
@@ -113,6 +137,6 @@ class ShardedTableAdam:
             src = sd["state"].get(i)
             if src is None:
                 continue
-            self.steps = int(float(src["step"]))
+            st["step"] = int(float(src["step"]))
             for k in ("exp_avg", "exp_avg_sq"):
                 st[k].copy_(self._shard(src[k].to(p.device, torch.float32).reshape(-1)))

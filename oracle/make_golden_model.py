@@ -147,6 +147,13 @@ def model_glue():
     total.backward()
     gold["g_field_table_abs_sum"] = m.field.hashgrid.static_grid.hash_table.grad.abs().sum()
     gold["g_prop1_table_abs_sum"] = m.proposal_fields[1].hashgrid.static_grid.hash_table.grad.abs().sum()
+    # the two table gradients themselves, sparse (flat element index, value): a sign error in half the rows passes an
+    # abs-sum comparison, not an element-wise one
+    for key, t in (("g_field_table", m.field.hashgrid.static_grid.hash_table.grad),
+                   ("g_prop1_table", m.proposal_fields[1].hashgrid.static_grid.hash_table.grad)):
+        flat = t.reshape(-1)
+        nz = flat.nonzero()[:, 0]
+        gold[key + "_idx"], gold[key + "_val"] = nz, flat[nz]
     gold["g_lidar_decoder_w0"] = m.lidar_decoder.layers[0].weight.grad
     gold["g_embedding"] = m.appearance_embedding.weight.grad
     gold["g_beta"] = m.field.sdf_to_density.beta.grad

@@ -90,7 +90,7 @@ def _grid(L, F, lg):
 
 
 def test_table_gradient_workspace_query_is_host_logic(lib):
-    """nrhip_encode_bwd_binned_workspace needs no GPU: one record slot per corner term + bookkeeping, flat beyond 2^20
+    """nrhip_encode_bwd_binned_workspace needs no GPU: one record slot per corner term + bookkeeping, flat beyond 2^23
     samples (larger batches go through in rounds), 0 for grids with more than 2048 slices per level."""
     fn = lib.nrhip_encode_bwd_binned_workspace
     fn.restype = ctypes.c_int
@@ -105,7 +105,7 @@ def test_table_gradient_workspace_query_is_host_logic(lib):
     for L, F, lg in [(16, 2, 19), (8, 4, 22), (6, 1, 20), (4, 4, 17)]:
         a, b = need(L, F, lg, 4096 * 128), need(L, F, lg, 2 * 4096 * 128)
         assert records(L, F, 4096 * 128) <= a <= records(L, F, 4096 * 128) + (64 << 20)
-        assert a < b and need(L, F, lg, 1 << 20) == need(L, F, lg, 1 << 24)
+        assert a < b and need(L, F, lg, 1 << 23) == need(L, F, lg, 1 << 24) > need(L, F, lg, 1 << 22)
     assert need(8, 8, 24, 4096) == 0  # 2^24 entries x 8 features: 8192 slices per level -> atomic entry point
     bad = ctypes.c_int64(0)
     assert fn(ctypes.byref(_grid(0, 2, 19)), ctypes.c_int64(16), ctypes.byref(bad)) != 0  # invalid grid is an error

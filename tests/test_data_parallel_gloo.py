@@ -201,3 +201,85 @@ def test_sharded_table_adam_world2_matches_one_process_on_the_mean_gradient():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_sharded_adam_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _uneven_overlap_worker(rank, world, port, ret):
+    """overlap=True with a large table only ONE rank has a local gradient for (an actor grid no ray of the other rank
+    hit): its reduce-scatter must not start from that rank's hook -- the other rank would issue it later, from sync(),
+    and the two ranks' collective sequences would differ"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(2048, 4))
+    b = torch.nn.Parameter(torch.randn(2048, 4))  # same size as `a`: a mix-up would not even raise
+    sync = GradientSynchronizer([a, b], average=True, large_threshold_bytes=1 << 14, usage="static", overlap=True)
+    ok = True
+    for step in range(3):
+        ga = torch.full((2048, 4), float(rank + 1))
+        gb = torch.full((2048, 4), 10.0)
+        a.grad = b.grad = None
+        loss = (a * ga).sum() + ((b * gb).sum() if rank == 0 else 0.0)  # b: a local gradient on rank 0 only
+        loss.backward()
+        sync.sync()
+        ok = ok and torch.allclose(a.grad, torch.full((2048, 4), 1.5)) and torch.allclose(b.grad, torch.full((2048, 4), 5.0))
+        ok = ok and sync.overlapped_last_step == (0 if step == 0 else 1)  # only `a` is exchanged from its hook
+    # a second backward before sync() is an error, not a double reduction
+    (a * 1.0).sum().backward()
+    try:
+        (a * 1.0).sum().backward()
+        ok = False
+    except RuntimeError:
+        pass
+    ret[rank] = bool(ok)
+    sync._inflight.pop(0)[0].wait()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlap_hook_only_for_gradients_every_rank_holds_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_uneven_overlap_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _sharded_adam_skip_worker(rank, world, port, ret):
+    """a table without a gradient on ANY rank is skipped (parameters, moments and ITS step count untouched) -- what
+    torch.optim.Adam does on grad is None; tables keep their own step counts through state_dict / load_state_dict"""
+    from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    tables = [torch.nn.Parameter(torch.randn(256, 4) * 0.1), torch.nn.Parameter(torch.randn(128, 4) * 0.1)]
+    ref_tables = [torch.nn.Parameter(t.detach().clone()) for t in tables]
+    ref_opt = torch.optim.Adam(ref_tables, lr=1e-2, eps=1e-15)
+    opt = ShardedTableAdam(tables, lr=1e-2, eps=1e-15, update_fn=_torch_adam_update)
+    for it in range(4):
+        for i, (t, rt) in enumerate(zip(tables, ref_tables)):
+            if i == 1 and it in (1, 2):  # the second table: no gradient anywhere in steps 1 and 2
+                t.grad = rt.grad = None
+                continue
+            g = torch.randn(t.shape, generator=torch.Generator().manual_seed(10 * it + i))
+            t.grad, rt.grad = g.clone(), g.clone()
+        opt.step()
+        ref_opt.step()
+    ok = all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(tables, ref_tables))
+    sd, rsd = opt.state_dict(), ref_opt.state_dict()
+    ok = ok and float(sd["state"][0]["step"]) == float(rsd["state"][0]["step"]) == 4.0
+    ok = ok and float(sd["state"][1]["step"]) == float(rsd["state"][1]["step"]) == 2.0
+    ok = ok and torch.allclose(sd["state"][1]["exp_avg"], rsd["state"][1]["exp_avg"], atol=1e-7)
+    opt2 = ShardedTableAdam(tables, lr=1.0, update_fn=_torch_adam_update)
+    opt2.load_state_dict(sd)
+    ok = ok and [st["step"] for st in opt2.state] == [4, 2]
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_table_adam_skips_tables_without_any_gradient_world2_gloo():
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_sharded_adam_skip_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)

@@ -393,12 +393,16 @@ def test_full_size_properties_config2(ops):
 
 
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 4096, 128), (8, 4, 16, 257, 33), (4, 8, 12, 64, 7), (6, 1, 20, 300, 48),
-                                 (2, 4, 9, 5, 3), (6, 1, 14, 9001, 128)])  # last: > 2^20 samples -> two rounds
+                                 (2, 4, 9, 5, 3), (6, 1, 14, 9001, 128),  # > 64 chunks: the two-level chunk prefix
+                                 (6, 1, 14, 9001, 128, 18), (8, 4, 16, 2051, 33, 15)])  # rounds of 2^18 / 2^15 samples
 def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     """B1 table gradient: the owner-computes path (LDS slices, no memory-side atomics) against the atomic
     scatter-add, from BASELINE config 2 at full size down to ragged batches and tables smaller than one slice.
-    Same terms, different summation order -> agreement to fp32 rounding; linearity in grad_out is exact-ish too."""
-    L, F, lg, R, S = cfg
+    Same terms, different summation order -> agreement to fp32 rounding; linearity in grad_out is exact-ish too.
+    A sixth entry sets NRHIP_BIN_ROUND_LOG2: the batch then goes through in several rounds."""
+    if len(cfg) == 6:
+        monkeypatch.setenv("NRHIP_BIN_ROUND_LOG2", str(cfg[5]))
+    L, F, lg, R, S = cfg[:5]
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     o, d, area, s, e, eu = _sample_rays(R, S, seed=5)
     do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
