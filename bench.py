@@ -17,6 +17,8 @@
 --config c2: BASELINE config[2], 8192 camera rays through the fused proposal sampler (2 rounds) + fused field/compositing
   with NeuRAD's default grids; roofline on the proposal sampler kernel (192 B per proposal evaluation).
 --config c3: the `train_full` step as the timed step.
+--config c4: BASELINE config[4], 65536 rays with dynamic actors, appearance embedding and fp16 tables (eval + one training step).
+NRHIP_DIST_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (labelled, not a measurement).
 """
 from __future__ import annotations
 
@@ -41,6 +43,7 @@ GRID = dict(num_levels=16, features_per_level=2, log2_hashmap_size=19, min_res=1
 HIDDEN = 64
 STATIC_SCALE = 100.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured streaming ceiling)
+L1_ACCESS_PEAK_G = 256 * 2.4  # vector L1: one cache-line access per clock and CU, 256 CUs x 2.4 GHz = 614 G accesses/s
 C3_CAMERA_RAYS, C3_LIDAR_RAYS = 40960, 16384  # ad_datamanager.py:38-41 (40 patches of 32x32 + 16384 lidar points)
 
 
@@ -79,9 +82,23 @@ def make_workload(device, seed):
 
 def recorded_traffic(name):
     """HBM bytes per launch of a kernel from the committed PMC summary profiles/traffic_<name>.json (FETCH_SIZE / WRITE_SIZE
-    passes, corrected as MI355X_MICROARCH.md prescribes); None when the file is missing"""
+    passes, corrected as MI355X_MICROARCH.md prescribes).  The file carries the sha1 of the kernel sources it was measured
+    on (scripts/traffic_stamp.py): when they differ from the tree's, the number is stale and None is reported instead."""
+    import hashlib
+
     tf = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
-    return json.load(open(tf)).get("hbm_bytes_per_launch") if os.path.exists(tf) else None
+    if not os.path.exists(tf):
+        return None
+    rec = json.load(open(tf))
+    for rel, want in rec.get("source_sha1", {}).items():
+        src = os.path.join(ROOT, "neurad_studio_amd", "csrc", rel)
+        if not os.path.exists(src) or hashlib.sha1(open(src, "rb").read()).hexdigest() != want:
+            TRAFFIC_NOTES[name] = f"profiles/traffic_{name}.json was measured on another version of {rel}: stale, not reported"
+            return None
+    return rec.get("hbm_bytes_per_launch")
+
+
+TRAFFIC_NOTES = {}
 
 
 def timed(step, steps, warmup, world, device):
@@ -160,26 +177,29 @@ def make_optimizer(params, sharded=False):
     return _Optimizers(params), "Adam: hash tables on nrhip_adam_step (dense, torch.optim.Adam arithmetic), MLPs on torch fused Adam"
 
 
-def train_section(device, rank, world, steps, warmup):
-    """train iters/sec on the config-1 workload: PowerSampler bins -> NeuRADField in training mode (fused field kernel
-    that stores its activations, torch head) -> C1/C2 compositing -> loss -> backward (MFMA data + weight gradients,
-    radix-partition table gradient without memory-side atomics) -> gradient exchange (RCCL reduce-scatter / all-gather
-    on the flat table gradient) -> Adam step."""
-    from neurad_studio_amd import autograd as ag
-    from neurad_studio_amd.cameras.rays import RayBundle
-    from neurad_studio_amd.field_components.field_heads import FieldHeadNames
+def train_section(device, rank, world, steps, warmup, beta=None, table_scale=None):
+    """train iters/sec on the config-1 workload: PowerSampler bins -> NeuRADField.render_train (ONE autograd node: fused field
+    kernel that stores its activations -> learnable-beta SDF head -> weights -> C1/C2 compositing) -> loss -> backward
+    (compositing + head incl. d beta in one kernel, MFMA data + weight gradients, radix-partition table gradient without
+    memory-side atomics) -> gradient exchange (RCCL reduce-scatter / all-gather on the flat table gradient) -> Adam step.
+    beta / table_scale: the non-saturating variant (see main)."""
+    from neurad_studio_amd import ops
     from neurad_studio_amd.fields.neurad_field import NeuRADField, NeuRADFieldConfig
-    from neurad_studio_amd.model_components.ray_samplers import PowerSampler
     from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
 
     torch.manual_seed(7)  # identical replicas on every rank
     cfg = NeuRADFieldConfig(geo_hidden_dim=HIDDEN, nff_hidden_dim=HIDDEN)
+    if beta is not None:
+        cfg.sdf_beta = beta
     st = cfg.grid.static
     st.num_levels, st.hashgrid_dim, st.log2_hashmap_size = GRID["num_levels"], GRID["features_per_level"], GRID["log2_hashmap_size"]
     st.base_res, st.max_res = GRID["min_res"], GRID["max_res"]
     fld = NeuRADField(cfg, actors=None, static_scale=STATIC_SCALE).to(device).train()
+    if table_scale is not None:
+        with torch.no_grad():
+            t = fld.hashgrid.static_grid.hash_table
+            t.mul_(table_scale / float(t.abs().max()))
     fld.order_rays = True  # random rays: the training forward walks them in the nrhip_ray_order order
-    sampler = PowerSampler(num_samples=N_SAMPLES, lambda_=-1.0, scaling=0.1).to(device).train()
     opt, opt_name = make_optimizer(fld.parameters())
     sync = GradientSynchronizer(fld.parameters(), average=True, usage="static")
     g = torch.Generator(device=device)
@@ -190,17 +210,13 @@ def train_section(device, rank, world, steps, warmup):
     target = torch.rand((R_RAYS, 32), device=device, generator=g)
     tdepth = torch.rand((R_RAYS, 1), device=device, generator=g) * 50
     area = torch.full((R_RAYS, 1), 2.43e-6, device=device)
-    nears, fars = torch.zeros((R_RAYS, 1), device=device), torch.full((R_RAYS, 1), 20000.0, device=device)
+    fars = torch.full((R_RAYS,), 20000.0, device=device)
     state = {}
 
     def step(_i=None):
-        rb = RayBundle(origins=o, directions=d, pixel_area=area, nears=nears, fars=fars)
-        rs = sampler(rb)
-        out = fld(rs)
-        w, _ = ag.WeightFromAlphaFn.apply(out[FieldHeadNames.ALPHA][..., 0])
-        fr = rs.frustums
-        feats, depth, acc = ag.CompositeFn.apply(w, out[FieldHeadNames.FEATURE], fr.starts[..., 0].contiguous(),
-                                                 fr.ends[..., 0].contiguous())
+        t_rand = torch.rand((R_RAYS, N_SAMPLES + 1), device=device)  # training-mode stratified jitter
+        eu = ops.power_sampler(None, fars, N_SAMPLES, -1.0, 0.1, t_rand)[1]
+        feats, depth, acc, w = fld.render_train(o, d, area, eu)
         loss = (feats - target).square().mean() + 1e-4 * (depth - tdepth).abs().mean() + 1e-3 * (w.square().sum(-1)).mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -420,13 +436,33 @@ def cpu_baseline(fs, origins, dirs, area, edges, budget_s=12.0):
 
 
 def reference_torch_cpu():
+    """The reference's own torch field-eval path on host cores.  Where a reference tree is present (NEURAD_REFERENCE_ROOT /
+    NEURAD_REFERENCE_DIR, default /root/reference) it is timed LIVE on this host with os.cpu_count() threads
+    (oracle/time_reference_cpu.py in a subprocess, ~30 s); the GPU box has no such tree, there the figure timed in the build
+    container (profiles/reference_torch_cpu.json) is quoted and labelled as such."""
+    import subprocess
+
+    ref_root = os.environ.get("NEURAD_REFERENCE_ROOT") or os.environ.get("NEURAD_REFERENCE_DIR") or "/root/reference"
+    if os.path.isdir(os.path.join(ref_root, "nerfstudio")):
+        try:
+            env = dict(os.environ, NEURAD_REFERENCE_ROOT=ref_root)
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference_cpu.py"), "--no-write"],
+                                 capture_output=True, text=True, timeout=300, env=env)
+            r = json.loads(res.stdout.strip().splitlines()[-1])
+            return {"value": r["forward_ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["cores"], "kind": "reference",
+                    "forward_backward_value": r["forward_backward_ray_samples_per_s"],
+                    "where": "this host, live: " + r["what"] + "; oracle/time_reference_cpu.py"}
+        except Exception as e:  # noqa: BLE001  (fall back to the recorded figure, say why)
+            note = f"live timing failed ({type(e).__name__}); "
+    else:
+        note = ""
     f = os.path.join(ROOT, "profiles", "reference_torch_cpu.json")
     if not os.path.exists(f):
         return None
     r = json.load(open(f))
     return {"value": r["forward_ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["cores"], "kind": "reference",
             "forward_backward_value": r["forward_backward_ray_samples_per_s"],
-            "where": "build container (the GPU box has no reference tree): " + r["what"] + "; oracle/time_reference_cpu.py"}
+            "where": note + "build container (the GPU box has no reference tree): " + r["what"] + "; oracle/time_reference_cpu.py"}
 
 
 def bench_c1(args, device, rank, world):
@@ -458,7 +494,7 @@ def bench_c1(args, device, rank, world):
         ops.render_fwd(fs, origins, dirs, area, eu[:, :-1], eu[:, 1:], out=(feats, depth, acc), order=order)
         if timed_kernel:
             events[i // ev_every][1].record()
-        state["edges"] = eu
+        state["edges"], state["order"] = eu, order
 
     elapsed = timed(step, args.steps, args.warmup, world, device)
     assert torch.isfinite(feats).all() and torch.isfinite(acc).all()
@@ -486,6 +522,28 @@ def bench_c1(args, device, rank, world):
                          "traffic": traffic, "algorithmic_bytes_per_launch": n_samples * bytes_per,
                          "kernel_ms": kernel_ms},
         }
+        # two NON-headline variants of the same kernel on the same batch (labelled; the headline stays fp32 / exact):
+        # fp16 table storage (BASELINE config 5's layout) and eval-time early ray termination at transmittance 1e-4
+        def kernel_us(fspec, **kw):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for k in range(13):
+                if k >= 3:
+                    evs[k - 3][0].record()
+                ops.render_fwd(fspec, origins, dirs, area, state["edges"][:, :-1], state["edges"][:, 1:], order=state["order"], **kw)
+                if k >= 3:
+                    evs[k - 3][1].record()
+            torch.cuda.synchronize()
+            return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
+
+        import dataclasses
+
+        fs16 = dataclasses.replace(fs, table=fs.table.half())
+        out["variants_not_headline"] = {
+            "fp16_table_kernel_us": kernel_us(fs16),
+            "early_stop_eps_1e-4_kernel_us": kernel_us(fs, early_stop_eps=1e-4),
+            "what": "render_kernel on the headline batch with (a) the hash table stored as fp16 (half the gather bytes, "
+                    "arithmetic unchanged) and (b) rays stopped once their transmittance is below 1e-4 (error bounded by "
+                    "it); neither is the headline configuration"}
     return out, (fs, origins, dirs, area, state["edges"], feats)
 
 
@@ -537,8 +595,13 @@ def bench_c2(args, device, rank, world):
     t_samp = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     t_rend = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     prop_bytes = n_prop * 6 * 8 * 1 * 4  # 192 B per proposal evaluation
-    achieved = prop_bytes / (t_samp * 1e-3) / 1e9
-    return {
+    # The kernel's 48 four-byte gathers per evaluation hit in L1 / L2 (0.19 M fabric reads per launch, the tables'
+    # compulsory footprint): it runs against the L1's tag-lookup rate -- one cache-line access per clock and CU --, not
+    # against HBM (profiles/r02_c2_sampler_pmc.txt: 63.7 M TCP accesses per launch).
+    gathers = n_prop * 6 * 8
+    l1_peak = L1_ACCESS_PEAK_G
+    ach = gathers / (t_samp * 1e-3) / 1e9
+    out = {
         "metric": "ray-samples/sec (8192 camera rays, proposal sampler 128+64 -> 32 field samples)",
         "value": world * n_field * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -547,12 +610,246 @@ def bench_c2(args, device, rank, world):
                                "fused field + compositing, NeuRAD default grids, eval", "rays_per_gpu": R,
                    "parallelism": f"rays sharded x{world}, no collective"},
         "rays_per_sec": world * R * args.steps / elapsed, "proposal_evals_per_sec": world * n_prop * args.steps / elapsed,
-        "roofline": {"kernel": "nrhip::proposal_sampler_kernel (all rounds on chip, one wave per ray)", "bound": "hbm",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "roofline": {"kernel": "nrhip::proposal_sampler_kernel (all rounds on chip, one wave per ray)", "bound": "l1",
+                     "achieved": ach, "peak": l1_peak, "unit": "Gaccess/s", "frac": ach / l1_peak,
+                     "what": "algorithmic 4-byte table gathers (48 per proposal evaluation) per second against the vector "
+                             "L1's tag-lookup peak, 256 CUs x 1 line access per clock x 2.4 GHz",
                      "traffic": recorded_traffic("proposal_sampler"), "algorithmic_bytes_per_launch": prop_bytes,
-                     "kernel_ms": t_samp},
+                     "hbm_frac_of_peak": prop_bytes / (t_samp * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_samp},
         "render_kernel_ms": t_rend,
     }
+    if world == 1:  # the whole chain of a 512-ray slice against the C restatement of the oracle
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import neurad_oracle as O
+        import oracle_c
+
+        n = 512
+        h = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        props, fp = _oracle_params(m, O)
+        so = oracle_c.proposal_sampler(props, h(o[:n]), h(d[:n]), h(area9[:n]).reshape(-1), np.zeros(n, np.float32),
+                                       np.full(n, sky, np.float32))
+        ref = oracle_c.render_fwd(fp, h(o[:n]), h(d[:n]), h(area9[:n]).reshape(-1), so["starts"], so["ends"])
+        feats = h(state["out"][0][:n])
+        out["parity_rel_l2_vs_oracle"] = {
+            "features": float(np.linalg.norm(feats - ref["features"]) / np.linalg.norm(ref["features"])),
+            "accumulation": float(np.linalg.norm(h(state["out"][2][:n]) - ref["accumulation"]) / np.linalg.norm(ref["accumulation"])),
+            "tolerance": 1e-4, "sample": f"{n} rays through oracle/neurad_oracle_c.c: proposal sampler (2 rounds) + field + "
+                                         "compositing, the step's own rays and parameters",
+            "compositing": "unpinned against nerfacc itself (DESIGN.md §3)"}
+    return out
+
+
+def _oracle_params(m, O):
+    """the hot-path model's parameters as the oracle's dataclasses"""
+    h = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    pg, fg = m.proposal_fields[0].hashgrid.config.static, m.field.hashgrid.config.static
+    props = [O.ProposalParams(O.GridParams(h(p.hashgrid.static_grid.hash_table), pg.num_levels, pg.base_res, pg.max_res,
+                                           pg.log2_hashmap_size), STATIC_SCALE, h(p.density_decoder.weight))
+             for p in m.proposal_fields]
+    f = m.field
+    fp = O.FieldParams(O.GridParams(h(f.hashgrid.static_grid.hash_table), fg.num_levels, fg.base_res, fg.max_res,
+                                    fg.log2_hashmap_size), STATIC_SCALE,
+                       [h(l.weight) for l in f.mlp_geo.layers], [h(l.bias) for l in f.mlp_geo.layers],
+                       [h(l.weight) for l in f.mlp_feature.layers], [h(l.bias) for l in f.mlp_feature.layers],
+                       beta=float(f.sdf_to_density.beta), use_sdf=True)
+    return props, fp
+
+
+def c3_parity(device, n_cam=1024, n_lidar=512):
+    """Forward outputs of a slice of the c3 workload (one camera patch + 512 lidar rays, the c3 model and grids) in eval mode
+    (no jitter) through the fused eval kernels AND through the fused TRAINING nodes, against the C oracle's chain."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import neurad_oracle as O
+    import oracle_c
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    torch.manual_seed(11)
+    m = NeuRADHotPath(NeuRADHotPathConfig(), static_scale=STATIC_SCALE, num_sensors=7, duration=8.0).to(device)
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(1000.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(2000.0)
+    o, d, area, times, md = joint_batch(device, 0, n_cam, n_lidar)
+    R = n_cam + n_lidar
+
+    def rb():
+        return RayBundle(origins=o, directions=d, pixel_area=area.clone(), nears=torch.zeros((R, 1), device=device), fars=None,
+                         times=times, metadata=dict(md))
+
+    m.eval()
+    with torch.no_grad():
+        ev = m.get_nff_outputs(rb())
+    m.train()
+    m.sampler.eval()  # the training nodes, without jitter
+    tr = m.get_nff_outputs(rb(), calc_lidar_losses=True)
+    h = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    props, fp = _oracle_params(m, O)
+    a = torch.where(md["is_lidar"], area, area * 9.0)
+    so = oracle_c.proposal_sampler(props, h(o), h(d), h(a).reshape(-1), np.zeros(R, np.float32), np.full(R, 20000.0, np.float32))
+    ref = oracle_c.render_fwd(fp, h(o), h(d), h(a).reshape(-1), so["starts"], so["ends"])
+    rl2 = lambda x, y: float(np.linalg.norm(x - y) / np.linalg.norm(y))  # noqa: E731
+    return {"eval_features": rl2(h(ev["features"][:, :32]), ref["features"]),
+            "eval_accumulation": rl2(h(ev["accumulation"]), ref["accumulation"]),
+            "train_nodes_features": rl2(h(tr["features"][:, :32]), ref["features"]),
+            "train_nodes_accumulation": rl2(h(tr["accumulation"]), ref["accumulation"]),
+            "train_nodes_prop_weights_0": rl2(h(tr["weights_list"][0][..., 0]), so["prop_weights"][0]),
+            "tolerance": 1e-4,
+            "sample": f"{n_cam} camera + {n_lidar} lidar rays of the c3 batch, NeuRAD-default grids, no jitter: fused eval "
+                      "kernels and fused training nodes vs oracle/neurad_oracle_c.c (sampler + field + compositing)",
+            "compositing": "unpinned against nerfacc itself (DESIGN.md §3)"}
+
+
+def actor_scene(n_actors, seed=21):
+    """n parked / slowly moving boxes (2 x 4.6 x 1.6 m) on a 60 m square, 9 poses over 4 s each"""
+    ts = torch.linspace(0.0, 4.0, 9)
+    gen = torch.Generator().manual_seed(seed)
+    trajs = []
+    for _ in range(n_actors):
+        x0, y0 = 60 * torch.rand(2, generator=gen) - 30
+        yaw, v = 6.28 * float(torch.rand(1, generator=gen)), 4 * float(torch.rand(1, generator=gen))
+        poses = torch.eye(4).repeat(len(ts), 1, 1)
+        c, sn = np.cos(yaw), np.sin(yaw)
+        poses[:, :3, :3] = torch.tensor([[c, -sn, 0.0], [sn, c, 0.0], [0.0, 0.0, 1.0]])
+        poses[:, 0, 3], poses[:, 1, 3], poses[:, 2, 3] = x0 + v * ts * c, y0 + v * ts * sn, 0.8
+        trajs.append({"timestamps": ts.clone(), "poses": poses, "dims": torch.tensor([2.0, 4.6, 1.6]),
+                      "symmetric": torch.tensor(True), "deformable": torch.tensor(False)})
+    return trajs, gen
+
+
+def bench_c4(args, device, rank, world):
+    """BASELINE config[4]: 65 536 rays per GPU, appearance embedding (16-d), 32 dynamic actors, the main field's static and
+    actor tables stored as fp16.  Step = one eval pass of get_outputs_for_ray_bundle (fused proposal sampler with per-sample
+    actor select + fused field / compositing with per-sample table select + appearance); the line also carries one
+    training step of the same scene (operator-level actor path, fp16-storage tables on HashGridAdam's fp32 master copy)."""
+    from neurad_studio_amd import ops
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+    from neurad_studio_amd.model_components.losses import distortion_loss, zipnerf_interlevel_loss
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    R, A = 65536, 32
+    trajs, gen = actor_scene(A)
+    torch.manual_seed(2)
+    m = NeuRADHotPath(NeuRADHotPathConfig(), static_scale=STATIC_SCALE, num_sensors=6, duration=4.0,
+                      actors=DynamicActors(DynamicActorsConfig(), trajectories=trajs)).to(device).eval()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(300.0)
+        for gr in m.field.hashgrid.actor_grids:
+            gr.hash_table.mul_(2000.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(500.0)
+        for gr in [m.field.hashgrid.static_grid, *m.field.hashgrid.actor_grids]:
+            gr.hash_table.data = gr.hash_table.data.half()
+    gen.manual_seed(31 + rank)
+    o = (torch.randn(R, 3, generator=gen) * torch.tensor([20.0, 20.0, 0.3]) + torch.tensor([0.0, 0.0, 1.5])).to(device)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.1]), dim=-1).to(device)
+    times = (4 * torch.rand(R, 1, generator=gen)).to(device)
+    sens = torch.randint(0, 6, (R, 1), generator=gen).to(device)
+    area = torch.full((R, 1), 2.7e-7, device=device)
+
+    def bundle():
+        return RayBundle(origins=o, directions=d, pixel_area=area, times=times, metadata={"sensor_idxs": sens})
+
+    state = {}
+    ev_every = 4
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range((args.steps + ev_every - 1) // ev_every)]
+    real_render = ops.render_fwd_actors
+
+    def timed_render(*a, **k):  # HIP events around the render stage (partition + static slice + ACT slice) of timed steps
+        e = state.get("ev")
+        if e is not None:
+            e[0].record()
+        r = real_render(*a, **k)
+        if e is not None:
+            e[1].record()
+        return r
+
+    def step(i=None):
+        state["ev"] = ev[i // ev_every] if i is not None and i % ev_every == 0 else None
+        state["out"] = m.get_outputs_for_ray_bundle(bundle(), num_rays_per_chunk=1 << 17)
+
+    ops.render_fwd_actors = timed_render
+    try:
+        elapsed = timed(step, args.steps, args.warmup, world, device)
+    finally:
+        ops.render_fwd_actors = real_render
+    assert torch.isfinite(state["out"]["features"]).all()
+    S = m.config.sampling.num_nerf_samples
+    n_field = R * S
+    # algorithmic bytes of the render stage: 512 B of fp16 table reads per sample (8 levels x 8 corners x 4 features x 2 B;
+    # a sample inside a box reads its actor's 4-level grid instead: 256 B) + 8 B interval + per-ray I/O
+    with torch.no_grad():
+        rb = bundle()
+        m._scale_pixel_area(rb)
+        n0 = torch.zeros(R, device=device)
+        spec, cand = m.field.hashgrid.prepare_actors(o, d, rb.pixel_area.reshape(-1), torch.stack([n0, n0 + 1], -1),
+                                                     torch.stack([n0 + 1, n0 + 2], -1), times.reshape(-1))
+        rb.fars = torch.full_like(rb.pixel_area, m.config.sampling.sky_distance)
+        rb.nears = torch.zeros_like(rb.fars)
+        rs, _, _ = m.sampler.generate_fused(rb, [m.proposal_fields[-1]] * 2, m.config.sampling.sky_distance, actor_cand=cand)
+        st_, en_ = rs.frustums.starts[..., 0].contiguous(), rs.frustums.ends[..., 0].contiguous()
+        hits = ops.actor_hits(spec, cand, o, d, rb.pixel_area.reshape(-1), st_, en_)
+        frac_hit = float((hits[:, 0] >= 0).float().mean())
+        rays_with_cand = float((cand[0] > 0).float().mean())
+    per_sample = algorithmic_bytes_per_sample(8, 4, 2, S)
+    alg = n_field * (per_sample - frac_hit * 256.0)
+    out = None
+    if rank == 0:
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        out = {
+            "metric": "ray-samples/sec (65536 rays, eval, actors + appearance, fp16 tables)",
+            "value": world * n_field * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 arithmetic, fp16 table storage", "data": "synthetic",
+            "config": {"workload": "BASELINE config[4]: 65536 rays per GPU, NeuRAD-default grids with the main field's static + "
+                                   f"{A} actor tables in fp16, appearance embedding, {A} dynamic actors, fused proposal sampler "
+                                   "(2 rounds, per-sample actor select) + fused field + compositing, eval",
+                       "rays_per_gpu": R, "actors": A, "samples_in_a_box": frac_hit, "rays_with_candidates": rays_with_cand,
+                       "parallelism": f"rays sharded x{world}, no collective"},
+            "rays_per_sec": world * R * args.steps / elapsed,
+            "roofline": {"kernel": "nrhip_render_fwd_actors: actor_partition + render_kernel<8,4,32,fp16,composite> over the rays "
+                                   "without candidates + render_kernel<8,4,32,fp16,composite,ACT> over the rays with",
+                         "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": recorded_traffic("render_actors_fp16"),
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
+                         "bytes_per_sample": "8 levels x 8 corners x 4 features x 2 B = 512 B (256 B for a sample inside an "
+                                             "actor box: its 4-level grid) + 8 B interval + per-ray I/O / S"}}
+        out["train_step"] = None
+    # ---- one training step of the same scene (operator-level path with actors) ----
+    del state["out"]
+    torch.cuda.empty_cache()
+    m.train()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt, opt_name = make_optimizer(params)
+    from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
+
+    sync = GradientSynchronizer(params, average=True, usage="dynamic")
+    Rt = 16384
+    target = torch.rand((Rt, 48), device=device)
+
+    def tstep(_i=None):
+        rb = RayBundle(origins=o[:Rt], directions=d[:Rt], pixel_area=area[:Rt].clone(), times=times[:Rt],
+                       metadata={"sensor_idxs": sens[:Rt]})
+        nff = m.get_nff_outputs(rb)
+        loss = (5.0 * (nff["features"] - target).square().mean()
+                + 0.001 * zipnerf_interlevel_loss(nff["weights_list"], nff["ray_samples_list"])
+                + 0.002 * distortion_loss(nff["weights_list"], nff["ray_samples_list"]))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        sync.sync()
+        opt.step()
+        state["loss"] = loss
+
+    tsteps = max(3, min(args.train_steps // 6, 10))
+    el = timed(tstep, tsteps, 3, world, device)
+    if rank == 0:
+        out["train_step"] = {"ms_per_iter": el / tsteps * 1e3, "iters_per_sec": tsteps / el, "rays_per_gpu": Rt,
+                             "rays_per_sec": world * Rt * tsteps / el, "optimizer": opt_name, "loss_finite": bool(torch.isfinite(state["loss"])),
+                             "what": "16384 rays of the same scene: sampler + field with actors (operator-level actor path) + "
+                                     "compositing + appearance, feature / interlevel / distortion losses, backward, Adam "
+                                     "(fp16-storage tables on an fp32 master copy)"}
+    return out
 
 
 def main():
@@ -560,7 +857,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=["c1", "c2", "c3"], default="c1")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4"], default="c1")
+    ap.add_argument("--sharded-adam", action="store_true",
+                    help="N > 1: hash tables on ShardedTableAdam (reduce-scatter of the gradient, Adam on 1/N of each table, "
+                         "all-gather of the parameters) instead of gradient all-reduce + a full-table Adam on every rank")
+    ap.add_argument("--no-rgb-decoder", action="store_true", help="train_full / c3 without the RGB CNN decoder (round-2 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train iters/sec sections")
     ap.add_argument("--train-steps", type=int, default=60)
@@ -571,24 +872,39 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # NRHIP_DIST_BACKEND=gloo: REHEARSAL of the N > 1 code path on a box with fewer GPUs than ranks (all ranks share the
+    # visible devices, collectives run over gloo on CUDA tensors) -- it exercises init_process_group, the gradient hooks on
+    # the real autograd nodes, the sharded optimizer and the max-over-ranks timing; it is NOT a scaling measurement.
+    backend = os.environ.get("NRHIP_DIST_BACKEND", "nccl")
+    n_dev = max(torch.cuda.device_count(), 1)
+    rehearsal = world > 1 and (backend != "nccl" or n_dev < world)
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     if args.config == "c2":
         out = bench_c2(args, device, rank, world)
+    elif args.config == "c4":
+        out = bench_c4(args, device, rank, world)
     elif args.config == "c3":
         steps = min(args.steps, 50)
-        tf = train_full_section(device, rank, world, steps, max(2, min(args.warmup, 5)))
+        tf = train_full_section(device, rank, world, steps, max(2, min(args.warmup, 5)), rgb_decoder=not args.no_rgb_decoder,
+                                sharded_adam=args.sharded_adam)
         out = {"metric": "train iters/sec (camera+lidar joint batch)", "value": tf["rays_per_sec"], "unit": "rays/s",
                "n_gpus": world, "steps": steps, "warmup": max(2, min(args.warmup, 5)), "ms_per_step": tf["ms_per_iter"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": tf["what"], "rays_per_gpu": tf["rays_per_gpu"],
                           "parallelism": f"dp{world}: rays sharded, table gradients reduce-scatter + all-gather"},
                "iters_per_sec": tf["iters_per_sec"], "roofline": tf.pop("roofline"), "train_full": tf}
+        if rank == 0 and world == 1:
+            out["parity_rel_l2_vs_oracle"] = c3_parity(device)
     else:
         out, (fs, origins, dirs, area, edges, feats) = bench_c1(args, device, rank, world)
         train = train_full = None
@@ -604,6 +920,14 @@ def main():
 
         if not args.no_train:
             train = guarded(train_section, device, rank, world, args.train_steps, max(5, args.warmup // 2))
+            if isinstance(train, dict) and "error" not in train:
+                soft = guarded(lambda: train_section(device, rank, world, max(args.train_steps // 2, 10), 5, beta=3.0,
+                                                     table_scale=1.0))
+                train["non_saturating"] = dict({k: soft[k] for k in ("iters_per_sec", "ms_per_iter", "error") if k in soft},
+                                               what="the same step on a scene that does not saturate: beta = 3 and an O(1) "
+                                                    "table (the default section's beta = 20 on random weights turns every "
+                                                    "ray opaque; 76 % of its samples then carry an exactly-zero gradient "
+                                                    "and are dropped by the table-gradient partition, DESIGN §5)")
             if args.train_full_steps > 0:
                 # the previous sections' buffers go back to the driver first: with them cached, the allocator was seen to
                 # fall back to fresh hipMallocs inside the first timed steps on a fresh box (19 instead of 11.6 ms/iter)
@@ -611,7 +935,20 @@ def main():
 
                 gc.collect()
                 torch.cuda.empty_cache()
-                train_full = guarded(train_full_section, device, rank, world, args.train_full_steps, 8)
+                train_full = guarded(lambda: train_full_section(device, rank, world, args.train_full_steps, 8,
+                                                                rgb_decoder=not args.no_rgb_decoder,
+                                                                sharded_adam=args.sharded_adam))
+                if not args.no_rgb_decoder and isinstance(train_full, dict) and "error" not in train_full:
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    hot = guarded(lambda: train_full_section(device, rank, world, max(args.train_full_steps // 2, 5), 5,
+                                                             rgb_decoder=False, sharded_adam=args.sharded_adam))
+                    if isinstance(hot, dict):
+                        hot.pop("roofline", None)
+                        train_full["hot_path_only"] = {k: hot[k] for k in ("iters_per_sec", "ms_per_iter", "rays_per_sec", "error")
+                                                       if k in hot}
+                        train_full["hot_path_only"]["what"] = ("the same step without the RGB CNN decoder (a feature "
+                                                               "regression stands in for it and the rgb loss): round 2's step")
         if rank == 0:
             if train is not None:
                 out["train"] = train
@@ -632,6 +969,11 @@ def main():
                                    "CPU (models/neurad.py:713-715); the oracle restates its dense formulas (DESIGN.md §3)",
                     "field": "oracle pinned to the reference's own outputs (tests/golden/, oracle/make_golden*.py)"}
     if rank == 0:
+        if rehearsal:
+            out["rehearsal"] = (f"{world} ranks over {backend} on {n_dev} visible GPU(s): a run of the N > 1 code path (process "
+                                "group, gradient hooks, exchange, max-over-ranks timing), NOT a scaling measurement")
+        if TRAFFIC_NOTES:
+            out["traffic_notes"] = TRAFFIC_NOTES
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -170,6 +170,24 @@ class NeuRADField(nn.Module):
         return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights,
                               early_stop_eps=early_stop_eps, order=order)
 
+    def render_train(self, origins, directions, pixel_area, edges, appearance=None):
+        """Training counterpart of ``render``: field -> learnable-beta SDF head -> weights -> compositing as ONE autograd
+        node (autograd.NffRenderTrainFn) from the bin edges [R,S+1] (last edge = sky distance).  appearance: None or
+        (embedding weight [E,A], sensor_idx [R,1] | None, times [R,1] | None, (duration, n_per_sensor, temporal)): the
+        appearance embedding is written beside the features.  -> features [R, 32 + A], depth [R,1], accumulation [R,1],
+        weights of the non-sky samples [R,S-1]"""
+        if not (self.config.use_sdf and self.fused_supported() and self._fused_train_ok()) or self.hashgrid.has_actors():
+            raise NotImplementedError("render_train: static scene with the SDF head and a fused-kernel configuration only")
+        g = self.hashgrid.static_grid
+        emb, sensor, times, emb_cfg = appearance if appearance is not None else (None, None, None, (1.0, 1, False))
+        order = ops.ray_order(origins, directions, self.hashgrid.static_scale) if self.order_rays else None
+        sd = self.sdf_to_density
+        return ag.NffRenderTrainFn.apply(
+            g.hash_table, g.spec, self.hashgrid.static_scale, sd.beta, float(sd.beta_min), origins, directions,
+            pixel_area.reshape(-1), edges, emb, sensor, times, emb_cfg, order,
+            *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
+            *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])
+
     # ---- Field.forward (neurad_field.py:128-152) ------------------------------------------------
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[FieldHeadNames, Tensor]:
         fr = ray_samples.frustums  # this package's RaySamples or the reference's (cameras/rays.py:142-187)

@@ -403,22 +403,13 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
             smp._steps_since_update = 0
         eu[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
         sp[:, -1] = 1 - EPS
-        f = self.field
-        g = f.hashgrid.static_grid
-        emb = sensor = times = None
-        emb_cfg = (1.0, 1, False)
+        appearance = None
         if cfg.appearance_dim > 0:
-            emb = self.appearance_embedding.weight
             sensor = ray_bundle.metadata.get("sensor_idxs")
             assert sensor is not None, "sensor_idxs must be present in metadata during training"
-            times = ray_bundle.times if cfg.use_temporal_appearance else None
-            emb_cfg = (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance))
-        order = ops.ray_order(o, d, f.hashgrid.static_scale) if f.order_rays else None
-        sd = f.sdf_to_density
-        features, depth, accumulation, w_ns = ag.NffRenderTrainFn.apply(
-            g.hash_table, g.spec, f.hashgrid.static_scale, sd.beta, float(sd.beta_min), o, d, a, eu, emb, sensor, times,
-            emb_cfg, order, *[t for l in f.mlp_geo.layers for t in (l.weight, l.bias)],
-            *[t for l in f.mlp_feature.layers for t in (l.weight, l.bias)])
+            appearance = (self.appearance_embedding.weight, sensor, ray_bundle.times if cfg.use_temporal_appearance else None,
+                          (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance)))
+        features, depth, accumulation, w_ns = self.field.render_train(o, d, a, eu, appearance)
         nff.update(features=features, depth=depth, accumulation=accumulation)
         S = counts[-1]
         if self.training:

@@ -34,6 +34,25 @@ def shard_range(n_items: int, rank: int, world: int, granule: int = 1) -> Tuple[
     return min(start * granule, n_items), min(end * granule, n_items)
 
 
+_NO_REDUCE_SCATTER = set()  # (backend, device type) pairs whose reduce_scatter_tensor raised once
+
+
+def reduce_scatter_flat(flat: Tensor, world: int, group=None, async_op: bool = False):
+    """SUM-reduce-scatter of a flat buffer -> (work | None, this rank's shard).  A backend without reduce_scatter_tensor
+    for the buffer's device (gloo on GPU tensors: the one-GPU rehearsal of the N > 1 path) gets an all-reduce of the whole
+    buffer instead and the shard comes back as None: ``flat`` then already holds the full sum."""
+    key = (dist.get_backend(group), flat.device.type)
+    if key not in _NO_REDUCE_SCATTER:
+        shard = flat.new_empty(flat.numel() // world)
+        try:
+            work = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            return (work if async_op else None), shard
+        except (RuntimeError, NotImplementedError):
+            _NO_REDUCE_SCATTER.add(key)
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return (work if async_op else None), None
+
+
 class GradientSynchronizer:
     """Averages (or sums) ``param.grad`` across ranks with large flat collectives."""
 
@@ -97,18 +116,25 @@ class GradientSynchronizer:
     def _start_large(self, i: int, async_op: bool):
         g = self.params[i].grad
         flat = g.view(-1)
-        shard = flat.new_empty(flat.numel() // self.world_size())
+        work, shard = reduce_scatter_flat(flat, self.world_size(), self.group, async_op)
         if not async_op:
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
             self._finish_large(flat, shard)
             return
-        work = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight[i] = (work, flat, shard)
 
-    def _finish_large(self, flat: Tensor, shard: Tensor) -> None:
+    def _finish_large(self, flat: Tensor, shard: Optional[Tensor]) -> None:
+        if shard is None:  # the backend had no reduce-scatter for this device: `flat` already holds the full sum
+            if self.average:
+                flat.div_(self.world_size())
+            return
         if self.average:
             shard.div_(self.world_size())
-        dist.all_gather_into_tensor(flat, shard, group=self.group)
+        try:
+            dist.all_gather_into_tensor(flat, shard, group=self.group)
+        except (RuntimeError, NotImplementedError):  # (gloo on GPU tensors: the rehearsal) gather into a list instead
+            parts = [torch.empty_like(shard) for _ in range(self.world_size())]
+            dist.all_gather(parts, shard, group=self.group)
+            flat.copy_(torch.cat(parts))
 
     def _on_grad_ready(self, i: int) -> None:
         """post-accumulate-grad hook (overlap): autograd is done with this gradient -> its reduce-scatter starts now, on

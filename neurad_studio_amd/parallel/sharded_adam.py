@@ -91,8 +91,11 @@ class ShardedTableAdam:
             grad = p.grad if p.grad is not None else torch.zeros_like(p)
             flat_g = grad.contiguous().view(-1)
             if self.world > 1:
-                g_shard = flat_g.new_empty(flat_g.numel() // self.world)
-                dist.reduce_scatter_tensor(g_shard, flat_g, op=dist.ReduceOp.SUM, group=self.group)
+                from .data_parallel import reduce_scatter_flat
+
+                _, g_shard = reduce_scatter_flat(flat_g, self.world, self.group)
+                if g_shard is None:  # no reduce-scatter on this backend / device: flat_g holds the full sum
+                    g_shard = self._shard(flat_g)
                 nbytes += 2 * flat_g.numel() * 4 * (self.world - 1) // self.world
             else:
                 g_shard = flat_g
@@ -102,7 +105,12 @@ class ShardedTableAdam:
             if self.world > 1:
                 # in place (send buffer = this rank's slot of the receive buffer) where the backend supports it
                 src = p_shard if dist.get_backend(self.group) == "nccl" else p_shard.clone()
-                dist.all_gather_into_tensor(flat_p, src, group=self.group)
+                try:
+                    dist.all_gather_into_tensor(flat_p, src, group=self.group)
+                except (RuntimeError, NotImplementedError):  # (gloo on GPU tensors: the rehearsal) gather into a list
+                    parts = [torch.empty_like(src) for _ in range(self.world)]
+                    dist.all_gather(parts, src, group=self.group)
+                    flat_p.copy_(torch.cat(parts))
         return nbytes
 
     def zero_grad(self, set_to_none: bool = True) -> None:

@@ -66,5 +66,8 @@ out = {"what": "reference NeuRADField(implementation='torch'), BASELINE config[1
                "4096 rays x 128 samples, fp32, torch CPU ops", "where": "build container", "cores": os.cpu_count(),
        "torch_threads": torch.get_num_threads(), "forward_s": tf, "forward_ray_samples_per_s": R * S / tf,
        "forward_backward_s": tb, "forward_backward_ray_samples_per_s": R * S / tb}
-json.dump(out, open(os.path.join(ROOT, "profiles", "reference_torch_cpu.json"), "w"), indent=1)
+if "--no-write" in sys.argv:  # bench.py's live timing on a host that has the reference tree: stdout only
+    out["where"] = "this host (live)"
+else:
+    json.dump(out, open(os.path.join(ROOT, "profiles", "reference_torch_cpu.json"), "w"), indent=1)
 print(json.dumps(out))

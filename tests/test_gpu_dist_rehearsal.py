@@ -1,0 +1,125 @@
+"""The N > 1 training path rehearsed on ONE GPU: two ranks share cuda:0 and exchange over gloo (NRHIP_DIST_BACKEND=gloo is
+the same switch in bench.py).  It runs what a multi-GPU box runs -- process group, the gradient hooks of
+GradientSynchronizer(overlap=True) on the real HIP autograd nodes (ProposalRoundFn / NffRenderTrainFn), HashGridAdam or
+ShardedTableAdam on nrhip_adam_step -- and checks the data-parallel contract: after three steps on different ray shards the
+replicas hold the parameters of ONE process trained on the mean loss.  Not a scaling measurement."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    c = NeuRADHotPathConfig(appearance_dim=16)
+    c.field.sdf_beta = 3.0
+    c.field.grid.static.log2_hashmap_size = 14
+    c.sampling.proposal_field_1.grid.static.log2_hashmap_size = 13
+    c.sampling.proposal_field_2.grid.static.log2_hashmap_size = 13
+    torch.manual_seed(0)
+    m = NeuRADHotPath(c, static_scale=100.0, num_sensors=3, duration=4.0).cuda().train()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(1000.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(2000.0)
+    m.sampler.eval()  # no jitter: both worlds walk the same samples
+    return m
+
+
+def _shard(rank, step, n=256):
+    from neurad_studio_amd.cameras.rays import RayBundle
+
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    o = torch.randn(n, 3, generator=g) * 5.0
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    return RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((n, 1), 2.7e-7, device="cuda"),
+                     nears=torch.zeros(n, 1, device="cuda"), fars=None, times=(4 * torch.rand(n, 1, generator=g)).cuda(),
+                     metadata={"sensor_idxs": torch.randint(0, 3, (n, 1), generator=g).cuda()})
+
+
+def _loss(m, rb):
+    from neurad_studio_amd.model_components.losses import distortion_loss, zipnerf_interlevel_loss
+
+    out = m.get_nff_outputs(rb)
+    return (out["features"].square().mean() + 1e-3 * out["depth"].mean()
+            + 0.01 * zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
+            + 0.02 * distortion_loss(out["weights_list"], out["ray_samples_list"]))
+
+
+def _optimizers(m, sharded):
+    from neurad_studio_amd.optim import HashGridAdam
+    from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
+
+    params = [p for p in m.parameters() if p.requires_grad]
+    tables = [p for p in params if p.numel() >= 1 << 14]
+    small = [p for p in params if p.numel() < 1 << 14]
+    topt = ShardedTableAdam(tables, lr=1e-2, eps=1e-15, usage="static") if sharded else HashGridAdam(tables, lr=1e-2, eps=1e-15)
+    return params, tables, topt, torch.optim.Adam(small, lr=1e-2, eps=1e-15)
+
+
+def _worker(rank, world, port, sharded, ret):
+    import torch.distributed as dist
+
+    from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _model()
+    params, tables, topt, sopt = _optimizers(m, sharded)
+    sync = GradientSynchronizer(params, average=True, large_threshold_bytes=1 << 14, usage="static", overlap=True,
+                                skip=tables if sharded else ())
+    overlapped = []
+    for step in range(3):
+        for o in (topt, sopt):
+            o.zero_grad(set_to_none=True)
+        _loss(m, _shard(rank, step)).backward()
+        sync.sync()
+        overlapped.append(sync.overlapped_last_step)
+        topt.step(), sopt.step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        ret["overlapped"] = overlapped
+        ret["params"] = {n: p.detach().cpu() for n, p in m.named_parameters()}
+    ret[f"done{rank}"] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True], ids=["allreduce+HashGridAdam", "ShardedTableAdam"])
+def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean_loss(sharded):
+    import torch.multiprocessing as mp
+
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), sharded, ret), nprocs=world, join=True)
+        assert ret.get("done0") and ret.get("done1")
+        got, overlapped = dict(ret["params"]), list(ret["overlapped"])
+    # one process, the mean loss of both shards
+    m = _model()
+    params, tables, topt, sopt = _optimizers(m, False)
+    for step in range(3):
+        for o in (topt, sopt):
+            o.zero_grad(set_to_none=True)
+        (sum(_loss(m, _shard(r, step)) for r in range(world)) / world).backward()
+        topt.step(), sopt.step()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        a, b = got[n].double(), p.detach().cpu().double()
+        err = float((a - b).norm() / (b.norm() + 1e-30))
+        worst = max(worst, err)
+        assert err < 2e-5, (n, err)
+    # step 0 agrees on the usage set; afterwards the large gradients that every rank holds are exchanged from their hooks
+    # (the field table and the one proposal table that trains; none when the sharded optimizer owns the tables)
+    assert overlapped[0] == 0 and overlapped[1] == overlapped[2] == (0 if sharded else 2), overlapped

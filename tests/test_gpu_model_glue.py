@@ -393,3 +393,43 @@ def test_config4_shape_actors_fp16_field_tables_appearance_65536_rays_chunked():
     op = m32.get_nff_outputs(sl)  # grad enabled -> operator-level path, fp32 tables with the same (rounded) values
     for k in ("features", "depth", "accumulation"):
         assert rel_l2(host(out[k][1000:3048]), host(op[k])) < 5e-5, k
+    # ---- and against the ORACLE's actor path (numpy, oracle/neurad_oracle.py: field_fwd_actors -> C1 -> C2) on a 256-ray
+    # slice, on the fp16-rounded tables: the fused per-sample table select + MLPs + compositing of this configuration,
+    # fed with the samples the fused proposal rounds placed for those rays
+    import neurad_oracle as O
+
+    a0, a1 = 2000, 2256
+    sl = _slice_bundle(rb, a0, a1)
+    with torch.no_grad():
+        m16._scale_pixel_area(sl)
+        sl.fars = torch.full_like(sl.pixel_area, m16.config.sampling.sky_distance)
+        sl.nears = torch.zeros_like(sl.fars)
+        so, sd_, st = sl.origins.contiguous(), sl.directions.contiguous(), sl.times.reshape(-1)
+        n = sl.nears.reshape(-1)
+        _, cand = m16.field.hashgrid.prepare_actors(so, sd_, sl.pixel_area.reshape(-1), torch.stack([n, n + 1], -1),
+                                                    torch.stack([n + 1, n + 2], -1), st)
+        pf = [m16.proposal_fields[-1]] * 2
+        rs, _, _ = m16.sampler.generate_fused(sl, pf, m16.config.sampling.sky_distance, actor_cand=cand)
+        starts = rs.frustums.starts[..., 0].contiguous()
+        ends = rs.frustums.ends[..., 0].clone()
+        ends[:, -1] = m16.config.sampling.sky_distance
+        feats, depth, acc = m16.field.render(so, sd_, sl.pixel_area, starts, ends, times=st, actor_cand=cand)[:3]
+    f, hg, act = m16.field, m16.field.hashgrid, m16.field.hashgrid.actors
+    gcfg = hg.config
+    grid = O.GridParams(host(hg.static_grid.hash_table.float()), gcfg.static.num_levels, gcfg.static.base_res,
+                        gcfg.static.max_res, gcfg.static.log2_hashmap_size)
+    fp = O.FieldParams(grid, 100.0, [host(l.weight) for l in f.mlp_geo.layers], [host(l.bias) for l in f.mlp_geo.layers],
+                       [host(l.weight) for l in f.mlp_feature.layers], [host(l.bias) for l in f.mlp_feature.layers],
+                       beta=float(f.sdf_to_density.beta), use_sdf=True)
+    ap = O.ActorParams(host(act.unique_timestamps), host(act.actor_positions), host(act.actor_rotations_6d),
+                       host(act.actor_present_at_time), host(act.actor_sizes), host(act.actor_padding),
+                       [O.GridParams(host(hg.actor_grids[i].hash_table.float()), gcfg.actor.num_levels, gcfg.actor.base_res,
+                                     gcfg.actor.max_res, gcfg.actor.log2_hashmap_size) for i in act.actor_to_id.tolist()],
+                       actor_scale=float(gcfg.actor.actor_scale))
+    ref = O.field_fwd_actors(fp, ap, host(so), host(sd_), host(sl.pixel_area.reshape(-1)), host(starts), host(ends), host(st))
+    w, _ = O.render_weight_from_alpha(ref["alpha"])
+    rf, rd, ra = O.composite(w, ref["feature"], host(starts), host(ends))
+    in_box = float((np.abs(ref["directions"] - host(sd_)[:, None, :]).max(-1) > 0).mean())
+    assert in_box > 0.005, f"the slice must contain actor samples ({in_box:.4f})"
+    assert rel_l2(host(feats), rf) < 1e-4 and rel_l2(host(acc), ra) < 1e-4 and rel_l2(host(depth), rd) < 1e-4
+    assert torch.equal(out["features"][a0:a1, :32], feats)  # the chunked entry rendered exactly this
