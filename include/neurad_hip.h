@@ -575,18 +575,19 @@ int nrhip_mask_compact(const uint8_t* mask, int64_t r, int64_t* rows, int64_t n_
  * depths: HOST array of n_levels DEVICE pointers [R] (level 0 = the field's depth, 1.. = prop_depth_i), read at
  * lidar_rows [n].  metrics [2 + n_levels] = depth_loss (mean over the rays below the `quantile` of the per-ray error,
  * torch.quantile's linear interpolation), intensity_loss (same rays & returned), ray_drop_loss (BCE with logits, target
- * = no return), depth_loss_0, ...  unit_grads [(n_levels + 2), n] = d metric / d prediction per lidar ray (depth levels,
- * intensity, logits); scratch [n].  One workgroup; the quantile is a radix select, nothing is sorted.                */
+ * = no return), depth_loss_0, ...  unit_grads [(n_levels + 2), n] and scratch (nrhip_lidar_losses_workspace floats) carry
+ * what the backward needs.  A per-ray pass + one single-workgroup pass; the quantile is a radix select, nothing is sorted. */
+int nrhip_lidar_losses_workspace(int64_t n, int64_t* floats /*host*/);
 int nrhip_lidar_losses(const float* const* depths, int32_t n_levels, const int64_t* lidar_rows, const float* distance,
                        const uint8_t* did_return, const float* intensity, const float* intensity_target,
                        const float* ray_drop_logits, int64_t n, float non_return_distance, float non_return_mult,
                        float quantile, float* metrics, float* unit_grads, float* scratch, void* stream);
-/* unit gradients x upstream [2 + n_levels] (device) scattered to the batch: grad_depths = HOST array of n_levels DEVICE
- * pointers [R] (0 for camera rays; entries may be NULL), grad_intensity / grad_logits [n] (may be NULL);
- * inverse [R] from nrhip_mask_compact                                                                               */
-int nrhip_lidar_losses_bwd(const float* unit_grads, const int32_t* inverse, const float* upstream, int32_t n_levels,
-                           int64_t r, int64_t n, float* const* grad_depths, float* grad_intensity, float* grad_logits,
-                           void* stream);
+/* d metrics / d predictions x upstream [2 + n_levels] (device) scattered to the batch: grad_depths = HOST array of
+ * n_levels DEVICE pointers [R] (0 for camera rays; entries may be NULL), grad_intensity / grad_logits [n] (may be NULL);
+ * unit_grads / scratch / did_return as given to (and filled by) nrhip_lidar_losses, inverse [R] from nrhip_mask_compact */
+int nrhip_lidar_losses_bwd(const float* unit_grads, const float* scratch, const uint8_t* did_return, const int32_t* inverse,
+                           const float* upstream, int32_t n_levels, int64_t r, int64_t n, float* const* grad_depths,
+                           float* grad_intensity, float* grad_logits, void* stream);
 
 #ifdef __cplusplus
 }

@@ -148,7 +148,8 @@ PROTOTYPES = {
     "nrhip_appearance_bwd": [P, I32, P, P, F32, I32, I32, I64, I32, I32, P, P],
     "nrhip_mask_compact": [P, I64, P, I64, P, P, P],
     "nrhip_lidar_losses": [C.POINTER(P), I32, P, P, P, P, P, P, I64, F32, F32, F32, P, P, P, P],
-    "nrhip_lidar_losses_bwd": [P, P, P, I32, I64, I64, C.POINTER(P), P, P, P],
+    "nrhip_lidar_losses_workspace": [I64, C.POINTER(I64)],
+    "nrhip_lidar_losses_bwd": [P, P, P, P, P, I32, I64, I64, C.POINTER(P), P, P, P],
 }
 
 _lib = None

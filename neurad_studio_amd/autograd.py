@@ -464,17 +464,17 @@ class LidarLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, lidar_rows, inverse, distance, did_return, intensity_target, intensity, logits, *depths):
-        metrics, unit = ops.lidar_losses(depths, lidar_rows, distance, did_return, intensity, intensity_target, logits,
-                                         cfg[0], cfg[1], cfg[2])
-        ctx.save_for_backward(unit, inverse)
+        metrics, saved = ops.lidar_losses(depths, lidar_rows, distance, did_return, intensity, intensity_target, logits,
+                                          cfg[0], cfg[1], cfg[2])
+        ctx.save_for_backward(inverse, *saved)
         ctx.n_levels, ctx.n_rays = len(depths), depths[0].shape[0]
         return metrics
 
     @staticmethod
     def backward(ctx, g):
-        unit, inverse = ctx.saved_tensors
+        inverse, *saved = ctx.saved_tensors
         need = ctx.needs_input_grad
-        gds, gi, gl = ops.lidar_losses_bwd(unit, inverse, g.contiguous(), ctx.n_levels, ctx.n_rays, need[8:], need[6], need[7])
+        gds, gi, gl = ops.lidar_losses_bwd(saved, inverse, g.contiguous(), ctx.n_levels, ctx.n_rays, need[8:], need[6], need[7])
         return (None,) * 6 + (gi, gl, *gds)
 
 

@@ -26,13 +26,32 @@ def _f32(t: Tensor) -> Tensor:
     return _chk(t.reshape(t.shape[0], -1).to(torch.float32), "sensor table")
 
 
+_ELIGIBLE: dict = {}  # id(cameras) -> (key, error message | None)
+
+
+def _check_cameras(cameras) -> None:
+    """PERSPECTIVE, undistorted cameras only.  The two `.any()` checks read the device, i.e. they synchronise the host with
+    the stream: they run ONCE per Cameras object (keyed on the identity and in-place version of its two tensors), not once
+    per training step."""
+    ct, dp = cameras.camera_type, getattr(cameras, "distortion_params", None)
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if isinstance(t, Tensor) else None for t in (ct, dp))
+    hit = _ELIGIBLE.get(id(cameras))
+    if hit is None or hit[0] != key:
+        err = None
+        if ct is not None and bool((ct != PERSPECTIVE).any()):
+            err = "device ray generation covers PERSPECTIVE cameras; use Cameras.generate_rays otherwise"
+        elif dp is not None and bool((dp != 0).any()):
+            err = "device ray generation covers undistorted cameras; use Cameras.generate_rays otherwise"
+        if len(_ELIGIBLE) >= 64:
+            _ELIGIBLE.clear()
+        hit = _ELIGIBLE[id(cameras)] = (key, err)
+    if hit[1] is not None:
+        raise NotImplementedError(hit[1])
+
+
 def camera_rays(cameras, camera_indices: Tensor, coords: Tensor, bundle_cls=RayBundle):
     """camera_indices [R,1] (or [R]) long, coords [R,2] = (y, x) pixel-centre coordinates."""
-    if cameras.camera_type is not None and bool((cameras.camera_type != PERSPECTIVE).any()):
-        raise NotImplementedError("device ray generation covers PERSPECTIVE cameras; use Cameras.generate_rays otherwise")
-    dp = getattr(cameras, "distortion_params", None)
-    if dp is not None and bool((dp != 0).any()):
-        raise NotImplementedError("device ray generation covers undistorted cameras; use Cameras.generate_rays otherwise")
+    _check_cameras(cameras)
     idx = _chk(camera_indices.reshape(-1).long(), "camera_indices", torch.int64)
     xy = _chk(coords.reshape(-1, 2).to(torch.float32), "coords")
     R, dev = idx.shape[0], idx.device

@@ -184,23 +184,25 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void weights_bwd_kernel(const f
 // indices for that (2 x 150 us per step at 57 344 rays); here every workgroup sums its rays into an LDS image of the
 // table and adds the image once (tables beyond 32 KB go straight to global atomics).
 constexpr int kEmbedLdsFloats = 8192;
+__device__ __forceinline__ int64_t clamp_row(int64_t i, int E) { return i < 0 ? 0 : (i >= E ? E - 1 : i); }
 
 __global__ __launch_bounds__(256) void embedding_lerp_fwd_kernel(const float* __restrict__ wgt,
                                                                  const int64_t* __restrict__ lo,
                                                                  const int64_t* __restrict__ hi,
-                                                                 const float* __restrict__ frac, int64_t R, int D,
+                                                                 const float* __restrict__ frac, int64_t R, int E, int D,
                                                                  float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R * D) return;
   const int64_t r = i / D;
   const int d = (int)(i - r * D);
-  const float a = wgt[lo[r] * D + d];
+  // indices are clamped into the table: a bad sensor / time index must not read (or, in the backward, add) out of bounds
+  const float a = wgt[clamp_row(lo[r], E) * D + d];
   if (!hi) {
     out[i] = a;
     return;
   }
   const float f = frac[r];
-  out[i] = a * (1.f - f) + wgt[hi[r] * D + d] * f;  // the reference's e_lo * (1 - frac) + e_hi * frac
+  out[i] = a * (1.f - f) + wgt[clamp_row(hi[r], E) * D + d] * f;  // the reference's e_lo * (1 - frac) + e_hi * frac
 }
 
 __global__ __launch_bounds__(256) void embedding_lerp_bwd_kernel(const float* __restrict__ g,
@@ -220,11 +222,11 @@ __global__ __launch_bounds__(256) void embedding_lerp_bwd_kernel(const float* __
     const int d = (int)(i - r * D);
     const float gv = g[i];
     if (!hi) {
-      atomicAdd(acc + lo[r] * D + d, gv);
+      atomicAdd(acc + clamp_row(lo[r], E) * D + d, gv);
     } else {
       const float f = frac[r];
-      atomicAdd(acc + lo[r] * D + d, gv * (1.f - f));
-      atomicAdd(acc + hi[r] * D + d, gv * f);
+      atomicAdd(acc + clamp_row(lo[r], E) * D + d, gv * (1.f - f));
+      atomicAdd(acc + clamp_row(hi[r], E) * D + d, gv * f);
     }
   }
   if (in_lds) {
@@ -490,8 +492,8 @@ extern "C" int nrhip_embedding_lerp_fwd(const float* weight, const int64_t* idx_
   NR_REQUIRE(weight && idx_lo && out && r >= 0 && n_embed >= 1 && dim >= 1 && (!idx_hi || frac), NRHIP_ERR_INVALID_ARG,
              "embedding_lerp_fwd: bad argument");
   if (r == 0) return NRHIP_OK;
-  embedding_lerp_fwd_kernel<<<grid_for(r * dim, 256), 256, 0, (hipStream_t)stream>>>(weight, idx_lo, idx_hi, frac, r, dim,
-                                                                                    out);
+  embedding_lerp_fwd_kernel<<<grid_for(r * dim, 256), 256, 0, (hipStream_t)stream>>>(weight, idx_lo, idx_hi, frac, r,
+                                                                                    n_embed, dim, out);
   return check_launch("embedding_lerp_fwd");
 }
 

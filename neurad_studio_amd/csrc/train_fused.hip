@@ -12,7 +12,7 @@
 //   appearance        models/neurad.py:423-441 with the slot arithmetic in the kernel
 //   mask_compact      rows of a boolean ray mask + the inverse map, no host sync (x[mask] is nonzero + a device->host read)
 //   lidar_losses      models/neurad.py:485-521: the three depth terms, the 0.95-quantile robust mean (radix select, no sort),
-//                     intensity, ray-drop BCE -- values and unit gradients in ONE single-workgroup launch
+//                     intensity, ray-drop BCE -- a per-ray pass + one single-workgroup pass; gradients in one scatter
 // One wavefront per ray for the per-ray scans, exactly like composite.hip.
 #include "common.h"
 
@@ -404,26 +404,49 @@ __global__ __launch_bounds__(256) void appearance_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* __restrict__ mask, int64_t R,
                                                             int64_t* __restrict__ rows, int64_t n_out,
                                                             int32_t* __restrict__ inverse, int32_t* __restrict__ count) {
+  // every thread takes 8 consecutive mask bytes per pass (one 8-byte load where the pointer allows): 8192 rays per pass
   __shared__ uint32_t wave_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool aligned = (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
   uint32_t base = 0;
-  for (int64_t start = 0; start < R; start += 1024) {
-    const int64_t i = start + tid;
-    const bool m = i < R && mask[i] != 0;
-    const unsigned long long b = __ballot(m);
-    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(b);
+  for (int64_t start = 0; start < R; start += 8192) {
+    const int64_t i0 = start + 8 * (int64_t)tid;
+    uint32_t bits = 0;  // bit k: ray i0 + k is set
+    if (i0 + 8 <= R && aligned) {
+      const unsigned long long v = *reinterpret_cast<const unsigned long long*>(mask + i0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bits |= ((v >> (8 * k)) & 0xffull) ? (1u << k) : 0u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k < R && mask[i0 + k]) bits |= 1u << k;
+    }
+    const uint32_t c = (uint32_t)__popc(bits);
+    uint32_t incl = c;  // inclusive prefix over the wave's lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     uint32_t before = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-      const uint32_t c = wave_tot[w];
-      before += w < wave ? c : 0u;
-      total += c;
+      const uint32_t t = wave_tot[w];
+      before += w < wave ? t : 0u;
+      total += t;
     }
-    if (i < R) {
-      const uint32_t pos = base + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-      if (m && (int64_t)pos < n_out && rows) rows[pos] = i;
-      if (inverse) inverse[i] = m ? (int32_t)pos : -1;
+    uint32_t pos = base + before + incl - c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = i0 + k;
+      if (i < R) {
+        const bool m = (bits >> k) & 1u;
+        if (m && (int64_t)pos < n_out && rows) rows[pos] = i;
+        if (inverse) inverse[i] = m ? (int32_t)pos : -1;
+        pos += m ? 1u : 0u;
+      }
     }
     base += total;
     __syncthreads();
@@ -431,8 +454,13 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* __res
   if (tid == 0 && count) count[0] = (int32_t)base;
 }
 
-// ---- lidar losses (models/neurad.py:485-521), one workgroup ---------------------------------------------------------
+// ---- lidar losses (models/neurad.py:485-521) ------------------------------------------------------------------------
+// pass 1 (thread per lidar ray, any number of workgroups): per-ray errors and their d/d prediction, per-workgroup partial
+// sums of the plain means; pass 2 (ONE workgroup): the 0.95 quantile of the field level's errors by radix select over an
+// LDS copy, the robust means, the metrics.  The kept-ray scaling of the field level's gradient happens in the backward
+// scatter (it needs the threshold).
 constexpr int kMaxDepthLevels = 4;
+constexpr int kLossLds = 32768;  // errors kept in LDS for the select (128 KB); larger batches re-read them from memory
 struct LidarLossArgs {
   const float* depth[kMaxDepthLevels];  // [R] each: level 0 = the field's depth, 1.. = proposal rounds
   int n_levels;
@@ -445,18 +473,20 @@ struct LidarLossArgs {
   int64_t n;
   float nr_dist, nr_mult, q;
   float* metrics;  // [2 + n_levels]: depth_loss, intensity_loss, ray_drop_loss, depth_loss_0, ...
-  float* unit;     // [(n_levels + 2), n]
-  float* err;      // [n] scratch: the field level's per-ray depth error
+  float* unit;     // [(n_levels + 2), n]: d err / d prediction per ray (rows 0 and n_levels are finished by the backward)
+  float* err;      // [n] the field level's per-ray depth error
+  float* part;     // [blocks, kMaxDepthLevels + 1] partial sums of pass 1: bce, level sums
+  float* stat;     // [4]: threshold, kept count, kept & returned count, (unused)
+  int blocks;
 };
 
-__device__ __forceinline__ float block_sum_1024(float v, float* sh16) {
+__device__ __forceinline__ float block_sum(float v, float* sh16, int nwaves) {
   v = tf_sum(v);
   __syncthreads();  // sh16 may still be read by the previous reduction
   if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = v;
   __syncthreads();
   float t = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) t += sh16[k];
+  for (int k = 0; k < nwaves; ++k) t += sh16[k];
   return t;
 }
 
@@ -470,16 +500,13 @@ __device__ __forceinline__ void depth_l1(float pred, float dist, bool ret, float
   *dpred = (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) * m;
 }
 
-__global__ __launch_bounds__(1024) void lidar_losses_kernel(LidarLossArgs A) {
+__global__ __launch_bounds__(256) void lidar_rays_kernel(LidarLossArgs A) {
   __shared__ float sh16[16];
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_k, s_cle, s_mgt;
-  const int tid = threadIdx.x;
   const int64_t n = A.n;
-  // ---- pass 1: per-ray errors of every level; the proposal levels' means and the BCE are finished here ----
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float bce = 0.f;
   float lsum[kMaxDepthLevels] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t j = tid; j < n; j += 1024) {
+  if (j < n) {
     const int64_t r = A.rows[j];
     const bool ret = A.ret[j] != 0;
     const float dist = A.distance[j];
@@ -490,23 +517,50 @@ __global__ __launch_bounds__(1024) void lidar_losses_kernel(LidarLossArgs A) {
       depth_l1(A.depth[l][r], dist, ret, A.nr_dist, A.nr_mult, &e, &dp);
       if (l == 0) {
         A.err[j] = e;
-        A.unit[j] = dp;  // scaled by keep / count below
+        A.unit[j] = dp;  // x keep / kept count in the backward
       } else {
-        lsum[l] += e;
+        lsum[l] = e;
         A.unit[(int64_t)l * n + j] = dp / (float)n;
       }
     }
     const float x = A.logits[j], y = ret ? 0.f : 1.f;
-    bce += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    bce = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
     A.unit[(int64_t)(A.n_levels + 1) * n + j] = (sigmoidf_(x) - y) / (float)n;
+    A.unit[(int64_t)A.n_levels * n + j] = -2.f * (A.intensity_target[j] - A.intensity[j]);  // x sel / count in the backward
   }
-  const float bce_t = block_sum_1024(bce, sh16);
-  if (tid == 0) A.metrics[2] = bce_t / (float)n;
+  const float b = block_sum(bce, sh16, 4);
+  if (threadIdx.x == 0) A.part[(size_t)blockIdx.x * (kMaxDepthLevels + 1)] = b;
   for (int l = 1; l < A.n_levels; ++l) {
-    const float t = block_sum_1024(lsum[l], sh16);
-    if (tid == 0) A.metrics[2 + l] = t / (float)n;
+    const float t = block_sum(lsum[l], sh16, 4);
+    if (threadIdx.x == 0) A.part[(size_t)blockIdx.x * (kMaxDepthLevels + 1) + l] = t;
   }
-  __syncthreads();  // err[] complete (global writes of this block are visible to it after the barrier)
+}
+
+__global__ __launch_bounds__(1024) void lidar_finish_kernel(LidarLossArgs A) {
+  extern __shared__ float tf_lds[];  // min(n, kLossLds) errors
+  __shared__ float sh16[16];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_k, s_cle, s_mgt;
+  const int tid = threadIdx.x;
+  const int64_t n = A.n;
+  const bool in_lds = n <= kLossLds;
+  const float* err = in_lds ? tf_lds : A.err;
+  if (in_lds)
+    for (int64_t j = tid; j < n; j += 1024) tf_lds[j] = A.err[j];
+  // the plain means: partial sums of pass 1, in a fixed order
+  {
+    float acc[kMaxDepthLevels + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = tid; b < A.blocks; b += 1024)
+#pragma unroll
+      for (int k = 0; k <= kMaxDepthLevels; ++k) acc[k] += A.part[(size_t)b * (kMaxDepthLevels + 1) + k];
+    const float bce = block_sum(acc[0], sh16, 16);
+    if (tid == 0) A.metrics[2] = bce / (float)n;
+    for (int l = 1; l < A.n_levels; ++l) {
+      const float t = block_sum(acc[l], sh16, 16);
+      if (tid == 0) A.metrics[2 + l] = t / (float)n;
+    }
+  }
+  __syncthreads();  // tf_lds complete
   // ---- torch.quantile(err, q), interpolation='linear' (ATen quantile_compute): radix select of the two order stats ----
   const float rank = A.q * (float)(n - 1);  // fp32, as `q * last_index` on a float32 tensor
   const int64_t k_lo = (int64_t)rank;       // rank >= 0
@@ -520,23 +574,26 @@ __global__ __launch_bounds__(1024) void lidar_losses_kernel(LidarLossArgs A) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int64_t j = tid; j < n; j += 1024) {
-      const uint32_t u = __float_as_uint(A.err[j]);
+      const uint32_t u = __float_as_uint(err[j]);
       if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t cum = 0, kk = k, pf = prefix;
-      for (int b = 0; b < 256; ++b) {
-        const uint32_t c = hist[b];
-        if (kk < cum + c) {
-          pf |= (uint32_t)b << shift;
-          kk -= cum;
-          break;
-        }
-        cum += c;
+    if (tid < 64) {  // one wave: 4 bins per lane, prefix over the lanes, the lane whose range holds rank k reports
+      const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+      const uint32_t tot = c0 + c1 + c2 + c3;
+      uint32_t incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (tid >= off) incl += u;
       }
-      s_prefix = pf;
-      s_k = kk;
+      const uint32_t excl = incl - tot;
+      if (k >= excl && k < incl) {
+        uint32_t kk = k - excl, b = 4 * tid;
+        if (kk >= c0) { kk -= c0, ++b; if (kk >= c1) { kk -= c1, ++b; if (kk >= c2) { kk -= c2, ++b; } } }
+        s_prefix = prefix | (b << shift);
+        s_k = kk;
+      }
     }
     __syncthreads();
     prefix = s_prefix;
@@ -550,7 +607,7 @@ __global__ __launch_bounds__(1024) void lidar_losses_kernel(LidarLossArgs A) {
   {
     uint32_t cle = 0, mgt = 0xffffffffu;
     for (int64_t j = tid; j < n; j += 1024) {
-      const uint32_t u = __float_as_uint(A.err[j]);
+      const uint32_t u = __float_as_uint(err[j]);
       cle += u <= prefix ? 1u : 0u;
       if (u > prefix && u < mgt) mgt = u;
     }
@@ -562,33 +619,26 @@ __global__ __launch_bounds__(1024) void lidar_losses_kernel(LidarLossArgs A) {
   const float v_hi = (k_hi == k_lo || (int64_t)s_cle > k_hi || s_mgt == 0xffffffffu) ? v_lo : __uint_as_float(s_mgt);
   // at::lerp: weight < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
   const float thr = wq < 0.5f ? v_lo + wq * (v_hi - v_lo) : v_hi - (v_hi - v_lo) * (1.f - wq);
-  // ---- pass 2: robust means ----
+  // ---- robust means ----
   float dsum = 0.f, dcnt = 0.f, isum = 0.f, icnt = 0.f;
   for (int64_t j = tid; j < n; j += 1024) {
-    const float e = A.err[j];
+    const float e = err[j];
     const bool keep = e < thr;
-    const bool sel = keep && A.ret[j] != 0;
     if (keep) dsum += e, dcnt += 1.f;
-    if (sel) {
+    if (keep && A.ret[j] != 0) {
       const float d = A.intensity_target[j] - A.intensity[j];
       isum += d * d;
       icnt += 1.f;
     }
   }
-  dsum = block_sum_1024(dsum, sh16);
-  dcnt = block_sum_1024(dcnt, sh16);
-  isum = block_sum_1024(isum, sh16);
-  icnt = block_sum_1024(icnt, sh16);
+  dsum = block_sum(dsum, sh16, 16);
+  dcnt = block_sum(dcnt, sh16, 16);
+  isum = block_sum(isum, sh16, 16);
+  icnt = block_sum(icnt, sh16, 16);
   if (tid == 0) {
     A.metrics[0] = dsum / dcnt;
     A.metrics[1] = isum / icnt;
-  }
-  for (int64_t j = tid; j < n; j += 1024) {
-    const float e = A.err[j];
-    const bool keep = e < thr;
-    const bool sel = keep && A.ret[j] != 0;
-    A.unit[j] = keep ? A.unit[j] / dcnt : 0.f;
-    A.unit[(int64_t)A.n_levels * n + j] = sel ? -2.f * (A.intensity_target[j] - A.intensity[j]) / icnt : 0.f;
+    A.stat[0] = thr, A.stat[1] = dcnt, A.stat[2] = icnt, A.stat[3] = 0.f;
   }
 }
 
@@ -596,6 +646,9 @@ struct LidarBwdArgs {
   float* gdepth[kMaxDepthLevels];  // [R] each (may be NULL)
   int n_levels;
   const float* unit;
+  const float* err;        // [n]
+  const float* stat;       // threshold, kept count, kept & returned count
+  const uint8_t* ret;      // [n]
   const int32_t* inverse;  // [R]
   const float* up;         // [2 + n_levels] upstream gradients of the metrics
   int64_t R, n;
@@ -604,16 +657,26 @@ struct LidarBwdArgs {
 };
 __global__ __launch_bounds__(256) void lidar_losses_bwd_kernel(LidarBwdArgs A) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float thr = A.stat[0], dcnt = A.stat[1], icnt = A.stat[2];
   if (i < A.R) {
     const int32_t j = A.inverse[i];
 #pragma unroll
     for (int l = 0; l < kMaxDepthLevels; ++l) {
       if (l >= A.n_levels) break;
-      if (A.gdepth[l]) A.gdepth[l][i] = j >= 0 ? A.unit[(int64_t)l * A.n + j] * A.up[l == 0 ? 0 : 2 + l] : 0.f;
+      if (!A.gdepth[l]) continue;
+      float g = 0.f;
+      if (j >= 0) {
+        g = A.unit[(int64_t)l * A.n + j] * A.up[l == 0 ? 0 : 2 + l];
+        if (l == 0) g = A.err[j] < thr ? g / dcnt : 0.f;
+      }
+      A.gdepth[l][i] = g;
     }
   }
   if (i < A.n) {
-    if (A.gint) A.gint[i] = A.unit[(int64_t)A.n_levels * A.n + i] * A.up[1];
+    if (A.gint) {
+      const bool sel = A.err[i] < thr && A.ret[i] != 0;
+      A.gint[i] = sel ? A.unit[(int64_t)A.n_levels * A.n + i] / icnt * A.up[1] : 0.f;
+    }
     if (A.glogit) A.glogit[i] = A.unit[(int64_t)(A.n_levels + 1) * A.n + i] * A.up[2];
   }
 }
@@ -728,6 +791,12 @@ extern "C" int nrhip_mask_compact(const uint8_t* mask, int64_t r, int64_t* rows,
   return check_launch("mask_compact");
 }
 
+extern "C" int nrhip_lidar_losses_workspace(int64_t n, int64_t* floats) {
+  NR_REQUIRE(floats && n >= 0, NRHIP_ERR_INVALID_ARG, "lidar_losses_workspace: bad argument");
+  *floats = n + 4 + ((n + 255) / 256) * (kMaxDepthLevels + 1);  // err [n], stat [4], per-workgroup partials
+  return NRHIP_OK;
+}
+
 extern "C" int nrhip_lidar_losses(const float* const* depths, int32_t n_levels, const int64_t* lidar_rows,
                                   const float* distance, const uint8_t* did_return, const float* intensity,
                                   const float* intensity_target, const float* ray_drop_logits, int64_t n,
@@ -747,21 +816,31 @@ extern "C" int nrhip_lidar_losses(const float* const* depths, int32_t n_levels, 
   a.n_levels = n_levels, a.rows = lidar_rows, a.distance = distance, a.ret = did_return, a.intensity = intensity;
   a.intensity_target = intensity_target, a.logits = ray_drop_logits, a.n = n;
   a.nr_dist = non_return_distance, a.nr_mult = non_return_mult, a.q = quantile;
-  a.metrics = metrics, a.unit = unit_grads, a.err = scratch;
-  lidar_losses_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a);
+  a.metrics = metrics, a.unit = unit_grads;
+  a.blocks = (int)((n + 255) / 256);
+  a.err = scratch, a.stat = scratch + n, a.part = scratch + n + 4;
+  static thread_local bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)lidar_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kLossLds * (int)sizeof(float));
+    configured = true;
+  }
+  lidar_rays_kernel<<<a.blocks, 256, 0, (hipStream_t)stream>>>(a);
+  lidar_finish_kernel<<<1, 1024, n <= kLossLds ? (size_t)n * sizeof(float) : 0, (hipStream_t)stream>>>(a);
   return check_launch("lidar_losses");
 }
 
-extern "C" int nrhip_lidar_losses_bwd(const float* unit_grads, const int32_t* inverse, const float* upstream,
-                                      int32_t n_levels, int64_t r, int64_t n, float* const* grad_depths,
-                                      float* grad_intensity, float* grad_logits, void* stream) {
-  NR_REQUIRE(unit_grads && inverse && upstream && grad_depths && n_levels >= 1 && n_levels <= kMaxDepthLevels && r >= 0 &&
-                 n >= 0,
+extern "C" int nrhip_lidar_losses_bwd(const float* unit_grads, const float* scratch, const uint8_t* did_return,
+                                      const int32_t* inverse, const float* upstream, int32_t n_levels, int64_t r, int64_t n,
+                                      float* const* grad_depths, float* grad_intensity, float* grad_logits, void* stream) {
+  NR_REQUIRE(unit_grads && scratch && did_return && inverse && upstream && grad_depths && n_levels >= 1 &&
+                 n_levels <= kMaxDepthLevels && r >= 0 && n >= 0,
              NRHIP_ERR_INVALID_ARG, "lidar_losses_bwd: bad argument");
   if (r == 0 && n == 0) return NRHIP_OK;
   LidarBwdArgs a{};
   for (int l = 0; l < n_levels; ++l) a.gdepth[l] = grad_depths[l];
-  a.n_levels = n_levels, a.unit = unit_grads, a.inverse = inverse, a.up = upstream, a.R = r, a.n = n;
+  a.n_levels = n_levels, a.unit = unit_grads, a.err = scratch, a.stat = scratch + n, a.ret = did_return;
+  a.inverse = inverse, a.up = upstream, a.R = r, a.n = n;
   a.gint = grad_intensity, a.glogit = grad_logits;
   const int64_t m = r > n ? r : n;
   lidar_losses_bwd_kernel<<<grid_for(m, 256), 256, 0, (hipStream_t)stream>>>(a);

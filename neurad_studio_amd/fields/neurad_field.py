@@ -130,9 +130,21 @@ class NeuRADField(nn.Module):
         return (g.get_out_dim() == 32 and g.num_levels % 4 == 0 and c.geo_num_layers == 2 and c.nff_num_layers == 3
                 and c.geo_hidden_dim == c.nff_hidden_dim and c.geo_hidden_dim in (32, 64) and c.nff_out_dim == 32)
 
+    def train(self, mode: bool = True):
+        """a mode switch drops the cached host copy of beta: writes through ``beta.data`` (EMA / weight averaging, some
+        optimizers) do not bump the version counter the cache is keyed on, and they happen between training and eval"""
+        self._beta_cache = (None, 0.0)
+        return super().train(mode)
+
+    def invalidate_caches(self) -> None:
+        """call after editing parameters through ``.data`` while staying in one mode"""
+        self._beta_cache = (None, 0.0)
+        self.hashgrid._actor_spec = (None, None)
+
     def _beta_value(self) -> float:
         """|beta| + beta_min as a host float, read from the device only when the parameter changed (an optimizer step or
-        a checkpoint load bumps its version counter) -- not once per eval chunk."""
+        a checkpoint load bumps its version counter; ``train()`` / ``eval()`` / ``invalidate_caches()`` drop it) -- not
+        once per eval chunk."""
         if not self.config.use_sdf:
             return 0.0
         b = self.sdf_to_density.beta

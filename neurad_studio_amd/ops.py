@@ -749,9 +749,13 @@ class ActorSpec:
     actor_scale: float = 10.0
 
     def c_actors(self):
-        cached = getattr(self, "_c_actors", None)  # plain pointers + sizes: valid for as long as this spec's tensors live
-        if cached is not None:
-            return cached
+        # plain pointers + sizes: valid while this spec's tensors are the same storage and `present` is unedited -- re-built
+        # when one of them is re-assigned or `present` is written in place
+        key = (self.timestamps.data_ptr(), self.positions.data_ptr(), self.rotations_6d.data_ptr(), self.present.data_ptr(),
+               self.present._version, self.bounds.data_ptr(), tuple(t.data_ptr() for t in self.tables), self.actor_scale)
+        cached = getattr(self, "_c_actors", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         present = self.present.contiguous()
         present = present.view(torch.uint8) if present.dtype == torch.bool else present.to(torch.uint8)  # bool is 1 byte
         keep = [_chk(self.timestamps, "timestamps"), _chk(self.positions, "positions"),
@@ -768,8 +772,8 @@ class ActorSpec:
         a.tables = ptrs.data_ptr()
         a.actor_scale = float(self.actor_scale)
         a.max_candidates = a.n_actors  # per-ray lists as long as the actor count: no ray can overflow, no host check
-        self._c_actors = (a, (keep, tabs, ptrs))
-        return self._c_actors
+        self._c_actors = (key, (a, (keep, tabs, ptrs)))
+        return self._c_actors[1]
 
 
 def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times):
@@ -1090,8 +1094,8 @@ def mask_compact(mask: Tensor, n_out: int):
 def lidar_losses(depths: Sequence[Tensor], lidar_rows: Tensor, distance: Tensor, did_return: Tensor, intensity: Tensor,
                  intensity_target: Tensor, ray_drop_logits: Tensor, non_return_distance: float, non_return_mult: float,
                  quantile: float):
-    """-> metrics [2 + n_levels] (depth_loss, intensity_loss, ray_drop_loss, depth_loss_0, ...), unit gradients
-    [(n_levels + 2), n]"""
+    """-> metrics [2 + n_levels] (depth_loss, intensity_loss, ray_drop_loss, depth_loss_0, ...), and what the backward
+    needs (per-ray gradients, scratch with the errors / threshold / counts, did_return as uint8)"""
     nl = len(depths)
     ds = [_chk(d.reshape(-1), f"depth[{i}]") for i, d in enumerate(depths)]
     rows = _chk(lidar_rows, "lidar_rows", torch.int64)
@@ -1106,23 +1110,27 @@ def lidar_losses(depths: Sequence[Tensor], lidar_rows: Tensor, distance: Tensor,
     dev = rows.device
     metrics = torch.empty((2 + nl,), device=dev, dtype=torch.float32)
     unit = torch.empty((nl + 2, n), device=dev, dtype=torch.float32)
-    scratch = torch.empty((n,), device=dev, dtype=torch.float32)
+    need = C.c_int64(0)
+    call("nrhip_lidar_losses_workspace", n, C.byref(need))
+    scratch = torch.empty((need.value,), device=dev, dtype=torch.float32)
     pd = (C.c_void_p * nl)(*[d.data_ptr() for d in ds])
     call("nrhip_lidar_losses", C.cast(pd, C.POINTER(C.c_void_p)), nl, _ptr(rows), _ptr(dist), _ptr(ret), _ptr(inten),
          _ptr(tgt), _ptr(lg), n, float(non_return_distance), float(non_return_mult), float(quantile), _ptr(metrics),
          _ptr(unit), _ptr(scratch), _stream())
-    return metrics, unit
+    return metrics, (unit, scratch, ret)
 
 
-def lidar_losses_bwd(unit: Tensor, inverse: Tensor, upstream: Tensor, n_levels: int, n_rays: int, need_depth: Sequence[bool],
+def lidar_losses_bwd(saved, inverse: Tensor, upstream: Tensor, n_levels: int, n_rays: int, need_depth: Sequence[bool],
                      need_intensity: bool = True, need_logits: bool = True):
-    """-> ([grad depth [R,1] or None per level], grad intensity [n,1] or None, grad logits [n,1] or None)"""
+    """saved = what lidar_losses returned beside the metrics.  -> ([grad depth [R,1] or None per level], grad intensity
+    [n,1] or None, grad logits [n,1] or None)"""
+    unit, scratch, ret = saved
     unit, inv, up = _chk(unit, "unit"), _chk(inverse, "inverse", torch.int32), _chk(upstream.reshape(-1), "upstream")
     n, dev = unit.shape[1], unit.device
     gds = [torch.empty((n_rays, 1), device=dev, dtype=torch.float32) if nd else None for nd in need_depth]
     gi = torch.empty((n, 1), device=dev, dtype=torch.float32) if need_intensity else None
     gl = torch.empty((n, 1), device=dev, dtype=torch.float32) if need_logits else None
     pg = (C.c_void_p * n_levels)(*[(0 if g is None else g.data_ptr()) for g in gds])
-    call("nrhip_lidar_losses_bwd", _ptr(unit), _ptr(inv), _ptr(up), n_levels, n_rays, n, C.cast(pg, C.POINTER(C.c_void_p)),
-         _ptr(gi), _ptr(gl), _stream())
+    call("nrhip_lidar_losses_bwd", _ptr(unit), _ptr(scratch), _ptr(ret), _ptr(inv), _ptr(up), n_levels, n_rays, n,
+         C.cast(pg, C.POINTER(C.c_void_p)), _ptr(gi), _ptr(gl), _stream())
     return gds, gi, gl
