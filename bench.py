@@ -820,6 +820,9 @@ def bench_c4(args, device, rank, world):
     del state["out"]
     torch.cuda.empty_cache()
     m.train()
+    with torch.no_grad():  # the operator-level actor path of TRAINING reads fp32 actor grids (the 537 MB static table, the one
+        for gr in m.field.hashgrid.actor_grids:  # that matters, stays fp16 with its fp32 master copy in the optimizer)
+            gr.hash_table.data = gr.hash_table.data.float()
     params = [p for p in m.parameters() if p.requires_grad]
     opt, opt_name = make_optimizer(params)
     from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
@@ -848,7 +851,8 @@ def bench_c4(args, device, rank, world):
                              "rays_per_sec": world * Rt * tsteps / el, "optimizer": opt_name, "loss_finite": bool(torch.isfinite(state["loss"])),
                              "what": "16384 rays of the same scene: sampler + field with actors (operator-level actor path) + "
                                      "compositing + appearance, feature / interlevel / distortion losses, backward, Adam "
-                                     "(fp16-storage tables on an fp32 master copy)"}
+                                     "(fp16-storage static table on an fp32 master copy; the 32 actor grids, 8 MB each, in fp32 for "
+                                     "this step: the operator-level actor path reads fp32 actor grids)"}
     return out
 
 
