@@ -458,7 +458,13 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 // A table fill covers kSub = 4 M / 8 samples (four corner terms per slot on average).  Where almost every entry is distinct
 // (lidar rays at the fine levels) about a quarter of the terms still find a slot and the rest go out as before; where
 // they are not (camera patches) records drop 2 - 10x.  Results: the same sums, each partial rounded to fp32 once more
-// (<= 1e-7 relative); still bit-reproducible run to run.  NRHIP_BIN_DEDUPE=0 selects the round-2 kernels (A/B).
+// (<= 1e-7 relative); still bit-reproducible run to run.
+// MEASURED (profiles/r03_dedupe_ab.txt, c3 step): records halve as predicted -- reduce<1> 326 -> 145 us, reduce<4> 592 ->
+// 352 us per call -- but the merge itself costs more than it saves: emit<1> 539 -> 740 us, emit<4> 754 -> 1333 us,
+// count 93 -> 250 us, the step 8.77 -> 9.51 ms.  LDS atomics on gfx950 retire about ONE LANE PER CLOCK and CU (32 K corner
+// terms x (ds_min + ds_read + F x ds_add_u64) = 95 us per workgroup and level at F = 4), not a full wave per few clocks;
+// the round-2 kernels spend one LDS atomic per RECORD (the queue rank) and are themselves ~60 % bound by it.  The merge is
+// therefore OPT-IN (NRHIP_BIN_DEDUPE=1: parity-tested like the default path) and the default stays the round-2 partition.
 template <int F>
 struct Dedup {
   static constexpr int M = F == 1 ? 8192 : (F == 2 ? 4096 : (F == 4 ? 2048 : 1024));  // slots
@@ -471,9 +477,9 @@ constexpr uint32_t kEmptyKey = 0xffffffffu;
 
 __device__ __forceinline__ uint32_t dedup_slot(uint32_t key, uint32_t mmask) { return (key ^ (key >> 13)) & mmask; }
 
-bool dedupe_enabled() {
+bool dedupe_enabled() {  // opt-in: measured slower on the c3 step (see the note above `Dedup`)
   const char* e = getenv("NRHIP_BIN_DEDUPE");
-  return !(e && e[0] == '0');
+  return e && e[0] == '1';
 }
 
 template <int F>

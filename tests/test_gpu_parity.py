@@ -395,13 +395,15 @@ def test_full_size_properties_config2(ops):
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 4096, 128), (8, 4, 16, 257, 33), (4, 8, 12, 64, 7), (6, 1, 20, 300, 48),
                                  (2, 4, 9, 5, 3), (6, 1, 14, 9001, 128),  # > 64 chunks: the two-level chunk prefix
                                  (6, 1, 14, 9001, 128, 18), (8, 4, 16, 2051, 33, 15)])  # rounds of 2^18 / 2^15 samples
-def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
+@pytest.mark.parametrize("dedupe", [False, True], ids=["partition", "partition+wg-merge"])
+def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, dedupe, monkeypatch):
     """B1 table gradient: the owner-computes path (LDS slices, no memory-side atomics) against the atomic
     scatter-add, from BASELINE config 2 at full size down to ragged batches and tables smaller than one slice.
     Same terms, different summation order -> agreement to fp32 rounding; linearity in grad_out is exact-ish too.
     A sixth entry sets NRHIP_BIN_ROUND_LOG2: the batch then goes through in several rounds."""
     if len(cfg) == 6:
         monkeypatch.setenv("NRHIP_BIN_ROUND_LOG2", str(cfg[5]))
+    monkeypatch.setenv("NRHIP_BIN_DEDUPE", "1" if dedupe else "0")  # the opt-in workgroup-level merge of equal entries
     L, F, lg, R, S = cfg[:5]
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     o, d, area, s, e, eu = _sample_rays(R, S, seed=5)
@@ -431,11 +433,13 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 2048, 64), (8, 4, 16, 257, 33), (6, 1, 14, 300, 48)])
-def test_table_gradient_skips_exactly_zero_samples_exactly(ops, cfg, monkeypatch):
+@pytest.mark.parametrize("dedupe", [False, True], ids=["partition", "partition+wg-merge"])
+def test_table_gradient_skips_exactly_zero_samples_exactly(ops, cfg, dedupe, monkeypatch):
     """Samples whose incoming gradient is exactly zero (the tail of a ray behind an opaque surface; scattered ones; whole
     rays) send no records.  The result must equal the atomic scatter-add of the same gradient, and -- integer
     accumulation -- must not change by a single bit when the silent samples' rows hold -0.0 instead of +0.0 or when
     silent samples sit between two samples of the same cell (they split a merged run, nothing else)."""
+    monkeypatch.setenv("NRHIP_BIN_DEDUPE", "1" if dedupe else "0")
     L, F, lg, R, S = cfg
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     o, d, area, s, e, eu = _sample_rays(R, S, seed=7)
