@@ -88,6 +88,11 @@ typedef struct {
   nrhip_mlp feat;
   int32_t use_sdf;          /* 1: ALPHA = sigmoid(-sdf*beta) ; 0: DENSITY = exp(geo_out) */
   float beta;               /* |beta| + beta_min already applied (model_components/utils.py:38-41) */
+  /* Optional, inference only (both NULL = off): the table re-laid out by nrhip_eval_layout_build and its description
+   * from nrhip_eval_layout_plan (HOST array [L][4]).  nrhip_render_fwd* then reads the coarse levels from their shadow
+   * copies; outputs are bit-identical to the plain table's.  A cache of the caller: rebuild after a parameter change. */
+  const void* eval_table;
+  const uint32_t* eval_layout;
 } nrhip_field;
 
 /* NeuRADProposalField (nerfstudio/fields/neurad_field.py:182-216): grid -> Linear(L*F,1,no bias) -> exp */
@@ -103,6 +108,15 @@ const char* nrhip_last_error(void);
 int nrhip_version(void);
 /* number of CUs / XCDs of the current device (host out-pointers) */
 int nrhip_device_info(int32_t* n_cus, int32_t* n_xcds, int64_t* hbm_bytes);
+
+/* ---- eval-time layout of the coarse levels (csrc/eval_layout.hip) ----------------------------------------------
+ * Levels whose lattice (0 .. ceil(scalings[l]))^3, padded to 2^s per axis, fits the table size are copied into a shadow
+ * region indexed ix | iy << s | iz << 2s (8 corners in 4 cache lines, neighbours share lines); the others keep the
+ * reference hash (encodings.py:419-444).  plan: layout [L][4] = {mulY, mulZ, mask, row0} per level and the eval table's
+ * row count (host outputs, no GPU needed); build: fills eval_table [rows, F] (table's dtype) from the table.        */
+int nrhip_eval_layout_plan(const nrhip_grid* g, uint32_t* layout /*host [L*4]*/, int64_t* rows /*host*/);
+int nrhip_eval_layout_build(const nrhip_grid* g, const void* table, const uint32_t* layout /*host*/, void* eval_table,
+                            void* stream);
 
 /* ---- H1: hash grid (replaces HashEncoding.pytorch_fwd, encodings.py:425-466; tcnn.Encoding
  *          {otype:"HashGrid"} call sites encodings.py:362-373,468-471) --------------------------- */

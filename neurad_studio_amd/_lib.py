@@ -36,7 +36,8 @@ class Rays(C.Structure):
 
 class Field(C.Structure):
     _fields_ = [("grid", Grid), ("table", C.c_void_p), ("static_scale", C.c_float), ("geo", Mlp), ("feat", Mlp),
-                ("use_sdf", C.c_int32), ("beta", C.c_float)]
+                ("use_sdf", C.c_int32), ("beta", C.c_float), ("eval_table", C.c_void_p),
+                ("eval_layout", C.POINTER(C.c_uint32))]
 
 
 class Proposal(C.Structure):
@@ -79,6 +80,8 @@ P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 PROTOTYPES = {
     "nrhip_version": [],
     "nrhip_device_info": [C.POINTER(I32), C.POINTER(I32), C.POINTER(I64)],
+    "nrhip_eval_layout_plan": [C.POINTER(Grid), C.POINTER(C.c_uint32), C.POINTER(I64)],
+    "nrhip_eval_layout_build": [C.POINTER(Grid), P, C.POINTER(C.c_uint32), P, P],
     "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],

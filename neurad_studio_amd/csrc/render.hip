@@ -53,6 +53,7 @@ struct FieldDev {
   const float* fw2; const float* fb2;   // feat layer 2: [32][H]
   int use_sdf;
   float beta;
+  uint32_t lay[NRHIP_MAX_LEVELS * 4];  // RELAY kernels: {mulY, mulZ, mask, row0} per level of the eval table (eval_layout.hip)
 };
 
 // Training forward (nrhip_field_fwd_train): what the hand-written backward needs, written in the layouts the
@@ -85,7 +86,8 @@ struct Lds {
   static constexpr int BF2 = BF1 + H;
   static constexpr int SCAL = BF2 + 32;    // per-level scalings
   static constexpr int RB = SCAL + NRHIP_MAX_LEVELS;  // per wave: this ray's bias of feat L0 (fb0 + SH part), 4 x H
-  static constexpr int TOTAL = RB + 4 * H;
+  static constexpr int LAY = RB + 4 * H;   // RELAY: per-level {mulY, mulZ, mask, row0} (uint32), 16-byte aligned
+  static constexpr int TOTAL = LAY + 4 * NRHIP_MAX_LEVELS;
   // ACT instantiations only:
   static constexpr int SHF = TOTAL;             // feat L0 SH part in fragment order: NB blocks x 4 steps
   static constexpr int ASCAL = SHF + 16 * H;    // actor grid: per-level scalings
@@ -367,9 +369,28 @@ __device__ __forceinline__ void load_pending(PendingTile& p, int64_t pos, int t,
 
 // H2 + H3 + the hash of H1 for one pending tile, then all gathers issued back to back (no waits in here beyond the
 // pending tile's own small loads, which were issued a whole tile earlier).
-template <int L, int F, bool HALF>
+// hash_corners with the level's own multipliers and mask (eval_layout.hip): the reference hash for the levels that keep it,
+// ix | iy << s | iz << 2s for the shadow levels -- one code path; the offsets are re-derived at blend time as before
+__device__ __forceinline__ void layout_corners(float x, float y, float z, float scale, uint32_t my, uint32_t mz,
+                                               uint32_t mask, uint32_t (&idx)[8]) {
+  const float sx = __fmul_rn(x, scale), sy = __fmul_rn(y, scale), sz = __fmul_rn(z, scale);
+  const uint32_t ifx = (uint32_t)(int)floorf(sx), ify = (uint32_t)(int)floorf(sy), ifz = (uint32_t)(int)floorf(sz);
+  const uint32_t icx = (uint32_t)(int)ceilf(sx), icy = (uint32_t)(int)ceilf(sy), icz = (uint32_t)(int)ceilf(sz);
+  const uint32_t hyc = icy * my, hyf = ify * my, hzc = icz * mz, hzf = ifz * mz;
+  idx[0] = (icx ^ hyc ^ hzc) & mask;
+  idx[1] = (icx ^ hyf ^ hzc) & mask;
+  idx[2] = (ifx ^ hyf ^ hzc) & mask;
+  idx[3] = (ifx ^ hyc ^ hzc) & mask;
+  idx[4] = (icx ^ hyc ^ hzf) & mask;
+  idx[5] = (icx ^ hyf ^ hzf) & mask;
+  idx[6] = (ifx ^ hyf ^ hzf) & mask;
+  idx[7] = (ifx ^ hyc ^ hzf) & mask;
+}
+
+template <int L, int F, bool HALF, bool RELAY = false>
 __device__ __forceinline__ void issue_tile(const FieldDev& fd, const PendingTile& pt, int g, uint32_t mask,
-                                           const float* scal_lds, TileFetch<L / 4, F>& tf) {
+                                           const float* scal_lds, TileFetch<L / 4, F>& tf,
+                                           const uint32_t* lay_lds = nullptr) {
   constexpr int LPL = L / 4;
   tf.t0 = pt.t0;
   tf.t1 = pt.t1;
@@ -377,10 +398,18 @@ __device__ __forceinline__ void issue_tile(const FieldDev& fd, const PendingTile
   tf.x = p.x, tf.y = p.y, tf.z = p.z, tf.std = p.std;
 #pragma unroll
   for (int q = 0; q < LPL; ++q) {
-    const Corners cs = hash_corners(p.x, p.y, p.z, scal_lds[q], mask);
+    if constexpr (RELAY) {
+      const uint4 ly = *reinterpret_cast<const uint4*>(lay_lds + 4 * q);  // mulY, mulZ, mask, row0 of this lane's level
+      uint32_t idx[8];
+      layout_corners(p.x, p.y, p.z, scal_lds[q], ly.x, ly.y, ly.z, idx);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      Entry<F, HALF>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs.idx[k], tf.fv[q][k]);
+      for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(fd.table, ly.w + idx[k], tf.fv[q][k]);
+    } else {
+      const Corners cs = hash_corners(p.x, p.y, p.z, scal_lds[q], mask);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        Entry<F, HALF>::load(fd.table, ((uint32_t)(LPL * g + q) << fd.grid.log2T) + cs.idx[k], tf.fv[q][k]);
+    }
   }
 }
 
@@ -522,7 +551,7 @@ __device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const fl
 }
 
 // L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2, ACT = dynamic actors.
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false>
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(
     FieldDev fd, int64_t n_rays, int S, int stride, const int32_t* __restrict__ order, const float* __restrict__ ro,
     const float* __restrict__ rd, const float* __restrict__ rarea, const float* __restrict__ rstarts,
@@ -536,6 +565,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   static_assert(!ACT || COMPOSITE, "actors: composited eval kernel (static and actor tables share one storage type)");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
   static_assert(!SPLIT || (COMPOSITE && !ACT), "split-bf16 matrix products: the composited static-scene kernel");
+  static_assert(!RELAY || (COMPOSITE && !ACT && !SPLIT), "eval-table layout: the composited static-scene kernel");
   using Ld = Lds<H, SPLIT>;
   constexpr int NB = H / 16;
   constexpr int LPL = L / 4;         // levels per lane
@@ -547,6 +577,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   if constexpr (ACT) {
     for (int e = threadIdx.x; e < 16 * H; e += 256) lds[Ld::SHF + e] = frag_src<true, NB, 4>(fd.fw0 + 32, 48, 0, e);
     if (threadIdx.x < ad.La) lds[Ld::ASCAL + threadIdx.x] = ad.scal[threadIdx.x];
+  }
+  if constexpr (RELAY) {
+    if (threadIdx.x < 4 * L) reinterpret_cast<uint32_t*>(lds + Ld::LAY)[threadIdx.x] = fd.lay[threadIdx.x];
   }
   __syncthreads();
 
@@ -568,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   const int64_t pos_step = (int64_t)nblk * 4;
 
   const float* scal_l = lds + Ld::SCAL + LPL * g;  // this lane's levels (re-read per tile: 1 ds_read, no VGPRs held)
+  const uint32_t* lay_l = reinterpret_cast<const uint32_t*>(lds + Ld::LAY) + 4 * LPL * g;  // RELAY: their layout constants
   float* rbw = lds + Ld::RB + wid * H;              // this wave's per-ray bias row
   int64_t pos = lo + (int64_t)lb * 4 + wid;
   if (pos >= rr.end) return;
@@ -582,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   load_pending(q, pos, 0, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);
   int64_t ray = q.ray;
   if constexpr (ACT) issue_tile_actors<L, F, HALF>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
-  else issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
+  else issue_tile<L, F, HALF, RELAY>(fd, q, g, mask, scal_l, tf, lay_l);
   {
     const bool wrap = ntile == 1;
     load_pending(q, wrap ? pos + pos_step : pos, wrap ? 0 : 1, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);
@@ -673,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     const int nt = q.t;
     // unconditional (see load_pending)
     if constexpr (ACT) issue_tile_actors<L, F, HALF>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
-    else issue_tile<L, F, HALF>(fd, q, g, mask, scal_l, tf);
+    else issue_tile<L, F, HALF, RELAY>(fd, q, g, mask, scal_l, tf, lay_l);
     {
       const bool wrap = nt + 1 == ntile;  // request the small loads of the tile after it
       load_pending(q, wrap ? npos + pos_step : npos, wrap ? 0 : nt + 1, rr, j, order, ro, rd, rarea, rstarts, rends,
@@ -915,6 +949,8 @@ static FieldDev to_dev(const nrhip_field& f) {
   d.fw2 = f.feat.weight[2], d.fb2 = f.feat.bias[2];
   d.use_sdf = f.use_sdf;
   d.beta = f.beta;
+  for (int i = 0; i < NRHIP_MAX_LEVELS * 4; ++i)
+    d.lay[i] = (f.eval_table && f.eval_layout && i < 4 * f.grid.num_levels) ? f.eval_layout[i] : 0u;
   return d;
 }
 
@@ -929,12 +965,12 @@ struct ActorLaunch {
   const void* const* tables;
 };
 
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false>
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
                          float* oal, const SaveDev& sv, float stop_eps, hipStream_t st,
                          const ActorLaunch& al = ActorLaunch()) {
   constexpr size_t lds = (ACT ? Lds<H, SPLIT>::TOTAL_ACT : Lds<H, SPLIT>::TOTAL) * sizeof(float);
-  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT, SPLIT>;
+  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT, SPLIT, RELAY>;
   static int cap = 0;  // persistent grid: CUs x resident workgroups per CU, queried once per instantiation
   if (!cap) {
     if (lds > 64 * 1024)
@@ -979,6 +1015,21 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
       SCASE(8, 4)
       SCASE(4, 8)
 #undef SCASE
+    }
+  }
+  if constexpr (COMPOSITE) {
+    // eval table given (nrhip_field.eval_table / eval_layout): the coarse levels are read from their shadow copies
+    if (f->eval_table && f->eval_layout) {
+      FieldDev fe = fd;
+      fe.table = f->eval_table;
+#define RCASE(L_, F_, H_)                                                                                              \
+  if (L == L_ && F == F_ && H == H_)                                                                                   \
+    return half ? launch_render<L_, F_, H_, true, true, false, false, true>(fe, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)  \
+                : launch_render<L_, F_, H_, false, true, false, false, true>(fe, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+      RCASE(16, 2, 64)
+      RCASE(8, 4, 32)
+      RCASE(8, 4, 64)
+#undef RCASE
     }
   }
 #define CASE(L_, F_, H_)                                                                                          \

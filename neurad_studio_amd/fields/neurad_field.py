@@ -140,6 +140,7 @@ class NeuRADField(nn.Module):
         """call after editing parameters through ``.data`` while staying in one mode"""
         self._beta_cache = (None, 0.0)
         self.hashgrid._actor_spec = (None, None)
+        ops.clear_eval_tables()
 
     def _beta_value(self) -> float:
         """|beta| + beta_min as a host float, read from the device only when the parameter changed (an optimizer step or

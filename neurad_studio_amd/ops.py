@@ -365,7 +365,7 @@ class FieldSpec:
     use_sdf: bool = True
     beta: float = 20.0 + 1e-4  # |beta| + beta_min (model_components/utils.py:38-41)
 
-    def c_field(self):
+    def c_field(self, eval_layout: bool = False):
         f = _lib.Field()
         f.grid = self.grid.c_grid(self.table)
         f.table = self.table.data_ptr()
@@ -374,7 +374,61 @@ class FieldSpec:
         f.feat, k2 = _c_mlp(self.feat_w, self.feat_b)
         f.use_sdf = 1 if self.use_sdf else 0
         f.beta = float(self.beta)
-        return f, (k1, k2)
+        k3 = None
+        if eval_layout:  # inference: the coarse levels from their shadow copies (bit-identical outputs)
+            k3 = eval_table(self.grid, self.table)
+            if k3 is not None:
+                f.eval_table, f.eval_layout = k3[0].data_ptr(), k3[1]
+        return f, (k1, k2, k3)
+
+
+# Eval-time layout of the coarse levels (csrc/eval_layout.hip).  NRHIP_EVAL_RELAYOUT=0 switches it off (A/B).
+_EVAL_RELAYOUT = os.environ.get("NRHIP_EVAL_RELAYOUT", "1") != "0"
+_EVAL_TABLES: dict = {}  # (data_ptr, version, dtype, shape, grid key) -> (eval table, layout array, n shadow levels)
+
+
+def eval_layout_plan(spec: GridSpec, table_dtype=torch.float32):
+    """host logic: -> (layout ctypes array [L*4] = {mulY, mulZ, mask, row0} per level, rows of the eval table, number of
+    levels that get a shadow copy)"""
+    g = _lib.Grid()
+    g.num_levels, g.n_features, g.log2_table_size = spec.num_levels, spec.features_per_level, spec.log2_hashmap_size
+    g.param_dtype = 1 if table_dtype == torch.float16 else 0
+    for i, v in enumerate(spec.scalings.tolist()):
+        g.scalings[i] = v
+    lay = (C.c_uint32 * (4 * spec.num_levels))()
+    rows = C.c_int64(0)
+    call("nrhip_eval_layout_plan", C.byref(g), lay, C.byref(rows))
+    n_shadow = sum(1 for l in range(spec.num_levels) if lay[4 * l] != 2654435761)
+    return lay, rows.value, n_shadow
+
+
+def eval_table(spec: GridSpec, table: Tensor):
+    """The table re-laid out for inference, cached per (storage, in-place version): -> (eval table, layout) or None when no
+    level qualifies or the layout is switched off.  A derived buffer: the parameter (and the state_dict) stay as they are;
+    writes through ``table.data`` do not bump the version -- call ``clear_eval_tables()`` after such edits."""
+    if not _EVAL_RELAYOUT or not table.is_cuda:
+        return None
+    key = (table.data_ptr(), table._version, table.dtype, tuple(table.shape), spec.num_levels, spec.min_res, spec.max_res)
+    hit = _EVAL_TABLES.get(key)
+    if hit is None:
+        lay, rows, n_shadow = eval_layout_plan(spec, table.dtype)
+        if n_shadow == 0:
+            hit = (None, None)
+        else:
+            out = torch.empty((rows, spec.features_per_level), device=table.device, dtype=table.dtype)
+            g = spec.c_grid(table)
+            call("nrhip_eval_layout_build", C.byref(g), _ptr(table), lay, _ptr(out), _stream())
+            hit = (out, lay)
+        for k in [k for k in _EVAL_TABLES if k[0] == key[0] and k != key]:  # older versions of the same parameter
+            del _EVAL_TABLES[k]
+        if len(_EVAL_TABLES) >= 4:
+            _EVAL_TABLES.clear()
+        _EVAL_TABLES[key] = hit
+    return None if hit[0] is None else hit
+
+
+def clear_eval_tables() -> None:
+    _EVAL_TABLES.clear()
 
 
 def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, order: Optional[Tensor] = None):
@@ -413,7 +467,7 @@ def render_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, ret
     early_stop_eps > 0 (eval option, default exact): rays stop once their transmittance is below it.
     order: processing order from ``ray_order`` (locality hint; outputs stay in batch order)."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends, order)
-    f, keep2 = fs.c_field()
+    f, keep2 = fs.c_field(eval_layout=not fs.table.requires_grad)
     R, S = r.n_rays, r.n_samples
     dev = origins.device
     if out is None:

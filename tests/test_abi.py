@@ -194,3 +194,30 @@ def test_power_sampler_ordered_host_checks(lib):
     assert fn(*args(-1, 8)) != 0 and b"bad argument" in lib.nrhip_last_error()
     assert fn(*args(4, 0)) != 0
     assert fn(*args(4, 8)) != 0 and b"NULL" in lib.nrhip_last_error()
+
+
+def test_eval_layout_plan_is_host_logic(lib):
+    """nrhip_eval_layout_plan needs no GPU: levels whose lattice, padded to 2^s per axis, fits the table get a shadow region
+    (power-of-two multipliers: OR == XOR), the others keep the reference's primes; regions are back to back."""
+    fn = lib.nrhip_eval_layout_plan
+    fn.restype = ctypes.c_int
+    g = _grid(16, 2, 19)
+    for i in range(16):  # BASELINE config[1]: floor(16 * g^l), g = 64^(1/15)
+        g.scalings[i] = float(int(16 * (64 ** (1 / 15)) ** i + 1e-9))
+    lay = (ctypes.c_uint32 * 64)()
+    rows = ctypes.c_int64(0)
+    assert fn(ctypes.byref(g), lay, ctypes.byref(rows)) == 0
+    acc = 0
+    for l in range(16):
+        my, mz, mask, row0 = lay[4 * l:4 * l + 4]
+        assert row0 == acc
+        if g.scalings[l] < 64:  # coordinates 0..ceil(scale) fit s bits with 3 s <= 19
+            s = my.bit_length() - 1
+            assert my == 1 << s and mz == 1 << (2 * s) and mask == (1 << (3 * s)) - 1 and (1 << s) > g.scalings[l]
+            acc += 1 << (3 * s)
+        else:
+            assert (my, mz, mask) == (2654435761, 805459861, (1 << 19) - 1)
+            acc += 1 << 19
+    assert rows.value == acc < 16 << 19
+    assert fn(ctypes.byref(g), None, ctypes.byref(rows)) != 0
+
