@@ -382,8 +382,11 @@ class FieldSpec:
         return f, (k1, k2, k3)
 
 
-# Eval-time layout of the coarse levels (csrc/eval_layout.hip).  NRHIP_EVAL_RELAYOUT=0 switches it off (A/B).
-_EVAL_RELAYOUT = os.environ.get("NRHIP_EVAL_RELAYOUT", "1") != "0"
+# Eval-time layout of the coarse levels (csrc/eval_layout.hip).  OPT-IN (NRHIP_EVAL_RELAYOUT=1): on BASELINE config[1] it
+# takes the render kernel's fabric reads from 5.53 M to 4.09 M per launch (HBM traffic 708 -> 511 MB, below the algorithmic
+# 542 MB) and the kernel from 168.7 to 173.1 us -- the kernel is not bound by those bytes (DESIGN.md §9,
+# profiles/r03_eval_relayout.txt); outputs are bit-identical either way.
+_EVAL_RELAYOUT = os.environ.get("NRHIP_EVAL_RELAYOUT", "0") == "1"
 _EVAL_TABLES: dict = {}  # (data_ptr, version, dtype, shape, grid key) -> (eval table, layout array, n shadow levels)
 
 
