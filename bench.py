@@ -538,12 +538,13 @@ def bench_c1(args, device, rank, world):
         import dataclasses
 
         fs16 = dataclasses.replace(fs, table=fs.table.half())
-        out["variants_not_headline"] = {
-            "fp16_table_kernel_us": kernel_us(fs16),
-            "early_stop_eps_1e-4_kernel_us": kernel_us(fs, early_stop_eps=1e-4),
-            "what": "render_kernel on the headline batch with (a) the hash table stored as fp16 (half the gather bytes, "
-                    "arithmetic unchanged) and (b) rays stopped once their transmittance is below 1e-4 (error bounded by "
-                    "it); neither is the headline configuration"}
+        if not args.no_variants:
+            out["variants_not_headline"] = {
+                "fp16_table_kernel_us": kernel_us(fs16),
+                "early_stop_eps_1e-4_kernel_us": kernel_us(fs, early_stop_eps=1e-4),
+                "what": "render_kernel on the headline batch with (a) the hash table stored as fp16 (half the gather bytes, "
+                        "arithmetic unchanged) and (b) rays stopped once their transmittance is below 1e-4 (error bounded "
+                        "by it); neither is the headline configuration"}
     return out, (fs, origins, dirs, area, state["edges"], feats)
 
 
@@ -868,6 +869,9 @@ def main():
     ap.add_argument("--no-rgb-decoder", action="store_true", help="train_full / c3 without the RGB CNN decoder (round-2 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train iters/sec sections")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="c1: skip the two labelled non-headline launches of the render kernel (profiling runs: their "
+                         "launches would enter the per-kernel averages)")
     ap.add_argument("--train-steps", type=int, default=60)
     ap.add_argument("--train-full-steps", type=int, default=30, help="0 skips the train_full section")
     args = ap.parse_args()

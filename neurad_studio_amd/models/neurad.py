@@ -114,6 +114,122 @@ class FusedEvalMixin:
         return nff
 
 
+class FusedTrainMixin:
+    """Training-time ``get_nff_outputs`` of a STATIC scene as a handful of autograd nodes (autograd.ProposalRoundFn per
+    sampler round, autograd.NffRenderTrainFn for field + head + compositing + appearance) instead of the reference's
+    orchestration over RaySamples views -- same outputs, ~1/4 of the launches.  Mixed into ``NeuRADHotPath`` and into the
+    nerfstudio plugin model (integration/neurad_hip.py: a subclass of the reference's NeuRADModel); expects on ``self`` what
+    ``NeuRADModel.populate_modules`` builds (models/neurad.py:167-254)."""
+
+    fused_training: bool = True
+    """False keeps the operator-level path (the reference's own orchestration over this package's modules): A/B, debugging."""
+    reference_output_keys: bool = False
+    """True (the plugin): also return ``non_nearby_weights`` as the reference's get_metrics_dict consumes it
+    (models/neurad.py:508: only its squared sum is used) -- here the DENSE masked weights, same squared sum, no nonzero /
+    host sync."""
+
+    def _carving_cfg(self):
+        c = getattr(self.config, "loss", self.config)  # the reference keeps these under config.loss (models/neurad.py:79,87)
+        return c.carving_epsilon, c.non_return_lidar_distance
+
+    def _scale_pixel_area_nosync(self, ray_bundle) -> None:
+        """_scale_pixel_area (models/neurad.py:702-709) as one ``where``: the reference's masked assignment is an index_put
+        with a boolean mask, i.e. a nonzero + a device->host read per step"""
+        up2 = float(self.config.rgb_upsample_factor**2)
+        is_lidar = ray_bundle.metadata.get("is_lidar")
+        if is_lidar is None:
+            ray_bundle.pixel_area = ray_bundle.pixel_area * up2
+        else:
+            ray_bundle.pixel_area = torch.where(is_lidar, ray_bundle.pixel_area, ray_bundle.pixel_area * up2)
+
+    def fused_training_possible(self) -> bool:
+        f = self.field
+        return (self.fused_training and self.training and torch.is_grad_enabled() and f.fused_training and f.config.use_sdf
+                and not f.hashgrid.has_actors() and f.fused_supported() and f._fused_train_ok()
+                and not any(p.hashgrid.has_actors() for p in self.proposal_fields)
+                and isinstance(self.sampler.initial_sampler, PowerSampler) and not self.config.normalize_depth)
+
+    def _fused_train_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool) -> Dict[str, Tensor]:
+        """get_nff_outputs (models/neurad.py:368-421) without the RaySamples plumbing: bin edges [R,S+1] go from kernel to
+        kernel.  ``ray_samples_list`` holds light RaySamples (edges as views, no deltas / metadata: the carving terms
+        recompute their masks from the edges)."""
+        cfg, smp = self.config, self.sampler
+        sky = cfg.sampling.sky_distance
+        self._scale_pixel_area_nosync(ray_bundle)
+        if ray_bundle.fars is None:
+            ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
+        else:
+            ray_bundle.fars.clamp_max_(sky)
+        if ray_bundle.nears is None:
+            ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
+        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        a = ray_bundle.pixel_area.reshape(-1)
+        R, dev = o.shape[0], o.device
+        init, pdf = smp.initial_sampler, smp.pdf_sampler
+        rounds = smp.num_proposal_network_iterations
+        counts = tuple(smp.num_proposal_samples_per_ray[:rounds]) + (smp.num_nerf_samples_per_ray,)
+        fn = PowerSpacing(ray_bundle.nears, ray_bundle.fars, init.lambda_, init.scaling)
+        t_rand = None
+        if init.train_stratified and init.training:
+            t_rand = (torch.rand((R, 1), device=dev).expand(R, counts[0] + 1).contiguous() if init.single_jitter
+                      else torch.rand((R, counts[0] + 1), device=dev))
+        sp, eu = ops.power_sampler(ray_bundle.nears, ray_bundle.fars, counts[0], init.lambda_, init.scaling, t_rand)
+        pfs = list(self.proposal_fields)
+        if getattr(self, "reproduce_late_binding_quirk", True):
+            pfs = [pfs[-1]] * len(pfs)
+        train_props = smp._proposals_train_this_step()
+        nff: Dict[str, Tensor] = {}
+        weights_list, samples_list = [], []
+        lidar_terms = self.training and calc_lidar_losses
+        if lidar_terms:
+            md = ray_bundle.metadata
+            carve = (md["is_lidar"], md.get("did_return"), md["directions_norm"], *self._carving_cfg())
+        for k in range(rounds):
+            pf = pfs[k]
+            g = pf.hashgrid.static_grid
+            with contextlib.nullcontext() if train_props else torch.no_grad():  # frozen between scheduled updates
+                w, pdepth = ag.ProposalRoundFn.apply(g.hash_table, pf.density_decoder.weight, g.spec, pf.hashgrid.static_scale,
+                                                     o, d, a, eu)
+            weights_list.append(w[..., None])
+            samples_list.append(_light_samples(ray_bundle, sp, eu, fn))
+            nff[f"prop_depth_{k}"] = pdepth
+            if lidar_terms:
+                nff[f"prop_weights_loss_{k}"] = ag.CarvingLossFn.apply(w, eu[:, :-1], eu[:, 1:], *carve)
+            rand = None
+            if pdf.train_stratified and pdf.training:
+                rand = torch.rand((R,) if pdf.single_jitter else (R, counts[k + 1] + 1), device=dev)
+            wd = w.detach()
+            sp, eu = ops.pdf_sample(wd if smp._anneal == 1.0 else wd.pow(smp._anneal), sp, fn.nears, fn.fars, counts[k + 1],
+                                    fn.lam, fn.scaling, pdf.histogram_padding, rand)
+        if train_props:
+            smp._steps_since_update = 0
+        eu[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
+        sp[:, -1] = 1 - EPS
+        appearance = None
+        if cfg.appearance_dim > 0:
+            sensor = ray_bundle.metadata.get("sensor_idxs")
+            assert sensor is not None, "sensor_idxs must be present in metadata during training"
+            appearance = (self.appearance_embedding.weight, sensor, ray_bundle.times if cfg.use_temporal_appearance else None,
+                          (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance)))
+        features, depth, accumulation, w_ns = self.field.render_train(o, d, a, eu, appearance)
+        nff.update(features=features, depth=depth, accumulation=accumulation)
+        S = counts[-1]
+        if self.training:
+            nff["weights_list"] = weights_list + [w_ns[..., None]]
+            # the sky sample plays no further role: the first S-1 samples = the first S edges
+            nff["ray_samples_list"] = samples_list + [_light_samples(ray_bundle, sp[:, :S], eu[:, :S], fn)]
+        if lidar_terms:
+            # sum((w * (is_lidar & ~is_close))^2) of the final samples: what the reference forms from `non_nearby_weights`
+            # (models/neurad.py:410-419,508-509) -- selecting them needs a nonzero + a host sync
+            if self.reference_output_keys:
+                close, _, _ = ops.lidar_carving(eu[:, :S - 1], eu[:, 1:S], *carve, want_mask=True)
+                nff["non_nearby_weights"] = (w_ns * (carve[0].reshape(-1, 1) & ~close))[..., None]
+                nff["non_nearby_lidar_ray_indices"] = None  # (unused by the reference: models/neurad.py:507)
+            else:
+                nff["non_nearby_weights_loss"] = ag.CarvingLossFn.apply(w_ns, eu[:, :S - 1], eu[:, 1:S], *carve)
+        return nff
+
+
 def _light_samples(rb: RayBundle, sp: Tensor, eu: Tensor, fn) -> RaySamples:
     """RaySamples of the fused training path: S samples from S+1 edges, every field a VIEW (per-ray fields stride-0 like
     rays.py:336-355, starts / ends two views of the edge tensor); no deltas, no metadata -- nothing is launched"""
@@ -172,7 +288,7 @@ class NeuRADHotPathConfig:
     consumer of the rendered features (SURVEY §8(f) row 1); the RGB CNN decoder stays in neurad-studio."""
 
 
-class NeuRADHotPath(FusedEvalMixin, nn.Module):
+class NeuRADHotPath(FusedEvalMixin, FusedTrainMixin, nn.Module):
     def __init__(self, config: NeuRADHotPathConfig, static_scale: float, num_sensors: int = 1, duration: float = 1.0,
                  actors=None) -> None:
         super().__init__()
@@ -332,95 +448,6 @@ class NeuRADHotPath(FusedEvalMixin, nn.Module):
         ray = lambda t: t[:, 0, 0]  # noqa: E731  (per-ray metadata is broadcast over the samples)
         return (starts, ends, ray(md["is_lidar"]), ray(md["did_return"]) if "did_return" in md else None,
                 ray(md["directions_norm"]), self.config.carving_epsilon, self.config.non_return_lidar_distance)
-
-    # ---- training step on the fused nodes ---------------------------------------------------------
-    fused_training: bool = True
-    """Static scenes, grad enabled: get_nff_outputs as a handful of autograd nodes (autograd.ProposalRoundFn per sampler
-    round, autograd.NffRenderTrainFn for field + head + compositing + appearance) instead of the reference's orchestration
-    over RaySamples views -- same outputs, ~1/4 of the launches.  False keeps the operator-level path (A/B, debugging)."""
-
-    def fused_training_possible(self) -> bool:
-        f = self.field
-        return (self.fused_training and self.training and torch.is_grad_enabled() and f.fused_training and f.config.use_sdf
-                and not f.hashgrid.has_actors() and f.fused_supported() and f._fused_train_ok()
-                and not any(p.hashgrid.has_actors() for p in self.proposal_fields)
-                and isinstance(self.sampler.initial_sampler, PowerSampler) and not self.config.normalize_depth)
-
-    def _fused_train_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool) -> Dict[str, Tensor]:
-        """get_nff_outputs (models/neurad.py:368-421) without the RaySamples plumbing: bin edges [R,S+1] go from kernel to
-        kernel.  ``ray_samples_list`` holds light RaySamples (edges as views, no deltas / metadata: the carving terms
-        recompute their masks from the edges)."""
-        cfg, smp = self.config, self.sampler
-        sky = cfg.sampling.sky_distance
-        self._scale_pixel_area(ray_bundle)
-        if ray_bundle.fars is None:
-            ray_bundle.fars = torch.full_like(ray_bundle.pixel_area, sky)
-        else:
-            ray_bundle.fars.clamp_max_(sky)
-        if ray_bundle.nears is None:
-            ray_bundle.nears = torch.zeros_like(ray_bundle.fars)
-        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
-        a = ray_bundle.pixel_area.reshape(-1)
-        R, dev = o.shape[0], o.device
-        init, pdf = smp.initial_sampler, smp.pdf_sampler
-        rounds = smp.num_proposal_network_iterations
-        counts = tuple(smp.num_proposal_samples_per_ray[:rounds]) + (smp.num_nerf_samples_per_ray,)
-        fn = PowerSpacing(ray_bundle.nears, ray_bundle.fars, init.lambda_, init.scaling)
-        t_rand = None
-        if init.train_stratified and init.training:
-            t_rand = (torch.rand((R, 1), device=dev).expand(R, counts[0] + 1).contiguous() if init.single_jitter
-                      else torch.rand((R, counts[0] + 1), device=dev))
-        sp, eu = ops.power_sampler(ray_bundle.nears, ray_bundle.fars, counts[0], init.lambda_, init.scaling, t_rand)
-        pfs = list(self.proposal_fields)
-        if self.reproduce_late_binding_quirk:
-            pfs = [pfs[-1]] * len(pfs)
-        train_props = smp._proposals_train_this_step()
-        nff: Dict[str, Tensor] = {}
-        weights_list, samples_list = [], []
-        lidar_terms = self.training and calc_lidar_losses
-        if lidar_terms:
-            md = ray_bundle.metadata
-            carve = (md["is_lidar"], md.get("did_return"), md["directions_norm"], cfg.carving_epsilon,
-                     cfg.non_return_lidar_distance)
-        for k in range(rounds):
-            pf = pfs[k]
-            g = pf.hashgrid.static_grid
-            with contextlib.nullcontext() if train_props else torch.no_grad():  # frozen between scheduled updates
-                w, pdepth = ag.ProposalRoundFn.apply(g.hash_table, pf.density_decoder.weight, g.spec, pf.hashgrid.static_scale,
-                                                     o, d, a, eu)
-            weights_list.append(w[..., None])
-            samples_list.append(_light_samples(ray_bundle, sp, eu, fn))
-            nff[f"prop_depth_{k}"] = pdepth
-            if lidar_terms:
-                nff[f"prop_weights_loss_{k}"] = ag.CarvingLossFn.apply(w, eu[:, :-1], eu[:, 1:], *carve)
-            rand = None
-            if pdf.train_stratified and pdf.training:
-                rand = torch.rand((R,) if pdf.single_jitter else (R, counts[k + 1] + 1), device=dev)
-            wd = w.detach()
-            sp, eu = ops.pdf_sample(wd if smp._anneal == 1.0 else wd.pow(smp._anneal), sp, fn.nears, fn.fars, counts[k + 1],
-                                    fn.lam, fn.scaling, pdf.histogram_padding, rand)
-        if train_props:
-            smp._steps_since_update = 0
-        eu[:, -1] = sky  # the sky stretch of the last sample (models/neurad.py:451-455)
-        sp[:, -1] = 1 - EPS
-        appearance = None
-        if cfg.appearance_dim > 0:
-            sensor = ray_bundle.metadata.get("sensor_idxs")
-            assert sensor is not None, "sensor_idxs must be present in metadata during training"
-            appearance = (self.appearance_embedding.weight, sensor, ray_bundle.times if cfg.use_temporal_appearance else None,
-                          (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance)))
-        features, depth, accumulation, w_ns = self.field.render_train(o, d, a, eu, appearance)
-        nff.update(features=features, depth=depth, accumulation=accumulation)
-        S = counts[-1]
-        if self.training:
-            nff["weights_list"] = weights_list + [w_ns[..., None]]
-            # the sky sample plays no further role: the first S-1 samples = the first S edges
-            nff["ray_samples_list"] = samples_list + [_light_samples(ray_bundle, sp[:, :S], eu[:, :S], fn)]
-        if lidar_terms:
-            # sum((w * (is_lidar & ~is_close))^2) of the final samples: what the reference forms from `non_nearby_weights`
-            # (models/neurad.py:410-419,508-509) -- selecting them needs a nonzero + a host sync
-            nff["non_nearby_weights_loss"] = ag.CarvingLossFn.apply(w_ns, eu[:, :S - 1], eu[:, 1:S], *carve)
-        return nff
 
     # ---- get_nff_outputs (models/neurad.py:368-421) ------------------------------------------------
     def get_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool = False) -> Dict[str, Tensor]:

@@ -382,10 +382,11 @@ class FieldSpec:
         return f, (k1, k2, k3)
 
 
-# Eval-time layout of the coarse levels (csrc/eval_layout.hip).  OPT-IN (NRHIP_EVAL_RELAYOUT=1): on BASELINE config[1] it
-# takes the render kernel's fabric reads from 5.53 M to 4.09 M per launch (HBM traffic 708 -> 511 MB, below the algorithmic
-# 542 MB) and the kernel from 168.7 to 173.1 us -- the kernel is not bound by those bytes (DESIGN.md §9,
-# profiles/r03_eval_relayout.txt); outputs are bit-identical either way.
+# Eval-time layout of the coarse levels (csrc/eval_layout.hip).  OPT-IN (NRHIP_EVAL_RELAYOUT=1): measured on BASELINE
+# config[1] it changes neither the fabric reads nor the L1 -> L2 requests of the render kernel (the coarse levels are L2
+# resident either way and the 16 lanes that share a level walk consecutive samples of one ray, i.e. the same lines in both
+# layouts) and costs 2.6 % of kernel time (168.7 -> 173.1 us: one more LDS read and two more live registers per level);
+# outputs are bit-identical.  profiles/r03_eval_relayout.txt.
 _EVAL_RELAYOUT = os.environ.get("NRHIP_EVAL_RELAYOUT", "0") == "1"
 _EVAL_TABLES: dict = {}  # (data_ptr, version, dtype, shape, grid key) -> (eval table, layout array, n shadow levels)
 

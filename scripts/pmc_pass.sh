@@ -4,7 +4,7 @@
 tag=$1; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu-baseline --no-train}
+ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu-baseline --no-train --no-variants}
 cd /tmp
 rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$tag -o $tag -- python $R/bench.py $ARGS > $R/gpurun_out/pmc_$tag.log 2>&1
 echo "pass $tag rc=$?"

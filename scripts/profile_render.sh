@@ -5,7 +5,7 @@ tag=${1:-r02}; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
-BENCH="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train $*"
+BENCH="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_trace -o trace -- $BENCH > $OUT/prof_${tag}_trace.log 2>&1
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace -d $OUT/prof_${tag}_$name -o $name -- $BENCH > $OUT/prof_${tag}_$name.log 2>&1; }

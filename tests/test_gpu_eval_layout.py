@@ -77,7 +77,7 @@ def test_eval_table_holds_the_hashed_entries_of_the_lattice(ops):
             assert torch.equal(et[row0:row0 + T], table[l * T:(l + 1) * T])
             continue
         s = my.bit_length() - 1
-        n = int(spec.scalings[l]) + 2
+        n = int(spec.scalings[l]) + 1  # lattice coordinates 0 .. ceil(scale)
         ix, iy, iz = torch.meshgrid(*[torch.arange(n, device="cuda")] * 3, indexing="ij")
         src = ((ix ^ (iy * 2654435761) ^ (iz * 805459861)) & (T - 1)) + l * T
         dst = row0 + (ix | (iy << s) | (iz << (2 * s)))
