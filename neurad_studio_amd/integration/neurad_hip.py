@@ -11,8 +11,10 @@ Nothing of neurad-studio is edited or re-typed: ``NeuRADHipModel`` IS the refere
     ``_target`` (configs/base_config.py:47-54); same state_dict names, so neurad checkpoints load;
   * ``sampler``, the renderers, ``lidar_decoder`` and the two sampler losses replaced by their HIP-backed namesakes
     after ``populate_modules``;
-  * ``get_nff_outputs`` running the two fused kernels for eval chunks (FusedEvalMixin) and the reference's OWN
-    ``get_nff_outputs`` (models/neurad.py:368-421) for training.
+  * ``get_nff_outputs`` running the two fused kernels for eval chunks (FusedEvalMixin), the fused training nodes for
+    training steps of a static scene (FusedTrainMixin: sampler rounds, field + head + compositing + appearance as a
+    handful of autograd nodes, same output keys) and the reference's OWN ``get_nff_outputs`` (models/neurad.py:368-421)
+    otherwise (scenes with dynamic actors, ``fused_training=False``).
 Per-actor 3-D grids are used (``use_4d_hashgrid=False``): the 4-D grid exists only inside tiny-cuda-nn.
 """
 from __future__ import annotations
@@ -36,7 +38,7 @@ from ..fields.neurad_field import NeuRADProposalField as HipNeuRADProposalField
 from ..model_components import losses as hip_losses
 from ..model_components import ray_samplers as hip_samplers
 from ..model_components import renderers as hip_renderers
-from ..models.neurad import FusedEvalMixin
+from ..models.neurad import FusedEvalMixin, FusedTrainMixin
 from ..shims import nerfacc as hip_nerfacc
 
 
@@ -68,6 +70,9 @@ class NeuRADHipModelConfig(NeuRADModelConfig):
     """> 0: eval rays stop marching once their transmittance is below it (bounded error); 0 = exact."""
     order_rays: bool = False
     """Cache-coherent processing order per eval chunk (pays for lidar scans / random pixels, not for image patches)."""
+    fused_training: bool = True
+    """Training steps of a static scene on the fused nodes (models/neurad.py FusedTrainMixin); False: the reference's own
+    get_nff_outputs over the HIP modules."""
 
 
 @contextlib.contextmanager
@@ -80,14 +85,16 @@ def _patched(module, name, value):
         setattr(module, name, old)
 
 
-class NeuRADHipModel(FusedEvalMixin, NeuRADModel):
+class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
     config: NeuRADHipModelConfig
+    reference_output_keys = True  # get_metrics_dict consumes outputs["non_nearby_weights"] (models/neurad.py:508)
 
     def populate_modules(self):
         super().populate_modules()  # fields come out of config._target -> this package's classes
         cfg = self.config
         assert isinstance(self.field, HipNeuRADField), "config.field._target must be the HIP NeuRADField"
         self.fused_eval, self.early_stop_eps, self.order_rays = cfg.fused_eval, cfg.early_stop_eps, cfg.order_rays
+        self.fused_training = cfg.fused_training
         s = cfg.sampling
         self.sampler = hip_samplers.ProposalNetworkSampler(
             num_proposal_samples_per_ray=s.num_proposal_samples, num_nerf_samples_per_ray=s.num_nerf_samples,
@@ -110,6 +117,8 @@ class NeuRADHipModel(FusedEvalMixin, NeuRADModel):
     def get_nff_outputs(self, ray_bundle, calc_lidar_losses: bool = False):
         if self.fused_eval_possible():
             return self.fused_nff_outputs(ray_bundle)
+        if self.fused_training_possible():
+            return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         return super().get_nff_outputs(ray_bundle, calc_lidar_losses)
 
     def get_metrics_dict(self, outputs, batch):

@@ -65,10 +65,11 @@ def test_render_with_eval_layout_is_bit_identical(ops, cfg, half, monkeypatch):
     assert torch.equal(after, plain) and not torch.equal(after, before)
 
 
-def test_eval_table_holds_the_hashed_entries_of_the_lattice(ops):
+def test_eval_table_holds_the_hashed_entries_of_the_lattice(ops, monkeypatch):
     """the shadow region of a level, read at ix | iy << s | iz << 2s, is the entry the reference's hash points at"""
     spec = ops.GridSpec(16, 2, 16, 16, 1024)
     table = torch.randn(spec.table_rows, 2, device="cuda")
+    monkeypatch.setattr(ops, "_EVAL_RELAYOUT", True)
     et, lay = ops.eval_table(spec, table)
     T = 1 << 16
     for l in range(16):
