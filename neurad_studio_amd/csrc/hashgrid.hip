@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256) void proposal_density_fwd_kernel(GridDev g, co
 // XCD order (block b on XCD b % 8; a wrong guess costs speed, not correctness): each XCD works through its units one
 // after the other, so its L2 holds one level at a time.  Output: the rescaled per-level features, LEVEL-MAJOR [L][N]
 // (coalesced), which the backward wants anyway; proposal_density_from_levels_kernel turns them into densities.
+// (Round 3 tried the lanes of a wave on 64 NEIGHBOURING RAYS of a camera patch at one sample index instead of 64 consecutive
+// samples of one ray -- the L1 charges a gather per distinct line, scripts/probes/l1_coalesce_probe.hip -- with the tiles
+// transposed through LDS: 691 / 704 us per call against 497 us for this kernel (profiles/r03_proposal_fwd_transposed.txt).
+// Consecutive samples of a ray already share the coarse levels' lines, and the tile form serialises four passes per wave.)
 template <bool HALF>
 __global__ __launch_bounds__(256) void proposal_levels_lp_kernel(GridDev g, const void* __restrict__ table, float scale,
                                                                   RaysDev r, float* __restrict__ lf, int64_t n,
@@ -237,81 +241,6 @@ __global__ __launch_bounds__(256) void proposal_levels_lp_kernel(GridDev g, cons
   hash_level<1, HALF, true>(table, (uint32_t)l << g.log2T, p.x, p.y, p.z, g.scal[l], mask, v);
   // streaming store: the feature stream must not push this XCD's level (exactly one L2) out of the L2
   __builtin_nontemporal_store(v[0] * rescale_weight(g.scal[l], p.std), lf + (size_t)l * n + i);
-}
-
-// The same lookups with the lanes of a wave on 64 NEIGHBOURING RAYS at one sample index instead of 64 consecutive samples
-// of one ray (round 3).  The kernel runs against the vector L1's line-access rate, and the L1 charges a wave's gather per
-// DISTINCT cache line, most cheaply when consecutive lanes share (scripts/probes/l1_coalesce_probe.hip: 70.9 ns per wave-load
-// with 64 distinct lines, 23.4 with 4 consecutive lanes per line, 14.6 with 16).  Training batches are 32 x 32 pixel patches
-// (image_lidar_datamanager.py, models/neurad.py:362-365): 64 consecutive rays are two pixel rows that run through the same
-// few cells at every level but the finest, while 64 consecutive samples of one ray sit in 64 different cells from the
-// second level on.  A workgroup takes a tile of 64 rays x 64 samples of one level: the edges come in row by row (coalesced)
-// through LDS, every wave walks sample columns with lane = ray, the features go back through LDS and leave row by row.
-// Needs the edge form of the samples (ends == starts + 1: one [R, S+1] tensor), which every caller of the training path
-// passes; lidar rays (no neighbours) cost what they cost before.  Same values bit for bit: same arithmetic per sample.
-constexpr int kTpRays = 64, kTpCols = 64, kTpPad = 65;
-template <bool HALF>
-__global__ __launch_bounds__(256) void proposal_levels_tp_kernel(GridDev g, const void* __restrict__ table, float scale,
-                                                                  RaysDev r, float* __restrict__ lf, int64_t n,
-                                                                  int col_tiles, int64_t tiles_per_quarter,
-                                                                  int64_t blocks_per_unit) {
-  __shared__ float e_lds[kTpRays * (kTpPad + 1)];  // 66 edges per ray row (64 samples -> 65 edges), padded
-  __shared__ float o_lds[kTpRays * kTpPad];
-  constexpr int kQuarters = 4;
-  const int xcd = blockIdx.x & 7;
-  const int64_t q = blockIdx.x >> 3;
-  const int unit = xcd + 8 * (int)(q / blocks_per_unit);
-  if (unit >= g.L * kQuarters) return;
-  const int l = unit / kQuarters, quarter = unit - l * kQuarters;
-  const int64_t tile = quarter * tiles_per_quarter + q % blocks_per_unit;
-  const int64_t row_tiles = (r.R + kTpRays - 1) / kTpRays;
-  if (q % blocks_per_unit >= tiles_per_quarter || tile >= row_tiles * col_tiles) return;
-  const int64_t r0 = (tile / col_tiles) * kTpRays;
-  const int s0 = (int)(tile % col_tiles) * kTpCols;
-  const int nr = r.R - r0 < kTpRays ? (int)(r.R - r0) : kTpRays;
-  const int nc = r.S - s0 < kTpCols ? r.S - s0 : kTpCols;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int idx = tid; idx < nr * (nc + 1); idx += 256) {
-    const int rr = idx / (nc + 1), k = idx - rr * (nc + 1);
-    e_lds[rr * (kTpPad + 1) + k] = r.starts[(r0 + rr) * r.stride + s0 + k];
-  }
-  __syncthreads();
-  const bool live_ray = lane < nr;
-  const int64_t ray = r0 + (live_ray ? lane : 0);
-  const float ox = r.o[3 * ray], oy = r.o[3 * ray + 1], oz = r.o[3 * ray + 2];
-  const float dx = r.d[3 * ray], dy = r.d[3 * ray + 1], dz = r.d[3 * ray + 2];
-  const float area = r.area[ray];
-  const uint32_t mask = (1u << g.log2T) - 1u;
-  const float sc = g.scal[l];
-  // four sample columns per pass: their 32 gathers are all issued before the first blend (one memory round trip per pass,
-  // not per column: with a column per pass the kernel waited on every gather in turn, 691 vs 497 us for the ray-major form)
-  const float* erow = e_lds + (live_ray ? lane : 0) * (kTpPad + 1);
-  const uint32_t row0 = (uint32_t)l << g.log2T;
-  for (int c0 = wave; c0 < nc; c0 += 16) {
-    Corners cs[4];
-    float f[4][8][1], stdv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + 4 * u < nc ? c0 + 4 * u : c0;  // columns past the tile repeat the first one (dropped below)
-      const SamplePos p = sample_position(ox, oy, oz, dx, dy, dz, area, erow[c], erow[c + 1], scale);
-      stdv[u] = p.std;
-      cs[u] = hash_corners(p.x, p.y, p.z, sc, mask);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) Entry<1, HALF>::load(table, row0 + cs[u].idx[k], f[u][k]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float v[1];
-      lerp_corners<1>(cs[u], f[u], v);
-      if (c0 + 4 * u < nc) o_lds[lane * kTpPad + c0 + 4 * u] = v[0] * rescale_weight(sc, stdv[u]);
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < nr * nc; idx += 256) {
-    const int rr = idx / nc, k = idx - rr * nc;
-    // streaming store: the feature stream must not push this XCD's level (exactly one L2) out of the L2
-    __builtin_nontemporal_store(o_lds[rr * kTpPad + k], lf + (size_t)l * n + (r0 + rr) * r.S + s0 + k);
-  }
 }
 
 __global__ __launch_bounds__(256) void proposal_density_from_levels_kernel(const float* __restrict__ lf,
@@ -485,25 +414,6 @@ extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_r
   if (n == 0) return NRHIP_OK;
   const GridDev gd = to_dev(p->grid);
   const RaysDev rd = to_dev(*rays);
-  if (level_features && rays->ends == rays->starts + 1 && getenv("NRHIP_PROP_FWD_RAYMAJOR") == nullptr) {
-    // training, samples given as bin edges: lanes on neighbouring rays (see proposal_levels_tp_kernel)
-    constexpr int kQuarters = 4;
-    const int col_tiles = (rd.S + kTpCols - 1) / kTpCols;
-    const int64_t tiles = ((rd.R + kTpRays - 1) / kTpRays) * col_tiles;
-    const int64_t tiles_per_quarter = (tiles + kQuarters - 1) / kQuarters;
-    const int units = gd.L * kQuarters;
-    const int64_t nblk = 8 * ((units + 7) / 8) * tiles_per_quarter;
-    if (gd.dtype == 1)
-      proposal_levels_tp_kernel<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(
-          gd, p->table, p->static_scale, rd, level_features, n, col_tiles, tiles_per_quarter, tiles_per_quarter);
-    else
-      proposal_levels_tp_kernel<false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(
-          gd, p->table, p->static_scale, rd, level_features, n, col_tiles, tiles_per_quarter, tiles_per_quarter);
-    if (int e = check_launch("proposal_density_fwd levels (ray-transposed)")) return e;
-    proposal_density_from_levels_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
-        level_features, p->decoder_weight, n, gd.L, density);
-    return check_launch("proposal_density_fwd");
-  }
   if (level_features) {  // training: level-partitioned lookups + a streaming pass for the densities
     constexpr int kQuarters = 4;
     const int64_t per_quarter = ((n + kQuarters - 1) / kQuarters + 255) / 256 * 256;

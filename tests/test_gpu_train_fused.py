@@ -328,29 +328,3 @@ def test_fused_training_path_with_jitter_runs_and_matches_operator_path_given_th
     assert set(res["fused"][1]) == set(res["operator"][1])
     for n in res["fused"][1]:
         assert rel_l2(host(res["fused"][1][n]), host(res["operator"][1][n])) < 1e-4, n
-
-
-@pytest.mark.parametrize("shape", [(300, 128), (64, 64), (130, 48), (1, 3), (4096, 128)])
-def test_proposal_forward_with_lanes_on_neighbouring_rays_equals_the_ray_major_kernel(ops, shape, monkeypatch):
-    """the training forward of the proposal field from bin EDGES (lanes = 64 neighbouring rays at one sample index, tiles
-    through LDS) against the ray-major kernel it replaces: the same arithmetic per sample -> the same bits, for ragged ray
-    counts, sample counts that are not a multiple of the tile and camera-patch-like as well as random rays"""
-    import test_gpu_parity as tp
-
-    R, S = shape
-    p = tp.prop_params(95, lg=14)
-    ps = tp.to_pspec(ops, p)
-    o, d, area, s, e, eu = tp._sample_rays(R, S, seed=3)
-    if R >= 1024:  # a camera patch: neighbouring rays differ by a pixel
-        o = np.repeat(o[:1], R, 0)
-        d = d[:1] + 5e-4 * np.stack([np.arange(R) % 32, np.arange(R) // 32, np.zeros(R)], -1).astype(np.float32)
-        d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
-    edges = dev(eu)
-    args = (dev(o), dev(d), dev(area), edges[:, :-1], edges[:, 1:])
-    dens_t, lf_t = ops.proposal_density_fwd(ps, *args, save_features=True)
-    monkeypatch.setenv("NRHIP_PROP_FWD_RAYMAJOR", "1")
-    dens_r, lf_r = ops.proposal_density_fwd(ps, *args, save_features=True)
-    assert torch.equal(lf_t, lf_r) and torch.equal(dens_t, dens_r)
-    monkeypatch.delenv("NRHIP_PROP_FWD_RAYMAJOR")
-    dens_e = ops.proposal_density_fwd(ps, *args)  # the eval kernel (all levels per thread)
-    assert rel_l2(host(dens_t), host(dens_e)) < 1e-6

@@ -139,7 +139,8 @@ class OracleOps:
         g = ps.grid
         p = O.ProposalParams(O.GridParams(N(ps.table), g.num_levels, g.min_res, g.max_res, g.log2_hashmap_size),
                              ps.static_scale, N(ps.decoder_weight))
-        return T(O.proposal_density(p, N(origins), N(directions), N(pixel_area), N(starts), N(ends)))
+        dens = T(O.proposal_density(p, N(origins), N(directions), N(pixel_area), N(starts), N(ends)))
+        return (dens, torch.zeros(g.num_levels, dens.numel())) if save_features else dens
 
     def proposal_sampler_fwd(self, props, origins, directions, pixel_area, nears, fars, num_samples=(128, 64, 32),
                              lam=-1.0, scaling=0.1, histogram_padding=0.01, sky_distance=20000.0, actor_specs=None,
@@ -157,6 +158,82 @@ class OracleOps:
         sps = [T(b) for b in so.prop_spacing] + [edges(so.spacing_starts, so.spacing_ends)]
         eus = [edges(s, e) for s, e in zip(so.prop_starts, so.prop_ends)] + [edges(so.starts, so.ends)]
         return [T(w) for w in so.prop_weights], sps, eus
+
+    # ---- the entry points of the fused TRAINING nodes (forward only: the CPU stand-in has no backward) ----------------
+    def install_training(self, monkeypatch):
+        from neurad_studio_amd import ops
+
+        for name in ("prop_weights_fwd", "pdf_sample", "field_fwd_train", "sdf_render_fwd", "appearance_fwd",
+                     "lidar_carving"):
+            monkeypatch.setattr(ops, name, getattr(self, name))
+
+    def prop_weights_fwd(self, edges, densities, want_depth=True):
+        self.calls.append(("prop_weights_fwd", tuple(densities.shape)))
+        e, dn = N(edges), N(densities)
+        w = O.weights_from_density(e[:, 1:] - e[:, :-1], dn)
+        return T(w), T((w * (e[:, 1:] + e[:, :-1]) / 2).sum(-1, keepdims=True).astype(np.float32))
+
+    def pdf_sample(self, weights, spacing_bins, nears, fars, num_samples, lam=-1.0, scaling=0.1, histogram_padding=0.01,
+                   rand=None):
+        self.calls.append(("pdf_sample", tuple(weights.shape), num_samples))
+        R = weights.shape[0]
+        n = np.zeros((R, 1), np.float32) if nears is None else N(nears).reshape(-1, 1)
+        f = N(fars).reshape(-1, 1)
+        sp = O.Spacing(O.power_fn(n * np.float32(scaling), lam), O.power_fn(f * np.float32(scaling), lam), lam, scaling)
+        bins, eu = O.pdf_sample(N(weights), N(spacing_bins), num_samples, sp, histogram_padding,
+                                rand=None if rand is None else N(rand).reshape(R, -1))
+        return T(bins), T(eu)
+
+    def field_fwd_train(self, fs, origins, directions, pixel_area, starts, ends, order=None):
+        self.calls.append(("field_fwd_train", tuple(starts.shape)))
+        out = O.field_fwd(self._field_params(fs), N(origins), N(directions), N(pixel_area), N(starts), N(ends))
+        n = starts.shape[0] * starts.shape[1]
+        z = torch.zeros(n, 1)
+        return (T(out["feature"]).reshape(n, -1), T(out["sdf"]).reshape(n), z[:, 0]), (z, z, z, z)
+
+    def sdf_render_fwd(self, sdf, beta, beta_min, features, edges, extra_cols=0):
+        self.calls.append(("sdf_render_fwd", tuple(sdf.shape)))
+        e = N(edges)
+        alpha = O.sigmoid(-N(sdf) * np.float32(abs(float(beta)) + beta_min))
+        w, _ = O.render_weight_from_alpha(alpha)
+        feats, depth, acc = O.composite(w, N(features), e[:, :-1], e[:, 1:])
+        out = torch.zeros(sdf.shape[0], feats.shape[1] + extra_cols)
+        out[:, :feats.shape[1]] = T(feats)
+        return T(alpha), T(w[:, :-1].copy()), out, T(depth).reshape(-1, 1), T(acc).reshape(-1, 1)
+
+    def appearance_fwd(self, weight, sensor_idx, times, duration, n_per_sensor, temporal, n_rays, out=None):
+        self.calls.append(("appearance_fwd", n_rays))
+        wt = N(weight)
+        s = np.zeros(n_rays, np.int64) if sensor_idx is None else N(sensor_idx).reshape(-1)
+        if temporal and times is not None:
+            ti = N(times).reshape(-1) / np.float32(duration) * np.float32(n_per_sensor)
+            lo = np.clip(np.floor(ti), 0, n_per_sensor - 1)
+            hi = np.clip(lo + 1, 0, n_per_sensor - 1)
+            fr = (ti - lo)[:, None].astype(np.float32)
+            val = wt[(lo + s * n_per_sensor).astype(np.int64)] * (1 - fr) + wt[(hi + s * n_per_sensor).astype(np.int64)] * fr
+        else:
+            val = wt[s]
+        out.copy_(T(val.astype(np.float32)))
+        return out
+
+    def lidar_carving(self, starts, ends, is_lidar, did_return, distance, carving_epsilon, non_return_lidar_distance,
+                      weights=None, want_mask=True, want_grad=True):
+        self.calls.append(("lidar_carving", tuple(starts.shape)))
+        mid = (N(starts) + N(ends)) * 0.5
+        lid = N(is_lidar).reshape(-1, 1).astype(bool)
+        dist = N(distance).reshape(-1, 1)
+        close_hit = np.abs(dist - mid) < carving_epsilon
+        if did_return is None:
+            close = lid & close_hit
+        else:
+            ret = N(did_return).reshape(-1, 1).astype(bool)
+            close = lid & ((ret & close_hit) | (~ret & (mid < non_return_lidar_distance)))
+        loss = gw = None
+        if weights is not None:
+            m = (lid & ~close).astype(np.float32)
+            loss = T(((N(weights) * m) ** 2).sum(-1).astype(np.float32))
+            gw = T((2 * N(weights) * m).astype(np.float32))
+        return (torch.from_numpy(close) if want_mask else None), loss, gw
 
     def render_fwd(self, fs, origins, directions, pixel_area, starts, ends, return_weights=False, out=None,
                    early_stop_eps=0.0, order=None):
@@ -309,3 +386,92 @@ def test_neurad_hip_method_builds_the_reference_model_and_matches_its_torch_eval
         assert got[k].shape == want[k].shape, k
         assert rel_l2(N(got[k]), N(want[k])) < 2e-4, (k, rel_l2(N(got[k]), N(want[k])))
     assert got["features"].shape == (R, 48)  # 32 field channels + 16 appearance channels
+
+
+def test_neurad_hip_plugin_training_step_on_the_fused_nodes_matches_the_reference_model(ref, monkeypatch):
+    """Training mode of the plugin model (a subclass of the reference's NeuRADModel): get_nff_outputs runs the fused
+    training orchestration (FusedTrainMixin: edges from kernel to kernel, ProposalRoundFn per round, NffRenderTrainFn for
+    field + head + compositing + appearance) and returns what the reference's own get_nff_outputs returns for the same
+    parameters and rays -- and the reference's get_metrics_dict consumes it.  The device is stood in for by the oracle."""
+    import nerfstudio.model_components.renderers as ref_renderers
+    import nerfstudio.models.neurad as ref_neurad
+    from nerfstudio.cameras.rays import RayBundle as RefRayBundle
+    from nerfstudio.data.scene_box import SceneBox
+
+    monkeypatch.setattr(ref_neurad, "VGGPerceptualLossPix2Pix", torch.nn.Identity)
+    from copy import deepcopy
+
+    from neurad_studio_amd.integration.neurad_hip import neurad_hip
+
+    def shrink(c):
+        c.field.grid.static.log2_hashmap_size = 10
+        c.field.sdf_beta = 3.0
+        for pf in (c.sampling.proposal_field_1, c.sampling.proposal_field_2):
+            pf.grid.static.log2_hashmap_size = 9
+        c.loss.vgg_mult = 0.0
+        return c
+
+    kw = dict(scene_box=SceneBox(aabb=torch.tensor([[-100.0] * 3, [100.0] * 3])), num_train_data=2,
+              metadata={"duration": 8.0, "sensor_idx_to_name": {0: "cam", 1: "lidar"}, "trajectories": []})
+    torch.manual_seed(0)
+    hip = shrink(deepcopy(neurad_hip.config.pipeline.model)).setup(**kw).train()
+    ref_cfg = shrink(ref_neurad.NeuRADModelConfig(implementation="torch"))
+    for c in (ref_cfg.field, ref_cfg.sampling.proposal_field_1, ref_cfg.sampling.proposal_field_2):
+        c.grid.actor.use_4d_hashgrid = False
+    refm = ref_cfg.setup(**kw).train()
+    with torch.no_grad():
+        hip.field.hashgrid.static_grid.hash_table.mul_(500.0)
+        for p in hip.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(2000.0)
+    refm.load_state_dict(hip.state_dict())
+    for m in (hip, refm):  # deterministic sampling in training mode, as in oracle/make_golden_model.py
+        m.sampler.eval(), m.field.eval()
+        for p in m.proposal_fields:
+            p.eval()
+    na = _tiny_nerfacc()
+    monkeypatch.setattr(ref_neurad, "nerfacc", na)
+    monkeypatch.setattr(ref_renderers, "nerfacc", na)
+    monkeypatch.setattr(type(refm), "_render_weights",
+                        lambda self, outputs, rs: na.render_weight_from_alpha(
+                            outputs[ref_neurad.FieldHeadNames.ALPHA].squeeze(-1))[0])
+    dev = OracleOps()
+    dev.install(monkeypatch)
+    dev.install_training(monkeypatch)
+    R, n_cam = 24, 8
+    o, d = _rays(R, seed=7)
+    g = np.random.default_rng(3)
+    is_lidar = torch.arange(R)[:, None] >= n_cam
+    did_return = torch.from_numpy(g.random((R, 1)) < 0.7) | ~is_lidar
+    dist = T(g.uniform(2.0, 60.0, (R, 1)).astype(np.float32))
+
+    def bundle():
+        return RefRayBundle(origins=T(o), directions=T(d), pixel_area=torch.where(is_lidar, 4.5e-6, 2.7e-7), nears=None,
+                            fars=None, times=T(g.uniform(0, 8, (R, 1)).astype(np.float32)) * 0 + 3.3,
+                            metadata={"sensor_idxs": is_lidar.long(), "is_lidar": is_lidar, "did_return": did_return,
+                                      "directions_norm": dist})
+
+    assert hip.fused_training_possible()
+    got = hip.get_nff_outputs(bundle(), calc_lidar_losses=True)
+    names = [c[0] for c in dev.calls]
+    assert names.count("field_fwd_train") == 1 and names.count("sdf_render_fwd") == 1 and names.count("prop_weights_fwd") == 2
+    assert "field_fwd" not in names and names.count("pdf_sample") == 2  # no operator-level field call, two resampling rounds
+    want = refm.get_nff_outputs(bundle(), calc_lidar_losses=True)
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert got[k].shape == want[k].shape, k
+        assert rel_l2(N(got[k]), N(want[k])) < 2e-4, (k, rel_l2(N(got[k]), N(want[k])))
+    for i in range(3):
+        assert got["weights_list"][i].shape == want["weights_list"][i].shape
+        assert rel_l2(N(got["weights_list"][i]), N(want["weights_list"][i])) < 2e-4, i
+    for i in range(2):
+        assert abs(float(got[f"prop_weights_loss_{i}"]) - float(want[f"prop_weights_loss_{i}"])) <= 2e-4 * float(want[f"prop_weights_loss_{i}"]) + 1e-9
+    # what get_metrics_dict forms from the non-nearby weights (models/neurad.py:508): the dense masked tensor has the same sum
+    a, b = float((got["non_nearby_weights"] ** 2).sum()), float((want["non_nearby_weights"] ** 2).sum())
+    assert abs(a - b) <= 2e-4 * b + 1e-9
+    # the reference's own loss functions read the light RaySamples of the fused path (spacing edges as one tensor)
+    from neurad_studio_amd.model_components.losses import ray_samples_to_sdist
+
+    for i in range(3):
+        ref_sd = torch.cat([want["ray_samples_list"][i].spacing_starts[..., 0],
+                            want["ray_samples_list"][i].spacing_ends[..., -1:, 0]], -1)
+        assert rel_l2(N(ray_samples_to_sdist(got["ray_samples_list"][i])), N(ref_sd)) < 1e-5, i
+
