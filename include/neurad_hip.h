@@ -201,6 +201,15 @@ int nrhip_field_fwd(const nrhip_field* f, const nrhip_rays* rays, float* feature
 int nrhip_field_fwd_train(const nrhip_field* f, const nrhip_rays* rays, float* feature, float* sdf, float* alpha,
                           float* save_enc, float* save_geo_hidden, float* save_feat_in, float* save_feat_hidden,
                           void* stream);
+/* The same with ROW OVERRIDES -- the training forward of a scene with dynamic actors (neurad_encoding.py:150-187): a
+ * sample with ovr_row[i] = p >= 0 (i = ray * S + sample) takes its encoding row from ovr_rows [P,32] (the actor grid's
+ * rescaled features, zero-padded, computed by the differentiable actor branch for the few samples inside a box) and the
+ * view direction of its SH inputs from ovr_dirs [P,3] (box frame, neurad_encoding.py:203-208) instead of the static
+ * lookup and the ray direction; ovr_row[i] = -1: the static scene.  save_enc then holds the overriding rows, so the
+ * backward's d/d enc of those samples is the gradient of ovr_rows.  fp32 and fp16 static tables. */
+int nrhip_field_fwd_train_ovr(const nrhip_field* f, const nrhip_rays* rays, const int32_t* ovr_row, const float* ovr_rows,
+                              const float* ovr_dirs, float* feature, float* sdf, float* alpha, float* save_enc,
+                              float* save_geo_hidden, float* save_feat_in, float* save_feat_hidden, void* stream);
 
 /* ---- C1: nerfacc 0.5.2 dense-mode (call sites models/neurad.py:716-723,734; renderers.py:88,345) */
 int nrhip_render_weight_from_alpha(const float* alphas /*[R,S]*/, int64_t r, int32_t s, float* weights,

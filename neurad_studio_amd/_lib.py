@@ -100,6 +100,7 @@ PROTOTYPES = {
     "nrhip_field_feature_bwd": [C.POINTER(Mlp), P, P, P, P, I64, P, C.POINTER(P), C.POINTER(P), P, I64, P],
     "nrhip_field_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P],
     "nrhip_field_fwd_train": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P, P, P, P],
+    "nrhip_field_fwd_train_ovr": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P, P, P, P, P, P, P],
     "nrhip_render_weight_from_alpha": [P, I64, I32, P, P, P],
     "nrhip_render_weight_from_alpha_bwd": [P, P, P, I64, I32, P, P],
     "nrhip_render_weight_from_density": [P, P, P, I64, I32, P, P, P, P],

@@ -129,9 +129,13 @@ class FieldTrainFn(torch.autograd.Function):
         return (gt, None, None, None, None, None, None, None, None, None, *grads, *([None] if ctx.has_order else []))
 
 
-def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends, enc, hg, xf, hf, params, g_feature, g_geo_out):
+def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends, enc, hg, xf, hf, params, g_feature, g_geo_out,
+                    override=None):
     """Backward of the fused field forward from (dL/dfeature [N,32], dL/dgeo_out [N]): feature-MLP gradients -> residual ->
-    geometry-MLP gradients -> table gradient.  -> (grad table or None, the ten MLP parameter gradients in argument order)"""
+    geometry-MLP gradients -> table gradient.  -> (grad table or None, the ten MLP parameter gradients in argument order
+    [, gradient of the override rows]).  override = (ovr_row [N], pair_idx [P]): samples whose encoding row came from the
+    caller (actor boxes) hand dL/d enc to those rows -- every (sample, actor) pair gets its sample's row, as the reference's
+    index_put does (neurad_encoding.py:184-185) -- and send nothing to the static table."""
     gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
     # feature = embedding + mlp_feature([embedding | sh])
     if ops.field_feature_bwd_supported(fw, fb):
@@ -143,8 +147,14 @@ def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends,
         g_geo[:, 0] = g_geo_out.reshape(-1)
         torch.add(g_feature, gxf[:, :32], out=g_geo[:, 1:])  # residual: feature = embedding + mlp_feature(...)
     genc, ggw, ggb = ops.mlp_bwd(enc, hg, g_geo, gw, gb)
+    g_rows = None
+    if override is not None:
+        ovr_row, pair_idx = override
+        g_rows = genc.index_select(0, pair_idx)
+        genc.masked_fill_((ovr_row >= 0)[:, None], 0.0)  # exactly-zero rows send no records (encode_bwd_binned: prep)
     gt = _like_param(ops.encode_bwd(spec, scale, o, d, a, starts, ends, genc), table_dtype) if need_table else None
-    return gt, [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
+    grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
+    return (gt, grads) if override is None else (gt, grads, g_rows)
 
 
 class MLPFn(torch.autograd.Function):
@@ -401,6 +411,27 @@ class ProposalRoundFn(torch.autograd.Function):
         return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None
 
 
+class PropWeightsFn(torch.autograd.Function):
+    """RaySamples.get_weights + render_depth_simple of a proposal round from its bin edges, for densities that come from
+    elsewhere (a proposal field with dynamic actors: static density + actor overlay at operator level).
+    args: edges [R,S+1], densities [R,S] -> weights [R,S], prop_depth [R,1]"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, edges, densities):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(edges, densities)
+        return ops.prop_weights_fwd(edges, densities)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, gw, gdepth):
+        edges, dens = ctx.saved_tensors
+        if gw is None and gdepth is None:
+            return None, None
+        return None, ops.prop_weights_bwd(edges, dens, None if gw is None else gw.contiguous(), gdepth)
+
+
 class NffRenderTrainFn(torch.autograd.Function):
     """get_nff_outputs behind the sampler (models/neurad.py:373-395) for the static scene as ONE node: fused field forward
     (NeuRADField.forward) -> SigmoidDensity with the learnable beta -> render_weight_from_alpha -> accumulation, sky
@@ -408,18 +439,21 @@ class NffRenderTrainFn(torch.autograd.Function):
 
     args: table, spec, static_scale, beta (raw parameter), beta_min, origins, directions, pixel_area, edges [R,S+1] (last
     edge = sky distance), emb_weight | None, sensor_idx | None, times | None, (duration, n_per_sensor, temporal), order |
-    None, gw0, gb0, gw1, gb1, fw0, fb0, fw1, fb1, fw2, fb2
+    None, ovr_row | None, ovr_rows | None, ovr_dirs | None, pair_idx | None (dynamic actors: the rows of the samples
+    inside a box, ops.field_fwd_train), gw0, gb0, gw1, gb1, fw0, fb0, fw1, fb1, fw2, fb2
     -> features [R, 32 + A], depth [R,1], accumulation [R,1], weights of the non-sky samples [R,S-1]"""
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, table, spec, static_scale, beta, beta_min, origins, directions, pixel_area, edges, emb_weight,
-                sensor_idx, times, emb_cfg, order, *params):
+                sensor_idx, times, emb_cfg, order, ovr_row, ovr_rows, ovr_dirs, pair_idx, *params):
         ctx.set_materialize_grads(False)
         gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
         fs = ops.FieldSpec(spec, table, static_scale, gw, gb, fw, fb, use_sdf=True, beta=1.0)  # (kernel head unused)
+        override = None if ovr_rows is None else (ovr_row, ovr_rows, ovr_dirs)
         (feature, sdf, _head), (enc, hg, xf, hf) = ops.field_fwd_train(fs, origins, directions, pixel_area, edges[:, :-1],
-                                                                      edges[:, 1:], order=order)
+                                                                      edges[:, 1:], order=order, override=override)
+        ctx.has_ovr = ovr_rows is not None
         R, S = edges.shape[0], edges.shape[1] - 1
         A = 0 if emb_weight is None else emb_weight.shape[1]
         alpha, w_ns, out, depth, acc = ops.sdf_render_fwd(sdf.view(R, S), beta, beta_min, feature.view(R, S, -1), edges,
@@ -429,7 +463,7 @@ class NffRenderTrainFn(torch.autograd.Function):
         ctx.spec, ctx.scale, ctx.table_dtype, ctx.beta_min, ctx.emb_cfg = spec, static_scale, table.dtype, beta_min, emb_cfg
         ctx.n_embed, ctx.A = (0 if emb_weight is None else emb_weight.shape[0]), A
         ctx.has = (sensor_idx is not None, times is not None)
-        opt = [t for t in (sensor_idx, times) if t is not None]
+        opt = [t for t in (sensor_idx, times) if t is not None] + ([ovr_row, pair_idx] if ctx.has_ovr else [])
         ctx.save_for_backward(origins, directions, pixel_area, edges, enc, hg, xf, hf, feature, sdf, alpha, beta, *params, *opt)
         return out, depth, acc, w_ns
 
@@ -450,10 +484,20 @@ class NffRenderTrainFn(torch.autograd.Function):
         if ctx.A and ctx.needs_input_grad[9]:
             g_emb = ops.appearance_bwd(g_out[:, C_:], sensor_idx, times, ctx.emb_cfg[0], ctx.emb_cfg[1], ctx.emb_cfg[2],
                                        ctx.n_embed)
-        gt, grads = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, edges[:, :-1],
-                                    edges[:, 1:], enc, hg, xf, hf, params, gfeat.view(R * S, C_), gsdf.view(-1))
+        g_rows = None
+        if ctx.has_ovr:
+            ovr_row, pair_idx = opt.pop(0), opt.pop(0)
+            gt, grads, g_rows = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a,
+                                                edges[:, :-1], edges[:, 1:], enc, hg, xf, hf, params, gfeat.view(R * S, C_),
+                                                gsdf.view(-1), override=(ovr_row, pair_idx))
+            if not ctx.needs_input_grad[15]:
+                g_rows = None
+        else:
+            gt, grads = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, edges[:, :-1],
+                                        edges[:, 1:], enc, hg, xf, hf, params, gfeat.view(R * S, C_), gsdf.view(-1))
         g_beta = gbeta.reshape(beta.shape) if ctx.needs_input_grad[3] else None
-        return (gt, None, None, g_beta, None, None, None, None, None, g_emb, None, None, None, None, *grads)
+        return (gt, None, None, g_beta, None, None, None, None, None, g_emb, None, None, None, None, None, g_rows, None, None,
+                *grads)
 
 
 class LidarLossFn(torch.autograd.Function):

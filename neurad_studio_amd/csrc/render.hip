@@ -551,7 +551,8 @@ __device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const fl
 }
 
 // L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2, ACT = dynamic actors.
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false>
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false,
+          bool OVR = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(
     FieldDev fd, int64_t n_rays, int S, int stride, const int32_t* __restrict__ order, const float* __restrict__ ro,
     const float* __restrict__ rd, const float* __restrict__ rarea, const float* __restrict__ rstarts,
@@ -566,6 +567,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
   static_assert(!SPLIT || (COMPOSITE && !ACT), "split-bf16 matrix products: the composited static-scene kernel");
   static_assert(!RELAY || (COMPOSITE && !ACT && !SPLIT), "eval-table layout: the composited static-scene kernel");
+  // OVR (training forward of a scene with dynamic actors): samples inside an actor box take their encoding row and view
+  // direction from the caller (the differentiable actor branch computed them for the few hit samples) instead of the
+  // static lookup.  The three ACT-only pointer arguments carry the overrides: cand_count = ovr_row [N] (row index or -1),
+  // cand_w2b = ovr_rows [P,32], bounds = ovr_dirs [P,3].
+  static_assert(!OVR || (!COMPOSITE && !ACT && !SPLIT && !RELAY), "row overrides: the per-sample training forward");
   using Ld = Lds<H, SPLIT>;
   constexpr int NB = H / 16;
   constexpr int LPL = L / 4;         // levels per lane
@@ -574,8 +580,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
 
   // ---- stage weights (once per workgroup; the grid is persistent over rays) ----------------------
   stage_field_weights<H, SPLIT>(fd, lds);
-  if constexpr (ACT) {
+  if constexpr (ACT || OVR) {
     for (int e = threadIdx.x; e < 16 * H; e += 256) lds[Ld::SHF + e] = frag_src<true, NB, 4>(fd.fw0 + 32, 48, 0, e);
+  }
+  if constexpr (ACT) {
     if (threadIdx.x < ad.La) lds[Ld::ASCAL + threadIdx.x] = ad.scal[threadIdx.x];
   }
   if constexpr (RELAY) {
@@ -617,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   int64_t ray = q.ray;
   if constexpr (ACT) issue_tile_actors<L, F, HALF>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
   else issue_tile<L, F, HALF, RELAY>(fd, q, g, mask, scal_l, tf, lay_l);
+  if constexpr (OVR) ta = (q.valid && j < S) ? cand_count[q.ray * S + j] : -1;  // override row of this lane's sample of `tf`
   {
     const bool wrap = ntile == 1;
     load_pending(q, wrap ? pos + pos_step : pos, wrap ? 0 : 1, rr, j, order, ro, rd, rarea, rstarts, rends, cand_count);
@@ -683,6 +692,24 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
                       rd[3 * ray + 1], rd[3 * ray + 2], cand_w2b, shb);
     } else {
       blend_tile<LPL, F>(tf, scal_l, feat);
+      if constexpr (OVR) {
+        tile_hit = __ballot(ta >= 0) != 0ull;  // wave-uniform; rare
+        if (tile_hit) {
+          float bx = rd[3 * ray], by = rd[3 * ray + 1], bz = rd[3 * ray + 2];
+          if (ta >= 0) {
+            const float* rp = cand_w2b + (size_t)ta * 32 + 8 * g;  // this lane's 8 columns of the override row
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) feat[k] = r0[k], feat[4 + k] = r1[k];
+            bx = bounds[3 * (size_t)ta], by = bounds[3 * (size_t)ta + 1], bz = bounds[3 * (size_t)ta + 2];
+          }
+          float sh[16];
+          sh4((bx + 1.f) / 2.f, (by + 1.f) / 2.f, (bz + 1.f) / 2.f, sh);
+#pragma unroll
+          for (int c = 0; c < 16; ++c)
+            if ((c >> 2) == g) shb[c & 3] = sh[c];
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -708,6 +735,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     // unconditional (see load_pending)
     if constexpr (ACT) issue_tile_actors<L, F, HALF>(fd, ad, q, g, mask, scal_l, ascal_l, cand_actor, cand_w2b, bounds, tables, tf, ta);
     else issue_tile<L, F, HALF, RELAY>(fd, q, g, mask, scal_l, tf, lay_l);
+    if constexpr (OVR) ta = (q.valid && 16 * q.t + j < S) ? cand_count[q.ray * S + 16 * q.t + j] : -1;
     {
       const bool wrap = nt + 1 == ntile;  // request the small loads of the tile after it
       load_pending(q, wrap ? npos + pos_step : npos, wrap ? 0 : nt + 1, rr, j, order, ro, rd, rarea, rstarts, rends,
@@ -776,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
         float* xp = sv.xf + srow * 48;
         stream_store(xp + 4 * g, e[0]);
         stream_store(xp + 16 + 4 * g, e[1]);
-        stream_store(xp + 32 + 4 * g, shq);
+        stream_store(xp + 32 + 4 * g, tile_hit ? f32x4{shb[0], shb[1], shb[2], shb[3]} : shq);
       }
     }
     if (!tile_hit) {
@@ -965,12 +993,13 @@ struct ActorLaunch {
   const void* const* tables;
 };
 
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false>
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false,
+          bool OVR = false>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
                          float* oal, const SaveDev& sv, float stop_eps, hipStream_t st,
                          const ActorLaunch& al = ActorLaunch()) {
-  constexpr size_t lds = (ACT ? Lds<H, SPLIT>::TOTAL_ACT : Lds<H, SPLIT>::TOTAL) * sizeof(float);
-  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT, SPLIT, RELAY>;
+  constexpr size_t lds = ((ACT || OVR) ? Lds<H, SPLIT>::TOTAL_ACT : Lds<H, SPLIT>::TOTAL) * sizeof(float);
+  auto kern = render_kernel<L, F, H, HALF, COMPOSITE, ACT, SPLIT, RELAY, OVR>;
   static int cap = 0;  // persistent grid: CUs x resident workgroups per CU, queried once per instantiation
   if (!cap) {
     if (lds > 64 * 1024)
@@ -1132,6 +1161,44 @@ extern "C" int nrhip_field_fwd_train(const nrhip_field* f, const nrhip_rays* ray
              NRHIP_ERR_INVALID_ARG, "field_fwd_train: save buffers must be 16-byte aligned");
   const SaveDev sv{save_enc, save_geo_hidden, save_feat_in, save_feat_hidden};
   return dispatch_render<false>(f, rays, feature, nullptr, nullptr, nullptr, sdf, alpha, stream, sv);
+}
+
+extern "C" int nrhip_field_fwd_train_ovr(const nrhip_field* f, const nrhip_rays* rays, const int32_t* ovr_row,
+                                         const float* ovr_rows, const float* ovr_dirs, float* feature, float* sdf,
+                                         float* alpha, float* save_enc, float* save_geo_hidden, float* save_feat_in,
+                                         float* save_feat_hidden, void* stream) {
+  if (int e = validate_field(f)) return e;
+  if (int e = validate_rays(rays)) return e;
+  if (rays->n_rays == 0 || rays->n_samples == 0) return NRHIP_OK;
+  NR_REQUIRE(feature && sdf && alpha && save_enc && save_geo_hidden && save_feat_in && save_feat_hidden && ovr_row &&
+                 ovr_rows && ovr_dirs,
+             NRHIP_ERR_INVALID_ARG, "field_fwd_train_ovr: NULL pointer");
+  NR_REQUIRE(((reinterpret_cast<uintptr_t>(save_enc) | reinterpret_cast<uintptr_t>(save_geo_hidden) |
+               reinterpret_cast<uintptr_t>(save_feat_in) | reinterpret_cast<uintptr_t>(save_feat_hidden) |
+               reinterpret_cast<uintptr_t>(ovr_rows)) & 15) == 0,
+             NRHIP_ERR_INVALID_ARG, "field_fwd_train_ovr: save buffers and override rows must be 16-byte aligned");
+  NR_REQUIRE(rays->n_rays * rays->n_samples < (INT64_C(1) << 31), NRHIP_ERR_UNSUPPORTED, "field_fwd_train_ovr: N >= 2^31");
+  const SaveDev sv{save_enc, save_geo_hidden, save_feat_in, save_feat_hidden};
+  ActorLaunch al = ActorLaunch();
+  al.cand_count = ovr_row, al.cand_w2b = ovr_rows, al.bounds = ovr_dirs;
+  const FieldDev fd = to_dev(*f);
+  const RaysDev rd = to_dev(*rays);
+  const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
+  NR_REQUIRE(f->grid.param_dtype == 0 || f->grid.param_dtype == 1, NRHIP_ERR_INVALID_ARG, "field_fwd_train_ovr: dtype");
+  const bool half = f->grid.param_dtype == 1;
+#define OCASE(L_, F_, H_)                                                                                                   \
+  if (L == L_ && F == F_ && H == H_)                                                                                        \
+    return half ? launch_render<L_, F_, H_, true, false, false, false, false, true>(fd, rd, feature, nullptr, nullptr, nullptr, \
+                                                                                    sdf, alpha, sv, 0.f, (hipStream_t)stream, al) \
+                : launch_render<L_, F_, H_, false, false, false, false, false, true>(fd, rd, feature, nullptr, nullptr,     \
+                                                                                     nullptr, sdf, alpha, sv, 0.f,          \
+                                                                                     (hipStream_t)stream, al);
+  OCASE(8, 4, 32)
+  OCASE(8, 4, 64)
+  OCASE(16, 2, 64)
+#undef OCASE
+  set_error("field_fwd_train_ovr: no instantiation for L=%d F=%d H=%d", L, F, H);
+  return NRHIP_ERR_UNSUPPORTED;
 }
 
 extern "C" int nrhip_render_fwd_ex(const nrhip_field* f, const nrhip_rays* rays, float* out_features, float* out_depth,

@@ -183,23 +183,59 @@ class NeuRADField(nn.Module):
         return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights,
                               early_stop_eps=early_stop_eps, order=order)
 
-    def render_train(self, origins, directions, pixel_area, edges, appearance=None):
+    def render_train(self, origins, directions, pixel_area, edges, appearance=None, times: Optional[Tensor] = None):
         """Training counterpart of ``render``: field -> learnable-beta SDF head -> weights -> compositing as ONE autograd
         node (autograd.NffRenderTrainFn) from the bin edges [R,S+1] (last edge = sky distance).  appearance: None or
         (embedding weight [E,A], sensor_idx [R,1] | None, times [R,1] | None, (duration, n_per_sensor, temporal)): the
-        appearance embedding is written beside the features.  -> features [R, 32 + A], depth [R,1], accumulation [R,1],
-        weights of the non-sky samples [R,S-1]"""
-        if not (self.config.use_sdf and self.fused_supported() and self._fused_train_ok()) or self.hashgrid.has_actors():
-            raise NotImplementedError("render_train: static scene with the SDF head and a fused-kernel configuration only")
-        g = self.hashgrid.static_grid
-        emb, sensor, times, emb_cfg = appearance if appearance is not None else (None, None, None, (1.0, 1, False))
-        order = ops.ray_order(origins, directions, self.hashgrid.static_scale) if self.order_rays else None
+        appearance embedding is written beside the features.  times [R]: needed with dynamic actors.
+        -> features [R, 32 + A], depth [R,1], accumulation [R,1], weights of the non-sky samples [R,S-1]
+
+        Dynamic actors (neurad_encoding.py:150-187): the kernels find which samples lie in which box; the differentiable
+        actor branch (``actor_pair_rows``: box-frame positions with their pose gradient, one multi-grid lookup) produces the
+        rows of those few samples, and the fused forward takes them -- and their box-frame view directions -- in place of
+        the static lookup (nrhip_field_fwd_train_ovr).  The backward hands every (sample, actor) pair its sample's row
+        gradient, as the reference's index_put does, and the static table nothing for those samples."""
+        hg = self.hashgrid
+        if not (self.config.use_sdf and self.fused_supported(with_actors=True) and self._fused_train_ok()):
+            raise NotImplementedError("render_train: SDF head and a fused-kernel configuration only")
+        g = hg.static_grid
+        emb, sensor, etimes, emb_cfg = appearance if appearance is not None else (None, None, None, (1.0, 1, False))
+        order = ops.ray_order(origins, directions, hg.static_scale) if self.order_rays else None
+        ovr = (None, None, None, None)
+        if hg.has_actors():
+            if times is None:
+                raise ValueError("dynamic actors need ray times")
+            ovr = self._actor_overrides(origins, directions, pixel_area.reshape(-1), edges, times.reshape(-1))
         sd = self.sdf_to_density
         return ag.NffRenderTrainFn.apply(
-            g.hash_table, g.spec, self.hashgrid.static_scale, sd.beta, float(sd.beta_min), origins, directions,
-            pixel_area.reshape(-1), edges, emb, sensor, times, emb_cfg, order,
+            g.hash_table, g.spec, hg.static_scale, sd.beta, float(sd.beta_min), origins, directions,
+            pixel_area.reshape(-1), edges, emb, sensor, etimes, emb_cfg, order, *ovr,
             *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
             *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])
+
+    def _actor_overrides(self, origins, directions, pixel_area, edges, times):
+        """-> (ovr_row int32 [N]: row of the sample's WINNING actor (highest index containing it) or -1, rows [P,32],
+        box-frame view directions [P,3], pair_idx [P]: flat sample index of every (sample, actor) pair) or four Nones"""
+        hg = self.hashgrid
+        starts, ends = edges[:, :-1], edges[:, 1:]
+        N = starts.shape[0] * starts.shape[1]
+        flip = hg.sample_ray_flip(origins)
+        with torch.no_grad():
+            spec, cand = hg.prepare_actors(origins, directions, pixel_area, starts, ends, times)
+            scratch = torch.empty((N, hg.get_out_dim()), device=origins.device, dtype=torch.float32)  # (hit rows land here)
+            dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, scratch, flip)
+            hits = ops.actor_hits(spec, cand, origins, directions, pixel_area, starts, ends)
+        pr = hg.actor_pair_rows(hit, hits, origins, directions, pixel_area, starts, ends, times, flip)
+        if pr is None:
+            return None, None, None, None
+        idx, winner, f = pr
+        rows = torch.nn.functional.pad(f, (0, hg.get_out_dim() - f.shape[1])).contiguous()
+        with torch.no_grad():
+            P = idx.shape[0]
+            slot = torch.where(winner, torch.arange(P, device=idx.device), -1)  # one winner per sample: amax picks it
+            ov = torch.full((N,), -1, device=idx.device, dtype=torch.int64).scatter_reduce_(0, idx, slot, reduce="amax")
+            pdirs = dirs.index_select(0, idx).contiguous()
+        return ov.to(torch.int32), rows, pdirs, idx
 
     # ---- Field.forward (neurad_field.py:128-152) ------------------------------------------------
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[FieldHeadNames, Tensor]:

@@ -115,7 +115,7 @@ class FusedEvalMixin:
 
 
 class FusedTrainMixin:
-    """Training-time ``get_nff_outputs`` of a STATIC scene as a handful of autograd nodes (autograd.ProposalRoundFn per
+    """Training-time ``get_nff_outputs`` as a handful of autograd nodes (autograd.ProposalRoundFn per
     sampler round, autograd.NffRenderTrainFn for field + head + compositing + appearance) instead of the reference's
     orchestration over RaySamples views -- same outputs, ~1/4 of the launches.  Mixed into ``NeuRADHotPath`` and into the
     nerfstudio plugin model (integration/neurad_hip.py: a subclass of the reference's NeuRADModel); expects on ``self`` what
@@ -145,8 +145,7 @@ class FusedTrainMixin:
     def fused_training_possible(self) -> bool:
         f = self.field
         return (self.fused_training and self.training and torch.is_grad_enabled() and f.fused_training and f.config.use_sdf
-                and not f.hashgrid.has_actors() and f.fused_supported() and f._fused_train_ok()
-                and not any(p.hashgrid.has_actors() for p in self.proposal_fields)
+                and f.fused_supported(with_actors=True) and f._fused_train_ok()
                 and isinstance(self.sampler.initial_sampler, PowerSampler) and not self.config.normalize_depth)
 
     def _fused_train_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool) -> Dict[str, Tensor]:
@@ -188,8 +187,14 @@ class FusedTrainMixin:
             pf = pfs[k]
             g = pf.hashgrid.static_grid
             with contextlib.nullcontext() if train_props else torch.no_grad():  # frozen between scheduled updates
-                w, pdepth = ag.ProposalRoundFn.apply(g.hash_table, pf.density_decoder.weight, g.spec, pf.hashgrid.static_scale,
-                                                     o, d, a, eu)
+                if pf.hashgrid.has_actors():
+                    # dynamic actors: the field's own density (static kernel + the actor overlay, operator level), then
+                    # weights and the round's depth from the edges
+                    dens = pf.get_density(_light_samples(ray_bundle, sp, eu, fn))[0][..., 0]
+                    w, pdepth = ag.PropWeightsFn.apply(eu, dens.contiguous())
+                else:
+                    w, pdepth = ag.ProposalRoundFn.apply(g.hash_table, pf.density_decoder.weight, g.spec,
+                                                         pf.hashgrid.static_scale, o, d, a, eu)
             weights_list.append(w[..., None])
             samples_list.append(_light_samples(ray_bundle, sp, eu, fn))
             nff[f"prop_depth_{k}"] = pdepth
@@ -211,7 +216,7 @@ class FusedTrainMixin:
             assert sensor is not None, "sensor_idxs must be present in metadata during training"
             appearance = (self.appearance_embedding.weight, sensor, ray_bundle.times if cfg.use_temporal_appearance else None,
                           (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance)))
-        features, depth, accumulation, w_ns = self.field.render_train(o, d, a, eu, appearance)
+        features, depth, accumulation, w_ns = self.field.render_train(o, d, a, eu, appearance, times=ray_bundle.times)
         nff.update(features=features, depth=depth, accumulation=accumulation)
         S = counts[-1]
         if self.training:

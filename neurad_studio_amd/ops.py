@@ -448,9 +448,12 @@ def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, orde
     return feature, sdf, alpha
 
 
-def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends, order: Optional[Tensor] = None):
+def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends, order: Optional[Tensor] = None,
+                    override=None):
     """field_fwd + the activations the backward needs: -> (feature [N,32], geo_out [N], head [N]),
-    (enc [N,32], geo_hidden [N,H], feat_in [N,48], feat_hidden [N,2H])"""
+    (enc [N,32], geo_hidden [N,H], feat_in [N,48], feat_hidden [N,2H]).
+    override = (ovr_row int32 [N] (row index or -1), ovr_rows [P,32], ovr_dirs [P,3]): samples inside an actor box take
+    their encoding row and SH direction from the caller (nrhip_field_fwd_train_ovr)."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends, order)
     f, keep2 = fs.c_field()
     n, dev = r.n_rays * r.n_samples, origins.device
@@ -459,8 +462,16 @@ def field_fwd_train(fs: FieldSpec, origins, directions, pixel_area, starts, ends
     feature, enc, hg, xf, hf = mk(32), mk(32), mk(H), mk(48), mk(2 * H)
     sdf = torch.empty((n,), device=dev, dtype=torch.float32)
     head = torch.empty((n,), device=dev, dtype=torch.float32)
-    call("nrhip_field_fwd_train", C.byref(f), C.byref(r), _ptr(feature), _ptr(sdf), _ptr(head), _ptr(enc), _ptr(hg),
-         _ptr(xf), _ptr(hf), _stream())
+    if override is not None:
+        ov, rows, dirs = override
+        ov, rows, dirs = _chk(ov.reshape(-1), "ovr_row", torch.int32), _chk(rows, "ovr_rows"), _chk(dirs, "ovr_dirs")
+        if ov.shape[0] != n or rows.dim() != 2 or rows.shape[1] != 32 or dirs.shape != (rows.shape[0], 3):
+            raise ValueError("field_fwd_train: override = (int32 [N], [P,32], [P,3])")
+        call("nrhip_field_fwd_train_ovr", C.byref(f), C.byref(r), _ptr(ov), _ptr(rows), _ptr(dirs), _ptr(feature), _ptr(sdf),
+             _ptr(head), _ptr(enc), _ptr(hg), _ptr(xf), _ptr(hf), _stream())
+    else:
+        call("nrhip_field_fwd_train", C.byref(f), C.byref(r), _ptr(feature), _ptr(sdf), _ptr(head), _ptr(enc), _ptr(hg),
+             _ptr(xf), _ptr(hf), _stream())
     return (feature, sdf, head), (enc, hg, xf, hf)
 
 

@@ -77,8 +77,18 @@ def train():
     loss.backward()
 
 
+def train_fused():  # the fused training node: field + head + compositing, actor rows as overrides (nrhip_field_fwd_train_ovr)
+    eu = torch.cat([sampler(rb).frustums.starts[..., 0], rb.fars], -1)
+    feats, depth, acc, w = fld.train().render_train(o, d, rb.pixel_area, eu, times=times)
+    loss = feats.square().mean() + acc.mean() + 1e-3 * depth.mean()
+    for p in fld.parameters():
+        p.grad = None
+    loss.backward()
+
+
 if len(sys.argv) > 3 and sys.argv[3] == "train":  # profile target: the training step alone
-    print(f"{NA} actors, {R} rays x {S} samples: train forward+backward {timeit(train, 20):.3f} ms")
+    print(f"{NA} actors, {R} rays x {S} samples: train forward+backward {timeit(train, 20):.3f} ms (operator level), "
+          f"{timeit(train_fused, 20):.3f} ms (fused node with row overrides)")
     sys.exit(0)
 rs = sampler(rb)
 fr = rs.frustums
@@ -111,3 +121,4 @@ print(f"  eval, operator-level path (per-sample outputs, no compositing) {timeit
 print(f"  eval, fused render with actors (prepare + split + 2 kernels)    {timeit(fused):.3f} ms")
 print(f"  eval, fused render of the static scene alone (floor)            {timeit(fused_static_only):.3f} ms")
 print(f"  train forward+backward (operator-level actor path)             {timeit(train):.3f} ms")
+print(f"  train forward+backward (fused node, actor rows as overrides)    {timeit(train_fused):.3f} ms")

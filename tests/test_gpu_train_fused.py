@@ -328,3 +328,76 @@ def test_fused_training_path_with_jitter_runs_and_matches_operator_path_given_th
     assert set(res["fused"][1]) == set(res["operator"][1])
     for n in res["fused"][1]:
         assert rel_l2(host(res["fused"][1][n]), host(res["operator"][1][n])) < 1e-4, n
+
+
+def _actor_model():
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+    from test_gpu_actors import trajectories
+
+    torch.manual_seed(1)
+    c = NeuRADHotPathConfig(appearance_dim=16)
+    c.field.grid.static.log2_hashmap_size = 12
+    c.field.grid.actor.log2_hashmap_size = 10
+    c.field.sdf_beta = 3.0
+    for pf in (c.sampling.proposal_field_1, c.sampling.proposal_field_2):
+        pf.grid.static.log2_hashmap_size = 11
+        pf.grid.actor.log2_hashmap_size = 9
+    actors = DynamicActors(DynamicActorsConfig(), trajectories=trajectories())
+    m = NeuRADHotPath(c, static_scale=100.0, num_sensors=2, duration=4.0, actors=actors).cuda().train()
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(500.0)
+        for gr in m.field.hashgrid.actor_grids:
+            gr.hash_table.mul_(3000.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(500.0)
+            for gr in p.hashgrid.actor_grids:
+                gr.hash_table.mul_(2000.0)
+    m.sampler.eval()  # no sampling jitter; the actors' per-ray flip stays on (same draws in both paths under one seed)
+    return m
+
+
+def _actor_rays(R=384):
+    from neurad_studio_amd.cameras.rays import RayBundle
+
+    gen = torch.Generator().manual_seed(5)
+    times = 1.0 + torch.rand(R, 1, generator=gen)  # all three trajectories exist in [1, 2]
+    a = torch.arange(R) % 3  # look at actor a, where it is at the ray's time (test_gpu_actors.trajectories), from ~4 m
+    tgt = torch.stack([12.0 + 2.0 * times[:, 0] + a, torch.tensor([8.0, -6.0, -5.0])[a], torch.full((R,), 0.5)], -1)
+    side = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.15]), dim=-1)
+    o = tgt + 4.0 * side
+    d = torch.nn.functional.normalize(tgt + 0.3 * torch.randn(R, 3, generator=gen) - o, dim=-1)
+    d[::4] = -d[::4]  # every fourth ray looks away
+    return RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((R, 1), 2.7e-7, device="cuda"),
+                     times=times.cuda(), metadata={"sensor_idxs": torch.randint(0, 2, (R, 1), generator=gen).cuda()})
+
+
+def test_fused_training_with_dynamic_actors_matches_the_operator_level_path():
+    """A scene with dynamic actors through the fused training nodes: samples inside a box take their encoding row and view
+    direction from the differentiable actor branch (nrhip_field_fwd_train_ovr), the proposal rounds take the fields' own
+    densities (static kernel + actor overlay).  Outputs and EVERY gradient -- static tables, actor grids, trajectory
+    parameters, MLPs, beta, embedding -- against the operator-level path of the same model, which is pinned to the
+    reference by the field_actors / field_actors_grads / proposal_actors goldens (tests/test_gpu_actors.py)."""
+    from neurad_studio_amd.model_components.losses import distortion_loss, zipnerf_interlevel_loss
+
+    res = {}
+    for mode in ("fused", "operator"):
+        m = _actor_model()
+        m.fused_training = mode == "fused"
+        assert m.field.hashgrid.has_actors() and m.fused_training_possible() == (mode == "fused")
+        torch.manual_seed(77)
+        out = m.get_nff_outputs(_actor_rays())
+        loss = (out["features"].square().mean() + 1e-3 * out["depth"].mean() + out["accumulation"].mean()
+                + 0.01 * zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
+                + 0.02 * distortion_loss(out["weights_list"], out["ray_samples_list"]) + 1e-3 * out["prop_depth_1"].mean())
+        loss.backward()
+        res[mode] = (out, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(host(res["fused"][0][k]), host(res["operator"][0][k])) < 5e-5, k
+    gf, go = res["fused"][1], res["operator"][1]
+    assert set(gf) == set(go), set(gf) ^ set(go)
+    touched = [n for n in gf if ".actor_grids." in n and float(gf[n].abs().sum()) > 0]
+    assert len(touched) >= 3, touched  # the scene exercises the actor grids of the field and of a proposal field
+    assert any("actor_positions" in n for n in gf) and any("actor_rotations_6d" in n for n in gf)
+    for n in gf:
+        assert rel_l2(host(gf[n]), host(go[n])) < 2e-4, (n, rel_l2(host(gf[n]), host(go[n])))

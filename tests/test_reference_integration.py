@@ -184,7 +184,8 @@ class OracleOps:
                                 rand=None if rand is None else N(rand).reshape(R, -1))
         return T(bins), T(eu)
 
-    def field_fwd_train(self, fs, origins, directions, pixel_area, starts, ends, order=None):
+    def field_fwd_train(self, fs, origins, directions, pixel_area, starts, ends, order=None, override=None):
+        assert override is None, "the stub covers the static scene"
         self.calls.append(("field_fwd_train", tuple(starts.shape)))
         out = O.field_fwd(self._field_params(fs), N(origins), N(directions), N(pixel_area), N(starts), N(ends))
         n = starts.shape[0] * starts.shape[1]
