@@ -86,6 +86,10 @@ def train_fused():  # the fused training node: field + head + compositing, actor
     loss.backward()
 
 
+if len(sys.argv) > 3 and sys.argv[3] in ("train_op", "train_fused"):  # profile targets: one path alone
+    fn = train if sys.argv[3] == "train_op" else train_fused
+    print(f"{NA} actors, {R} rays x {S} samples: {sys.argv[3]} forward+backward {timeit(fn, 20):.3f} ms")
+    sys.exit(0)
 if len(sys.argv) > 3 and sys.argv[3] == "train":  # profile target: the training step alone
     print(f"{NA} actors, {R} rays x {S} samples: train forward+backward {timeit(train, 20):.3f} ms (operator level), "
           f"{timeit(train_fused, 20):.3f} ms (fused node with row overrides)")
