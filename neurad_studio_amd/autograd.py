@@ -67,6 +67,9 @@ class MultiHashGridFn(torch.autograd.Function):
     def forward(ctx, x, grid_id, spec, *tables):
         ctx.spec = spec
         grid_id = grid_id.to(torch.int32)
+        # which grids the batch touches: read HERE (the caller has just read the batch size from the device, the queue is
+        # empty) so that the backward, in the middle of a full queue, does not stall on a device->host read
+        ctx.present = ops.grids_present(grid_id, len(tables)) if any(t.requires_grad for t in tables) else None
         ctx.save_for_backward(x, grid_id, *tables)
         return ops.hashgrid_multi_fwd(spec, tables, grid_id, x)
 
@@ -75,8 +78,8 @@ class MultiHashGridFn(torch.autograd.Function):
     def backward(ctx, g):
         x, grid_id, *tables = ctx.saved_tensors
         g = g.contiguous()
-        gts = ops.hashgrid_multi_bwd(ctx.spec, len(tables), grid_id, x, g) if any(ctx.needs_input_grad[3:]) else \
-            [None] * len(tables)
+        gts = ops.hashgrid_multi_bwd(ctx.spec, len(tables), grid_id, x, g, present=ctx.present) \
+            if any(ctx.needs_input_grad[3:]) else [None] * len(tables)
         gx = ops.hashgrid_multi_bwd_input(ctx.spec, tables, grid_id, x, g) if ctx.needs_input_grad[0] else None
         return (gx, None, None, *gts)
 

@@ -375,15 +375,21 @@ class NeuRADProposalField(nn.Module):
         w = self.density_decoder.weight[0, : rows.shape[1]]     # features are zero-padded up to the static width
         logit = rows @ w
         shape = dens.shape
-        flat = dens.reshape(-1).index_put((idx[winner],), trunc_exp(logit[winner]))
-        if not bool(winner.all()):
-            # overlapping boxes: the reference's features[ray, sample] = ... hands the merged row's gradient to every
-            # duplicate (neurad_encoding.py:184-185); value unchanged
-            lose = ~winner
-            # (only the shadowed actors' FEATURES see that gradient; the decoder's own gradient comes from the merged
-            # row, i.e. from the winner -> the weight is detached here)
-            shadow = rows[lose] @ w.detach()
-            flat = flat.index_put((idx[lose],), (shadow - shadow.detach()) * flat[idx[lose]].detach(), accumulate=True)
+        # No boolean indexing and no `if winner.all()`: both are device->host reads in the middle of the step.  The winner of
+        # a sample writes its value, every other pair adds 0 to the value -- the winner rows through `where`, the losers
+        # through a factor 0 -- so one index_put with accumulate over ALL pairs does it: the base is zeroed at the hit
+        # samples first (each has exactly one winner).
+        is_hit = torch.zeros_like(dens.reshape(-1), dtype=torch.bool).index_fill_(0, idx, True)
+        base = torch.where(is_hit, torch.zeros_like(dens.reshape(-1)), dens.reshape(-1))
+        win_val = trunc_exp(logit)
+        # overlapping boxes: the reference's features[ray, sample] = ... hands the merged row's gradient to every duplicate
+        # (neurad_encoding.py:184-185), value unchanged: (shadow - shadow.detach()) * merged value.  Only the shadowed
+        # actors' FEATURES see that gradient (the decoder's own comes from the winner): the weight is detached there.
+        shadow = rows @ w.detach()
+        merged = torch.zeros_like(base).index_put((idx,), torch.where(winner, win_val.detach(), torch.zeros_like(win_val)),
+                                                   accumulate=True)
+        lose_val = (shadow - shadow.detach()) * merged.index_select(0, idx)
+        flat = base.index_put((idx,), torch.where(winner, win_val, lose_val), accumulate=True)
         return flat.view(shape)
 
     def get_outputs(self, ray_samples, density_embedding=None) -> dict:

@@ -202,22 +202,53 @@ def hashgrid_multi_fwd(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor
     return out
 
 
-def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, grad_out: Tensor):
+def grids_present(grid_id: Tensor, n_grids: int) -> List[bool]:
+    """which grids a batch of rows refers to, as a host list (ONE device->host read; callers do it in the forward, right
+    behind the read that sized the batch, so that the backward needs none)"""
+    return torch.bincount(grid_id, minlength=n_grids).gt(0).tolist()
+
+
+def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, grad_out: Tensor,
+                       present: Optional[List[bool]] = None):
     """-> one gradient per grid, None for grids no sample refers to (like the reference's per-id loop, which never
-    touches them: their optimizer state must not decay)."""
+    touches them: their optimizer state must not decay).  present: ``grids_present(grid_id, n_grids)`` when the caller
+    already has it -- the backward then runs without a device->host read and without a host->device copy."""
     x, grid_id, grad_out = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32), _chk(grad_out, "grad_out")
-    present = torch.bincount(grid_id, minlength=n_grids).gt(0).tolist()  # one small device->host read per backward
+    if present is None:
+        present = grids_present(grid_id, n_grids)
     if not any(present):
         return [None] * n_grids
     # one zero-filled block for all touched grids (a scene has ~100 actor grids: one fill, not one per grid)
     flat = torch.zeros((sum(present), spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
     views = iter(flat.unbind(0))
     gts = [next(views) if p else None for p in present]
-    g = spec.c_grid(next(t for t in gts if t is not None))
-    ptrs = torch.tensor([0 if t is None else t.data_ptr() for t in gts], dtype=torch.int64, device=x.device)
+    g = spec.c_grid(flat[0])
+    # device array of the gradient tables' addresses, computed ON the device (base + slot * stride; 0 for untouched grids):
+    # a torch.tensor(list, device=...) here is a pageable host->device copy, i.e. a stream synchronisation per backward
+    slot = _present_slots(tuple(present), x.device)
+    ptrs = torch.where(slot >= 0, slot * (flat[0].numel() * 4) + flat.data_ptr(), torch.zeros_like(slot))
     call("nrhip_hashgrid_multi_bwd", C.byref(g), n_grids, _ptr(grid_id), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(ptrs),
          _stream())
     return gts
+
+
+_SLOT_TABLES: dict = {}
+
+
+def _present_slots(present: Tuple[bool, ...], device) -> Tensor:
+    """int64 [n_grids]: position of each touched grid in the packed gradient block, -1 for untouched ones; uploaded once per
+    distinct pattern"""
+    key = (device, present)
+    t = _SLOT_TABLES.get(key)
+    if t is None:
+        if len(_SLOT_TABLES) >= 64:
+            _SLOT_TABLES.clear()
+        k, slots = 0, []
+        for p in present:
+            slots.append(k if p else -1)
+            k += int(p)
+        t = _SLOT_TABLES[key] = torch.tensor(slots, dtype=torch.int64, device=device)
+    return t
 
 
 def hashgrid_multi_bwd_input(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor, x: Tensor, grad_out: Tensor):
