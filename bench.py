@@ -228,7 +228,10 @@ def train_section(device, rank, world, steps, warmup, beta=None, table_scale=Non
     assert torch.isfinite(state["loss"])
     return {"iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "ray_samples_per_sec": world * R_RAYS * N_SAMPLES * steps / el,
-            "grad_exchange_bytes_per_rank": state["bytes"], "optimizer": opt_name,
+            "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
+            "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
+                              f"{sync.last_list_levels}") if level_tables else "dense reduce-scatter + all-gather",
+            "optimizer": opt_name,
             "what": "fwd + bwd + gradient exchange + optimizer step, 4096 rays x 128 samples per GPU"}
 
 
@@ -268,7 +271,7 @@ def joint_batch(device, rank, n_cam, n_lidar):
 
 
 def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, rgb_decoder=True,
-                       cfg_edit=None, sharded_adam=False):
+                       cfg_edit=None, sharded_adam=False, sparse_exchange=False):
     """The whole training step at the reference's default sizes (models/neurad.py defaults: static grid L=8, F=4, T=2^22;
     proposal grids L=6, F=1, T=2^20; 128+64 proposal samples, 32 field samples; 32-wide MLPs; 16-d appearance embedding;
     lidar head; RGB CNN decoder) on a camera+lidar joint batch: get_nff_outputs (training mode, jitter, lidar metadata) ->
@@ -300,8 +303,12 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1)
     # static scene: the used-parameter set is agreed once (no per-step host read); the proposal tables' exchange starts
     # from their gradient hooks, under the field backward
+    level_tables = None
+    if sparse_exchange and world > 1 and not hasattr(opt, "owned_params"):  # coarse table levels as (row, values) lists
+        grids = [m.field.hashgrid.static_grid] + [p.hashgrid.static_grid for p in m.proposal_fields]
+        level_tables = {g.hash_table: g.num_levels for g in grids if g.hash_table.dtype == torch.float32}
     sync = GradientSynchronizer(params, average=True, usage="static", overlap=world > 1,
-                                skip=opt.owned_params() if hasattr(opt, "owned_params") else ())
+                                skip=opt.owned_params() if hasattr(opt, "owned_params") else (), level_tables=level_tables)
     o, d, area, times, md = joint_batch(device, rank, n_cam, n_lidar)
     R = n_cam + n_lidar
     g = torch.Generator(device=device)
@@ -394,7 +401,10 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     return {"roofline": roof, "iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
-            "grad_exchange_bytes_per_rank": state["bytes"], "optimizer": opt_name,
+            "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
+            "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
+                              f"{sync.last_list_levels}") if level_tables else "dense reduce-scatter + all-gather",
+            "optimizer": opt_name,
             "rgb_decoder": ("CNN decoder (4 BasicBlocks of 7x7 convs + 3x transposed conv, MIOpen under fp16 autocast) + rgb "
                             f"MSE in the step; standalone forward+backward {dec_ms:.2f} ms") if dec is not None
             else "not in this step (feature regression stands in)",
@@ -866,6 +876,8 @@ def main():
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1: hash tables on ShardedTableAdam (reduce-scatter of the gradient, Adam on 1/N of each table, "
                          "all-gather of the parameters) instead of gradient all-reduce + a full-table Adam on every rank")
+    ap.add_argument("--sparse-exchange", action="store_true",
+                    help="N > 1: coarse hash-table levels travel as (row, values) lists (GradientSynchronizer level_tables)")
     ap.add_argument("--no-rgb-decoder", action="store_true", help="train_full / c3 without the RGB CNN decoder (round-2 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train iters/sec sections")
@@ -904,7 +916,7 @@ def main():
     elif args.config == "c3":
         steps = min(args.steps, 50)
         tf = train_full_section(device, rank, world, steps, max(2, min(args.warmup, 5)), rgb_decoder=not args.no_rgb_decoder,
-                                sharded_adam=args.sharded_adam)
+                                sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange)
         out = {"metric": "train iters/sec (camera+lidar joint batch)", "value": tf["rays_per_sec"], "unit": "rays/s",
                "n_gpus": world, "steps": steps, "warmup": max(2, min(args.warmup, 5)), "ms_per_step": tf["ms_per_iter"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -945,12 +957,12 @@ def main():
                 torch.cuda.empty_cache()
                 train_full = guarded(lambda: train_full_section(device, rank, world, args.train_full_steps, 8,
                                                                 rgb_decoder=not args.no_rgb_decoder,
-                                                                sharded_adam=args.sharded_adam))
+                                                                sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange))
                 if not args.no_rgb_decoder and isinstance(train_full, dict) and "error" not in train_full:
                     gc.collect()
                     torch.cuda.empty_cache()
                     hot = guarded(lambda: train_full_section(device, rank, world, max(args.train_full_steps // 2, 5), 5,
-                                                             rgb_decoder=False, sharded_adam=args.sharded_adam))
+                                                             rgb_decoder=False, sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange))
                     if isinstance(hot, dict):
                         hot.pop("roofline", None)
                         train_full["hot_path_only"] = {k: hot[k] for k in ("iters_per_sec", "ms_per_iter", "rays_per_sec", "error")

@@ -14,6 +14,11 @@ MI355X-first choices (xGMI is point-to-point, 7 links x ~153 GB/s per GPU; a rin
     bitmap.  ``usage="dynamic"`` agrees on that set every step (one tiny MAX all-reduce + a host read: needed when actor
     grids come and go); ``usage="static"`` agrees once and from then on only checks, on the host and without any
     device read, that the local pattern has not changed (static scenes: no per-step host sync at all).
+  * OPT-IN, ``level_tables=`` (bench.py --sparse-exchange): a hash table's COARSE levels receive few distinct rows per step
+    (config[3] step, scripts/grad_density.py: 0.3 / 1 / 3 / 8 / 17 / 33 / 52 / 67 % of the rows of the field table's eight
+    levels), so those levels travel as (row, values) lists in one all-gather and every rank adds the lists in rank order
+    (bit-identical replicas); the fine levels stay dense.  Which levels go as lists is decided per step from the agreed
+    maximum row count: a list pays while (N-1) * rows * (4 + 4F) bytes < the 2 (N-1)/N * T * 4F of the dense pair.
 Backend-agnostic (``"nccl"`` == RCCL on ROCm, ``"gloo"`` in the CPU tests)."""
 from __future__ import annotations
 
@@ -58,7 +63,8 @@ class GradientSynchronizer:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, average: bool = True,
                  large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False,
-                 skip: Iterable[torch.nn.Parameter] = ()) -> None:
+                 skip: Iterable[torch.nn.Parameter] = (),
+                 level_tables: Optional[Dict[torch.nn.Parameter, int]] = None) -> None:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         if overlap and usage != "static":
@@ -76,9 +82,19 @@ class GradientSynchronizer:
         self._inflight: Dict[int, Tuple[object, Tensor, Tensor]] = {}  # param index -> (work, flat grad, shard)
         self._hooks = []
         self.overlapped_last_step = 0
+        # level-sparse exchange (opt-in): parameter index -> number of levels of a [levels * T, F] hash table
+        self._levels: Dict[int, int] = {}
+        for p, n_levels in (level_tables or {}).items():
+            i = next((k for k, q in enumerate(self.params) if q is p), None)
+            if i is not None:
+                if p.dim() != 2 or p.shape[0] % n_levels or not p.is_contiguous():
+                    raise ValueError("level_tables: contiguous [levels * T, F] tables only")
+                self._levels[i] = int(n_levels)
+        self.last_wire_bytes = 0        # bytes this rank SENT in the last sync()
+        self.last_list_levels: Dict[int, List[int]] = {}
         if overlap:
             for i, p in enumerate(self.params):
-                if self._is_large(p):
+                if self._is_large(p) and i not in self._levels:  # level tables wait for the agreed row counts
                     self._hooks.append(p.register_post_accumulate_grad_hook(lambda param, i=i: self._on_grad_ready(i)))
 
     def world_size(self) -> int:
@@ -136,6 +152,90 @@ class GradientSynchronizer:
             dist.all_gather(parts, shard, group=self.group)
             flat.copy_(torch.cat(parts))
 
+    # ---- level-sparse exchange ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _row_mask(g: Tensor, n_levels: int) -> Tensor:
+        return (g.view(n_levels, -1, g.shape[-1]) != 0).any(-1)  # [levels, T]
+
+    def _sync_level_tables(self, todo: List[int]) -> None:
+        """Hash-table gradients whose coarse levels go as (row, values) lists.  One MAX all-reduce of the per-level row counts
+        and ONE host read size the lists for every table; lists are padded to the agreed count with row -1."""
+        world = self.world_size()
+        masks = {i: self._row_mask(self.params[i].grad, self._levels[i]) for i in todo}
+        counts = torch.cat([masks[i].sum(1) for i in todo]).to(torch.int64)
+        dist.all_reduce(counts, op=dist.ReduceOp.MAX, group=self.group)
+        counts, off = counts.tolist(), 0
+        for i in todo:
+            g, L = self.params[i].grad, self._levels[i]
+            T, F = g.shape[0] // L, g.shape[1]
+            cap = counts[off:off + L]
+            off += L
+            # a list costs (N-1) * cap * (4 + 4F) bytes per rank, the dense pair 2 (N-1)/N * T * 4F
+            lists = [l for l in range(L) if cap[l] * (1 + F) * world < 2 * T * F and (T * F) % world == 0]
+            self.last_list_levels[i] = lists
+            flat = g.view(-1)
+            l = 0
+            while l < L:  # maximal runs of dense levels: reduce-scatter + all-gather in place, as for any large gradient
+                if l in lists:
+                    l += 1
+                    continue
+                e = l
+                while e < L and e not in lists:
+                    e += 1
+                run = flat[l * T * F:e * T * F]
+                if run.numel() % world:
+                    dist.all_reduce(run, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.average:
+                        run.div_(world)
+                else:
+                    _, shard = reduce_scatter_flat(run, world, self.group)
+                    self._finish_large(run, shard)
+                self.last_wire_bytes += 2 * (world - 1) * run.numel() * 4 // world
+                l = e
+            if not lists or sum(cap[l] for l in lists) == 0:
+                continue
+            total = sum(cap[l] for l in lists)
+            rows = torch.full((total,), -1, device=g.device, dtype=torch.int32)
+            vals = torch.zeros((total, F), device=g.device, dtype=g.dtype)
+            ar = torch.arange(T, device=g.device, dtype=torch.int32)
+            o = 0
+            for l in lists:  # ordered compaction without a host read: the capacity is known, a dump slot takes the rest
+                c = cap[l]
+                if c:
+                    m = masks[i][l]
+                    slot = torch.where(m, m.cumsum(0) - 1, c)
+                    buf = torch.full((c + 1,), -1, device=g.device, dtype=torch.int32)
+                    buf.scatter_(0, slot, ar)
+                    rows[o:o + c] = buf[:c]
+                    o += c
+            gl = g.view(L, T, F)
+            o = 0
+            for l in lists:
+                c = cap[l]
+                if c:
+                    r = rows[o:o + c]
+                    vals[o:o + c] = gl[l][r.clamp(min=0).long()] * (r >= 0).unsqueeze(1)
+                    o += c
+            if self.average:
+                vals.mul_(1.0 / world)
+            all_rows = [torch.empty_like(rows) for _ in range(world)]
+            all_vals = [torch.empty_like(vals) for _ in range(world)]
+            dist.all_gather(all_rows, rows, group=self.group)
+            dist.all_gather(all_vals, vals, group=self.group)
+            self.last_wire_bytes += (world - 1) * total * (4 + 4 * F)
+            o = 0
+            for l in lists:
+                c = cap[l]
+                if not c:
+                    continue
+                # own rows -> 0 (a padded -1 clears row 0 only if row 0 is not in the list, i.e. is zero already), then
+                # every rank's list in RANK order: all replicas form the same sums in the same order
+                gl[l].index_fill_(0, rows[o:o + c].clamp(min=0).long(), 0.0)
+                for k in range(world):
+                    r = all_rows[k][o:o + c]
+                    gl[l].index_add_(0, r.clamp(min=0).long(), all_vals[k][o:o + c] * (r >= 0).unsqueeze(1))
+                o += c
+
     def _on_grad_ready(self, i: int) -> None:
         """post-accumulate-grad hook (overlap): autograd is done with this gradient -> its reduce-scatter starts now, on
         the backend's own stream, while the rest of the backward keeps the compute stream busy.  Only after the usage
@@ -156,7 +256,8 @@ class GradientSynchronizer:
         if world == 1 or not self.params:
             return 0
         used = self._used_mask()
-        small, nbytes = [], 0
+        small, nbytes, level_todo = [], 0, []
+        self.last_wire_bytes, self.last_list_levels = 0, {}
         self.overlapped_last_step = len(self._inflight)
         for i, (p, u) in enumerate(zip(self.params, used)):
             if not u:
@@ -165,6 +266,11 @@ class GradientSynchronizer:
                 p.grad = torch.zeros_like(p)
             g = p.grad
             nbytes += g.numel() * g.element_size()
+            if i in self._levels and g.dtype == torch.float32 and g.is_contiguous():
+                level_todo.append(i)
+                continue
+            if i in self._inflight or self._is_large(g):
+                self.last_wire_bytes += 2 * (world - 1) * g.numel() * g.element_size() // world
             if i in self._inflight:  # started from the hook: wait for the scatter, finish with the gather
                 work, flat, shard = self._inflight.pop(i)
                 work.wait()
@@ -175,8 +281,11 @@ class GradientSynchronizer:
             else:
                 small.append(g)
         assert not self._inflight, "a hooked gradient was not consumed by sync()"
+        if level_todo:
+            self._sync_level_tables(level_todo)
         if small:
             flat = torch.cat([g.reshape(-1) for g in small])
+            self.last_wire_bytes += 2 * (world - 1) * flat.numel() * flat.element_size() // world
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 flat.div_(world)

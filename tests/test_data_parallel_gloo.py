@@ -283,3 +283,53 @@ def test_sharded_table_adam_skips_tables_without_any_gradient_world2_gloo():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_sharded_adam_skip_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _worker_levels(rank, world, port, ret):
+    """a 4-level table: level 0 gets 3 rows per rank, level 1 ~5 %, level 2 ~40 %, level 3 every row; a second table whose
+    levels are all sparse; rank 1 has an all-zero level (empty list, padding only)"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L, T, F = 4, 1024, 4
+    g = torch.Generator().manual_seed(77 + rank)
+
+    def grads():
+        a = torch.zeros(L, T, F)
+        for lvl, frac in enumerate((3 / T, 0.05, 0.4, 1.0)):
+            rows = torch.randperm(T, generator=g)[:max(int(frac * T), 1)]
+            a[lvl, rows] = torch.randn(len(rows), F, generator=g)
+        a[0, 0] = 1.0 + rank  # row 0 in both lists: the padding's clamp target must survive
+        b = torch.zeros(2, 512, 2)
+        if rank == 0:
+            b[0, torch.randperm(512, generator=g)[:20]] = torch.randn(20, 2, generator=g)
+        b[1, torch.randperm(512, generator=g)[:7]] = torch.randn(7, 2, generator=g)
+        return a.reshape(L * T, F), b.reshape(2 * 512, 2)
+
+    ga, gb = grads()
+    out = {}
+    for mode in ("dense", "lists"):
+        ta, tb = torch.nn.Parameter(torch.zeros(L * T, F)), torch.nn.Parameter(torch.zeros(1024, 2))
+        small = torch.nn.Parameter(torch.zeros(5))
+        ta.grad, tb.grad, small.grad = ga.clone(), gb.clone(), torch.full((5,), float(rank))
+        sync = GradientSynchronizer([ta, tb, small], average=True, large_threshold_bytes=1 << 10,
+                                    level_tables={ta: L, tb: 2} if mode == "lists" else None)
+        sync.sync()
+        out[mode] = (ta.grad.clone(), tb.grad.clone(), small.grad.clone(), sync.last_wire_bytes, dict(sync.last_list_levels))
+    # the truth: mean of both ranks' gradients
+    both = [torch.empty_like(ga) for _ in range(world)]
+    dist.all_gather(both, ga)
+    ok = torch.equal(out["dense"][0], (both[0] + both[1]) / 2)
+    ok = ok and all(torch.equal(out["dense"][k], out["lists"][k]) for k in range(3))  # world 2: a + b in either order
+    ok = ok and out["lists"][4] == {0: [0, 1, 2], 1: [0, 1]}  # level 2: 2 * 410 * 5 < 2 * 1024 * 4 still pays at N = 2
+    ok = ok and out["lists"][3] < out["dense"][3]
+    ret[rank] = (bool(ok), out["dense"][3], out["lists"][3])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_sparse_exchange_equals_the_dense_exchange_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_levels, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret[r][0] for r in range(world)), dict(ret)

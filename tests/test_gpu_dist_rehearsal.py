@@ -70,7 +70,7 @@ def _optimizers(m, sharded):
     return params, tables, topt, torch.optim.Adam(small, lr=1e-2, eps=1e-3)
 
 
-def _worker(rank, world, port, sharded, ret):
+def _worker(rank, world, port, mode, ret):
     import torch.distributed as dist
 
     from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
@@ -79,9 +79,15 @@ def _worker(rank, world, port, sharded, ret):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _model()
+    sharded = mode == "sharded"
     params, tables, topt, sopt = _optimizers(m, sharded)
+    levels = None
+    if mode == "level-sparse":  # coarse levels of the hash tables as (row, values) lists
+        grids = [m.field.hashgrid.static_grid] + [p.hashgrid.static_grid for p in m.proposal_fields]
+        levels = {g.hash_table: g.num_levels for g in grids}
     sync = GradientSynchronizer(params, average=True, large_threshold_bytes=1 << 14, usage="static", overlap=True,
-                                skip=tables if sharded else ())
+                                skip=tables if sharded else (), level_tables=levels)
+    lists = []
     overlapped = []
     for step in range(3):
         for o in (topt, sopt):
@@ -89,26 +95,29 @@ def _worker(rank, world, port, sharded, ret):
         _loss(m, _shard(rank, step)).backward()
         sync.sync()
         overlapped.append(sync.overlapped_last_step)
+        lists.append(sum(len(v) for v in sync.last_list_levels.values()))
         topt.step(), sopt.step()
     torch.cuda.synchronize()
     if rank == 0:
         ret["overlapped"] = overlapped
+        ret["lists"] = lists
         ret["params"] = {n: p.detach().cpu() for n, p in m.named_parameters()}
     ret[f"done{rank}"] = True
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sharded", [False, True], ids=["allreduce+HashGridAdam", "ShardedTableAdam"])
-def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean_loss(sharded):
+@pytest.mark.parametrize("mode", ["allreduce", "sharded", "level-sparse"],
+                         ids=["allreduce+HashGridAdam", "ShardedTableAdam", "level-sparse exchange"])
+def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean_loss(mode):
     import torch.multiprocessing as mp
 
     world = 2
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), sharded, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
         assert ret.get("done0") and ret.get("done1")
-        got, overlapped = dict(ret["params"]), list(ret["overlapped"])
+        got, overlapped, lists = dict(ret["params"]), list(ret["overlapped"]), list(ret["lists"])
     # one process, the mean loss of both shards
     m = _model()
     params, tables, topt, sopt = _optimizers(m, False)
@@ -125,4 +134,6 @@ def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean
         assert err < 2e-5, (n, err)
     # step 0 agrees on the usage set; afterwards the large gradients that every rank holds are exchanged from their hooks
     # (the field table and the one proposal table that trains; none when the sharded optimizer owns the tables)
-    assert overlapped[0] == 0 and overlapped[1] == overlapped[2] == (0 if sharded else 2), overlapped
+    assert overlapped[0] == 0 and overlapped[1] == overlapped[2] == (2 if mode == "allreduce" else 0), overlapped
+    if mode == "level-sparse":  # 256 rays x 32 samples into 2^14-row levels: the coarse levels of both tables go as lists
+        assert min(lists) >= 2, lists
