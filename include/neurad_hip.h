@@ -612,6 +612,22 @@ int nrhip_lidar_losses_bwd(const float* unit_grads, const float* scratch, const 
                            const float* upstream, int32_t n_levels, int64_t r, int64_t n, float* const* grad_depths,
                            float* grad_intensity, float* grad_logits, void* stream);
 
+/* ---- (f)-1: RGB CNN decoder (models/neurad.py:198-216,359-366; model_components/cnns.py:20-46) on fp16 operands with
+ *          fp32 accumulation -- the arithmetic of the reference's mixed-precision trainer.  Activations are NHWC fp16:
+ *          [B, H, W, 32].                                                                                              */
+/* torch Conv2d weight [32][32][7][7] fp32 -> the kernel's fragment order, 49*2*64*16 bytes.  mode 0: forward (replaces
+ * the four BasicBlocks' Conv2d.forward, cnns.py:38-44); mode 1: the same convolution's input gradient (flipped taps,
+ * channels swapped), i.e. nrhip_conv7x7 on a packed mode-1 weight IS conv2d_backward w.r.t. the input.               */
+int nrhip_conv7x7_pack(const float* weight, int32_t mode, void* wfrag, void* stream);
+/* workgroups per image for an h x w image (a workgroup covers 4*rows_per_wave rows x 32 columns): stats_partial below is
+ * [b * tiles, 64] floats.                                                                                             */
+int nrhip_conv7x7_tiles(int32_t h, int32_t w, int32_t rows_per_wave, int32_t* tiles);
+/* out = conv7x7(in, padding 3) + bias (bias may be NULL).  stats_partial (optional): per workgroup the sum and the sum
+ * of squares of the ROUNDED outputs per channel (BatchNorm2d's batch statistics, cnns.py:40,43, in a fixed order).
+ * rows_per_wave in {1, 2, 4}.                                                                                          */
+int nrhip_conv7x7(const void* in, const void* wfrag, const float* bias, void* out, float* stats_partial, int32_t b,
+                  int32_t h, int32_t w, int32_t rows_per_wave, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

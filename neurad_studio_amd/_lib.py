@@ -82,6 +82,9 @@ PROTOTYPES = {
     "nrhip_device_info": [C.POINTER(I32), C.POINTER(I32), C.POINTER(I64)],
     "nrhip_eval_layout_plan": [C.POINTER(Grid), C.POINTER(C.c_uint32), C.POINTER(I64)],
     "nrhip_eval_layout_build": [C.POINTER(Grid), P, C.POINTER(C.c_uint32), P, P],
+    "nrhip_conv7x7_pack": [P, I32, P, P],
+    "nrhip_conv7x7_tiles": [I32, I32, I32, C.POINTER(I32)],
+    "nrhip_conv7x7": [P, P, P, P, P, I32, I32, I32, I32, P],
     "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],
