@@ -627,6 +627,13 @@ int nrhip_conv7x7_tiles(int32_t h, int32_t w, int32_t rows_per_wave, int32_t* ti
  * rows_per_wave in {1, 2, 4}.                                                                                          */
 int nrhip_conv7x7(const void* in, const void* wfrag, const float* bias, void* out, float* stats_partial, int32_t b,
                   int32_t h, int32_t w, int32_t rows_per_wave, void* stream);
+/* Weight and bias gradient of the same convolution (conv2d_backward w.r.t. weight / bias): x = the convolution's input,
+ * grad_out = the gradient of its output, both NHWC fp16.  grad_weight [32][32][7][7] and grad_bias [32] (optional) are fp32
+ * and ACCUMULATED into.  workspace: nrhip_conv7x7_wgrad_workspace floats (per-workgroup partial sums, reduced in a fixed
+ * order: bit-reproducible).                                                                                            */
+int nrhip_conv7x7_wgrad_workspace(int32_t b, int32_t h, int32_t w, int64_t* floats);
+int nrhip_conv7x7_wgrad(const void* x, const void* grad_out, float* workspace, float* grad_weight, float* grad_bias,
+                        int32_t b, int32_t h, int32_t w, void* stream);
 
 #ifdef __cplusplus
 }

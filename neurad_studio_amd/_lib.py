@@ -85,6 +85,8 @@ PROTOTYPES = {
     "nrhip_conv7x7_pack": [P, I32, P, P],
     "nrhip_conv7x7_tiles": [I32, I32, I32, C.POINTER(I32)],
     "nrhip_conv7x7": [P, P, P, P, P, I32, I32, I32, I32, P],
+    "nrhip_conv7x7_wgrad_workspace": [I32, I32, I32, C.POINTER(I64)],
+    "nrhip_conv7x7_wgrad": [P, P, P, P, P, I32, I32, I32, P],
     "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],

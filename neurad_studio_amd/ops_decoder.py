@@ -48,3 +48,20 @@ def conv7x7(x: Tensor, wfrag: Tensor, bias: Optional[Tensor] = None, stats: bool
     bias_f = None if bias is None else _chk(bias.detach().to(torch.float32), "bias")
     call("nrhip_conv7x7", _ptr(x), _ptr(wfrag), _ptr(bias_f), _ptr(out), _ptr(part), b, h, w, r, _stream())
     return out, part
+
+
+def conv7x7_wgrad(x: Tensor, grad_out: Tensor, grad_weight: Tensor, grad_bias: Optional[Tensor] = None) -> None:
+    """grad_weight [32,32,7,7] (+ grad_bias [32]) += the convolution's weight (bias) gradient; x, grad_out NHWC fp16"""
+    for t, n in ((x, "x"), (grad_out, "grad_out")):
+        if t.dtype != torch.float16 or t.dim() != 4 or t.shape[-1] != 32 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"conv7x7_wgrad: {n} must be a contiguous cuda fp16 [B, H, W, 32] tensor")
+    if x.shape != grad_out.shape:
+        raise ValueError("conv7x7_wgrad: x and grad_out differ in shape")
+    b, h, w, _ = x.shape
+    gw = _chk(grad_weight, "grad_weight")
+    if gw.data_ptr() != grad_weight.data_ptr() or tuple(gw.shape) != (32, 32, 7, 7):
+        raise ValueError("conv7x7_wgrad: grad_weight must be a contiguous fp32 [32, 32, 7, 7] tensor")
+    n = C.c_int64(0)
+    call("nrhip_conv7x7_wgrad_workspace", b, h, w, C.byref(n))
+    ws = torch.empty((n.value,), device=x.device, dtype=torch.float32)
+    call("nrhip_conv7x7_wgrad", _ptr(x), _ptr(grad_out), _ptr(ws), _ptr(gw), _ptr(grad_bias), b, h, w, _stream())

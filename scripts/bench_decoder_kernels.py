@@ -34,6 +34,10 @@ def main():
             for st in (False, True):
                 us = timeit(lambda: D.conv7x7(x, wf, bias, stats=st, rows_per_wave=r))
                 res[f"conv7x7 {B}x{H}x{W} R={r} stats={int(st)}"] = {"us": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1)}
+        gw = torch.zeros((32, 32, 7, 7), device="cuda")
+        gb = torch.zeros((32,), device="cuda")
+        us = timeit(lambda: D.conv7x7_wgrad(x, x, gw, gb))
+        res[f"conv7x7_wgrad {B}x{H}x{W}"] = {"us": round(us, 1), "TFLOPs": round(flops / us / 1e6, 1)}
         xc = x.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
         wh = w.half().contiguous(memory_format=torch.channels_last)
         us = timeit(lambda: torch.nn.functional.conv2d(xc, wh, None, padding=3))

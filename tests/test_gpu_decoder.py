@@ -45,3 +45,22 @@ def test_conv7x7_on_mode1_weights_is_the_input_gradient():
     got, _ = D.conv7x7(gyh, D.conv7x7_pack(w, 1))
     ref = x.grad
     assert (got.float().permute(0, 3, 1, 2) - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 32), (2, 96, 96), (2, 20, 50), (1, 5, 17)])
+def test_conv7x7_weight_and_bias_gradient_match_torch(shape):
+    from neurad_studio_amd import ops_decoder as D
+
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xh = _nhwc16(torch.randn((B, 32, H, W), device="cuda", generator=g))
+    gh = _nhwc16(torch.randn((B, 32, H, W), device="cuda", generator=g))
+    w = torch.zeros((32, 32, 7, 7), device="cuda", requires_grad=True)
+    bias = torch.zeros((32,), device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(xh.float().permute(0, 3, 1, 2), w, bias, padding=3).backward(gh.float().permute(0, 3, 1, 2))
+    gw = torch.full((32, 32, 7, 7), 0.5, device="cuda")  # accumulated into
+    gb = torch.full((32,), -1.0, device="cuda")
+    D.conv7x7_wgrad(xh, gh, gw, gb)
+    # exact products of fp16 operands, fp32 accumulation on both sides: only the summation order differs
+    assert (gw - 0.5 - w.grad).abs().max() <= 2e-5 * w.grad.abs().max() + 1e-4
+    assert (gb + 1.0 - bias.grad).abs().max() <= 2e-5 * bias.grad.abs().max() + 1e-4
