@@ -619,6 +619,9 @@ int nrhip_lidar_losses_bwd(const float* unit_grads, const float* scratch, const 
  * the four BasicBlocks' Conv2d.forward, cnns.py:38-44); mode 1: the same convolution's input gradient (flipped taps,
  * channels swapped), i.e. nrhip_conv7x7 on a packed mode-1 weight IS conv2d_backward w.r.t. the input.               */
 int nrhip_conv7x7_pack(const float* weight, int32_t mode, void* wfrag, void* stream);
+/* the same for up to 8 convolutions in one launch: weights = HOST array of n device pointers; wfrag [n][2][49*2*64*16 bytes]
+ * receives mode 0 and mode 1 of every weight (the decoder packs once per step).                                       */
+int nrhip_conv7x7_pack_many(const float* const* weights, int32_t n, void* wfrag, void* stream);
 /* workgroups per image for an h x w image (a workgroup covers 4*rows_per_wave rows x 32 columns): stats_partial below is
  * [b * tiles, 64] floats.                                                                                             */
 int nrhip_conv7x7_tiles(int32_t h, int32_t w, int32_t rows_per_wave, int32_t* tiles);
@@ -633,7 +636,57 @@ int nrhip_conv7x7(const void* in, const void* wfrag, const float* bias, void* ou
  * order: bit-reproducible).                                                                                            */
 int nrhip_conv7x7_wgrad_workspace(int32_t b, int32_t h, int32_t w, int64_t* floats);
 int nrhip_conv7x7_wgrad(const void* x, const void* grad_out, float* workspace, float* grad_weight, float* grad_bias,
-                        int32_t b, int32_t h, int32_t w, void* stream);
+                        const float* grad_scale, int32_t b, int32_t h, int32_t w, void* stream);
+
+/* The decoder's other layers.  All reductions over pixels go through per-workgroup partial sums in `workspace` that are
+ * added in a fixed order; gradients of parameters are ACCUMULATED into (caller zeroes), fp32, in torch's layouts.
+ * grad_scale (optional, every backward entry point): device {S, 1/S} from nrhip_dec_grad_scale.  The fp16 gradient
+ * tensors inside the decoder carry the factor S -- the per-call equivalent of the loss scale the reference's
+ * mixed-precision trainer applies (engine/trainer.py:189,553), without which gradients of order 1e-7 fall into fp16's
+ * subnormals -- and every fp32 result (parameter gradients, grad_features) is multiplied by 1/S.                       */
+/* scale [3 floats: S, 1/S, scratch]: S = the power of two that brings max |grad| into [0.5, 1)                        */
+int nrhip_dec_grad_scale(const float* grad, int64_t n, float* scale, void* stream);
+/* BatchNorm2d, training mode (cnns.py:40,43; functional.batch_norm): batch statistics from nrhip_conv7x7's stats_partial
+ * [n_partial, 64]; coef [4][32] = scale, shift, mean, rstd; running_mean / running_var (both or neither) are updated as
+ * torch does (momentum, unbiased variance).                                                                            */
+int nrhip_dec_bn_finalize(const float* stats_partial, int32_t n_partial, int64_t count, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          float* coef, void* stream);
+/* out = relu(c * scale + shift [+ skip]) with the reference's fp16 roundings (BasicBlock.forward, cnns.py:31,38-44)   */
+int nrhip_dec_bn_act(const void* c, const float* coef, const void* skip, void* out, int64_t n_pixels, void* stream);
+/* backward of the above w.r.t. c (and gamma, beta): grad_c = batch_norm_backward(grad_out * (act > 0)), act = the
+ * forward's output.  workspace: nrhip_dec_bn_bwd_workspace floats.                                                     */
+int nrhip_dec_bn_bwd_workspace(int64_t n_pixels, int64_t* floats);
+int nrhip_dec_bn_bwd(const void* grad_out, const void* act, const void* c, const float* gamma, const float* coef,
+                     float* workspace, float* grad_gamma, float* grad_beta, const float* grad_scale, void* grad_c,
+                     int64_t n_pixels, void* stream);
+/* out = a + grad_out * (act > 0): a residual block's input gradient (convolution path + skip path)                    */
+int nrhip_dec_add_masked(const void* a, const void* grad_out, const void* act, void* out, int64_t n_pixels, void* stream);
+/* Conv2d(cin, 32, 1) + ReLU on the rendered feature rows (models/neurad.py:201-203, 361-364): features [n, cin] fp32 ->
+ * h [n, 32] fp16; and its backward (grad_features [n, cin] fp32 is written, not accumulated).                          */
+int nrhip_dec_conv1x1_in_fwd(const float* features, const float* weight /*[32,cin]*/, const float* bias, void* out,
+                             int64_t n, int32_t cin, void* stream);
+int nrhip_dec_conv1x1_in_bwd_workspace(int64_t n, int32_t cin, int64_t* floats);
+int nrhip_dec_conv1x1_in_bwd(const float* features, const void* h, const void* grad_h, const float* weight,
+                             float* workspace, float* grad_features, float* grad_weight, float* grad_bias,
+                             const float* grad_scale, int64_t n, int32_t cin, void* stream);
+/* ConvTranspose2d(32, 32, kernel_size = stride = 3) (models/neurad.py:206-211): [b,h,w,32] -> [b,3h,3w,32] as nine
+ * [pixels,32] x [32,32] products on the matrix cores.  pack: weight [32 in][32 out][3][3] fp32 -> wup, 2*9*2*64*16 bytes
+ * (forward and input-gradient fragment orders).                                                                        */
+int nrhip_dec_upsample_pack(const float* weight, void* wup, void* stream);
+int nrhip_dec_upsample_fwd(const void* h, const void* wup, const float* bias, void* out, int32_t b, int32_t hh, int32_t w,
+                           void* stream);
+int nrhip_dec_upsample_bwd_workspace(int32_t b, int32_t hh, int32_t w, int64_t* floats);
+int nrhip_dec_upsample_bwd(const void* h, const void* grad_out, const void* wup, float* workspace, void* grad_h,
+                           float* grad_weight, float* grad_bias, const float* grad_scale, int32_t b, int32_t hh, int32_t w,
+                           void* stream);
+/* Conv2d(32, 3, 1) + Sigmoid (models/neurad.py:214-215): rgb [n_pixels, 3] fp32, and its backward                    */
+int nrhip_dec_rgb_fwd(const void* h, const float* weight /*[3,32]*/, const float* bias, float* rgb, int64_t n_pixels,
+                      void* stream);
+int nrhip_dec_rgb_bwd_workspace(int64_t n_pixels, int64_t* floats);
+int nrhip_dec_rgb_bwd(const void* h, const float* rgb, const float* grad_rgb, const float* weight, float* workspace,
+                      void* grad_h, float* grad_weight, float* grad_bias, const float* grad_scale, int64_t n_pixels,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,10 +83,27 @@ PROTOTYPES = {
     "nrhip_eval_layout_plan": [C.POINTER(Grid), C.POINTER(C.c_uint32), C.POINTER(I64)],
     "nrhip_eval_layout_build": [C.POINTER(Grid), P, C.POINTER(C.c_uint32), P, P],
     "nrhip_conv7x7_pack": [P, I32, P, P],
+    "nrhip_conv7x7_pack_many": [P, I32, P, P],
     "nrhip_conv7x7_tiles": [I32, I32, I32, C.POINTER(I32)],
     "nrhip_conv7x7": [P, P, P, P, P, I32, I32, I32, I32, P],
     "nrhip_conv7x7_wgrad_workspace": [I32, I32, I32, C.POINTER(I64)],
-    "nrhip_conv7x7_wgrad": [P, P, P, P, P, I32, I32, I32, P],
+    "nrhip_conv7x7_wgrad": [P, P, P, P, P, P, I32, I32, I32, P],
+    "nrhip_dec_bn_finalize": [P, I32, I64, P, P, F32, F32, P, P, P, P],
+    "nrhip_dec_bn_act": [P, P, P, P, I64, P],
+    "nrhip_dec_bn_bwd_workspace": [I64, C.POINTER(I64)],
+    "nrhip_dec_bn_bwd": [P, P, P, P, P, P, P, P, P, P, I64, P],
+    "nrhip_dec_grad_scale": [P, I64, P, P],
+    "nrhip_dec_add_masked": [P, P, P, P, I64, P],
+    "nrhip_dec_conv1x1_in_fwd": [P, P, P, P, I64, I32, P],
+    "nrhip_dec_conv1x1_in_bwd_workspace": [I64, I32, C.POINTER(I64)],
+    "nrhip_dec_conv1x1_in_bwd": [P, P, P, P, P, P, P, P, P, I64, I32, P],
+    "nrhip_dec_upsample_pack": [P, P, P],
+    "nrhip_dec_upsample_fwd": [P, P, P, P, I32, I32, I32, P],
+    "nrhip_dec_upsample_bwd_workspace": [I32, I32, I32, C.POINTER(I64)],
+    "nrhip_dec_upsample_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, P],
+    "nrhip_dec_rgb_fwd": [P, P, P, P, I64, P],
+    "nrhip_dec_rgb_bwd_workspace": [I64, C.POINTER(I64)],
+    "nrhip_dec_rgb_bwd": [P, P, P, P, P, P, P, P, P, I64, P],
     "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],

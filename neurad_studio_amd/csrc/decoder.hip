@@ -48,6 +48,29 @@ __global__ void conv7_pack_kernel(const float* __restrict__ w, int mode, uint4* 
   wfrag[t] = f.u;
 }
 
+struct PackMany {
+  const float* w[8];
+};
+// all convolutions of the decoder in one launch: wfrag[(i * 2 + mode)] for i < n, mode in {0, 1}
+__global__ void conv7_pack_many_kernel(PackMany src, int n, uint4* __restrict__ wfrag) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int which = blockIdx.y;  // i * 2 + mode
+  if (t >= 49 * 2 * 64 || which >= 2 * n) return;
+  const float* w = src.w[which >> 1];
+  const int mode = which & 1;
+  const int lane = t & 63, h = (t >> 6) & 1, tap = t >> 7;
+  const int kx = tap / 7, ky = tap - kx * 7;
+  const int j = lane & 31, k0 = 16 * h + 8 * (lane >> 5);
+  Frag f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    const float v = mode == 0 ? w[((j * kC + k) * 7 + ky) * 7 + kx] : w[((k * kC + j) * 7 + (6 - ky)) * 7 + (6 - kx)];
+    f.h[e] = (_Float16)v;
+  }
+  wfrag[(size_t)which * (49 * 2 * 64) + t] = f.u;
+}
+
 template <int R, bool STATS>
 __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__ in, const uint4* __restrict__ wfrag,
                                                     const float* __restrict__ bias, _Float16* __restrict__ out,
@@ -78,14 +101,22 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
       for (int r = 0; r < 16; ++r) acc[y][r] = bj;
   }
   const unsigned char* abase = lds + ((wave * R) * kCols + px) * kPix + kb * 16;
-#pragma unroll 1
-  for (int kx = 0; kx < 7; ++kx) {
-    Frag Bf[7][2];
-    const uint4* wp = wfrag + (size_t)kx * 7 * 2 * 64 + lane;
+  // the tap column's weights are double-buffered: column kx + 1 is requested before column kx's 14 R MFMAs are issued
+  Frag Bf[2][7][2];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-      Bf[ky][0].u = wp[(ky * 2 + 0) * 64];
-      Bf[ky][1].u = wp[(ky * 2 + 1) * 64];
+  for (int ky = 0; ky < 7; ++ky) {
+    Bf[0][ky][0].u = wfrag[(ky * 2 + 0) * 64 + lane];
+    Bf[0][ky][1].u = wfrag[(ky * 2 + 1) * 64 + lane];
+  }
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) {
+    if (kx + 1 < 7) {
+      const uint4* wp = wfrag + (size_t)(kx + 1) * 7 * 2 * 64 + lane;
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        Bf[(kx + 1) & 1][ky][0].u = wp[(ky * 2 + 0) * 64];
+        Bf[(kx + 1) & 1][ky][1].u = wp[(ky * 2 + 1) * 64];
+      }
     }
     Frag A[R + 6][2];
 #pragma unroll
@@ -98,8 +129,8 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
           A[row][0].u = *(const uint4*)(ap);
           A[row][1].u = *(const uint4*)(ap + 32);
         }
-        acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[row][0].h, Bf[ky][0].h, acc[y], 0, 0, 0);
-        acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[row][1].h, Bf[ky][1].h, acc[y], 0, 0, 0);
+        acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[row][0].h, Bf[kx & 1][ky][0].h, acc[y], 0, 0, 0);
+        acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[row][1].h, Bf[kx & 1][ky][1].h, acc[y], 0, 0, 0);
       }
     }
   }
@@ -346,7 +377,8 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv7_wgrad_kernel(const _Fl
 __global__ __launch_bounds__(256) void conv7_wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                  const float* __restrict__ partial_db, int n,
                                                                  float* __restrict__ grad_weight,
-                                                                 float* __restrict__ grad_bias) {
+                                                                 float* __restrict__ grad_bias,
+                                                                 const float* __restrict__ gscale) {
   __shared__ float red[8][32];
   const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const bool is_bias = blockIdx.x == 49 * 32;
@@ -368,6 +400,7 @@ __global__ __launch_bounds__(256) void conv7_wgrad_reduce_kernel(const float* __
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += red[q][o];
+    if (gscale) s *= gscale[1];
     if (is_bias) {
       grad_bias[o] += s;
     } else {
@@ -393,6 +426,586 @@ inline void wgrad_plan(int b, int h, int* rows_per_strip, int* strips_per_image)
   *strips_per_image = (h + rps - 1) / rps;
 }
 
+
+// ---- the decoder's other layers --------------------------------------------------------------------------------------
+// Elementwise kernels on NHWC-32 fp16 tensors: a thread owns 8 channels of one pixel (16 bytes).  Reductions over pixels
+// write per-workgroup partial sums that a second kernel adds in a fixed order (bit-reproducible, no atomics).
+__device__ __forceinline__ void load8(const _Float16* p, float (&f)[8]) {
+  Frag t;
+  t.u = *(const uint4*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)t.h[e];
+}
+__device__ __forceinline__ void store8(_Float16* p, const float (&f)[8]) {
+  Frag t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t.h[e] = (_Float16)f[e];
+  *(uint4*)p = t.u;
+}
+__device__ __forceinline__ float round_h(float v) { return (float)(_Float16)v; }
+
+// sum of column (threadIdx.x & 63) of partial [n][64] over all n rows, valid in threads 0..63; 1024 threads
+__device__ __forceinline__ double colsum64(const float* __restrict__ partial, int n, double* red /*[16][64]*/) {
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  double a = 0.0, b = 0.0;
+  int k = sl;
+  for (; k + 16 < n; k += 32) {
+    a += (double)partial[(size_t)k * 64 + col];
+    b += (double)partial[(size_t)(k + 16) * 64 + col];
+  }
+  if (k < n) a += (double)partial[(size_t)k * 64 + col];
+  red[sl * 64 + col] = a + b;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x < 64)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q * 64 + threadIdx.x];
+  return s;
+}
+
+// BatchNorm2d in training mode (cnns.py:40,43; torch.nn.functional.batch_norm): batch statistics from the convolution's
+// per-workgroup sums, coefficients for the apply pass, running statistics updated like torch (unbiased variance).
+// coef [4][32] = scale, shift, mean, rstd
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int n, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ coef) {
+  __shared__ double red[16 * 64];
+  __shared__ double tot[64];
+  const double s = colsum64(partial, n, red);
+  if (threadIdx.x < 64) tot[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    const double mean = tot[c] / count;
+    double var = tot[32 + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    coef[c] = sc;
+    coef[32 + c] = beta[c] - (float)mean * sc;
+    coef[64 + c] = (float)mean;
+    coef[96 + c] = rstd;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count > 1.0 ? count - 1.0 : 1.0));
+    }
+  }
+}
+
+// out = relu(bn(c) [+ skip]) with the roundings of the reference's fp16 chain: BatchNorm's output is rounded to fp16, the
+// residual sum is an fp16 add (cnns.py:31, 38-44)
+__global__ __launch_bounds__(256) void bn_act_kernel(const _Float16* __restrict__ c, const float* __restrict__ coef,
+                                                    const _Float16* __restrict__ skip, _Float16* __restrict__ out,
+                                                    int64_t n8) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n8) return;
+  const int q = (int)(idx & 3);
+  float v[8], k[8];
+  load8(c + idx * 8, v);
+  if (skip) load8(skip + idx * 8, k);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float y = round_h(fmaf(v[e], coef[8 * q + e], coef[32 + 8 * q + e]));
+    if (skip) y = round_h(y + k[e]);
+    v[e] = fmaxf(y, 0.f);
+  }
+  store8(out + idx * 8, v);
+}
+
+// backward of relu(bn(c) [+ skip]): g = dout * (act > 0); per channel sum g and sum g * c  -> partial [blocks][64]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const _Float16* __restrict__ dout,
+                                                           const _Float16* __restrict__ act,
+                                                           const _Float16* __restrict__ c, int64_t n8,
+                                                           float* __restrict__ partial) {
+  __shared__ float red[256][17];
+  float sg[8], sgc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sg[e] = sgc[e] = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * 256) {
+    float d[8], a[8], v[8];
+    load8(dout + idx * 8, d);
+    load8(act + idx * 8, a);
+    load8(c + idx * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float g = a[e] > 0.f ? d[e] : 0.f;
+      sg[e] += g;
+      sgc[e] = fmaf(g, v[e], sgc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x][e] = sg[e];
+    red[threadIdx.x][8 + e] = sgc[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // the stride of the loop is a multiple of 4: thread t always owns channel octet t & 3
+    const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += red[4 * k + q][j];
+    partial[(size_t)blockIdx.x * 64 + (j < 8 ? 0 : 32) + 8 * q + (j & 7)] = s;
+  }
+}
+
+// -> bcoef [3][32] with dc = A g + B c + C (the batch-norm backward as an affine map per channel), dgamma, dbeta (+=)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int n, double count,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ coef, float* __restrict__ bcoef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              const float* __restrict__ gscale) {
+  __shared__ double red[16 * 64];
+  __shared__ double tot[64];
+  const double s = colsum64(partial, n, red);
+  if (threadIdx.x < 64) tot[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    const double mean = coef[64 + c], rstd = coef[96 + c];
+    const double sum_g = tot[c], sum_gc = tot[32 + c];
+    const double dg = rstd * (sum_gc - mean * sum_g);  // sum g * xhat
+    const double A = (double)gamma[c] * rstd;
+    const double B = -A * rstd * dg / count;
+    bcoef[c] = (float)A;
+    bcoef[32 + c] = (float)B;
+    bcoef[64 + c] = (float)(-A * sum_g / count - B * mean);
+    const double inv = gscale ? (double)gscale[1] : 1.0;
+    if (dgamma) dgamma[c] += (float)(dg * inv);
+    if (dbeta) dbeta[c] += (float)(sum_g * inv);
+  }
+}
+
+// mode 0: out = A g + B c + C (gradient of the convolution's output); mode 1: out = a + g (the block's input gradient:
+// convolution path + skip path); g = dout * (act > 0)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const _Float16* __restrict__ dout,
+                                                          const _Float16* __restrict__ act,
+                                                          const _Float16* __restrict__ c /* mode 1: a */,
+                                                          const float* __restrict__ bcoef, int mode,
+                                                          _Float16* __restrict__ out, int64_t n8) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n8) return;
+  const int q = (int)(idx & 3);
+  float d[8], a[8], v[8];
+  load8(dout + idx * 8, d);
+  load8(act + idx * 8, a);
+  load8(c + idx * 8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float g = a[e] > 0.f ? d[e] : 0.f;
+    v[e] = mode == 0 ? fmaf(bcoef[8 * q + e], g, fmaf(bcoef[32 + 8 * q + e], v[e], bcoef[64 + 8 * q + e])) : v[e] + g;
+  }
+  store8(out + idx * 8, v);
+}
+
+// the first `cols` columns of partial [n][k] -> out [cols] (= or +=), fixed order; 256 threads = 32 columns x 8 slices
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ partial, int n, int k, int cols,
+                                                         float* __restrict__ out, int accumulate,
+                                                         const float* __restrict__ gscale) {
+  __shared__ float red[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + o;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < cols) {
+    int r = sl;
+    for (; r + 8 < n; r += 16) {
+      s0 += partial[(size_t)r * k + col];
+      s1 += partial[(size_t)(r + 8) * k + col];
+    }
+    if (r < n) s0 += partial[(size_t)r * k + col];
+  }
+  red[sl][o] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && col < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][o];
+    if (gscale) s *= gscale[1];
+    out[col] = accumulate ? out[col] + s : s;
+  }
+}
+
+// first layer: Conv2d(cin, 32, 1) + ReLU on the rendered feature rows (models/neurad.py:201-203): features [n][cin] fp32 ->
+// h [n][32] fp16.  fp16 operands, fp32 accumulation.  256 threads = 64 pixels x 4 channel octets.
+constexpr int kMaxCin = 64;
+__global__ __launch_bounds__(256) void conv1x1_in_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                            int64_t n, int cin) {
+  __shared__ float W[kMaxCin][32];       // [i][o]
+  __shared__ float X[64][kMaxCin + 1];
+  for (int t = threadIdx.x; t < 32 * cin; t += 256) {
+    const int o = t / cin, i = t - o * cin;
+    W[i][o] = round_h(w[t]);
+  }
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  for (int t = threadIdx.x; t < 64 * cin; t += 256) {
+    const int p = t / cin, i = t - p * cin;
+    X[p][i] = p0 + p < n ? round_h(feat[(p0 + p) * cin + i]) : 0.f;
+  }
+  __syncthreads();
+  const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
+  if (p0 + p >= n) return;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = bias[8 * q + e];
+  for (int i = 0; i < cin; ++i) {
+    const float x = X[p][i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, W[i][8 * q + e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+  store8(out + ((p0 + p) * 32 + 8 * q), acc);
+}
+
+// its backward: g = dh * (h > 0); dfeat [n][cin] fp32 = g W; partial [blocks][32 * cin + 32] = (g^T feat, sum g)
+__global__ __launch_bounds__(256) void conv1x1_in_bwd_kernel(const float* __restrict__ feat, const _Float16* __restrict__ h,
+                                                            const _Float16* __restrict__ dh, const float* __restrict__ w,
+                                                            float* __restrict__ dfeat, float* __restrict__ partial,
+                                                            const float* __restrict__ gscale, int64_t n, int cin) {
+  __shared__ float W[32][kMaxCin + 1];   // [o][i]
+  __shared__ float X[64][kMaxCin + 1];
+  __shared__ float G[64][33];
+  for (int t = threadIdx.x; t < 32 * cin; t += 256) W[t / cin][t % cin] = round_h(w[t]);
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  for (int t = threadIdx.x; t < 64 * cin; t += 256) {
+    const int p = t / cin, i = t - p * cin;
+    X[p][i] = p0 + p < n ? round_h(feat[(p0 + p) * cin + i]) : 0.f;
+  }
+  {
+    const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
+    float a[8], d[8];
+    if (p0 + p < n) {
+      load8(h + (p0 + p) * 32 + 8 * q, a);
+      load8(dh + (p0 + p) * 32 + 8 * q, d);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) G[p][8 * q + e] = (p0 + p < n && a[e] > 0.f) ? d[e] : 0.f;
+  }
+  __syncthreads();
+  {  // data gradient: thread = (pixel, quarter of the inputs)
+    const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int per = (cin + 3) / 4, i0 = q * per, i1 = min(cin, i0 + per);
+    if (p0 + p < n)
+      for (int i = i0; i < i1; ++i) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int o = 0; o < 32; ++o) s = fmaf(G[p][o], W[o][i], s);
+        dfeat[(p0 + p) * cin + i] = gscale ? s * gscale[1] : s;
+      }
+  }
+  {  // weight gradient of this block's 64 pixels: thread = (o, eighth of the inputs)
+    const int o = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const int per = (cin + 7) / 8, i0 = q * per;
+    float acc[8], sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int p = 0; p < 64; ++p) {
+      const float g = G[p][o];
+      sb += g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < per && i0 + k < cin) acc[k] = fmaf(g, X[p][i0 + k], acc[k]);
+    }
+    float* dst = partial + (size_t)blockIdx.x * (32 * cin + 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < per && i0 + k < cin) dst[o * cin + i0 + k] = acc[k];
+    if (q == 0) dst[32 * cin + o] = sb;
+  }
+}
+
+// ConvTranspose2d(32, 32, kernel = stride = 3) (models/neurad.py:206-211): every input pixel writes its own 3x3 block of
+// output pixels, i.e. nine [pixels, 32] x [32, 32] products -- on the matrix cores, one wave per 32 input pixels.
+// weight [ci][co][3][3] -> B fragments wup[dir][tap][h][lane]: dir 0 (forward) B[k = ci][j = co] = w[k][j][tap];
+// dir 1 (input gradient) B[k = co][j = ci] = w[j][k][tap]
+__global__ void upsample_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wup) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * 9 * 2 * 64) return;
+  const int lane = t & 63, h = (t >> 6) & 1, tap = (t >> 7) % 9, dir = t / (9 * 128);
+  const int j = lane & 31, k0 = 16 * h + 8 * (lane >> 5);
+  Frag f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    f.h[e] = (_Float16)(dir == 0 ? w[(k * 32 + j) * 9 + tap] : w[(j * 32 + k) * 9 + tap]);
+  }
+  wup[t] = f.u;
+}
+
+// element offset of the 3x3 output block of flattened input pixel p
+__device__ __forceinline__ int up_block_offset(int64_t p, int H, int W) {
+  const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+  return (((b * 3 * H + 3 * y) * 3 * W) + 3 * x) * 32;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const _Float16* __restrict__ h, const uint4* __restrict__ wup,
+                                                          const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                          int H, int W, int64_t npix) {
+  const int lane = threadIdx.x & 63, ch = lane & 31, kb = lane >> 5;
+  Frag Bf[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    Bf[t][0].u = wup[(t * 2 + 0) * 64 + lane];
+    Bf[t][1].u = wup[(t * 2 + 1) * 64 + lane];
+  }
+  const float bj = bias[ch];
+  const int64_t ngroups = (npix + 31) / 32;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t p = grp * 32 + ch;
+    Frag a0, a1;
+    a0.u = a1.u = uint4{0u, 0u, 0u, 0u};
+    int base = 0;
+    if (p < npix) {
+      const uint4* src = (const uint4*)(h + p * 32);
+      a0.u = src[kb];
+      a1.u = src[2 + kb];
+      base = up_block_offset(p, H, W);
+    }
+    int obase[16];  // C layout: register r of this lane belongs to pixel (r & 3) + 8 (r >> 2) + 4 kb of the group
+#pragma unroll
+    for (int r = 0; r < 16; ++r) obase[r] = __shfl(base, (r & 3) + 8 * (r >> 2) + 4 * kb, 64);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bj;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, Bf[t][0].h, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, Bf[t][1].h, acc, 0, 0, 0);
+      const int toff = ((t / 3) * 3 * W + (t % 3)) * 32 + ch;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb < npix) out[obase[r] + toff] = (_Float16)acc[r];
+    }
+  }
+}
+
+// dh [pixel][ci] = sum over taps and co of dup[3y+dy, 3x+dx][co] w[ci][co][tap]
+__global__ __launch_bounds__(256) void upsample_bwd_data_kernel(const _Float16* __restrict__ dup,
+                                                               const uint4* __restrict__ wup /* dir 1 */,
+                                                               _Float16* __restrict__ dh, int H, int W, int64_t npix) {
+  const int lane = threadIdx.x & 63, ch = lane & 31, kb = lane >> 5;
+  Frag Bf[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    Bf[t][0].u = wup[(t * 2 + 0) * 64 + lane];
+    Bf[t][1].u = wup[(t * 2 + 1) * 64 + lane];
+  }
+  const int64_t ngroups = (npix + 31) / 32;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t p = grp * 32 + ch;
+    const bool ok = p < npix;
+    const int base = ok ? up_block_offset(p, H, W) : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      Frag a0, a1;
+      a0.u = a1.u = uint4{0u, 0u, 0u, 0u};
+      if (ok) {
+        const uint4* src = (const uint4*)(dup + base + ((t / 3) * 3 * W + (t % 3)) * 32);
+        a0.u = src[kb];
+        a1.u = src[2 + kb];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, Bf[t][0].h, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, Bf[t][1].h, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t pp = grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+      if (pp < npix) dh[pp * 32 + ch] = (_Float16)acc[r];
+    }
+  }
+}
+
+// dw [ci][co][tap] = sum over pixels of h[p][ci] dup[p, tap][co], dbias [co] = sum of dup: contraction over pixels, so both
+// operands are transposed by identity MFMAs (as in conv7_wgrad_kernel) -- their C-layout registers, rounded back to fp16,
+// ARE the next MFMA's operands (both sides hold the same pixels in the same slots).  Per WAVE partial [9*1024 + 32].
+__device__ __forceinline__ void transpose_regs(const Frag& a0, const Frag& a1, const Frag (&ident)[2], Frag (&out)[2],
+                                               float* sum) {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, ident[0].h, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, ident[1].h, c, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    out[r >> 3].h[r & 7] = (_Float16)c[r];
+    if (sum) *sum += c[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_weight_kernel(const _Float16* __restrict__ h,
+                                                                 const _Float16* __restrict__ dup,
+                                                                 float* __restrict__ partial, int H, int W, int64_t npix) {
+  const int lane = threadIdx.x & 63, ch = lane & 31, kb = lane >> 5;
+  Frag ident[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ident[hh].h[e] = (ch == 16 * hh + 8 * kb + e) ? (_Float16)1.f : (_Float16)0.f;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float db = 0.f;
+  const int64_t ngroups = (npix + 31) / 32;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t grp = wave_id; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t p = grp * 32 + ch;
+    const bool ok = p < npix;
+    const int base = ok ? up_block_offset(p, H, W) : 0;
+    Frag a0, a1, hT[2];
+    a0.u = a1.u = uint4{0u, 0u, 0u, 0u};
+    if (ok) {
+      const uint4* src = (const uint4*)(h + p * 32);
+      a0.u = src[kb];
+      a1.u = src[2 + kb];
+    }
+    transpose_regs(a0, a1, ident, hT, nullptr);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      Frag g0, g1, gT[2];
+      g0.u = g1.u = uint4{0u, 0u, 0u, 0u};
+      if (ok) {
+        const uint4* src = (const uint4*)(dup + base + ((t / 3) * 3 * W + (t % 3)) * 32);
+        g0.u = src[kb];
+        g1.u = src[2 + kb];
+      }
+      transpose_regs(g0, g1, ident, gT, &db);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hT[0].h, gT[0].h, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hT[1].h, gT[1].h, acc[t], 0, 0, 0);
+    }
+  }
+  float* dst = partial + (size_t)wave_id * (9 * 1024 + 32);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(((r & 3) + 8 * (r >> 2) + 4 * kb) * 32 + ch) * 9 + t] = acc[t][r];
+  db += __shfl_xor(db, 32, 64);
+  if (kb == 0) dst[9 * 1024 + ch] = db;
+}
+
+// the backward's working scale (mixed-precision training keeps fp16 gradients away from the subnormals with a loss scale,
+// engine/trainer.py:553; inside the decoder the same is done per call): scale = {S, 1/S}, S the power of two that brings
+// max |grad_rgb| to [0.5, 1)
+__global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ g, int64_t n, uint32_t* __restrict__ amax) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = fabsf(g[i]);
+    if (v < INFINITY) m = fmaxf(m, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(amax, __float_as_uint(m));  // non-negative floats order like their bits; one atomic per block
+  }
+}
+__global__ void grad_scale_kernel(const uint32_t* __restrict__ amax, float* __restrict__ scale) {
+  const float m = __uint_as_float(*amax);
+  int e = 0;
+  if (m > 0.f) {
+    frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+    e = -e;
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+  }
+  scale[0] = ldexpf(1.f, e);
+  scale[1] = ldexpf(1.f, -e);
+}
+
+// last layer: Conv2d(32, 3, 1) + Sigmoid (models/neurad.py:214-215): rgb [n][3] fp32.  thread = pixel
+__global__ __launch_bounds__(256) void rgb_fwd_kernel(const _Float16* __restrict__ h, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ rgb, int64_t n) {
+  __shared__ float Wl[3][32];
+  if (threadIdx.x < 96) Wl[threadIdx.x >> 5][threadIdx.x & 31] = round_h(w[threadIdx.x]);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+#pragma unroll
+  for (int c8 = 0; c8 < 4; ++c8) {
+    float v[8];
+    load8(h + p * 32 + 8 * c8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a0 = fmaf(v[k], Wl[0][8 * c8 + k], a0);
+      a1 = fmaf(v[k], Wl[1][8 * c8 + k], a1);
+      a2 = fmaf(v[k], Wl[2][8 * c8 + k], a2);
+    }
+  }
+  rgb[p * 3 + 0] = 1.f / (1.f + __expf(-a0));
+  rgb[p * 3 + 1] = 1.f / (1.f + __expf(-a1));
+  rgb[p * 3 + 2] = 1.f / (1.f + __expf(-a2));
+}
+
+constexpr int kRgbChunks = 4;
+// its backward: dl = drgb * rgb (1 - rgb); dh = W^T dl (fp16); partial [blocks of 1024 pixels][99] = (dl^T h [3][32], sum dl [3])
+__global__ __launch_bounds__(256) void rgb_bwd_kernel(const _Float16* __restrict__ h, const float* __restrict__ rgb,
+                                                     const float* __restrict__ drgb, const float* __restrict__ w,
+                                                     _Float16* __restrict__ dh, float* __restrict__ partial,
+                                                     const float* __restrict__ gscale, int64_t n) {
+  __shared__ float Wl[3][32];
+  __shared__ float Hs[256][33];
+  __shared__ float Ds[256][3];
+  if (threadIdx.x < 96) Wl[threadIdx.x >> 5][threadIdx.x & 31] = round_h(w[threadIdx.x]);
+  float s0 = 0.f, s1 = 0.f;
+  const float up = gscale ? gscale[0] : 1.f;  // the fp16 gradients below carry this factor, parameter gradients undo it
+  for (int chunk = 0; chunk < kRgbChunks; ++chunk) {
+    const int64_t p = ((int64_t)blockIdx.x * kRgbChunks + chunk) * 256 + threadIdx.x;
+    __syncthreads();
+    float dl[3] = {0.f, 0.f, 0.f};
+    if (p < n) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float r = rgb[p * 3 + k];
+        dl[k] = drgb[p * 3 + k] * up * r * (1.f - r);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Ds[threadIdx.x][k] = dl[k];
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      float v[8], o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if (p < n) load8(h + p * 32 + 8 * c8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        Hs[threadIdx.x][8 * c8 + e] = v[e];
+        o[e] = fmaf(dl[0], Wl[0][8 * c8 + e], fmaf(dl[1], Wl[1][8 * c8 + e], dl[2] * Wl[2][8 * c8 + e]));
+      }
+      if (p < n) store8(dh + p * 32 + 8 * c8, o);
+    }
+    __syncthreads();
+    if (threadIdx.x < 99) {
+      const int k = threadIdx.x < 96 ? threadIdx.x >> 5 : threadIdx.x - 96, c = threadIdx.x & 31;
+      if (threadIdx.x < 96) {
+        for (int q = 0; q < 256; q += 2) {
+          s0 = fmaf(Ds[q][k], Hs[q][c], s0);
+          s1 = fmaf(Ds[q + 1][k], Hs[q + 1][c], s1);
+        }
+      } else {
+        for (int q = 0; q < 256; q += 2) {
+          s0 += Ds[q][k];
+          s1 += Ds[q + 1][k];
+        }
+      }
+    }
+  }
+  if (threadIdx.x < 99) partial[(size_t)blockIdx.x * 99 + threadIdx.x] = s0 + s1;
+}
+
+inline int ew_blocks(int64_t n8) { return (int)((n8 + 255) / 256); }
+inline int reduce_blocks(int64_t n8) {
+  int64_t b = (n8 + 256 * 16 - 1) / (256 * 16);  // >= 16 items per thread
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
 }  // namespace
 }  // namespace nrhip
 
@@ -403,6 +1016,16 @@ extern "C" int nrhip_conv7x7_pack(const float* weight, int32_t mode, void* wfrag
   hipLaunchKernelGGL(conv7_pack_kernel, dim3((49 * 2 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, mode,
                      (uint4*)wfrag);
   return check_launch("conv7x7_pack");
+}
+
+extern "C" int nrhip_conv7x7_pack_many(const float* const* weights, int32_t n, void* wfrag, void* stream) {
+  NR_REQUIRE(weights && wfrag && n >= 1 && n <= 8, NRHIP_ERR_INVALID_ARG, "conv7x7_pack_many: bad argument");
+  PackMany src;
+  for (int i = 0; i < 8; ++i) src.w[i] = i < n ? weights[i] : nullptr;
+  for (int i = 0; i < n; ++i) NR_REQUIRE(src.w[i], NRHIP_ERR_INVALID_ARG, "conv7x7_pack_many: weight %d is null", i);
+  hipLaunchKernelGGL(conv7_pack_many_kernel, dim3((49 * 2 * 64 + 255) / 256, 2 * n), dim3(256), 0, (hipStream_t)stream, src,
+                     n, (uint4*)wfrag);
+  return check_launch("conv7x7_pack_many");
 }
 
 extern "C" int nrhip_conv7x7_tiles(int32_t h, int32_t w, int32_t rows_per_wave, int32_t* tiles) {
@@ -436,7 +1059,8 @@ extern "C" int nrhip_conv7x7_wgrad_workspace(int32_t b, int32_t h, int32_t w, in
 }
 
 extern "C" int nrhip_conv7x7_wgrad(const void* x, const void* grad_out, float* workspace, float* grad_weight,
-                                   float* grad_bias, int32_t b, int32_t h, int32_t w, void* stream) {
+                                   float* grad_bias, const float* grad_scale, int32_t b, int32_t h, int32_t w,
+                                   void* stream) {
   NR_REQUIRE(x && grad_out && workspace && grad_weight && b >= 0 && h > 0 && w > 0, NRHIP_ERR_INVALID_ARG,
              "conv7x7_wgrad: bad argument");
   if (b == 0) return NRHIP_OK;
@@ -456,6 +1080,188 @@ extern "C" int nrhip_conv7x7_wgrad(const void* x, const void* grad_out, float* w
   hipLaunchKernelGGL(conv7_wgrad_kernel, dim3(n), dim3(kWgradWaves * 64), smem, st, (const _Float16*)x,
                      (const _Float16*)grad_out, workspace, partial_db, h, w, rps, spi);
   hipLaunchKernelGGL(conv7_wgrad_reduce_kernel, dim3(49 * 32 + 1), dim3(256), 0, st, workspace, partial_db, n, grad_weight,
-                     grad_bias);
+                     grad_bias, grad_scale);
   return check_launch("conv7x7_wgrad");
+}
+
+// ---- entry points of the other layers -------------------------------------------------------------------------------
+extern "C" int nrhip_dec_bn_finalize(const float* stats_partial, int32_t n_partial, int64_t count, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, float* coef, void* stream) {
+  NR_REQUIRE(stats_partial && n_partial > 0 && count > 0 && gamma && beta && coef && (!running_mean == !running_var),
+             NRHIP_ERR_INVALID_ARG, "dec_bn_finalize: bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats_partial, n_partial,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, coef);
+  return check_launch("dec_bn_finalize");
+}
+
+extern "C" int nrhip_dec_bn_act(const void* c, const float* coef, const void* skip, void* out, int64_t n_pixels,
+                                void* stream) {
+  NR_REQUIRE(c && coef && out && n_pixels >= 0, NRHIP_ERR_INVALID_ARG, "dec_bn_act: bad argument");
+  if (n_pixels == 0) return NRHIP_OK;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(ew_blocks(n_pixels * 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)c,
+                     coef, (const _Float16*)skip, (_Float16*)out, n_pixels * 4);
+  return check_launch("dec_bn_act");
+}
+
+extern "C" int nrhip_dec_bn_bwd(const void* grad_out, const void* act, const void* c, const float* gamma,
+                                const float* coef, float* workspace, float* grad_gamma, float* grad_beta,
+                                const float* grad_scale, void* grad_c, int64_t n_pixels, void* stream) {
+  NR_REQUIRE(grad_out && act && c && gamma && coef && workspace && grad_c && n_pixels > 0, NRHIP_ERR_INVALID_ARG,
+             "dec_bn_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = reduce_blocks(n_pixels * 4);
+  float* bcoef = workspace + (size_t)nb * 64;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, (const _Float16*)grad_out, (const _Float16*)act,
+                     (const _Float16*)c, n_pixels * 4, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, (double)n_pixels, gamma, coef, bcoef,
+                     grad_gamma, grad_beta, grad_scale);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n_pixels * 4)), dim3(256), 0, st, (const _Float16*)grad_out,
+                     (const _Float16*)act, (const _Float16*)c, bcoef, 0, (_Float16*)grad_c, n_pixels * 4);
+  return check_launch("dec_bn_bwd");
+}
+
+extern "C" int nrhip_dec_bn_bwd_workspace(int64_t n_pixels, int64_t* floats) {
+  NR_REQUIRE(floats && n_pixels >= 0, NRHIP_ERR_INVALID_ARG, "dec_bn_bwd_workspace: bad argument");
+  *floats = (int64_t)reduce_blocks(n_pixels * 4) * 64 + 96;
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_dec_add_masked(const void* a, const void* grad_out, const void* act, void* out, int64_t n_pixels,
+                                    void* stream) {
+  NR_REQUIRE(a && grad_out && act && out && n_pixels >= 0, NRHIP_ERR_INVALID_ARG, "dec_add_masked: bad argument");
+  if (n_pixels == 0) return NRHIP_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n_pixels * 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)grad_out, (const _Float16*)act, (const _Float16*)a, (const float*)nullptr, 1,
+                     (_Float16*)out, n_pixels * 4);
+  return check_launch("dec_add_masked");
+}
+
+extern "C" int nrhip_dec_conv1x1_in_fwd(const float* features, const float* weight, const float* bias, void* out,
+                                        int64_t n, int32_t cin, void* stream) {
+  NR_REQUIRE(features && weight && bias && out && n >= 0, NRHIP_ERR_INVALID_ARG, "dec_conv1x1_in_fwd: bad argument");
+  NR_REQUIRE(cin >= 1 && cin <= kMaxCin, NRHIP_ERR_UNSUPPORTED, "dec_conv1x1_in_fwd: %d input channels (max %d)", cin,
+             kMaxCin);
+  if (n == 0) return NRHIP_OK;
+  hipLaunchKernelGGL(conv1x1_in_fwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, features,
+                     weight, bias, (_Float16*)out, n, cin);
+  return check_launch("dec_conv1x1_in_fwd");
+}
+
+extern "C" int nrhip_dec_conv1x1_in_bwd_workspace(int64_t n, int32_t cin, int64_t* floats) {
+  NR_REQUIRE(floats && n >= 0 && cin >= 1 && cin <= kMaxCin, NRHIP_ERR_INVALID_ARG, "dec_conv1x1_in_bwd_workspace: bad argument");
+  *floats = ((n + 63) / 64) * (32 * (int64_t)cin + 32);
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_dec_conv1x1_in_bwd(const float* features, const void* h, const void* grad_h, const float* weight,
+                                        float* workspace, float* grad_features, float* grad_weight, float* grad_bias,
+                                        const float* grad_scale, int64_t n, int32_t cin, void* stream) {
+  NR_REQUIRE(features && h && grad_h && weight && workspace && grad_features && grad_weight && grad_bias && n > 0,
+             NRHIP_ERR_INVALID_ARG, "dec_conv1x1_in_bwd: bad argument");
+  NR_REQUIRE(cin >= 1 && cin <= kMaxCin, NRHIP_ERR_UNSUPPORTED, "dec_conv1x1_in_bwd: %d input channels (max %d)", cin,
+             kMaxCin);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((n + 63) / 64), k = 32 * cin + 32;
+  hipLaunchKernelGGL(conv1x1_in_bwd_kernel, dim3(nb), dim3(256), 0, st, features, (const _Float16*)h,
+                     (const _Float16*)grad_h, weight, grad_features, workspace, grad_scale, n, cin);
+  // columns [0, 32 cin) -> grad_weight, [32 cin, +32) -> grad_bias (accumulated)
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(cin), dim3(256), 0, st, workspace, nb, k, 32 * cin, grad_weight, 1, grad_scale);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 32 * cin, nb, k, 32, grad_bias, 1, grad_scale);
+  return check_launch("dec_conv1x1_in_bwd");
+}
+
+constexpr int kUpWgs = 64;  // workgroups of the transposed convolution's weight gradient: 256 waves, one partial each
+
+extern "C" int nrhip_dec_upsample_pack(const float* weight, void* wup, void* stream) {
+  NR_REQUIRE(weight && wup, NRHIP_ERR_INVALID_ARG, "dec_upsample_pack: bad argument");
+  hipLaunchKernelGGL(upsample_pack_kernel, dim3((2 * 9 * 2 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight,
+                     (uint4*)wup);
+  return check_launch("dec_upsample_pack");
+}
+
+extern "C" int nrhip_dec_upsample_fwd(const void* h, const void* wup, const float* bias, void* out, int32_t b,
+                                      int32_t hh, int32_t w, void* stream) {
+  NR_REQUIRE(h && wup && bias && out && b >= 0 && hh > 0 && w > 0, NRHIP_ERR_INVALID_ARG, "dec_upsample_fwd: bad argument");
+  const int64_t npix = (int64_t)b * hh * w;
+  NR_REQUIRE(npix * 9 * 32 < (int64_t)1 << 31, NRHIP_ERR_UNSUPPORTED, "dec_upsample_fwd: %lld output elements (32-bit offsets)",
+             (long long)(npix * 9 * 32));
+  if (b == 0) return NRHIP_OK;
+  const int64_t wgs = ((npix + 31) / 32 + 3) / 4;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)(wgs > 1024 ? 1024 : wgs)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)h, (const uint4*)wup, bias, (_Float16*)out, hh, w, npix);
+  return check_launch("dec_upsample_fwd");
+}
+
+extern "C" int nrhip_dec_upsample_bwd_workspace(int32_t b, int32_t hh, int32_t w, int64_t* floats) {
+  NR_REQUIRE(floats && b >= 0 && hh > 0 && w > 0, NRHIP_ERR_INVALID_ARG, "dec_upsample_bwd_workspace: bad argument");
+  *floats = (int64_t)kUpWgs * 4 * (9 * 1024 + 32);
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_dec_upsample_bwd(const void* h, const void* grad_out, const void* wup, float* workspace, void* grad_h,
+                                      float* grad_weight, float* grad_bias, const float* grad_scale, int32_t b, int32_t hh,
+                                      int32_t w, void* stream) {
+  NR_REQUIRE(h && grad_out && wup && workspace && grad_h && grad_weight && grad_bias && b > 0 && hh > 0 && w > 0,
+             NRHIP_ERR_INVALID_ARG, "dec_upsample_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t npix = (int64_t)b * hh * w;
+  NR_REQUIRE(npix * 9 * 32 < (int64_t)1 << 31, NRHIP_ERR_UNSUPPORTED, "dec_upsample_bwd: %lld output elements (32-bit offsets)",
+             (long long)(npix * 9 * 32));
+  const int k = 9 * 1024 + 32;
+  const int64_t wgs = ((npix + 31) / 32 + 3) / 4;
+  hipLaunchKernelGGL(upsample_bwd_data_kernel, dim3((unsigned)(wgs > 1024 ? 1024 : wgs)), dim3(256), 0, st,
+                     (const _Float16*)grad_out, (const uint4*)wup + 9 * 2 * 64, (_Float16*)grad_h, hh, w, npix);
+  hipLaunchKernelGGL(upsample_bwd_weight_kernel, dim3(kUpWgs), dim3(256), 0, st, (const _Float16*)h,
+                     (const _Float16*)grad_out, workspace, hh, w, npix);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(9 * 32), dim3(256), 0, st, workspace, kUpWgs * 4, k, 9 * 1024, grad_weight, 1,
+                     grad_scale);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 9 * 1024, kUpWgs * 4, k, 32, grad_bias, 1,
+                     grad_scale);
+  return check_launch("dec_upsample_bwd");
+}
+
+extern "C" int nrhip_dec_grad_scale(const float* grad, int64_t n, float* scale, void* stream) {
+  NR_REQUIRE(grad && scale && n >= 0, NRHIP_ERR_INVALID_ARG, "dec_grad_scale: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* amax = (uint32_t*)(scale + 2);
+  if (hipMemsetAsync(amax, 0, sizeof(uint32_t), st) != hipSuccess) {
+    set_error("dec_grad_scale: memset failed");
+    return NRHIP_ERR_LAUNCH;
+  }
+  if (n > 0) {
+    const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(grad_amax_kernel, dim3((unsigned)(blocks > 128 ? 128 : blocks)), dim3(256), 0, st, grad, n, amax);
+  }
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, amax, scale);
+  return check_launch("dec_grad_scale");
+}
+
+extern "C" int nrhip_dec_rgb_fwd(const void* h, const float* weight, const float* bias, float* rgb, int64_t n_pixels,
+                                 void* stream) {
+  NR_REQUIRE(h && weight && bias && rgb && n_pixels >= 0, NRHIP_ERR_INVALID_ARG, "dec_rgb_fwd: bad argument");
+  if (n_pixels == 0) return NRHIP_OK;
+  hipLaunchKernelGGL(rgb_fwd_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)h, weight, bias, rgb, n_pixels);
+  return check_launch("dec_rgb_fwd");
+}
+
+extern "C" int nrhip_dec_rgb_bwd_workspace(int64_t n_pixels, int64_t* floats) {
+  NR_REQUIRE(floats && n_pixels >= 0, NRHIP_ERR_INVALID_ARG, "dec_rgb_bwd_workspace: bad argument");
+  *floats = ((n_pixels + 256 * kRgbChunks - 1) / (256 * kRgbChunks)) * 99;
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_dec_rgb_bwd(const void* h, const float* rgb, const float* grad_rgb, const float* weight,
+                                 float* workspace, void* grad_h, float* grad_weight, float* grad_bias,
+                                 const float* grad_scale, int64_t n_pixels, void* stream) {
+  NR_REQUIRE(h && rgb && grad_rgb && weight && workspace && grad_h && grad_weight && grad_bias && n_pixels > 0,
+             NRHIP_ERR_INVALID_ARG, "dec_rgb_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((n_pixels + 256 * kRgbChunks - 1) / (256 * kRgbChunks));
+  hipLaunchKernelGGL(rgb_bwd_kernel, dim3(nb), dim3(256), 0, st, (const _Float16*)h, rgb, grad_rgb, weight,
+                     (_Float16*)grad_h, workspace, grad_scale, n_pixels);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(3), dim3(256), 0, st, workspace, nb, 99, 96, grad_weight, 1, grad_scale);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 96, nb, 99, 3, grad_bias, 1, grad_scale);
+  return check_launch("dec_rgb_bwd");
 }

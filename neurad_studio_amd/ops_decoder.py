@@ -24,6 +24,18 @@ def conv7x7_pack(weight: Tensor, mode: int = 0) -> Tensor:
     return out
 
 
+def conv7x7_pack_many(weights) -> Tensor:
+    """up to 8 Conv2d weights -> [n, 2, ...] fragment-ordered fp16 weights (mode 0 and mode 1 of each) in ONE launch"""
+    ws = [_chk(w.detach().to(torch.float32), "weight") for w in weights]
+    for w in ws:
+        if tuple(w.shape) != (32, 32, 7, 7):
+            raise ValueError(f"conv7x7_pack_many: weight {tuple(w.shape)}, expected (32, 32, 7, 7)")
+    out = torch.empty((len(ws), 2, _WFRAG_BYTES // 2), device=ws[0].device, dtype=torch.float16)
+    ptrs = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    call("nrhip_conv7x7_pack_many", ptrs, len(ws), _ptr(out), _stream())
+    return out
+
+
 def _rows_per_wave(h: int, w: int, b: int) -> int:
     # 16 x 32 output tiles once they fill the chip, smaller ones for the 32 x 32 stage (40 patches = 80 tiles of 16 rows)
     for r in (4, 2, 1):
@@ -50,7 +62,8 @@ def conv7x7(x: Tensor, wfrag: Tensor, bias: Optional[Tensor] = None, stats: bool
     return out, part
 
 
-def conv7x7_wgrad(x: Tensor, grad_out: Tensor, grad_weight: Tensor, grad_bias: Optional[Tensor] = None) -> None:
+def conv7x7_wgrad(x: Tensor, grad_out: Tensor, grad_weight: Tensor, grad_bias: Optional[Tensor] = None,
+                  grad_scale: Optional[Tensor] = None) -> None:
     """grad_weight [32,32,7,7] (+ grad_bias [32]) += the convolution's weight (bias) gradient; x, grad_out NHWC fp16"""
     for t, n in ((x, "x"), (grad_out, "grad_out")):
         if t.dtype != torch.float16 or t.dim() != 4 or t.shape[-1] != 32 or not t.is_contiguous() or not t.is_cuda:
@@ -64,4 +77,223 @@ def conv7x7_wgrad(x: Tensor, grad_out: Tensor, grad_weight: Tensor, grad_bias: O
     n = C.c_int64(0)
     call("nrhip_conv7x7_wgrad_workspace", b, h, w, C.byref(n))
     ws = torch.empty((n.value,), device=x.device, dtype=torch.float32)
-    call("nrhip_conv7x7_wgrad", _ptr(x), _ptr(grad_out), _ptr(ws), _ptr(gw), _ptr(grad_bias), b, h, w, _stream())
+    call("nrhip_conv7x7_wgrad", _ptr(x), _ptr(grad_out), _ptr(ws), _ptr(gw), _ptr(grad_bias), _ptr(grad_scale), b, h, w,
+         _stream())
+
+
+# ---- the other layers ------------------------------------------------------------------------------------------------
+def _f32(t: Tensor, name: str) -> Tensor:
+    return _chk(t.detach() if t.requires_grad else t, name)
+
+
+def _ws(entry: str, *dims, device) -> Tensor:
+    n = C.c_int64(0)
+    call(entry, *dims, C.byref(n))
+    return torch.empty((max(n.value, 1),), device=device, dtype=torch.float32)
+
+
+def bn_finalize(part: Tensor, count: int, gamma: Tensor, beta: Tensor, eps: float, momentum: float,
+                running_mean: Optional[Tensor], running_var: Optional[Tensor]) -> Tensor:
+    """-> coef [4, 32] = scale, shift, mean, rstd; running statistics updated in place like torch's batch_norm"""
+    coef = torch.empty((4, 32), device=part.device, dtype=torch.float32)
+    call("nrhip_dec_bn_finalize", _ptr(part), part.shape[0], count, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+         float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(coef), _stream())
+    return coef
+
+
+def bn_act(c: Tensor, coef: Tensor, skip: Optional[Tensor] = None) -> Tensor:
+    out = torch.empty_like(c)
+    call("nrhip_dec_bn_act", _ptr(c), _ptr(coef), _ptr(skip), _ptr(out), c.numel() // 32, _stream())
+    return out
+
+
+def grad_scale(grad: Tensor) -> Tensor:
+    """-> device [3] = {S, 1/S, scratch}: the power of two S that brings max |grad| into [0.5, 1) (the decoder backward's
+    working scale: its fp16 gradient tensors carry S, every fp32 result is multiplied by 1/S)"""
+    g = _chk(grad, "grad")
+    scale = torch.empty((3,), device=g.device, dtype=torch.float32)
+    call("nrhip_dec_grad_scale", _ptr(g), g.numel(), _ptr(scale), _stream())
+    return scale
+
+
+def bn_bwd(grad_out: Tensor, act: Tensor, c: Tensor, gamma: Tensor, coef: Tensor, grad_gamma: Tensor,
+           grad_beta: Tensor, grad_scale: Optional[Tensor] = None) -> Tensor:
+    npix = c.numel() // 32
+    ws = _ws("nrhip_dec_bn_bwd_workspace", npix, device=c.device)
+    out = torch.empty_like(c)
+    call("nrhip_dec_bn_bwd", _ptr(grad_out), _ptr(act), _ptr(c), _ptr(_f32(gamma, "gamma")), _ptr(coef), _ptr(ws),
+         _ptr(grad_gamma), _ptr(grad_beta), _ptr(grad_scale), _ptr(out), npix, _stream())
+    return out
+
+
+def add_masked(a: Tensor, grad_out: Tensor, act: Tensor) -> Tensor:
+    out = torch.empty_like(a)
+    call("nrhip_dec_add_masked", _ptr(a), _ptr(grad_out), _ptr(act), _ptr(out), a.numel() // 32, _stream())
+    return out
+
+
+def conv1x1_in_fwd(features: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    f = _chk(features, "features")
+    n, cin = f.shape
+    out = torch.empty((n, 32), device=f.device, dtype=torch.float16)
+    call("nrhip_dec_conv1x1_in_fwd", _ptr(f), _ptr(_f32(weight, "weight").reshape(32, cin)), _ptr(_f32(bias, "bias")),
+         _ptr(out), n, cin, _stream())
+    return out
+
+
+def conv1x1_in_bwd(features: Tensor, h: Tensor, grad_h: Tensor, weight: Tensor, grad_weight: Tensor, grad_bias: Tensor,
+                   grad_scale: Optional[Tensor] = None):
+    f = _chk(features, "features")
+    n, cin = f.shape
+    ws = _ws("nrhip_dec_conv1x1_in_bwd_workspace", n, cin, device=f.device)
+    gf = torch.empty_like(f)
+    call("nrhip_dec_conv1x1_in_bwd", _ptr(f), _ptr(h), _ptr(grad_h), _ptr(_f32(weight, "weight")), _ptr(ws), _ptr(gf),
+         _ptr(grad_weight), _ptr(grad_bias), _ptr(grad_scale), n, cin, _stream())
+    return gf
+
+
+def upsample_pack(weight: Tensor) -> Tensor:
+    """ConvTranspose2d weight [32, 32, 3, 3] -> fragment-ordered fp16 weights (forward, then input gradient)"""
+    w = _f32(weight, "weight")
+    if tuple(w.shape) != (32, 32, 3, 3):
+        raise ValueError(f"upsample_pack: weight {tuple(w.shape)}, expected (32, 32, 3, 3)")
+    out = torch.empty((2, 9 * 2 * 64 * 8), device=w.device, dtype=torch.float16)
+    call("nrhip_dec_upsample_pack", _ptr(w), _ptr(out), _stream())
+    return out
+
+
+def upsample_fwd(h: Tensor, wup: Tensor, bias: Tensor) -> Tensor:
+    b, hh, w, _ = h.shape
+    out = torch.empty((b, 3 * hh, 3 * w, 32), device=h.device, dtype=torch.float16)
+    call("nrhip_dec_upsample_fwd", _ptr(h), _ptr(wup), _ptr(_f32(bias, "bias")), _ptr(out), b, hh, w, _stream())
+    return out
+
+
+def upsample_bwd(h: Tensor, grad_out: Tensor, wup: Tensor, grad_weight: Tensor, grad_bias: Tensor,
+                 grad_scale: Optional[Tensor] = None) -> Tensor:
+    b, hh, w, _ = h.shape
+    ws = _ws("nrhip_dec_upsample_bwd_workspace", b, hh, w, device=h.device)
+    gh = torch.empty_like(h)
+    call("nrhip_dec_upsample_bwd", _ptr(h), _ptr(grad_out), _ptr(wup), _ptr(ws), _ptr(gh), _ptr(grad_weight),
+         _ptr(grad_bias), _ptr(grad_scale), b, hh, w, _stream())
+    return gh
+
+
+def rgb_fwd(h: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    b, hh, w, _ = h.shape
+    rgb = torch.empty((b, hh, w, 3), device=h.device, dtype=torch.float32)
+    call("nrhip_dec_rgb_fwd", _ptr(h), _ptr(_f32(weight, "weight")), _ptr(_f32(bias, "bias")), _ptr(rgb), b * hh * w,
+         _stream())
+    return rgb
+
+
+def rgb_bwd(h: Tensor, rgb: Tensor, grad_rgb: Tensor, weight: Tensor, grad_weight: Tensor, grad_bias: Tensor,
+            grad_scale: Optional[Tensor] = None) -> Tensor:
+    npix = h.numel() // 32
+    ws = _ws("nrhip_dec_rgb_bwd_workspace", npix, device=h.device)
+    gh = torch.empty_like(h)
+    call("nrhip_dec_rgb_bwd", _ptr(h), _ptr(rgb), _ptr(_chk(grad_rgb, "grad_rgb")), _ptr(_f32(weight, "weight")), _ptr(ws),
+         _ptr(gh), _ptr(grad_weight), _ptr(grad_bias), _ptr(grad_scale), npix, _stream())
+    return gh
+
+
+# ---- the decoder as one autograd node --------------------------------------------------------------------------------
+class _BnState:
+    """what BatchNorm2d carries besides its parameters (not differentiable)"""
+
+    def __init__(self, running_mean, running_var, eps, momentum):
+        self.running_mean, self.running_var, self.eps, self.momentum = running_mean, running_var, eps, momentum
+
+
+class RgbDecoderFn(torch.autograd.Function):
+    """rgb_decoder of models/neurad.py:198-216 on [n, cin] feature rows of ph x pw patches -> rgb [B, 3 ph, 3 pw, 3] fp32.
+    params: w0, b0, 4 x (wa, ba, gamma1, beta1, wb, bb, gamma2, beta2), wu, bu, wo, bo (36 tensors, torch layouts)."""
+
+    @staticmethod
+    def forward(ctx, features, patch, training, bn_states, *params):
+        ph, pw = patch
+        n = features.shape[0]
+        if n % (ph * pw):
+            raise ValueError(f"decode_rgb: {n} feature rows are not whole {ph}x{pw} patches")
+        b = n // (ph * pw)
+        p = list(params)
+        w0, b0, blocks, (wu, bu, wo, bo) = p[0], p[1], [p[2 + 8 * k:10 + 8 * k] for k in range(4)], p[34:38]
+        feats = _chk(features.detach(), "features")
+        h0 = conv1x1_in_fwd(feats, w0, b0).view(b, ph, pw, 32)
+        packed = conv7x7_pack_many([blocks[k][i] for k in range(4) for i in (0, 4)])  # [8, 2, .]: (block, a|b) x (fwd, dgrad)
+
+        def block(x, k):
+            wa, ba, g1, be1, wb, bb, g2, be2 = blocks[k]
+            s1, s2 = bn_states[2 * k], bn_states[2 * k + 1]
+            count = x.numel() // 32
+            c1, part = conv7x7(x, packed[2 * k, 0], ba, stats=training)
+            coef1 = (bn_finalize(part, count, g1, be1, s1.eps, s1.momentum, s1.running_mean, s1.running_var) if training
+                     else _eval_coef(g1, be1, s1))
+            u1 = bn_act(c1, coef1)
+            c2, part = conv7x7(u1, packed[2 * k + 1, 0], bb, stats=training)
+            coef2 = (bn_finalize(part, count, g2, be2, s2.eps, s2.momentum, s2.running_mean, s2.running_var) if training
+                     else _eval_coef(g2, be2, s2))
+            out = bn_act(c2, coef2, skip=x)
+            return out, (x, c1, coef1, u1, c2, coef2, out)
+
+        saved = []
+        x = h0
+        for k in (0, 1):
+            x, sv = block(x, k)
+            saved.append(sv)
+        h2 = x
+        wup = upsample_pack(wu)
+        x = upsample_fwd(h2, wup, bu)
+        for k in (2, 3):
+            x, sv = block(x, k)
+            saved.append(sv)
+        rgb = rgb_fwd(x, wo, bo)
+        ctx.training = training
+        ctx.saved = (feats, h0, saved, h2, x, rgb, packed, wup)
+        ctx.params = [t.detach() for t in p]
+        ctx.need = [features.requires_grad] + [t.requires_grad for t in p]
+        return rgb
+
+    @staticmethod
+    def backward(ctx, grad_rgb):
+        if not ctx.training:
+            raise RuntimeError("decode_rgb: backward through the eval-mode decoder (running statistics) is not implemented")
+        feats, h0, saved, h2, h4, rgb, packed, wup = ctx.saved
+        p = ctx.params
+        w0, blocks, (wu, bu, wo, bo) = p[0], [p[2 + 8 * k:10 + 8 * k] for k in range(4)], p[34:38]
+        flat = torch.zeros((sum(t.numel() for t in p),), device=feats.device, dtype=torch.float32)  # one fill for all 38
+        g, off = [], 0
+        for t in p:
+            g.append(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        gblocks = [g[2 + 8 * k:10 + 8 * k] for k in range(4)]
+        grad_rgb = grad_rgb.contiguous().float()
+        gs = grad_scale(grad_rgb)  # the fp16 gradients below carry S = gs[0]; fp32 results are multiplied by 1/S
+        d = rgb_bwd(h4, rgb, grad_rgb, wo, g[36], g[37], gs)
+
+        def block_bwd(d_out, k):
+            wa, ba, g1, be1, wb, bb, g2, be2 = blocks[k]
+            gwa, gba, gg1, gbe1, gwb, gbb, gg2, gbe2 = gblocks[k]
+            x, c1, coef1, u1, c2, coef2, out = saved[k]
+            dc2 = bn_bwd(d_out, out, c2, g2, coef2, gg2, gbe2, gs)
+            conv7x7_wgrad(u1, dc2, gwb, gbb, gs)
+            du1, _ = conv7x7(dc2, packed[2 * k + 1, 1])
+            dc1 = bn_bwd(du1, u1, c1, g1, coef1, gg1, gbe1, gs)
+            conv7x7_wgrad(x, dc1, gwa, gba, gs)
+            dx, _ = conv7x7(dc1, packed[2 * k, 1])
+            return add_masked(dx, d_out, out)
+
+        for k in (3, 2):
+            d = block_bwd(d, k)
+        d = upsample_bwd(h2, d, wup, g[34], g[35], gs)
+        for k in (1, 0):
+            d = block_bwd(d, k)
+        gf = conv1x1_in_bwd(feats, h0.view(-1, 32), d.view(-1, 32), w0.reshape(32, -1), g[0], g[1], gs)
+        grads = [gf if ctx.need[0] else None] + [gi if need else None for gi, need in zip(g, ctx.need[1:])]
+        return (grads[0], None, None, None, *grads[1:])
+
+
+def _eval_coef(gamma: Tensor, beta: Tensor, st: _BnState) -> Tensor:
+    scale = gamma.detach().float() * torch.rsqrt(st.running_var.float() + st.eps)
+    return torch.stack([scale, beta.detach().float() - st.running_mean.float() * scale, st.running_mean.float(),
+                        torch.rsqrt(st.running_var.float() + st.eps)]).contiguous()
