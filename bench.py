@@ -271,12 +271,13 @@ def joint_batch(device, rank, n_cam, n_lidar):
 
 
 def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, rgb_decoder=True,
-                       cfg_edit=None, sharded_adam=False, sparse_exchange=False):
+                       cfg_edit=None, sharded_adam=False, sparse_exchange=False, torch_decoder=False):
     """The whole training step at the reference's default sizes (models/neurad.py defaults: static grid L=8, F=4, T=2^22;
     proposal grids L=6, F=1, T=2^20; 128+64 proposal samples, 32 field samples; 32-wide MLPs; 16-d appearance embedding;
     lidar head; RGB CNN decoder) on a camera+lidar joint batch: get_nff_outputs (training mode, jitter, lidar metadata) ->
-    lidar head + RGB CNN decoder (32x32 feature patches -> 96x96 rgb, models/neurad.py:198-216,359-366; under fp16 autocast
-    like the reference's mixed_precision=True trainer, configs/method_configs.py:401) -> rgb MSE + lidar depth / intensity /
+    lidar head + RGB CNN decoder (32x32 feature patches -> 96x96 rgb, models/neurad.py:198-216,359-366; fp16 operands with
+    fp32 accumulation like the reference's mixed_precision=True trainer, configs/method_configs.py:401: the HIP kernels of
+    csrc/decoder.hip, or with torch_decoder=True the torch modules = MIOpen under fp16 autocast) -> rgb MSE + lidar depth / intensity /
     ray-drop / carving losses + interlevel + distortion (reference multipliers, models/neurad.py:65-94,534-560) -> backward
     -> gradient exchange -> Adam.  rgb_decoder=False: a feature regression stands in for the decoder + rgb loss (round 2's
     step, kept as the `hot path only` variant)."""
@@ -328,6 +329,12 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     nears = torch.zeros((R, 1), device=device)
     state = {}
 
+    def decode(cam_features):
+        if not torch_decoder:
+            return decode_rgb(dec, cam_features, (32, 32))
+        with torch.autocast("cuda", dtype=torch.float16):
+            return decode_rgb(dec, cam_features, (32, 32), fused=False).float()
+
     def step(_i=None):
         rb = RayBundle(origins=o, directions=d, pixel_area=area.clone(), nears=nears, fars=None, times=times,
                        metadata=dict(md))
@@ -338,9 +345,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
         terms["interlevel"] = zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
         terms["distortion"] = distortion_loss(out["weights_list"], out["ray_samples_list"])
         if dec is not None:
-            with torch.autocast("cuda", dtype=torch.float16):
-                rgb = decode_rgb(dec, out["features"][:n_cam], (32, 32))
-            terms["rgb"] = torch.nn.functional.mse_loss(rgb.float(), image)
+            terms["rgb"] = torch.nn.functional.mse_loss(decode(out["features"][:n_cam]), image)
         else:
             terms["feature"] = (out["features"][:n_cam] - target).square().mean()
         loss = total_loss(terms)
@@ -377,9 +382,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
         for k in range(7):
             if k >= 2:
                 evd[k - 2][0].record()
-            with torch.autocast("cuda", dtype=torch.float16):
-                rgb = decode_rgb(dec, f48, (32, 32))
-            torch.nn.functional.mse_loss(rgb.float(), image).backward()
+            torch.nn.functional.mse_loss(decode(f48), image).backward()
             if k >= 2:
                 evd[k - 2][1].record()
         torch.cuda.synchronize()
@@ -405,8 +408,10 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
                               f"{sync.last_list_levels}") if level_tables else "dense reduce-scatter + all-gather",
             "optimizer": opt_name,
-            "rgb_decoder": ("CNN decoder (4 BasicBlocks of 7x7 convs + 3x transposed conv, MIOpen under fp16 autocast) + rgb "
-                            f"MSE in the step; standalone forward+backward {dec_ms:.2f} ms") if dec is not None
+            "rgb_decoder": ("CNN decoder (4 BasicBlocks of 7x7 convs + BatchNorm, 3x transposed conv) + rgb MSE in the step, "
+                            + ("torch modules = MIOpen under fp16 autocast" if torch_decoder else
+                               "HIP kernels (csrc/decoder.hip: fp16 operands, fp32 accumulation, v_mfma_f32_32x32x16_f16)")
+                            + f"; standalone forward+backward {dec_ms:.2f} ms") if dec is not None
             else "not in this step (feature regression stands in)",
             "rgb_decoder_fwd_bwd_ms": dec_ms,
             "what": "BASELINE config[3] shape per GPU: NeuRAD-default grids, sampler (2 rounds) + field + compositing + "
@@ -878,6 +883,8 @@ def main():
                          "all-gather of the parameters) instead of gradient all-reduce + a full-table Adam on every rank")
     ap.add_argument("--sparse-exchange", action="store_true",
                     help="N > 1: coarse hash-table levels travel as (row, values) lists (GradientSynchronizer level_tables)")
+    ap.add_argument("--torch-decoder", action="store_true",
+                    help="train_full / c3: the RGB decoder on the torch modules (MIOpen, fp16 autocast) instead of the HIP kernels")
     ap.add_argument("--no-rgb-decoder", action="store_true", help="train_full / c3 without the RGB CNN decoder (round-2 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train iters/sec sections")
@@ -916,7 +923,8 @@ def main():
     elif args.config == "c3":
         steps = min(args.steps, 50)
         tf = train_full_section(device, rank, world, steps, max(2, min(args.warmup, 5)), rgb_decoder=not args.no_rgb_decoder,
-                                sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange)
+                                sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange,
+                                torch_decoder=args.torch_decoder)
         out = {"metric": "train iters/sec (camera+lidar joint batch)", "value": tf["rays_per_sec"], "unit": "rays/s",
                "n_gpus": world, "steps": steps, "warmup": max(2, min(args.warmup, 5)), "ms_per_step": tf["ms_per_iter"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -957,7 +965,8 @@ def main():
                 torch.cuda.empty_cache()
                 train_full = guarded(lambda: train_full_section(device, rank, world, args.train_full_steps, 8,
                                                                 rgb_decoder=not args.no_rgb_decoder,
-                                                                sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange))
+                                                                sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange,
+                                                                torch_decoder=args.torch_decoder))
                 if not args.no_rgb_decoder and isinstance(train_full, dict) and "error" not in train_full:
                     gc.collect()
                     torch.cuda.empty_cache()

@@ -10,6 +10,9 @@
 //     column by column: the seven B fragments of a tap column (weights, pre-packed in fragment order, L1/L2 resident) are
 //     held in registers, the A fragments (one input row at one horizontal shift) are read from LDS once and serve the up to
 //     R (output row, ky) pairs that touch them.  0.6 LDS/L1 reads of 16 B per MFMA;
+//     Measured at 40 x 96 x 96 (scripts/bench_decoder_kernels.py, profiles/r03_decoder_conv7x7.json): 44 us = 840 TFLOP/s
+//     (MIOpen's implicit GEMM: 233 us); with the tile load switched off 34 us, with the stores off 36 us, with both off
+//     28.5 us (1.3 PFLOP/s): the two WGs of a CU run in lockstep, so the load and store phases are not hidden yet;
 //   * the input gradient of a convolution is the same kernel on flipped / transposed weights (pack mode 1).
 #include "common.h"
 
@@ -81,13 +84,24 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = tx * kTW, y0 = ty * TH;
   const _Float16* img = in + (size_t)b * H * W * kC;
-  for (int c = threadIdx.x; c < ROWS * kCols * 4; c += 256) {
-    const int q = c & 3, p = c >> 2;
-    const int row = p / kCols, col = p - row * kCols;
-    const int y = y0 - 3 + row, x = x0 - 3 + col;
-    uint4 v = {0u, 0u, 0u, 0u};
-    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const uint4*)(img + ((size_t)y * W + x) * kC + q * 8);
-    *(uint4*)(lds + p * kPix + q * 16) = v;
+  {  // all of this thread's 16-byte pieces of the tile are requested before the first one is written to LDS
+    constexpr int NCH = ROWS * kCols * 4, NIT = (NCH + 255) / 256;
+    uint4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = threadIdx.x + it * 256;
+      const int q = c & 3, p = c >> 2;
+      const int row = p / kCols, col = p - row * kCols;
+      const int y = y0 - 3 + row, x = x0 - 3 + col;
+      v[it] = uint4{0u, 0u, 0u, 0u};
+      if (c < NCH && y >= 0 && y < H && x >= 0 && x < W)
+        v[it] = *(const uint4*)(img + ((size_t)y * W + x) * kC + q * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = threadIdx.x + it * 256;
+      if (c < NCH) *(uint4*)(lds + (c >> 2) * kPix + (c & 3) * 16) = v[it];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,12 +115,20 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
       for (int r = 0; r < 16; ++r) acc[y][r] = bj;
   }
   const unsigned char* abase = lds + ((wave * R) * kCols + px) * kPix + kb * 16;
-  // the tap column's weights are double-buffered: column kx + 1 is requested before column kx's 14 R MFMAs are issued
+  // Software pipeline, pinned with scheduling barriers (left alone, the compiler sinks every load to its first use and the
+  // wave then waits an L2 round trip per four MFMAs): the NEXT tap column's 14 weight fragments are requested before this
+  // column's 14 R MFMAs, and the one input row a step needs is read from LDS one step (2 R MFMAs) ahead.
   Frag Bf[2][7][2];
+  Frag A[R + 6][2];
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky) {
     Bf[0][ky][0].u = wfrag[(ky * 2 + 0) * 64 + lane];
     Bf[0][ky][1].u = wfrag[(ky * 2 + 1) * 64 + lane];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    A[r][0].u = *(const uint4*)(abase + (r * kCols) * kPix);
+    A[r][1].u = *(const uint4*)(abase + (r * kCols) * kPix + 32);
   }
 #pragma unroll
   for (int kx = 0; kx < 7; ++kx) {
@@ -118,41 +140,64 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
         Bf[(kx + 1) & 1][ky][1].u = wp[(ky * 2 + 1) * 64];
       }
     }
-    Frag A[R + 6][2];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
+      if (ky < 6) {  // the row step ky + 1 adds
+        const unsigned char* ap = abase + ((ky + R) * kCols + kx) * kPix;
+        A[ky + R][0].u = *(const uint4*)(ap);
+        A[ky + R][1].u = *(const uint4*)(ap + 32);
+      } else if (kx + 1 < 7) {  // the next column's first R rows (rows 0 .. R-1 of this column are dead by now)
 #pragma unroll
-      for (int y = 0; y < R; ++y) {
-        const int row = y + ky;
-        if (ky == 0 || y == R - 1) {  // first use of this input row at this shift
-          const unsigned char* ap = abase + (row * kCols + kx) * kPix;
-          A[row][0].u = *(const uint4*)(ap);
-          A[row][1].u = *(const uint4*)(ap + 32);
+        for (int r = 0; r < R; ++r) {
+          const unsigned char* ap = abase + (r * kCols + kx + 1) * kPix;
+          A[r][0].u = *(const uint4*)(ap);
+          A[r][1].u = *(const uint4*)(ap + 32);
         }
-        acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[row][0].h, Bf[kx & 1][ky][0].h, acc[y], 0, 0, 0);
-        acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[row][1].h, Bf[kx & 1][ky][1].h, acc[y], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // the R accumulators take turns: no MFMA waits for the one before it
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int y = 0; y < R; ++y)
+          acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[y + ky][h].h, Bf[kx & 1][ky][h].h, acc[y], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // C layout: column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // Two channels per store: lanes j and j ^ 1 (same pixels, neighbouring channels) swap one value per register pair, the
+  // even lane then holds channels (j, j + 1) of the pair's first pixel, the odd lane (j - 1, j) of its second.
   float s1 = 0.f, s2 = 0.f;
   _Float16* oimg = out + (size_t)b * H * W * kC;
+  const bool odd = lane & 1;
 #pragma unroll
   for (int y = 0; y < R; ++y) {
     const int yy = y0 + wave * R + y;
     if (yy >= H) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-      if (x < W) {
-        const _Float16 hv = (_Float16)acc[y][r];
-        oimg[((size_t)yy * W + x) * kC + px] = hv;
-        if (STATS) {  // BatchNorm sees the rounded activation
-          const float v = (float)hv;
-          s1 += v;
-          s2 += v * v;
-        }
+    for (int r = 0; r < 16; r += 2) {
+      const _Float16 h0 = (_Float16)acc[y][r], h1 = (_Float16)acc[y][r + 1];
+      if (STATS) {  // BatchNorm sees the rounded activation
+        const int xa = x0 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        const float v0 = xa < W ? (float)h0 : 0.f, v1 = xa + 1 < W ? (float)h1 : 0.f;
+        s1 += v0 + v1;
+        s2 += v0 * v0 + v1 * v1;
       }
+      union {
+        _Float16 h[2];
+        uint32_t u;
+      } pk;
+      union {
+        _Float16 h;
+        unsigned short s;
+      } snd, rcv;
+      snd.h = odd ? h0 : h1;
+      rcv.s = (unsigned short)__shfl_xor((int)snd.s, 1, 64);
+      pk.h[0] = odd ? rcv.h : h0;
+      pk.h[1] = odd ? h1 : rcv.h;
+      const int x = x0 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2) + 4 * kb;
+      if (x < W) *(uint32_t*)(oimg + ((size_t)yy * W + x) * kC + (px & ~1)) = pk.u;
     }
   }
   if (STATS) {

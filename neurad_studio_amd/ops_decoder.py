@@ -276,11 +276,11 @@ class RgbDecoderFn(torch.autograd.Function):
             gwa, gba, gg1, gbe1, gwb, gbb, gg2, gbe2 = gblocks[k]
             x, c1, coef1, u1, c2, coef2, out = saved[k]
             dc2 = bn_bwd(d_out, out, c2, g2, coef2, gg2, gbe2, gs)
+            du1, _ = conv7x7(dc2, packed[2 * k + 1, 1])  # input gradient first: dc2 is still in the caches
             conv7x7_wgrad(u1, dc2, gwb, gbb, gs)
-            du1, _ = conv7x7(dc2, packed[2 * k + 1, 1])
             dc1 = bn_bwd(du1, u1, c1, g1, coef1, gg1, gbe1, gs)
-            conv7x7_wgrad(x, dc1, gwa, gba, gs)
             dx, _ = conv7x7(dc1, packed[2 * k, 1])
+            conv7x7_wgrad(x, dc1, gwa, gba, gs)
             return add_masked(dx, d_out, out)
 
         for k in (3, 2):

@@ -24,6 +24,15 @@ def timeit(fn, n=20, warm=3):
 
 def main():
     res = {}
+    if "--profile" in sys.argv:  # few launches of the two big kernels, for counter passes
+        x = torch.randn((40, 96, 96, 32), device="cuda").half()
+        wf = D.conv7x7_pack(torch.randn((32, 32, 7, 7), device="cuda") * 0.05, 0)
+        gw, gb = torch.zeros((32, 32, 7, 7), device="cuda"), torch.zeros((32,), device="cuda")
+        for _ in range(5):
+            D.conv7x7(x, wf, gb, stats=True, rows_per_wave=4)
+            D.conv7x7_wgrad(x, x, gw, gb)
+        torch.cuda.synchronize()
+        return
     w = torch.randn((32, 32, 7, 7), device="cuda") * 0.05
     wf = D.conv7x7_pack(w, 0)
     bias = torch.zeros(32, device="cuda")
