@@ -25,6 +25,8 @@ from copy import deepcopy
 from dataclasses import dataclass
 from typing import Type
 
+import torch
+
 import nerfstudio.models.neurad as _ref_neurad
 from nerfstudio.configs.method_configs import method_configs
 from nerfstudio.field_components.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig
@@ -66,6 +68,8 @@ class NeuRADHipModelConfig(NeuRADModelConfig):
     field: NeuRADFieldConfig = dataclasses.field(default_factory=_field_config)  # (shadows dataclasses.field below)
     fused_eval: bool = True
     """Eval chunks through the two fused kernels (False: operator-level path everywhere)."""
+    fused_decoder: bool = True
+    """decode_features' RGB CNN decoder on csrc/decoder.hip (False: the torch modules)."""
     early_stop_eps: float = 0.0
     """> 0: eval rays stop marching once their transmittance is below it (bounded error); 0 = exact."""
     order_rays: bool = False
@@ -73,6 +77,22 @@ class NeuRADHipModelConfig(NeuRADModelConfig):
     fused_training: bool = True
     """Training steps of a static scene on the fused nodes (models/neurad.py FusedTrainMixin); False: the reference's own
     get_nff_outputs over the HIP modules."""
+
+
+class _NchwDecoderAdapter(torch.nn.Module):
+    """what the reference's decode_features calls in place of ``self.rgb_decoder`` (models/neurad.py:362-365): it receives
+    the NCHW VIEW of the pixel-major feature rows and hands an NCHW view of the pixel-major result back, so neither permute
+    moves a byte, and the convolutions run on csrc/decoder.hip (model_components/cnns.py:decode_rgb)."""
+
+    def __init__(self, decoder):
+        super().__init__()
+        self.__dict__["decoder"] = decoder  # not a registered submodule: the state_dict stays the reference's
+
+    def forward(self, x):
+        from neurad_studio_amd.model_components.cnns import decode_rgb
+
+        b, c, h, w = x.shape
+        return decode_rgb(self.decoder, x.permute(0, 2, 3, 1).reshape(-1, c).float(), (h, w)).permute(0, 3, 1, 2)
 
 
 @contextlib.contextmanager
@@ -120,6 +140,18 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
         if self.fused_training_possible():
             return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         return super().get_nff_outputs(ray_bundle, calc_lidar_losses)
+
+    def decode_features(self, features, patch_size, is_lidar=None, intensity_for_cam=False):
+        """the reference's method (models/neurad.py:337-366) with the RGB CNN decoder on the HIP kernels: fp16 operands, fp32
+        accumulation -- what the reference's mixed-precision trainer runs through MIOpen"""
+        if not (self.config.fused_decoder and features.is_cuda):
+            return super().decode_features(features, patch_size, is_lidar, intensity_for_cam)
+        decoder = self._modules["rgb_decoder"]
+        self._modules["rgb_decoder"] = _NchwDecoderAdapter(decoder)
+        try:
+            return super().decode_features(features, patch_size, is_lidar, intensity_for_cam)
+        finally:
+            self._modules["rgb_decoder"] = decoder
 
     def get_metrics_dict(self, outputs, batch):
         # the reference calls the module-level distortion_loss (models/neurad.py:524): the HIP one for this call only

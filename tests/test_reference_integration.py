@@ -476,3 +476,28 @@ def test_neurad_hip_plugin_training_step_on_the_fused_nodes_matches_the_referenc
                             want["ray_samples_list"][i].spacing_ends[..., -1:, 0]], -1)
         assert rel_l2(N(ray_samples_to_sdist(got["ray_samples_list"][i])), N(ref_sd)) < 1e-5, i
 
+
+
+def test_plugin_decoder_adapter_is_the_reference_decoder_call_without_a_copy(ref):
+    """NeuRADHipModel.decode_features hands the reference's own method an adapter in place of ``rgb_decoder``: it must return
+    what the decoder returns for the NCHW view (on CPU decode_rgb runs the torch modules), and reach the pixel-major rows
+    without copying them."""
+    from nerfstudio.model_components.cnns import BasicBlock as RefBlock
+
+    from neurad_studio_amd.integration.neurad_hip import _NchwDecoderAdapter
+    from neurad_studio_amd.model_components.cnns import _fused_decoder_args
+
+    torch.manual_seed(0)
+    dec = torch.nn.Sequential(  # the reference's own construction (models/neurad.py:201-216)
+        torch.nn.Conv2d(48, 32, kernel_size=1, padding=0), torch.nn.ReLU(inplace=True),
+        RefBlock(32, 32, kernel_size=7, padding=3, use_bn=True), RefBlock(32, 32, kernel_size=7, padding=3, use_bn=True),
+        torch.nn.ConvTranspose2d(32, 32, kernel_size=3, stride=3),
+        RefBlock(32, 32, kernel_size=7, padding=3, use_bn=True), RefBlock(32, 32, kernel_size=7, padding=3, use_bn=True),
+        torch.nn.Conv2d(32, 3, kernel_size=1, padding=0), torch.nn.Sigmoid()).eval()
+    args = _fused_decoder_args(dec)  # the HIP path recognises the reference's module tree
+    assert args is not None and len(args[0]) == 38 and len(args[1]) == 8
+    rows = torch.randn(2 * 8 * 8, 48)
+    x = rows.view(2, 8, 8, 48).permute(0, 3, 1, 2)  # what decode_features passes (models/neurad.py:362-363)
+    assert x.permute(0, 2, 3, 1).reshape(-1, 48).data_ptr() == rows.data_ptr()
+    with torch.no_grad():
+        assert torch.equal(_NchwDecoderAdapter(dec)(x), dec(x))
