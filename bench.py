@@ -229,8 +229,6 @@ def train_section(device, rank, world, steps, warmup, beta=None, table_scale=Non
     return {"iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "ray_samples_per_sec": world * R_RAYS * N_SAMPLES * steps / el,
             "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
-            "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
-                              f"{sync.last_list_levels}") if level_tables else "dense reduce-scatter + all-gather",
             "optimizer": opt_name,
             "what": "fwd + bwd + gradient exchange + optimizer step, 4096 rays x 128 samples per GPU"}
 
