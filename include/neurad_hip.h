@@ -688,6 +688,38 @@ int nrhip_dec_rgb_bwd(const void* h, const float* rgb, const float* grad_rgb, co
                       void* grad_h, float* grad_weight, float* grad_bias, const float* grad_scale, int64_t n_pixels,
                       void* stream);
 
+/* The whole decoder behind one entry point per direction (what a binding needs; the per-layer entry points above are its
+ * parts and stay callable).  Parameters in torch's layouts, fp32; features [n_patches * patch_h * patch_w, cin] fp32 in
+ * patch order (models/neurad.py:361-362); rgb [n_patches, 3 patch_h, 3 patch_w, 3] fp32.  conv_w/conv_b/bn_*[2k + j] =
+ * convolution j (0: first, 1: second) of BasicBlock k (0, 1 before the upsampling, 2, 3 after).                        */
+typedef struct {
+  int32_t n_patches, patch_h, patch_w, cin;
+  int32_t training; /* BatchNorm2d: 1 = batch statistics (running statistics are updated), 0 = running statistics      */
+  const float* conv_in_w; /* [32, cin] */
+  const float* conv_in_b;
+  const float* conv_w[8]; /* [32, 32, 7, 7] */
+  const float* conv_b[8];
+  const float* bn_gamma[8];
+  const float* bn_beta[8];
+  float* bn_running_mean[8];
+  float* bn_running_var[8];
+  float bn_eps[8];
+  float bn_momentum[8];
+  const float* up_w; /* [32 in, 32 out, 3, 3] */
+  const float* up_b;
+  const float* out_w; /* [3, 32] */
+  const float* out_b;
+} nrhip_rgb_decoder;
+/* bytes of `saved` (activations kept for the backward) and `workspace` (scratch), floats of grad_params                */
+int nrhip_rgb_decoder_sizes(const nrhip_rgb_decoder* d, int64_t* saved_bytes, int64_t* workspace_bytes,
+                            int64_t* grad_param_floats);
+int nrhip_rgb_decoder_fwd(const nrhip_rgb_decoder* d, const float* features, void* saved, void* workspace, float* rgb,
+                          void* stream);
+/* grad_params (written, not accumulated): conv_in (w, b), then per convolution i = 0..7 (w, b, gamma, beta), up (w, b),
+ * out (w, b).  training mode only.                                                                                     */
+int nrhip_rgb_decoder_bwd(const nrhip_rgb_decoder* d, const float* features, const void* saved, const float* rgb,
+                          const float* grad_rgb, void* workspace, float* grad_features, float* grad_params, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

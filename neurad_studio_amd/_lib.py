@@ -55,6 +55,15 @@ class Actors(C.Structure):
                 ("tables", C.c_void_p), ("actor_scale", C.c_float), ("max_candidates", C.c_int32)]
 
 
+class RgbDecoder(C.Structure):
+    _fields_ = [("n_patches", C.c_int32), ("patch_h", C.c_int32), ("patch_w", C.c_int32), ("cin", C.c_int32),
+                ("training", C.c_int32), ("conv_in_w", C.c_void_p), ("conv_in_b", C.c_void_p),
+                ("conv_w", C.c_void_p * 8), ("conv_b", C.c_void_p * 8), ("bn_gamma", C.c_void_p * 8),
+                ("bn_beta", C.c_void_p * 8), ("bn_running_mean", C.c_void_p * 8), ("bn_running_var", C.c_void_p * 8),
+                ("bn_eps", C.c_float * 8), ("bn_momentum", C.c_float * 8), ("up_w", C.c_void_p), ("up_b", C.c_void_p),
+                ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
+
+
 class OccGrid(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
 
@@ -104,6 +113,9 @@ PROTOTYPES = {
     "nrhip_dec_rgb_fwd": [P, P, P, P, I64, P],
     "nrhip_dec_rgb_bwd_workspace": [I64, C.POINTER(I64)],
     "nrhip_dec_rgb_bwd": [P, P, P, P, P, P, P, P, P, I64, P],
+    "nrhip_rgb_decoder_sizes": [C.POINTER(RgbDecoder), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)],
+    "nrhip_rgb_decoder_fwd": [C.POINTER(RgbDecoder), P, P, P, P, P],
+    "nrhip_rgb_decoder_bwd": [C.POINTER(RgbDecoder), P, P, P, P, P, P, P, P],
     "nrhip_hashgrid_fwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd": [C.POINTER(Grid), P, P, I64, P, P],
     "nrhip_hashgrid_bwd_input": [C.POINTER(Grid), P, P, P, I64, P, P],

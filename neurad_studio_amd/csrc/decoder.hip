@@ -1045,6 +1045,20 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(const _Float16* __restrict
   if (threadIdx.x < 99) partial[(size_t)blockIdx.x * 99 + threadIdx.x] = s0 + s1;
 }
 
+// BatchNorm2d in eval mode: coefficients from the running statistics
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                    float* __restrict__ coef) {
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  const float rstd = 1.f / sqrtf(running_var[c] + eps);
+  const float sc = gamma[c] * rstd;
+  coef[c] = sc;
+  coef[32 + c] = beta[c] - running_mean[c] * sc;
+  coef[64 + c] = running_mean[c];
+  coef[96 + c] = rstd;
+}
+
 inline int ew_blocks(int64_t n8) { return (int)((n8 + 255) / 256); }
 inline int reduce_blocks(int64_t n8) {
   int64_t b = (n8 + 256 * 16 - 1) / (256 * 16);  // >= 16 items per thread
@@ -1309,4 +1323,221 @@ extern "C" int nrhip_dec_rgb_bwd(const void* h, const float* rgb, const float* g
   hipLaunchKernelGGL(reduce_cols_kernel, dim3(3), dim3(256), 0, st, workspace, nb, 99, 96, grad_weight, 1, grad_scale);
   hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 96, nb, 99, 3, grad_bias, 1, grad_scale);
   return check_launch("dec_rgb_bwd");
+}
+
+// ---- the whole decoder behind one entry point per direction ----------------------------------------------------------
+namespace {
+
+inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+constexpr int64_t kWfragBytes = 49 * 2 * 64 * 16;
+constexpr int64_t kWupBytes = 2 * 9 * 2 * 64 * 16;
+
+struct DecLayout {
+  int64_t n_lo, n_hi;                  // pixels at the patch resolution / at 3x
+  int64_t h0, blk[4][4], up;           // byte offsets in `saved`: per block c1, u1, c2, out
+  int64_t coef, packed, wup, saved_bytes;
+  int rows_lo, rows_hi;                // conv7x7 rows per wave
+  int64_t stats_floats, ws_floats, grad_buf_bytes, workspace_bytes;
+};
+
+inline int rows_per_wave_for(int b, int h, int w) {
+  const int r[3] = {4, 2, 1};
+  for (int i = 0; i < 3; ++i)
+    if ((int64_t)b * ((w + 31) / 32) * ((h + 4 * r[i] - 1) / (4 * r[i])) >= 512) return r[i];
+  return 1;
+}
+
+int dec_layout(const nrhip_rgb_decoder* d, DecLayout* L) {
+  const int b = d->n_patches, h = d->patch_h, w = d->patch_w;
+  L->n_lo = (int64_t)b * h * w;
+  L->n_hi = 9 * L->n_lo;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    const int64_t o = off;
+    off += align256(bytes);
+    return o;
+  };
+  L->h0 = take(L->n_lo * 64);
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 4; ++j) L->blk[k][j] = take((k < 2 ? L->n_lo : L->n_hi) * 64);
+  L->up = take(L->n_hi * 64);
+  L->coef = take(8 * 128 * sizeof(float));
+  L->packed = take(8 * 2 * kWfragBytes);
+  L->wup = take(kWupBytes);
+  L->saved_bytes = off;
+  L->rows_lo = rows_per_wave_for(b, h, w);
+  L->rows_hi = rows_per_wave_for(b, 3 * h, 3 * w);
+  int32_t t_lo = 0, t_hi = 0;
+  nrhip_conv7x7_tiles(h, w, L->rows_lo, &t_lo);
+  nrhip_conv7x7_tiles(3 * h, 3 * w, L->rows_hi, &t_hi);
+  L->stats_floats = (int64_t)b * (t_lo > t_hi ? t_lo : t_hi) * 64;
+  int64_t m = L->stats_floats, v = 0;
+  nrhip_conv7x7_wgrad_workspace(b, 3 * h, 3 * w, &v);
+  m = v > m ? v : m;
+  nrhip_conv7x7_wgrad_workspace(b, h, w, &v);
+  m = v > m ? v : m;
+  nrhip_dec_bn_bwd_workspace(L->n_hi, &v);
+  m = v > m ? v : m;
+  nrhip_dec_upsample_bwd_workspace(b, h, w, &v);
+  m = v > m ? v : m;
+  nrhip_dec_rgb_bwd_workspace(L->n_hi, &v);
+  m = v > m ? v : m;
+  nrhip_dec_conv1x1_in_bwd_workspace(L->n_lo, d->cin, &v);
+  m = v > m ? v : m;
+  L->ws_floats = m;
+  L->grad_buf_bytes = align256(L->n_hi * 64);
+  L->workspace_bytes = align256(m * 4) + 3 * L->grad_buf_bytes + 256;
+  return NRHIP_OK;
+}
+
+int dec_validate(const nrhip_rgb_decoder* d, const char* who) {
+  NR_REQUIRE(d, NRHIP_ERR_INVALID_ARG, "%s: null decoder", who);
+  NR_REQUIRE(d->n_patches >= 1 && d->patch_h >= 1 && d->patch_w >= 1 && d->cin >= 1 && d->cin <= kMaxCin,
+             NRHIP_ERR_INVALID_ARG, "%s: bad shape (%d patches of %d x %d, %d channels)", who, d->n_patches, d->patch_h,
+             d->patch_w, d->cin);
+  NR_REQUIRE((int64_t)d->n_patches * d->patch_h * d->patch_w * 9 * 32 < (int64_t)1 << 31, NRHIP_ERR_UNSUPPORTED,
+             "%s: batch too large for 32-bit offsets", who);
+  bool ok = d->conv_in_w && d->conv_in_b && d->up_w && d->up_b && d->out_w && d->out_b;
+  for (int i = 0; i < 8; ++i)
+    ok = ok && d->conv_w[i] && d->conv_b[i] && d->bn_gamma[i] && d->bn_beta[i] && d->bn_running_mean[i] && d->bn_running_var[i];
+  NR_REQUIRE(ok, NRHIP_ERR_INVALID_ARG, "%s: null parameter", who);
+  return NRHIP_OK;
+}
+
+#define DEC_TRY(call)            \
+  do {                           \
+    const int rc_ = (call);      \
+    if (rc_ != NRHIP_OK) return rc_; \
+  } while (0)
+
+}  // namespace
+
+extern "C" int nrhip_rgb_decoder_sizes(const nrhip_rgb_decoder* d, int64_t* saved_bytes, int64_t* workspace_bytes,
+                                       int64_t* grad_param_floats) {
+  DEC_TRY(dec_validate(d, "rgb_decoder_sizes"));
+  NR_REQUIRE(saved_bytes && workspace_bytes && grad_param_floats, NRHIP_ERR_INVALID_ARG, "rgb_decoder_sizes: null output");
+  DecLayout L;
+  dec_layout(d, &L);
+  *saved_bytes = L.saved_bytes;
+  *workspace_bytes = L.workspace_bytes;
+  *grad_param_floats = 32 * (int64_t)d->cin + 32 + 8 * (32 * 32 * 49 + 32 + 32 + 32) + (32 * 32 * 9 + 32) + (96 + 3);
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_rgb_decoder_fwd(const nrhip_rgb_decoder* d, const float* features, void* saved, void* workspace,
+                                     float* rgb, void* stream) {
+  DEC_TRY(dec_validate(d, "rgb_decoder_fwd"));
+  NR_REQUIRE(features && saved && workspace && rgb, NRHIP_ERR_INVALID_ARG, "rgb_decoder_fwd: null buffer");
+  DecLayout L;
+  dec_layout(d, &L);
+  char* sv = (char*)saved;
+  float* stats = (float*)workspace;
+  float* coef = (float*)(sv + L.coef);
+  const int b = d->n_patches;
+  DEC_TRY(nrhip_conv7x7_pack_many(d->conv_w, 8, sv + L.packed, stream));
+  DEC_TRY(nrhip_dec_upsample_pack(d->up_w, sv + L.wup, stream));
+  DEC_TRY(nrhip_dec_conv1x1_in_fwd(features, d->conv_in_w, d->conv_in_b, sv + L.h0, L.n_lo, d->cin, stream));
+  const void* x = sv + L.h0;
+  for (int k = 0; k < 4; ++k) {
+    const bool hi = k >= 2;
+    const int h = hi ? 3 * d->patch_h : d->patch_h, w = hi ? 3 * d->patch_w : d->patch_w, rows = hi ? L.rows_hi : L.rows_lo;
+    const int64_t npix = hi ? L.n_hi : L.n_lo;
+    if (k == 2) {
+      DEC_TRY(nrhip_dec_upsample_fwd(x, sv + L.wup, d->up_b, sv + L.up, b, d->patch_h, d->patch_w, stream));
+      x = sv + L.up;
+    }
+    int32_t tiles = 0;
+    nrhip_conv7x7_tiles(h, w, rows, &tiles);
+    void *c1 = sv + L.blk[k][0], *u1 = sv + L.blk[k][1], *c2 = sv + L.blk[k][2], *out = sv + L.blk[k][3];
+    for (int j = 0; j < 2; ++j) {  // conv a -> bn -> relu, conv b -> bn -> + skip -> relu
+      const int i = 2 * k + j;
+      float* cf = coef + 128 * i;
+      DEC_TRY(nrhip_conv7x7(j == 0 ? x : u1, sv + L.packed + (int64_t)(2 * i) * kWfragBytes, d->conv_b[i], j == 0 ? c1 : c2,
+                            d->training ? stats : nullptr, b, h, w, rows, stream));
+      if (d->training) {
+        DEC_TRY(nrhip_dec_bn_finalize(stats, b * tiles, npix, d->bn_gamma[i], d->bn_beta[i], d->bn_eps[i],
+                                      d->bn_momentum[i], d->bn_running_mean[i], d->bn_running_var[i], cf, stream));
+      } else {
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d->bn_gamma[i], d->bn_beta[i],
+                           d->bn_running_mean[i], d->bn_running_var[i], d->bn_eps[i], cf);
+      }
+      DEC_TRY(nrhip_dec_bn_act(j == 0 ? c1 : c2, cf, j == 0 ? nullptr : x, j == 0 ? u1 : out, npix, stream));
+    }
+    x = out;
+  }
+  DEC_TRY(nrhip_dec_rgb_fwd(x, d->out_w, d->out_b, rgb, L.n_hi, stream));
+  return check_launch("rgb_decoder_fwd");
+}
+
+extern "C" int nrhip_rgb_decoder_bwd(const nrhip_rgb_decoder* d, const float* features, const void* saved,
+                                     const float* rgb, const float* grad_rgb, void* workspace, float* grad_features,
+                                     float* grad_params, void* stream) {
+  DEC_TRY(dec_validate(d, "rgb_decoder_bwd"));
+  NR_REQUIRE(features && saved && rgb && grad_rgb && workspace && grad_features && grad_params, NRHIP_ERR_INVALID_ARG,
+             "rgb_decoder_bwd: null buffer");
+  NR_REQUIRE(d->training, NRHIP_ERR_UNSUPPORTED, "rgb_decoder_bwd: backward through running statistics is not implemented");
+  DecLayout L;
+  dec_layout(d, &L);
+  hipStream_t st = (hipStream_t)stream;
+  const char* sv = (const char*)saved;
+  char* wsb = (char*)workspace;
+  float* ws = (float*)wsb;
+  char* gbuf[3] = {wsb + align256(L.ws_floats * 4), wsb + align256(L.ws_floats * 4) + L.grad_buf_bytes,
+                   wsb + align256(L.ws_floats * 4) + 2 * L.grad_buf_bytes};
+  float* gscale = (float*)(wsb + align256(L.ws_floats * 4) + 3 * L.grad_buf_bytes);
+  const float* coef = (const float*)(sv + L.coef);
+  const int b = d->n_patches;
+  // grad_params: conv_in (w, b), 4 x (wa, ba, gamma1, beta1, wb, bb, gamma2, beta2), up (w, b), out (w, b)
+  int64_t n_par = 0, sb = 0, wb = 0;
+  nrhip_rgb_decoder_sizes(d, &sb, &wb, &n_par);
+  if (hipMemsetAsync(grad_params, 0, n_par * sizeof(float), st) != hipSuccess) {
+    set_error("rgb_decoder_bwd: memset failed");
+    return NRHIP_ERR_LAUNCH;
+  }
+  float* g_in_w = grad_params;
+  float* g_in_b = g_in_w + 32 * d->cin;
+  float* g_blk = g_in_b + 32;
+  const int64_t per_conv = 32 * 32 * 49 + 32 + 32 + 32;
+  float* g_up_w = g_blk + 8 * per_conv;
+  float* g_up_b = g_up_w + 32 * 32 * 9;
+  float* g_out_w = g_up_b + 32;
+  float* g_out_b = g_out_w + 96;
+  DEC_TRY(nrhip_dec_grad_scale(grad_rgb, L.n_hi * 3, gscale, stream));
+  const void* h4 = sv + L.blk[3][3];
+  void* dcur = gbuf[0];  // gradient w.r.t. the current block's output
+  DEC_TRY(nrhip_dec_rgb_bwd(h4, rgb, grad_rgb, d->out_w, ws, dcur, g_out_w, g_out_b, gscale, L.n_hi, stream));
+  for (int k = 3; k >= 0; --k) {
+    const bool hi = k >= 2;
+    const int h = hi ? 3 * d->patch_h : d->patch_h, w = hi ? 3 * d->patch_w : d->patch_w, rows = hi ? L.rows_hi : L.rows_lo;
+    const int64_t npix = hi ? L.n_hi : L.n_lo;
+    const void* x = k == 0 ? sv + L.h0 : (k == 2 ? sv + L.up : sv + L.blk[k - 1][3]);
+    const void *c1 = sv + L.blk[k][0], *u1 = sv + L.blk[k][1], *c2 = sv + L.blk[k][2], *out = sv + L.blk[k][3];
+    void* t1 = dcur == gbuf[0] ? gbuf[1] : gbuf[0];
+    void* t2 = (dcur != gbuf[2] && t1 != gbuf[2]) ? gbuf[2] : (dcur != gbuf[1] && t1 != gbuf[1] ? gbuf[1] : gbuf[0]);
+    float* ga = g_blk + (2 * k) * per_conv;  // conv a: w, b, gamma, beta
+    float* gb = g_blk + (2 * k + 1) * per_conv;
+    const int ia = 2 * k, ib = 2 * k + 1;
+    // dc2 -> t1; du1 = conv^T(dc2) -> t2; wgrad b
+    DEC_TRY(nrhip_dec_bn_bwd(dcur, out, c2, d->bn_gamma[ib], coef + 128 * ib, ws, gb + 32 * 32 * 49 + 32,
+                             gb + 32 * 32 * 49 + 64, gscale, t1, npix, stream));
+    DEC_TRY(nrhip_conv7x7(t1, sv + L.packed + (int64_t)(2 * ib + 1) * kWfragBytes, nullptr, t2, nullptr, b, h, w, rows, stream));
+    DEC_TRY(nrhip_conv7x7_wgrad(u1, t1, ws, gb, gb + 32 * 32 * 49, gscale, b, h, w, stream));
+    // dc1 -> t1 (dc2 is dead); dx = conv^T(dc1) -> t2 (du1 is dead after bn_bwd); wgrad a
+    DEC_TRY(nrhip_dec_bn_bwd(t2, u1, c1, d->bn_gamma[ia], coef + 128 * ia, ws, ga + 32 * 32 * 49 + 32,
+                             ga + 32 * 32 * 49 + 64, gscale, t1, npix, stream));
+    DEC_TRY(nrhip_conv7x7(t1, sv + L.packed + (int64_t)(2 * ia + 1) * kWfragBytes, nullptr, t2, nullptr, b, h, w, rows, stream));
+    DEC_TRY(nrhip_conv7x7_wgrad(x, t1, ws, ga, ga + 32 * 32 * 49, gscale, b, h, w, stream));
+    // block input gradient = convolution path + skip path -> t1
+    DEC_TRY(nrhip_dec_add_masked(t2, dcur, out, t1, npix, stream));
+    dcur = t1;
+    if (k == 2) {  // through the transposed convolution
+      void* dlo = dcur == gbuf[0] ? gbuf[1] : gbuf[0];
+      DEC_TRY(nrhip_dec_upsample_bwd(sv + L.blk[1][3], dcur, sv + L.wup, ws, dlo, g_up_w, g_up_b, gscale, b, d->patch_h,
+                                     d->patch_w, stream));
+      dcur = dlo;
+    }
+  }
+  DEC_TRY(nrhip_dec_conv1x1_in_bwd(features, sv + L.h0, dcur, d->conv_in_w, ws, grad_features, g_in_w, g_in_b, gscale, L.n_lo,
+                                   d->cin, stream));
+  return check_launch("rgb_decoder_bwd");
 }

@@ -205,95 +205,72 @@ class _BnState:
         self.running_mean, self.running_var, self.eps, self.momentum = running_mean, running_var, eps, momentum
 
 
+def _decoder_struct(b: int, ph: int, pw: int, cin: int, training: bool, bn_states, p):
+    """-> (nrhip_rgb_decoder, keep-alive list): params p = w0, b0, 4 x (wa, ba, gamma1, beta1, wb, bb, gamma2, beta2), wu, bu,
+    wo, bo in torch layouts; contiguous fp32 copies are made where a parameter is not one already"""
+    from ._lib import RgbDecoder
+
+    keep = [_f32(t, "decoder parameter") for t in p]
+    d = RgbDecoder()
+    d.n_patches, d.patch_h, d.patch_w, d.cin, d.training = b, ph, pw, cin, int(training)
+    d.conv_in_w, d.conv_in_b = keep[0].data_ptr(), keep[1].data_ptr()
+    for i in range(8):
+        w, bias, gamma, beta = keep[2 + 4 * i:6 + 4 * i]
+        if tuple(w.shape) != (32, 32, 7, 7):
+            raise ValueError(f"decode_rgb: convolution weight {tuple(w.shape)}, expected (32, 32, 7, 7)")
+        d.conv_w[i], d.conv_b[i], d.bn_gamma[i], d.bn_beta[i] = w.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        st = bn_states[i]
+        for t in (st.running_mean, st.running_var):
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError("decode_rgb: BatchNorm running statistics must be contiguous cuda fp32 tensors")
+        d.bn_running_mean[i], d.bn_running_var[i] = st.running_mean.data_ptr(), st.running_var.data_ptr()
+        d.bn_eps[i], d.bn_momentum[i] = float(st.eps), float(st.momentum)
+    d.up_w, d.up_b, d.out_w, d.out_b = (t.data_ptr() for t in keep[34:38])
+    return d, keep
+
+
 class RgbDecoderFn(torch.autograd.Function):
-    """rgb_decoder of models/neurad.py:198-216 on [n, cin] feature rows of ph x pw patches -> rgb [B, 3 ph, 3 pw, 3] fp32.
-    params: w0, b0, 4 x (wa, ba, gamma1, beta1, wb, bb, gamma2, beta2), wu, bu, wo, bo (36 tensors, torch layouts)."""
+    """rgb_decoder of models/neurad.py:198-216 on [n, cin] feature rows of ph x pw patches -> rgb [B, 3 ph, 3 pw, 3] fp32: ONE
+    call into the library per direction (nrhip_rgb_decoder_fwd / _bwd).
+    params: w0, b0, 4 x (wa, ba, gamma1, beta1, wb, bb, gamma2, beta2), wu, bu, wo, bo (38 tensors, torch layouts)."""
 
     @staticmethod
     def forward(ctx, features, patch, training, bn_states, *params):
         ph, pw = patch
         n = features.shape[0]
-        if n % (ph * pw):
+        if n == 0 or n % (ph * pw):
             raise ValueError(f"decode_rgb: {n} feature rows are not whole {ph}x{pw} patches")
         b = n // (ph * pw)
-        p = list(params)
-        w0, b0, blocks, (wu, bu, wo, bo) = p[0], p[1], [p[2 + 8 * k:10 + 8 * k] for k in range(4)], p[34:38]
         feats = _chk(features.detach(), "features")
-        h0 = conv1x1_in_fwd(feats, w0, b0).view(b, ph, pw, 32)
-        packed = conv7x7_pack_many([blocks[k][i] for k in range(4) for i in (0, 4)])  # [8, 2, .]: (block, a|b) x (fwd, dgrad)
-
-        def block(x, k):
-            wa, ba, g1, be1, wb, bb, g2, be2 = blocks[k]
-            s1, s2 = bn_states[2 * k], bn_states[2 * k + 1]
-            count = x.numel() // 32
-            c1, part = conv7x7(x, packed[2 * k, 0], ba, stats=training)
-            coef1 = (bn_finalize(part, count, g1, be1, s1.eps, s1.momentum, s1.running_mean, s1.running_var) if training
-                     else _eval_coef(g1, be1, s1))
-            u1 = bn_act(c1, coef1)
-            c2, part = conv7x7(u1, packed[2 * k + 1, 0], bb, stats=training)
-            coef2 = (bn_finalize(part, count, g2, be2, s2.eps, s2.momentum, s2.running_mean, s2.running_var) if training
-                     else _eval_coef(g2, be2, s2))
-            out = bn_act(c2, coef2, skip=x)
-            return out, (x, c1, coef1, u1, c2, coef2, out)
-
-        saved = []
-        x = h0
-        for k in (0, 1):
-            x, sv = block(x, k)
-            saved.append(sv)
-        h2 = x
-        wup = upsample_pack(wu)
-        x = upsample_fwd(h2, wup, bu)
-        for k in (2, 3):
-            x, sv = block(x, k)
-            saved.append(sv)
-        rgb = rgb_fwd(x, wo, bo)
-        ctx.training = training
-        ctx.saved = (feats, h0, saved, h2, x, rgb, packed, wup)
-        ctx.params = [t.detach() for t in p]
-        ctx.need = [features.requires_grad] + [t.requires_grad for t in p]
+        d, keep = _decoder_struct(b, ph, pw, feats.shape[1], training, bn_states, params)
+        sizes = [C.c_int64(0), C.c_int64(0), C.c_int64(0)]
+        call("nrhip_rgb_decoder_sizes", C.byref(d), *(C.byref(v) for v in sizes))
+        saved = torch.empty((sizes[0].value,), device=feats.device, dtype=torch.uint8)
+        work = torch.empty((sizes[1].value,), device=feats.device, dtype=torch.uint8)
+        rgb = torch.empty((b, 3 * ph, 3 * pw, 3), device=feats.device, dtype=torch.float32)
+        call("nrhip_rgb_decoder_fwd", C.byref(d), _ptr(feats), _ptr(saved), _ptr(work), _ptr(rgb), _stream())
+        ctx.training, ctx.dec, ctx.keep = training, d, keep
+        ctx.saved, ctx.sizes = (feats, saved, rgb), sizes
+        ctx.shapes = [t.shape for t in params]
+        ctx.need = [features.requires_grad] + [t.requires_grad for t in params]
         return rgb
 
     @staticmethod
     def backward(ctx, grad_rgb):
         if not ctx.training:
             raise RuntimeError("decode_rgb: backward through the eval-mode decoder (running statistics) is not implemented")
-        feats, h0, saved, h2, h4, rgb, packed, wup = ctx.saved
-        p = ctx.params
-        w0, blocks, (wu, bu, wo, bo) = p[0], [p[2 + 8 * k:10 + 8 * k] for k in range(4)], p[34:38]
-        flat = torch.zeros((sum(t.numel() for t in p),), device=feats.device, dtype=torch.float32)  # one fill for all 38
-        g, off = [], 0
-        for t in p:
-            g.append(flat[off:off + t.numel()].view(t.shape))
-            off += t.numel()
-        gblocks = [g[2 + 8 * k:10 + 8 * k] for k in range(4)]
-        grad_rgb = grad_rgb.contiguous().float()
-        gs = grad_scale(grad_rgb)  # the fp16 gradients below carry S = gs[0]; fp32 results are multiplied by 1/S
-        d = rgb_bwd(h4, rgb, grad_rgb, wo, g[36], g[37], gs)
-
-        def block_bwd(d_out, k):
-            wa, ba, g1, be1, wb, bb, g2, be2 = blocks[k]
-            gwa, gba, gg1, gbe1, gwb, gbb, gg2, gbe2 = gblocks[k]
-            x, c1, coef1, u1, c2, coef2, out = saved[k]
-            dc2 = bn_bwd(d_out, out, c2, g2, coef2, gg2, gbe2, gs)
-            du1, _ = conv7x7(dc2, packed[2 * k + 1, 1])  # input gradient first: dc2 is still in the caches
-            conv7x7_wgrad(u1, dc2, gwb, gbb, gs)
-            dc1 = bn_bwd(du1, u1, c1, g1, coef1, gg1, gbe1, gs)
-            dx, _ = conv7x7(dc1, packed[2 * k, 1])
-            conv7x7_wgrad(x, dc1, gwa, gba, gs)
-            return add_masked(dx, d_out, out)
-
-        for k in (3, 2):
-            d = block_bwd(d, k)
-        d = upsample_bwd(h2, d, wup, g[34], g[35], gs)
-        for k in (1, 0):
-            d = block_bwd(d, k)
-        gf = conv1x1_in_bwd(feats, h0.view(-1, 32), d.view(-1, 32), w0.reshape(32, -1), g[0], g[1], gs)
-        grads = [gf if ctx.need[0] else None] + [gi if need else None for gi, need in zip(g, ctx.need[1:])]
-        return (grads[0], None, None, None, *grads[1:])
-
-
-def _eval_coef(gamma: Tensor, beta: Tensor, st: _BnState) -> Tensor:
-    scale = gamma.detach().float() * torch.rsqrt(st.running_var.float() + st.eps)
-    return torch.stack([scale, beta.detach().float() - st.running_mean.float() * scale, st.running_mean.float(),
-                        torch.rsqrt(st.running_var.float() + st.eps)]).contiguous()
+        feats, saved, rgb = ctx.saved
+        grad_rgb = _chk(grad_rgb.contiguous().float(), "grad_rgb")
+        work = torch.empty((ctx.sizes[1].value,), device=feats.device, dtype=torch.uint8)
+        gf = torch.empty_like(feats)
+        flat = torch.empty((ctx.sizes[2].value,), device=feats.device, dtype=torch.float32)
+        call("nrhip_rgb_decoder_bwd", C.byref(ctx.dec), _ptr(feats), _ptr(saved), _ptr(rgb), _ptr(grad_rgb), _ptr(work),
+             _ptr(gf), _ptr(flat), _stream())
+        grads, off = [], 0
+        for shape, need in zip(ctx.shapes, ctx.need[1:]):
+            k = 1
+            for v in shape:
+                k *= v
+            grads.append(flat[off:off + k].view(shape) if need else None)
+            off += k
+        return (gf if ctx.need[0] else None, None, None, None, *grads)

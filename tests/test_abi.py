@@ -57,6 +57,31 @@ def test_struct_layouts_match_header_sizes(lib):
     assert ctypes.sizeof(_lib.Grid) == 16 + 4 * 32
     assert ctypes.sizeof(_lib.Mlp) == 16 + 8 * 8 * 2
     assert ctypes.sizeof(_lib.Rays) == 72
+    assert ctypes.sizeof(_lib.RgbDecoder) == 24 + 16 + 6 * 64 + 2 * 32 + 32  # 5 int32 (+ pad), 2 + 48 + 4 pointers, 16 floats
+
+
+def test_rgb_decoder_sizes_is_host_logic_and_matches_the_module_tree(lib):
+    """nrhip_rgb_decoder_sizes runs without a GPU: the gradient buffer it describes has one slot per parameter element of the
+    reference-shaped decoder, in module order (what ops_decoder.RgbDecoderFn slices it by)."""
+    from neurad_studio_amd import _lib
+    from neurad_studio_amd.model_components.cnns import _fused_decoder_args, make_rgb_decoder
+
+    dec = make_rgb_decoder(48, 32, 3)
+    params, states, _ = _fused_decoder_args(dec)
+    d = _lib.RgbDecoder()
+    d.n_patches, d.patch_h, d.patch_w, d.cin, d.training = 40, 32, 32, 48, 1
+    one = 0x1000  # any non-null address: nothing is dereferenced
+    d.conv_in_w = d.conv_in_b = d.up_w = d.up_b = d.out_w = d.out_b = one
+    for i in range(8):
+        d.conv_w[i] = d.conv_b[i] = d.bn_gamma[i] = d.bn_beta[i] = d.bn_running_mean[i] = d.bn_running_var[i] = one
+    sizes = [ctypes.c_int64(0) for _ in range(3)]
+    _lib.call("nrhip_rgb_decoder_sizes", ctypes.byref(d), *(ctypes.byref(v) for v in sizes))
+    assert sizes[2].value == sum(p.numel() for p in params) == sum(p.numel() for p in dec.parameters())
+    n_lo, n_hi = 40 * 32 * 32, 40 * 96 * 96
+    assert sizes[0].value >= (9 * n_lo + 9 * n_hi) * 64 and sizes[1].value >= 3 * n_hi * 64
+    d.cin = 65  # unsupported width: an error code and a message, no crash
+    with pytest.raises(_lib.NeuradHipError):
+        _lib.call("nrhip_rgb_decoder_sizes", ctypes.byref(d), *(ctypes.byref(v) for v in sizes))
 
 
 def test_version_and_error_string(lib):
