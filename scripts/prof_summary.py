@@ -20,7 +20,8 @@ for path in sys.argv[1:]:
     grp = {"nrhip": [0, 0.0], "other": [0, 0.0]}
     others = []
     for name, calls, total in cur.execute("select name,total_calls,total_duration from top_kernels"):
-        k = "nrhip" if "nrhip::" in name else "other"
+        # kernels whose templates the tool leaves mangled (_ZN5nrhip...) are this library's as well
+        k = "nrhip" if ("nrhip::" in name or "_ZN5nrhip" in name) else "other"
         grp[k][0] += calls
         grp[k][1] += total
         if k == "other":
