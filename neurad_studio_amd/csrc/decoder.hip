@@ -25,7 +25,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kC = 32;                // channels of the decoder's hidden layers
 constexpr int kTW = 32;               // tile width = the MFMA's 32 rows
 constexpr int kCols = kTW + 6;        // + halo
-constexpr int kPix = 80;              // bytes per pixel in LDS: 64 + 16 of padding (ds_read_b128 conflict-free, stride 20 dwords)
+constexpr int kPix = 64;              // bytes per pixel in LDS, no padding: the four 16-byte channel groups of tile column c sit
+                                      // at (group ^ ((c >> 2) & 3)) -- ds_read_b128 of 32 consecutive columns is conflict-free,
+                                      // and a 22 x 38 tile is 53.5 KB
 
 union Frag {
   uint4 u;
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = threadIdx.x + it * 256;
-      if (c < NCH) *(uint4*)(lds + (c >> 2) * kPix + (c & 3) * 16) = v[it];
+      const int p = c >> 2, col = p % kCols;
+      if (c < NCH) *(uint4*)(lds + p * kPix + (((c & 3) ^ ((col >> 2) & 3)) << 4)) = v[it];
     }
   }
   __syncthreads();
@@ -114,45 +117,45 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[y][r] = bj;
   }
-  const unsigned char* abase = lds + ((wave * R) * kCols + px) * kPix + kb * 16;
+  const unsigned char* abase = lds + ((wave * R) * kCols + px) * kPix;  // + the swizzled channel group, per tap column
   // Software pipeline, pinned with scheduling barriers (left alone, the compiler sinks every load to its first use and the
-  // wave then waits an L2 round trip per four MFMAs): the NEXT tap column's 14 weight fragments are requested before this
-  // column's 14 R MFMAs, and the one input row a step needs is read from LDS one step (2 R MFMAs) ahead.
-  Frag Bf[2][7][2];
+  // wave then waits an L2 round trip per four MFMAs): a tap's two weight fragments are re-requested for the NEXT tap column
+  // as soon as this column's MFMAs on them are issued (6 steps = 12 R MFMAs before their use), and the one input row a step
+  // needs is read from LDS one step (2 R MFMAs) ahead.
+  Frag Bf[7][2];
   Frag A[R + 6][2];
+  // channel groups kb (k = 0..15) and 2 + kb (k = 16..31) of tile column px + kx, at their swizzled places
+  auto col_base = [&](int kx, const unsigned char*& c0, const unsigned char*& c1) {
+    const int g = kb ^ (((px + kx) >> 2) & 3);
+    c0 = abase + kx * kPix + (g << 4);
+    c1 = abase + kx * kPix + ((g ^ 2) << 4);
+  };
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky) {
-    Bf[0][ky][0].u = wfrag[(ky * 2 + 0) * 64 + lane];
-    Bf[0][ky][1].u = wfrag[(ky * 2 + 1) * 64 + lane];
+    Bf[ky][0].u = wfrag[(ky * 2 + 0) * 64 + lane];
+    Bf[ky][1].u = wfrag[(ky * 2 + 1) * 64 + lane];
   }
+  const unsigned char *a0, *a1;
+  col_base(0, a0, a1);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    A[r][0].u = *(const uint4*)(abase + (r * kCols) * kPix);
-    A[r][1].u = *(const uint4*)(abase + (r * kCols) * kPix + 32);
+    A[r][0].u = *(const uint4*)(a0 + (r * kCols) * kPix);
+    A[r][1].u = *(const uint4*)(a1 + (r * kCols) * kPix);
   }
 #pragma unroll
   for (int kx = 0; kx < 7; ++kx) {
-    if (kx + 1 < 7) {
-      const uint4* wp = wfrag + (size_t)(kx + 1) * 7 * 2 * 64 + lane;
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        Bf[(kx + 1) & 1][ky][0].u = wp[(ky * 2 + 0) * 64];
-        Bf[(kx + 1) & 1][ky][1].u = wp[(ky * 2 + 1) * 64];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char *n0, *n1;
+    col_base(kx + 1 < 7 ? kx + 1 : kx, n0, n1);
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       if (ky < 6) {  // the row step ky + 1 adds
-        const unsigned char* ap = abase + ((ky + R) * kCols + kx) * kPix;
-        A[ky + R][0].u = *(const uint4*)(ap);
-        A[ky + R][1].u = *(const uint4*)(ap + 32);
+        A[ky + R][0].u = *(const uint4*)(a0 + ((ky + R) * kCols) * kPix);
+        A[ky + R][1].u = *(const uint4*)(a1 + ((ky + R) * kCols) * kPix);
       } else if (kx + 1 < 7) {  // the next column's first R rows (rows 0 .. R-1 of this column are dead by now)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const unsigned char* ap = abase + (r * kCols + kx + 1) * kPix;
-          A[r][0].u = *(const uint4*)(ap);
-          A[r][1].u = *(const uint4*)(ap + 32);
+          A[r][0].u = *(const uint4*)(n0 + (r * kCols) * kPix);
+          A[r][1].u = *(const uint4*)(n1 + (r * kCols) * kPix);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -161,11 +164,18 @@ __global__ __launch_bounds__(256) void conv7_kernel(const _Float16* __restrict__
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int y = 0; y < R; ++y)
-          acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[y + ky][h].h, Bf[kx & 1][ky][h].h, acc[y], 0, 0, 0);
+          acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[y + ky][h].h, Bf[ky][h].h, acc[y], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kx + 1 < 7) {  // this tap's registers are free: the next column's tap ky is requested 6 steps before its use
+        const uint4* wp = wfrag + (size_t)((kx + 1) * 7 + ky) * 2 * 64 + lane;
+        Bf[ky][0].u = wp[0];
+        Bf[ky][1].u = wp[64];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+    a0 = n0;
+    a1 = n1;
   }
-  // C layout: column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   // Two channels per store: lanes j and j ^ 1 (same pixels, neighbouring channels) swap one value per register pair, the
   // even lane then holds channels (j, j + 1) of the pair's first pixel, the odd lane (j - 1, j) of its second.
   float s1 = 0.f, s2 = 0.f;

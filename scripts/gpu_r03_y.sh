@@ -1,0 +1,10 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT
+export TMPDIR=/tmp
+cd $R
+timeout 300 python -m pytest tests/test_gpu_decoder.py -m gpu -q -p no:cacheprovider -x > $OUT/r03y_pytest.log 2>&1
+echo "pytest rc=$?"; grep -E "^E  |passed|failed|Error" $OUT/r03y_pytest.log | cut -c1-300 | head
+timeout 200 python scripts/bench_decoder_kernels.py 2>/dev/null | python -c "
+import json,sys; d=json.load(sys.stdin)
+for k,v in d.items(): print(k, v)"
+timeout 200 python scripts/bench_decoder.py 2>/dev/null

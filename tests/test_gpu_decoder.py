@@ -12,7 +12,8 @@ def _nhwc16(x):  # [B,C,H,W] fp32 -> NHWC fp16
     return x.permute(0, 2, 3, 1).contiguous().half()
 
 
-@pytest.mark.parametrize("shape,rows", [((3, 32, 32), 1), ((3, 32, 32), 2), ((2, 96, 96), 4), ((2, 40, 50), 2), ((1, 7, 33), 4)])
+@pytest.mark.parametrize("shape,rows", [((3, 32, 32), 1), ((3, 32, 32), 2), ((2, 96, 96), 4), ((2, 40, 50), 2), ((1, 7, 33), 4),
+                                        ((30, 96, 96), 4), ((29, 90, 70), 4)])  # the last two: >= 2 tiles per CU -> persistent kernel
 def test_conv7x7_forward_and_stats_match_torch(shape, rows):
     from neurad_studio_amd import ops_decoder as D
 
