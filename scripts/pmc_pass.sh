@@ -6,5 +6,5 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu-baseline --no-train --no-variants}
 cd /tmp
-rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$tag -o $tag -- python $R/bench.py $ARGS > $R/gpurun_out/pmc_$tag.log 2>&1
+timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d $R/gpurun_out/pmc_$tag -o $tag -- python $R/bench.py $ARGS > $R/gpurun_out/pmc_$tag.log 2>&1
 echo "pass $tag rc=$?"

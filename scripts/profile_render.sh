@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 BENCH="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants $*"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_trace -o trace -- $BENCH > $OUT/prof_${tag}_trace.log 2>&1
-pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace -d $OUT/prof_${tag}_$name -o $name -- $BENCH > $OUT/prof_${tag}_$name.log 2>&1; }
+timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_trace -o trace -- $BENCH > $OUT/prof_${tag}_trace.log 2>&1
+pass() { name=$1; shift; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/prof_${tag}_$name -o $name -- $BENCH > $OUT/prof_${tag}_$name.log 2>&1; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum
