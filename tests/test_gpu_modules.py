@@ -291,3 +291,46 @@ def test_full_size_neurad_default_chain_vs_c_oracle():
     ref = oracle_c.render_fwd(fp, o, d, area, so["starts"], so["ends"])
     for k in ("features", "accumulation", "depth"):
         assert rel_l2(host(out[k]), ref[k]) < TOL, k
+
+
+def test_neurader_sized_grids_take_the_fused_kernels_and_match_the_c_oracle():
+    """The reference's larger methods (`neurader`, `neuradest`, the `-paper` / `-scaleopt` variants,
+    configs/method_configs.py:468-510) change the grids only: base_res and max_res x 2, log2_hashmap_size + 1 for the field
+    AND both proposal fields (static 8 x 2^23 x 4 = 1.07 GB).  Same kernel instantiations as the default method -- this pins
+    that shape against the C restatement of the chain on 2048 rays."""
+    import oracle_c
+    from neurad_studio_amd.models.neurad import NeuRADHotPath, NeuRADHotPathConfig
+
+    torch.manual_seed(0)
+    cfg = NeuRADHotPathConfig(appearance_dim=0)
+    for fc in (cfg.field, cfg.sampling.proposal_field_1, cfg.sampling.proposal_field_2):
+        fc.grid.static.max_res *= 2
+        fc.grid.static.base_res *= 2
+        fc.grid.static.log2_hashmap_size += 1
+    m = NeuRADHotPath(cfg, static_scale=100.0).cuda().eval()
+    assert m.fused_eval_possible() if hasattr(m, "fused_eval_possible") else True
+    with torch.no_grad():
+        m.field.hashgrid.static_grid.hash_table.mul_(300.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(1000.0)
+    R = 2048
+    o, d, area, _ = synth.rays(R, 22)
+    with torch.no_grad():
+        out = m.get_nff_outputs(bundle(o, d, area / 9))
+        rs, wl, _ = m.sampler.generate_fused(bundle(o, d, area), [m.proposal_fields[1]] * 2)
+    pg, fg = cfg.sampling.proposal_field_1.grid.static, cfg.field.grid.static
+    props = [O.ProposalParams(O.GridParams(host(p.hashgrid.static_grid.hash_table), pg.num_levels, pg.base_res, pg.max_res,
+                                           pg.log2_hashmap_size), 100.0, host(p.density_decoder.weight))
+             for p in m.proposal_fields]
+    so = oracle_c.proposal_sampler(props, o, d, area, np.zeros(R, np.float32), np.full(R, 20000.0, np.float32))
+    for i in range(2):
+        assert rel_l2(host(wl[i][..., 0]), so["prop_weights"][i]) < TOL, i
+    f = m.field
+    fp = O.FieldParams(O.GridParams(host(f.hashgrid.static_grid.hash_table), fg.num_levels, fg.base_res, fg.max_res,
+                                    fg.log2_hashmap_size), 100.0,
+                       [host(l.weight) for l in f.mlp_geo.layers], [host(l.bias) for l in f.mlp_geo.layers],
+                       [host(l.weight) for l in f.mlp_feature.layers], [host(l.bias) for l in f.mlp_feature.layers],
+                       beta=float(f.sdf_to_density.beta), use_sdf=True)
+    ref = oracle_c.render_fwd(fp, o, d, area, so["starts"], so["ends"])
+    for k in ("features", "accumulation", "depth"):
+        assert rel_l2(host(out[k]), ref[k]) < TOL, k
