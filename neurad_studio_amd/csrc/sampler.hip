@@ -133,18 +133,15 @@ __device__ __forceinline__ void wave_fence() {
 // S4 for one ray (ray_samplers.py:306-366).  w_lds[Sp] raw weights, bins_lds[Sp+1] existing spacing bins,
 // cdf_lds[Sp+1] scratch.  Writes the Sn+1 new spacing bins to new_bins (LDS or global) and, if eu_out, the
 // euclidean bins.  rand_row: NULL (eval) / jitter values, rand_stride 0 = single jitter.
-__device__ __forceinline__ void pdf_resample_ray(const float* w_lds, const float* bins_lds, float* cdf_lds, int Sp,
-                                                 int Sn, float pad, const float* rand_row, int rand_stride,
-                                                 const Spacing& spc, float* new_bins, float* eu_out, int lane) {
+// cdf_lds[0 .. Sp] = min(1, cumsum of the padded, normalised weights), cdf[0] = 0 (ray_samplers.py:318-331); one wave
+__device__ __forceinline__ void pdf_build_cdf(const float* w_lds, float* cdf_lds, int Sp, float pad, int lane) {
   constexpr float eps = 1e-5f;
-  // weights + histogram padding, their sum
   float tot = 0.f;
   for (int k = lane; k < Sp; k += 64) tot += w_lds[k] + pad;
   tot = wsum(tot);
   const float padding = fmaxf(eps - tot, 0.f);
   const float add = padding / (float)Sp;
   tot += padding;
-  // cdf = min(1, cumsum(pdf)), cdf[0] = 0
   float carry = 0.f;
   for (int k0 = 0; k0 < Sp; k0 += 64) {
     const int k = k0 + lane;
@@ -154,31 +151,49 @@ __device__ __forceinline__ void pdf_resample_ray(const float* w_lds, const float
     carry += __shfl(incl, 63, 64);
   }
   if (lane == 0) cdf_lds[0] = 0.f;
+}
+
+// new spacing bin i of nb = Sn + 1 (ray_samplers.py:333-366): inverse CDF at u_i
+__device__ __forceinline__ float pdf_sample_bin(const float* cdf_lds, const float* bins_lds, int Sp, int nb, int i,
+                                                const float* rand_row, int rand_stride) {
+  float u = linspace_at(0.f, 1.f - (1.f / (float)nb), nb, i);
+  if (rand_row) u += rand_row[rand_stride ? i : 0] / (float)nb;
+  else u += 1.f / (float)(2 * nb);
+  // searchsorted(cdf, u, side="right") over Sp+1 entries = #{cdf <= u}
+  int lo = 0, hi = Sp + 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cdf_lds[mid] <= u) lo = mid + 1;
+    else hi = mid;
+  }
+  const int below = min(max(lo - 1, 0), Sp), above = min(max(lo, 0), Sp);
+  const float c0 = cdf_lds[below], c1 = cdf_lds[above];
+  const float b0 = bins_lds[below], b1 = bins_lds[above];
+  float tt = (u - c0) / (c1 - c0);
+  if (tt != tt) tt = 0.f;  // nan_to_num(nan=0); +-inf are clipped below
+  tt = fminf(fmaxf(tt, 0.f), 1.f);
+  return b0 + tt * (b1 - b0);
+}
+
+// S4 for one ray (ray_samplers.py:306-366).  w_lds[Sp] raw weights, bins_lds[Sp+1] existing spacing bins,
+// cdf_lds[Sp+1] scratch.  Writes the Sn+1 new spacing bins to new_bins (LDS or global) and, if eu_out, the
+// euclidean bins.  rand_row: NULL (eval) / jitter values, rand_stride 0 = single jitter.
+__device__ __forceinline__ void pdf_resample_ray(const float* w_lds, const float* bins_lds, float* cdf_lds, int Sp,
+                                                 int Sn, float pad, const float* rand_row, int rand_stride,
+                                                 const Spacing& spc, float* new_bins, float* eu_out, int lane) {
+  pdf_build_cdf(w_lds, cdf_lds, Sp, pad, lane);
   wave_fence();
   const int nb = Sn + 1;
   for (int i = lane; i < nb; i += 64) {
-    float u = linspace_at(0.f, 1.f - (1.f / (float)nb), nb, i);
-    if (rand_row) u += rand_row[rand_stride ? i : 0] / (float)nb;
-    else u += 1.f / (float)(2 * nb);
-    // searchsorted(cdf, u, side="right") over Sp+1 entries = #{cdf <= u}
-    int lo = 0, hi = Sp + 1;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cdf_lds[mid] <= u) lo = mid + 1;
-      else hi = mid;
-    }
-    const int below = min(max(lo - 1, 0), Sp), above = min(max(lo, 0), Sp);
-    const float c0 = cdf_lds[below], c1 = cdf_lds[above];
-    const float b0 = bins_lds[below], b1 = bins_lds[above];
-    float tt = (u - c0) / (c1 - c0);
-    if (tt != tt) tt = 0.f;  // nan_to_num(nan=0); +-inf are clipped below
-    tt = fminf(fmaxf(tt, 0.f), 1.f);
-    const float nbv = b0 + tt * (b1 - b0);
+    const float nbv = pdf_sample_bin(cdf_lds, bins_lds, Sp, nb, i, rand_row, rand_stride);
     new_bins[i] = nbv;
     if (eu_out) eu_out[i] = spc.to_euclid(nbv);
   }
 }
 
+// Standalone S4 (the training path's rounds): a workgroup = 4 rays.  Each wave builds its ray's CDF; the 4 (Sn + 1) new bins
+// are then spread over all 256 threads -- with one wave per ray, the odd bin (Sn + 1 = 65, 33) costs that wave a second pass
+// of searches and a powf for a single lane.
 __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict__ weights,
                                                           const float* __restrict__ bins,
                                                           const float* __restrict__ nears,
@@ -187,18 +202,38 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
                                                           const float* __restrict__ rand, int rand_stride,
                                                           float* __restrict__ new_sp, float* __restrict__ new_eu) {
   __shared__ float slab[4][3 * (kSMax + 1)];
+  __shared__ float s_near[4], s_far[4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * 4 + wid;
-  if (ray >= R) return;
-  float* w_lds = slab[wid];
-  float* b_lds = w_lds + kSMax + 1;
-  float* c_lds = b_lds + kSMax + 1;
-  for (int k = lane; k < Sp; k += 64) w_lds[k] = weights[ray * Sp + k];
-  for (int k = lane; k <= Sp; k += 64) b_lds[k] = bins[ray * (Sp + 1) + k];
-  wave_fence();
-  const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
-  pdf_resample_ray(w_lds, b_lds, c_lds, Sp, Sn, pad, rand ? rand + ray * (rand_stride ? rand_stride : 1) : nullptr,
-                   rand_stride, spc, new_sp + ray * (Sn + 1), new_eu + ray * (Sn + 1), lane);
+  const int64_t ray0 = (int64_t)blockIdx.x * 4;
+  const int n_rays = (int)min((int64_t)4, R - ray0);
+  if (wid < n_rays) {
+    const int64_t ray = ray0 + wid;
+    float* w_lds = slab[wid];
+    float* b_lds = w_lds + kSMax + 1;
+    float* c_lds = b_lds + kSMax + 1;
+    for (int k = lane; k < Sp; k += 64) w_lds[k] = weights[ray * Sp + k];
+    for (int k = lane; k <= Sp; k += 64) b_lds[k] = bins[ray * (Sp + 1) + k];
+    wave_fence();
+    pdf_build_cdf(w_lds, c_lds, Sp, pad, lane);
+    if (lane == 0) {
+      const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
+      s_near[wid] = spc.s_near;
+      s_far[wid] = spc.s_far;
+    }
+  }
+  __syncthreads();
+  const int nb = Sn + 1;
+  for (int j = threadIdx.x; j < n_rays * nb; j += 256) {
+    const int r = j / nb, i = j - r * nb;
+    const float* w_lds = slab[r];
+    const float* b_lds = w_lds + kSMax + 1;
+    const float* c_lds = b_lds + kSMax + 1;
+    const int64_t ray = ray0 + r;
+    const float nbv = pdf_sample_bin(c_lds, b_lds, Sp, nb, i, rand ? rand + ray * (rand_stride ? rand_stride : 1) : nullptr,
+                                     rand_stride);
+    new_sp[ray * nb + i] = nbv;
+    new_eu[ray * nb + i] = Spacing{s_near[r], s_far[r], lam, scaling}.to_euclid(nbv);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
