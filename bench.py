@@ -12,8 +12,9 @@
   `roofline` (dominant kernel, HIP-event timed inside the timed region), `train` (iters/s of the config-1 field),
   `train_full` (iters/s of the whole NeuRAD-default training step on BASELINE config[3]'s camera+lidar joint batch,
   40 960 + 16 384 rays per GPU, incl. losses, gradient exchange and Adam -- the train-iters/sec half of the metric) and,
-  at N=1, `cpu_baseline` (C port of the oracle on the host cores) + `reference_torch_cpu` (the reference's own torch path,
-  timed in the build container, profiles/reference_torch_cpu.json).
+  at N=1, `cpu_baseline` (C port of the oracle on the host cores) + `reference_torch_cpu` (the reference's own torch path:
+  live where its tree is importable, else the figure timed in the build container, profiles/reference_torch_cpu.json) +
+  `reference_torch_cpu_port_here` (the same torch op sequence restated in oracle/torch_cpu_port.py, timed on THIS host).
 --config c2: BASELINE config[2], 8192 camera rays through the fused proposal sampler (2 rounds) + fused field/compositing
   with NeuRAD's default grids; roofline on the proposal sampler kernel (192 B per proposal evaluation).
 --config c3: the `train_full` step as the timed step.
@@ -446,6 +447,34 @@ def cpu_baseline(fs, origins, dirs, area, edges, budget_s=12.0):
             "kind": "port",
             "sample": f"{reps} passes over the full bench batch ({R_RAYS} rays x {N_SAMPLES} samples), {t:.1f} s of "
                       "oracle/neurad_oracle_c.c (C + OpenMP on all host cores, fp32)"}, (R_RAYS, out)
+
+
+def torch_port_cpu(fs, origins, dirs, area, edges, budget_s=10.0):
+    """The reference's field-eval path as torch ops on THIS host's cores (oracle/torch_cpu_port.py: the op sequence of
+    HashEncoding.pytorch_fwd + MLP.pytorch_fwd + the dense compositing, pinned to the numpy oracle by
+    tests/test_oracle_torch_port.py), on a bounded slice of the bench batch.  What the GPU box can time of "the reference's
+    CPU PyTorch path": the reference tree itself is not there."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import neurad_oracle as O
+    import torch_cpu_port as P
+
+    h = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    grid = O.GridParams(h(fs.table), GRID["num_levels"], GRID["min_res"], GRID["max_res"], GRID["log2_hashmap_size"])
+    p = O.FieldParams(grid, STATIC_SCALE, [h(w) for w in fs.geo_w], [h(b) for b in fs.geo_b], [h(w) for w in fs.feat_w],
+                      [h(b) for b in fs.feat_b], beta=20.0, use_sdf=True)
+    n = 512  # rays per pass (x 128 samples): ~1 s of torch CPU work
+    o, d, a, e = (t.detach().cpu()[:n].contiguous() for t in (origins, dirs, area, edges))
+    s0, e0 = e[:, :-1].contiguous(), e[:, 1:].contiguous()
+    P.render_rays(p, o, d, a, s0, e0)  # warm: thread pool, page-in of the table
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        P.render_rays(p, o, d, a, s0, e0)
+        reps += 1
+    t = time.perf_counter() - t0
+    return {"value": reps * n * N_SAMPLES / t, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} passes over {n} rays x {N_SAMPLES} samples of the bench batch, {t:.1f} s",
+            "what": "oracle/torch_cpu_port.py: the reference's torch formulation of the field eval + dense compositing "
+                    "(forward, fp32, torch CPU ops on all host threads), live on this host"}
 
 
 def reference_torch_cpu():
@@ -989,6 +1018,12 @@ def main():
                 rt = reference_torch_cpu()
                 if rt is not None:
                     out["reference_torch_cpu"] = rt
+                if rt is None or not rt.get("where", "").startswith("this host"):
+                    # no reference tree on this box: its torch formulation, restated, timed here on the host cores
+                    try:
+                        out["reference_torch_cpu_port_here"] = torch_port_cpu(fs, origins, dirs, area, edges)
+                    except Exception as e:  # noqa: BLE001  (a baseline leg must not cost the headline line)
+                        out["reference_torch_cpu_port_here"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 err = float(np.linalg.norm(feats[:n].cpu().numpy() - ref["features"]) / np.linalg.norm(ref["features"]))
                 out["parity_rel_l2_vs_oracle"] = {
                     "features": err, "tolerance": 1e-4,
