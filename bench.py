@@ -797,7 +797,8 @@ def bench_c4(args, device, rank, world):
     state = {}
     ev_every = 4
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range((args.steps + ev_every - 1) // ev_every)]
-    real_render = ops.render_fwd_actors
+    ev_s = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(len(ev))]
+    real_render, real_sampler = ops.render_fwd_actors, ops.proposal_sampler_fwd
 
     def timed_render(*a, **k):  # HIP events around the render stage (partition + static slice + ACT slice) of timed steps
         e = state.get("ev")
@@ -808,15 +809,25 @@ def bench_c4(args, device, rank, world):
             e[1].record()
         return r
 
+    def timed_sampler(*a, **k):  # ... and around the fused proposal sampler (per-sample actor select): the step's largest kernel
+        e = state.get("ev_s")
+        if e is not None:
+            e[0].record()
+        r = real_sampler(*a, **k)
+        if e is not None:
+            e[1].record()
+        return r
+
     def step(i=None):
         state["ev"] = ev[i // ev_every] if i is not None and i % ev_every == 0 else None
+        state["ev_s"] = ev_s[i // ev_every] if i is not None and i % ev_every == 0 else None
         state["out"] = m.get_outputs_for_ray_bundle(bundle(), num_rays_per_chunk=1 << 17)
 
-    ops.render_fwd_actors = timed_render
+    ops.render_fwd_actors, ops.proposal_sampler_fwd = timed_render, timed_sampler
     try:
         elapsed = timed(step, args.steps, args.warmup, world, device)
     finally:
-        ops.render_fwd_actors = real_render
+        ops.render_fwd_actors, ops.proposal_sampler_fwd = real_render, real_sampler
     assert torch.isfinite(state["out"]["features"]).all()
     S = m.config.sampling.num_nerf_samples
     n_field = R * S
@@ -840,6 +851,10 @@ def bench_c4(args, device, rank, world):
     out = None
     if rank == 0:
         k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        s_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_s]))
+        sc = m.config.sampling
+        n_prop = R * sum(sc.num_proposal_samples)
+        gathers = n_prop * 6 * 8  # the static proposal grid's 48 four-byte gathers per evaluation (actor lookups not counted)
         out = {
             "metric": "ray-samples/sec (65536 rays, eval, actors + appearance, fp16 tables)",
             "value": world * n_field * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
@@ -851,7 +866,17 @@ def bench_c4(args, device, rank, world):
                        "rays_per_gpu": R, "actors": A, "samples_in_a_box": frac_hit, "rays_with_candidates": rays_with_cand,
                        "parallelism": f"rays sharded x{world}, no collective"},
             "rays_per_sec": world * R * args.steps / elapsed,
-            "roofline": {"kernel": "nrhip_render_fwd_actors: actor_partition + render_kernel<8,4,32,fp16,composite> over the rays "
+            # the step's dominant kernel: the fused proposal sampler with the per-sample actor select.  Like config[2]'s it
+            # runs against the vector L1's access rate, not HBM (its tables are cache resident)
+            "roofline": {"kernel": "nrhip::proposal_sampler_kernel<ACT> (both rounds on chip, one wave per ray, per-sample actor "
+                                   "select; HIP events around nrhip_proposal_sampler_fwd_actors in the timed steps)",
+                         "bound": "l1", "achieved": gathers / (s_ms * 1e-3) / 1e9, "peak": L1_ACCESS_PEAK_G,
+                         "unit": "Gaccess/s", "frac": gathers / (s_ms * 1e-3) / 1e9 / L1_ACCESS_PEAK_G, "traffic": None,
+                         "kernel_ms": s_ms, "accesses_per_launch": gathers,
+                         "what": "algorithmic 4-byte gathers of the STATIC proposal grid (48 per proposal evaluation, "
+                                 f"{n_prop} evaluations per launch) per second against the vector L1's access rate; config[2]'s "
+                                 "sampler without actors reaches 0.8 of it"},
+            "render_roofline": {"kernel": "nrhip_render_fwd_actors: actor_partition + render_kernel<8,4,32,fp16,composite> over the rays "
                                    "without candidates + render_kernel<8,4,32,fp16,composite,ACT> over the rays with",
                          "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": recorded_traffic("render_actors_fp16"),
