@@ -355,7 +355,16 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
         m.sampler.step_cb(0)
         state["loss"] = loss
 
-    el = timed(step, steps, warmup, world, device)
+    def _device_allocs():
+        st = torch.cuda.memory_stats(device)
+        return int(st.get("num_device_alloc", 0)), int(st.get("num_alloc_retries", 0))
+
+    for _ in range(warmup):  # the caching allocator reaches its steady state here, outside timed()'s own warm-up
+        step()
+    torch.cuda.synchronize()
+    allocs0 = _device_allocs()
+    el = timed(step, steps, 1, world, device)
+    allocs1 = _device_allocs()
     assert torch.isfinite(state["loss"]), "non-finite loss"
     s = m.config.sampling
     # roofline of the step's largest single kernel, the fused training forward of the main field (render_kernel storing its
@@ -403,6 +412,8 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     return {"roofline": roof, "iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
+            "device_allocations_during_the_timed_steps": allocs1[0] - allocs0[0],  # hipMalloc calls: 0 in steady state
+            "allocator_retries_during_the_timed_steps": allocs1[1] - allocs0[1],
             "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
             "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
                               f"{sync.last_list_levels}") if level_tables else "dense reduce-scatter + all-gather",
