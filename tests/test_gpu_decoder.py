@@ -240,3 +240,24 @@ def test_decoder_backward_is_scale_free():
         if n.endswith("main_branch.0.bias") or n.endswith("main_branch.3.bias"):
             continue
         assert float((gp1[n] - gp2[n]).norm() / (gp1[n].norm() + 1e-30)) <= 4e-3, n
+
+
+def test_eval_mode_decoder_on_a_wide_chunk_matches_the_torch_modules():
+    """eval renders image rows, not 32 x 32 patches (models/neurad.py:623-675 -> decode_features with the chunk's shape): a
+    6 x 200 chunk through the HIP decoder with BatchNorm on its running statistics vs the torch modules in fp32."""
+    from neurad_studio_amd.model_components.cnns import decode_rgb, make_rgb_decoder
+
+    torch.manual_seed(11)
+    dec = make_rgb_decoder(48, 32, 3).cuda()
+    with torch.no_grad():
+        for m in dec.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+    dec.eval()
+    f = torch.randn((2 * 6 * 200, 48), device="cuda")
+    with torch.no_grad():
+        a = decode_rgb(dec, f, (6, 200))
+        b = decode_rgb(dec, f, (6, 200), fused=False)
+    assert a.shape == (2, 18, 600, 3) and (a - b).abs().max() <= 3e-3
