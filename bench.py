@@ -218,7 +218,10 @@ def train_section(device, rank, world, steps, warmup, beta=None, table_scale=Non
         t_rand = torch.rand((R_RAYS, N_SAMPLES + 1), device=device)  # training-mode stratified jitter
         eu = ops.power_sampler(None, fars, N_SAMPLES, -1.0, 0.1, t_rand)[1]
         feats, depth, acc, w = fld.render_train(o, d, area, eu)
-        loss = (feats - target).square().mean() + 1e-4 * (depth - tdepth).abs().mean() + 1e-3 * (w.square().sum(-1)).mean()
+        # feature L2 + depth L1 + a weight regulariser, in torch's fused forms (the same three terms as
+        # (feats - target).square().mean() + 1e-4 * (depth - tdepth).abs().mean() + 1e-3 * w.square().sum(-1).mean())
+        loss = (torch.nn.functional.mse_loss(feats, target) + 1e-4 * torch.nn.functional.l1_loss(depth, tdepth)
+                + (1e-3 / R_RAYS) * w.square().sum())
         opt.zero_grad(set_to_none=True)
         loss.backward()
         state["bytes"] = sync.sync()
