@@ -92,6 +92,22 @@ def _ws(entry: str, *dims, device) -> Tensor:
     return torch.empty((max(n.value, 1),), device=device, dtype=torch.float32)
 
 
+def _act16(t: Tensor, name: str, like: Optional[Tensor] = None) -> Tensor:
+    """an activation / gradient tensor of the decoder: contiguous cuda fp16 with 32 channels last (no CPU path)"""
+    if not isinstance(t, Tensor) or not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous() or t.shape[-1] != 32:
+        raise ValueError(f"{name}: expected a contiguous cuda fp16 tensor with 32 channels last, got "
+                         f"{tuple(t.shape) if isinstance(t, Tensor) else type(t)} {getattr(t, 'dtype', '')} on {getattr(t, 'device', '?')}")
+    if like is not None and t.shape != like.shape:
+        raise ValueError(f"{name}: shape {tuple(t.shape)} differs from {tuple(like.shape)}")
+    return t
+
+
+def _coef(t: Tensor, name: str, rows: int) -> Tensor:
+    if not isinstance(t, Tensor) or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != rows * 32:
+        raise ValueError(f"{name}: expected a contiguous cuda fp32 [{rows}, 32] tensor")
+    return t
+
+
 def bn_finalize(part: Tensor, count: int, gamma: Tensor, beta: Tensor, eps: float, momentum: float,
                 running_mean: Optional[Tensor], running_var: Optional[Tensor]) -> Tensor:
     """-> coef [4, 32] = scale, shift, mean, rstd; running statistics updated in place like torch's batch_norm"""
@@ -102,6 +118,9 @@ def bn_finalize(part: Tensor, count: int, gamma: Tensor, beta: Tensor, eps: floa
 
 
 def bn_act(c: Tensor, coef: Tensor, skip: Optional[Tensor] = None) -> Tensor:
+    _act16(c, "c"), _coef(coef, "coef", 4)
+    if skip is not None:
+        _act16(skip, "skip", c)
     out = torch.empty_like(c)
     call("nrhip_dec_bn_act", _ptr(c), _ptr(coef), _ptr(skip), _ptr(out), c.numel() // 32, _stream())
     return out
@@ -118,6 +137,7 @@ def grad_scale(grad: Tensor) -> Tensor:
 
 def bn_bwd(grad_out: Tensor, act: Tensor, c: Tensor, gamma: Tensor, coef: Tensor, grad_gamma: Tensor,
            grad_beta: Tensor, grad_scale: Optional[Tensor] = None) -> Tensor:
+    _act16(c, "c"), _act16(grad_out, "grad_out", c), _act16(act, "act", c), _coef(coef, "coef", 4)
     npix = c.numel() // 32
     ws = _ws("nrhip_dec_bn_bwd_workspace", npix, device=c.device)
     out = torch.empty_like(c)
@@ -127,6 +147,7 @@ def bn_bwd(grad_out: Tensor, act: Tensor, c: Tensor, gamma: Tensor, coef: Tensor
 
 
 def add_masked(a: Tensor, grad_out: Tensor, act: Tensor) -> Tensor:
+    _act16(a, "a"), _act16(grad_out, "grad_out", a), _act16(act, "act", a)
     out = torch.empty_like(a)
     call("nrhip_dec_add_masked", _ptr(a), _ptr(grad_out), _ptr(act), _ptr(out), a.numel() // 32, _stream())
     return out
@@ -163,6 +184,9 @@ def upsample_pack(weight: Tensor) -> Tensor:
 
 
 def upsample_fwd(h: Tensor, wup: Tensor, bias: Tensor) -> Tensor:
+    _act16(h, "h")
+    if h.dim() != 4 or wup.dtype != torch.float16 or wup.numel() != 2 * 9 * 2 * 64 * 8:
+        raise ValueError("upsample_fwd: h must be [B, H, W, 32] and wup the output of upsample_pack")
     b, hh, w, _ = h.shape
     out = torch.empty((b, 3 * hh, 3 * w, 32), device=h.device, dtype=torch.float16)
     call("nrhip_dec_upsample_fwd", _ptr(h), _ptr(wup), _ptr(_f32(bias, "bias")), _ptr(out), b, hh, w, _stream())
@@ -171,6 +195,9 @@ def upsample_fwd(h: Tensor, wup: Tensor, bias: Tensor) -> Tensor:
 
 def upsample_bwd(h: Tensor, grad_out: Tensor, wup: Tensor, grad_weight: Tensor, grad_bias: Tensor,
                  grad_scale: Optional[Tensor] = None) -> Tensor:
+    _act16(h, "h"), _act16(grad_out, "grad_out")
+    if h.dim() != 4 or grad_out.shape != (h.shape[0], 3 * h.shape[1], 3 * h.shape[2], 32) or wup.numel() != 2 * 9 * 2 * 64 * 8:
+        raise ValueError("upsample_bwd: h [B, H, W, 32], grad_out [B, 3H, 3W, 32], wup from upsample_pack")
     b, hh, w, _ = h.shape
     ws = _ws("nrhip_dec_upsample_bwd_workspace", b, hh, w, device=h.device)
     gh = torch.empty_like(h)
@@ -180,6 +207,9 @@ def upsample_bwd(h: Tensor, grad_out: Tensor, wup: Tensor, grad_weight: Tensor, 
 
 
 def rgb_fwd(h: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    _act16(h, "h")
+    if h.dim() != 4 or weight.numel() != 96 or bias.numel() != 3:
+        raise ValueError("rgb_fwd: h must be [B, H, W, 32], weight [3, 32(, 1, 1)], bias [3]")
     b, hh, w, _ = h.shape
     rgb = torch.empty((b, hh, w, 3), device=h.device, dtype=torch.float32)
     call("nrhip_dec_rgb_fwd", _ptr(h), _ptr(_f32(weight, "weight")), _ptr(_f32(bias, "bias")), _ptr(rgb), b * hh * w,
@@ -189,7 +219,10 @@ def rgb_fwd(h: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
 
 def rgb_bwd(h: Tensor, rgb: Tensor, grad_rgb: Tensor, weight: Tensor, grad_weight: Tensor, grad_bias: Tensor,
             grad_scale: Optional[Tensor] = None) -> Tensor:
+    _act16(h, "h")
     npix = h.numel() // 32
+    if rgb.numel() != 3 * npix or grad_rgb.numel() != 3 * npix or grad_weight.numel() != 96 or grad_bias.numel() != 3:
+        raise ValueError("rgb_bwd: rgb / grad_rgb must hold 3 values per pixel of h, grad_weight 96, grad_bias 3")
     ws = _ws("nrhip_dec_rgb_bwd_workspace", npix, device=h.device)
     gh = torch.empty_like(h)
     call("nrhip_dec_rgb_bwd", _ptr(h), _ptr(rgb), _ptr(_chk(grad_rgb, "grad_rgb")), _ptr(_f32(weight, "weight")), _ptr(ws),
