@@ -12,9 +12,11 @@
   `roofline` (dominant kernel, HIP-event timed inside the timed region), `train` (iters/s of the config-1 field),
   `train_full` (iters/s of the whole NeuRAD-default training step on BASELINE config[3]'s camera+lidar joint batch,
   40 960 + 16 384 rays per GPU, incl. losses, gradient exchange and Adam -- the train-iters/sec half of the metric) and,
-  at N=1, `cpu_baseline` (C port of the oracle on the host cores) + `reference_torch_cpu` (the reference's own torch path:
-  live where its tree is importable, else the figure timed in the build container, profiles/reference_torch_cpu.json) +
-  `reference_torch_cpu_port_here` (the same torch op sequence restated in oracle/torch_cpu_port.py, timed on THIS host).
+  at N=1, `cpu_baseline` = the reference's own torch field eval timed live on this host's cores (kind "reference": the tree
+  is /root/reference in the build container, the byte-compiled oracle/_ref on the GPU box) with `cpu_port_c` (C/OpenMP port
+  of the oracle, the parity checker) beside it; without a reference tree: `cpu_baseline` = the C port (kind "port"),
+  `reference_torch_cpu` = the figure recorded in the build container, `reference_torch_cpu_port_here` = the torch op
+  sequence restated in oracle/torch_cpu_port.py timed on this host.
 --config c2: BASELINE config[2], 8192 camera rays through the fused proposal sampler (2 rounds) + fused field/compositing
   with NeuRAD's default grids; roofline on the proposal sampler kernel (192 B per proposal evaluation).
 --config c3: the `train_full` step as the timed step.
@@ -492,33 +494,40 @@ def torch_port_cpu(fs, origins, dirs, area, edges, budget_s=10.0):
 
 
 def reference_torch_cpu():
-    """The reference's own torch field-eval path on host cores.  Where a reference tree is present (NEURAD_REFERENCE_ROOT /
-    NEURAD_REFERENCE_DIR, default /root/reference) it is timed LIVE on this host with os.cpu_count() threads
-    (oracle/time_reference_cpu.py in a subprocess, ~30 s); the GPU box has no such tree, there the figure timed in the build
-    container (profiles/reference_torch_cpu.json) is quoted and labelled as such."""
+    """The reference's OWN torch field-eval path (NeuRADField(implementation="torch"): fields/neurad_field.py:128-152,
+    field_components/encodings.py:406-466) timed LIVE on this host's cores, ``torch.get_num_threads()`` threads
+    (oracle/time_reference_cpu.py in a subprocess, ~30 s).  The tree it imports: /root/reference in the build container,
+    oracle/_ref (the reference byte-compiled by oracle/make_ref.py; ships with the lease) on the GPU box.  Only where
+    neither exists the figure recorded in the build container (profiles/reference_torch_cpu.json) is quoted, labelled."""
     import subprocess
 
-    ref_root = os.environ.get("NEURAD_REFERENCE_ROOT") or os.environ.get("NEURAD_REFERENCE_DIR") or "/root/reference"
-    if os.path.isdir(os.path.join(ref_root, "nerfstudio")):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_import
+
+    note = ""
+    if ref_import.reference_available():
         try:
-            env = dict(os.environ, NEURAD_REFERENCE_ROOT=ref_root)
             res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference_cpu.py"), "--no-write"],
-                                 capture_output=True, text=True, timeout=300, env=env)
+                                 capture_output=True, text=True, timeout=420)
             r = json.loads(res.stdout.strip().splitlines()[-1])
-            return {"value": r["forward_ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["cores"], "kind": "reference",
+            return {"value": r["forward_ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["torch_threads"],
+                    "host_cpus": r["cores"], "kind": "reference",
                     "forward_backward_value": r["forward_backward_ray_samples_per_s"],
-                    "where": "this host, live: " + r["what"] + "; oracle/time_reference_cpu.py"}
+                    "sample": f"median forward pass over {r['rays']} rays x {r['samples']} samples of the bench workload "
+                              f"({r['forward_s']:.2f} s) at the best of the thread counts tried "
+                              f"({r['forward_s_by_threads']} s per pass; torch's default here: {r['torch_threads_default']}); "
+                              f"forward+backward {r['forward_backward_s']:.2f} s per pass",
+                    "where": f"this host, live ({ref_import.reference_kind()} tree): " + r["what"]
+                             + "; oracle/time_reference_cpu.py"}
         except Exception as e:  # noqa: BLE001  (fall back to the recorded figure, say why)
-            note = f"live timing failed ({type(e).__name__}); "
-    else:
-        note = ""
+            note = f"live timing failed ({type(e).__name__}: {str(e)[:120]}); "
     f = os.path.join(ROOT, "profiles", "reference_torch_cpu.json")
     if not os.path.exists(f):
         return None
     r = json.load(open(f))
     return {"value": r["forward_ray_samples_per_s"], "unit": "ray-samples/s", "cores": r["cores"], "kind": "reference",
             "forward_backward_value": r["forward_backward_ray_samples_per_s"],
-            "where": note + "build container (the GPU box has no reference tree): " + r["what"] + "; oracle/time_reference_cpu.py"}
+            "where": note + "build container (no reference tree on this host): " + r["what"] + "; oracle/time_reference_cpu.py"}
 
 
 def bench_c1(args, device, rank, world):
@@ -1053,11 +1062,16 @@ def main():
                 out["train_full"] = train_full
             if world == 1 and not args.no_cpu_baseline:
                 cb, (n, ref) = cpu_baseline(fs, origins, dirs, area, edges)
-                out["cpu_baseline"] = cb
                 rt = reference_torch_cpu()
-                if rt is not None:
-                    out["reference_torch_cpu"] = rt
-                if rt is None or not rt.get("where", "").startswith("this host"):
+                if rt is not None and rt.get("where", "").startswith("this host"):
+                    # north_star's CPU leg: the reference's own torch field eval on this box's cores; the C/OpenMP port of
+                    # the oracle (the checker of this line's parity figure) is reported beside it
+                    out["cpu_baseline"] = rt
+                    out["cpu_port_c"] = cb
+                else:
+                    out["cpu_baseline"] = cb
+                    if rt is not None:
+                        out["reference_torch_cpu"] = rt
                     # no reference tree on this box: its torch formulation, restated, timed here on the host cores
                     try:
                         out["reference_torch_cpu_port_here"] = torch_port_cpu(fs, origins, dirs, area, edges)

@@ -69,7 +69,9 @@ class MultiHashGridFn(torch.autograd.Function):
         grid_id = grid_id.to(torch.int32)
         # which grids the batch touches: read HERE (the caller has just read the batch size from the device, the queue is
         # empty) so that the backward, in the middle of a full queue, does not stall on a device->host read
-        ctx.present = ops.grids_present(grid_id, len(tables)) if any(t.requires_grad for t in tables) else None
+        # (inside a custom Function's forward grad mode is always off: ctx.needs_input_grad is what tells a recording
+        # call from an eval / no_grad one, where the tables' requires_grad stays True but no backward will come)
+        ctx.present = ops.grids_present(grid_id, len(tables)) if any(ctx.needs_input_grad[3:]) else None
         ctx.save_for_backward(x, grid_id, *tables)
         return ops.hashgrid_multi_fwd(spec, tables, grid_id, x)
 

@@ -19,7 +19,14 @@
 //             position in every slice queue, exactly; queues are as long as their slice needs, whatever the sample
 //             distribution (real scenes put most samples into a thin slab of the volume: a fixed per-slice capacity
 //             overflowed there, and the overflow went to the memory-side atomics this path exists to avoid).
-//   emit    : same walk as `count`; each record (entry, F values) goes to base + LDS rank.  No global atomics.
+//   emit    : same walk as `count`; each record goes to base + LDS rank.  No global atomics.
+//             A record is an X-PAIR (round 4): the (floor x, ceil x) corners of one (y, z) hash to entries that differ
+//             only by xm = (floor x ^ ceil x) & mask -- the same small value for all four pairs of a sample -- so they
+//             lie in the same slice and one record {entry-in-slice | xm << 16, F values for the floor corner, F values
+//             for the ceil corner} carries both: 4 records per (sample, level) instead of 8, half the LDS rank atomics
+//             and store transactions, 12 instead of 16 bytes per corner pair at F = 1 (36 / 40 at F = 4).  Where xm
+//             reaches the slice bits (only possible when a level's resolution exceeds the slice length) the pair goes
+//             out as two records with xm = 0.
 //   reduce  : one 1024-thread workgroup per (level, slice) streams its queue, accumulates into the slice image in
 //             LDS, and adds the image to grad_table with plain 16-byte loads/stores.  The image is 64-bit FIXED
 //             POINT: ds_add_f32 turned out ~10x slower than the integer LDS atomics on gfx950 (493 vs 147 us for
@@ -39,6 +46,9 @@ constexpr int kSamplesPerBlock = 4096;      // count/emit: 1024 threads x 4 samp
 constexpr int kMaxSlices = 2048;            // per level (LDS histogram + base table = 16 KB)
 constexpr int kTileBytes = 128 * 1024;      // slice image in LDS
 constexpr int kSegChunks = 64;              // the chunk-prefix scan runs per segment of 64 chunks, then over the segments
+// x-pairs of the reference corner order (common.h hash_corners): (floor x, ceil x) corner of (y, z) = cc, fc, cf, ff
+__device__ constexpr int kPairF[4] = {3, 2, 7, 6};
+__device__ constexpr int kPairC[4] = {0, 1, 4, 5};
 
 // Samples per count/scan/emit/reduce round: bounds the scratch (one record slot per corner term).  Round 2 used 2^20
 // (400 MB for the proposal grid); the c3 step then ran 11 rounds of seven launches each for its two proposal calls.  With
@@ -60,6 +70,7 @@ struct BinPlan {
   int chunks, lgroups;   // count/emit grid: sample chunks x level groups (levels dealt round-robin)
   int nmax;              // per-level partial maxima (one per emit wave)
   int nseg;              // segments of kSegChunks chunks (two-level prefix over the chunks)
+  int rec_slots;         // record slots per (sample, level): 4 x-pairs, 8 if pairs can straddle slices
   size_t off_counts, off_seg, off_totals, off_offsets, off_qmax, off_pos, off_idx, off_live, off_rec, total_bytes;
 };
 
@@ -96,7 +107,12 @@ bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
   p->off_pos = o, o += align256((size_t)p->chunks * kSamplesPerBlock * sizeof(float4));
   p->off_idx = o, o += align256((size_t)p->chunks * kSamplesPerBlock * sizeof(uint16_t));
   p->off_live = o, o += align256((size_t)p->chunks * sizeof(uint32_t));
-  p->off_rec = o, o += (size_t)n * 8 * g.L * (g.F + 1) * sizeof(float);  // every corner term its own record: worst case
+  // worst case every x-pair its own record: 4 per (sample, level); 8 where a pair can straddle two slices (a level whose
+  // resolution reaches the slice length: floor x ^ ceil x can then carry into the slice bits)
+  float smax = 0.f;
+  for (int l = 0; l < g.L; ++l) smax = g.scal[l] > smax ? g.scal[l] : smax;
+  p->rec_slots = (smax + 2.f < (float)(1 << log2TS)) ? 4 : 8;
+  p->off_rec = o, o += (size_t)n * p->rec_slots * g.L * (2 * g.F + 1) * sizeof(float);
   p->total_bytes = o;
   return true;
 }
@@ -258,10 +274,15 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, 
       const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t key = live ? c.idx[k] : 0xffffffffu;  // a silent sample never joins a run of equal entries
-        const uint32_t prev = dpp_row_shr<1>(key, ~key);  // first lane of a 16-lane row always heads a run
-        if (live && prev != key) atomicAdd(&hist[key >> log2TS], 1u);
+      for (int k = 0; k < 4; ++k) {
+        // a silent sample never joins a run of equal pairs
+        const uint32_t kf = live ? c.idx[kPairF[k]] : 0xffffffffu, kc = live ? c.idx[kPairC[k]] : 0xffffffffu;
+        // first lane of a 16-lane row always heads a run
+        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || dpp_row_shr<1>(kc, ~kc) != kc;
+        if (live && head) {
+          atomicAdd(&hist[kf >> log2TS], 1u);
+          if ((kf ^ kc) >> log2TS) atomicAdd(&hist[kc >> log2TS], 1u);  // the pair straddles two slices: two records
+        }
       }
     }
     __syncthreads();
@@ -394,14 +415,13 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
         for (int k = 0; k < F; ++k) gv[k] = 0.f;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t key = live ? c.idx[k] : 0xffffffffu;
-        const uint32_t prev = dpp_row_shr<1>(key, ~key);
-        const bool head = prev != key;
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t kf = live ? c.idx[kPairF[k]] : 0xffffffffu, kc = live ? c.idx[kPairC[k]] : 0xffffffffu;
+        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || dpp_row_shr<1>(kc, ~kc) != kc;
         const unsigned long long hm = __ballot(head);
-        float v[F];
+        float v[2 * F];  // floor-corner terms, then ceil-corner terms
 #pragma unroll
-        for (int j = 0; j < F; ++j) v[j] = w[k] * gv[j];
+        for (int j = 0; j < F; ++j) v[j] = w[kPairF[k]] * gv[j], v[F + j] = w[kPairC[k]] * gv[j];
         if (hm != ~0ull) {
           // some run is longer than 1: segmented suffix sum onto the run heads, inside each 16-lane row, on DPP
           // row shifts (VALU rate; a 64-lane __shfl version goes through the LDS crossbar 18x per corner)
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 #define NR_SEG_STEP(OFF)                                                   \
   {                                                                        \
     const bool same = dpp_row_shl<OFF>(run, 0xffffffffu) == run;           \
-    _Pragma("unroll") for (int j = 0; j < F; ++j) {                        \
+    _Pragma("unroll") for (int j = 0; j < 2 * F; ++j) {                    \
       const float t = dpp_row_shl<OFF>(v[j], 0.f);                         \
       if (same) v[j] += t;                                                 \
     }                                                                      \
@@ -421,284 +441,29 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 #undef NR_SEG_STEP
         }
         if (head && live) {
-          const uint32_t b = key >> log2TS;
-          const uint32_t at = base[b] + atomicAdd(&rank[b], 1u);
-          float* rec = qrec + (size_t)at * (F + 1);
-          rec[0] = __uint_as_float(key & tsmask);
 #pragma unroll
-          for (int j = 0; j < F; ++j) {
-            rec[1 + j] = v[j];
+          for (int j = 0; j < 2 * F; ++j) {
             const float av = fabsf(v[j]);
             if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);  // Inf/NaN do not set the scale; they poison in `reduce`
           }
-        }
-      }
-    }
-    // level maximum of |value|: one slot per wave, read back by `reduce`
+          const uint32_t xm = kf ^ kc;
+          const uint32_t b = kf >> log2TS;
+          if ((xm >> log2TS) == 0) {  // (always, unless the level's resolution reaches the slice length)
+            float* rec = qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * (2 * F + 1);
+            rec[0] = __uint_as_float((kf & tsmask) | (xm << 16));
 #pragma unroll
-    for (int off = 32; off; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-    if (lane == 0) qmax[(size_t)l * nmax + (size_t)blockIdx.x * (nt >> 6) + (tid >> 6)] = vmax;
-  }
-}
-
-// ---- count / emit with a workgroup-level merge of equal entries (round 3) -----------------------------------------
-// `emit` is bound by its record stores: every record is its own 8..36-byte write transaction into one of hundreds of
-// queues, and `reduce` by reading them back (profiles/r03_*: 3 TB/s and 5 TB/s of record traffic on the c3 step).  The
-// only lever left is FEWER records -- and a training batch has them to give: the 32 rays of one pixel row of a 32 x 32
-// camera patch run through the same cells at every level but the finest, so the 4096 samples a workgroup walks send
-// 6 - 60x fewer DISTINCT entries than corner terms, while the DPP run merge only catches equal entries of neighbouring
-// samples of one ray.  So the workgroup merges in LDS before it sends:
-//   * a direct-mapped table of M slots (key + F 64-bit fixed-point accumulators, ~100 KB); slot = a hash of the entry;
-//   * pass A: every corner term does atomicMin(slot.key, entry): after it each slot belongs to the SMALLEST entry that
-//     maps to it -- a rule that depends on the set of entries only, not on the order the waves ran in, so `count` and
-//     `emit` (separate launches) agree on it exactly;
-//   * pass B: a term whose entry owns its slot adds its value into the slot (integer adds: order-independent bits);
-//     every other term takes the old path (DPP run merge among those lanes, one record per run head);
-//   * flush: one record per occupied slot.
-// A table fill covers kSub = 4 M / 8 samples (four corner terms per slot on average).  Where almost every entry is distinct
-// (lidar rays at the fine levels) about a quarter of the terms still find a slot and the rest go out as before; where
-// they are not (camera patches) records drop 2 - 10x.  Results: the same sums, each partial rounded to fp32 once more
-// (<= 1e-7 relative); still bit-reproducible run to run.
-// MEASURED (profiles/r03_dedupe_ab.txt, c3 step): records halve as predicted -- reduce<1> 326 -> 145 us, reduce<4> 592 ->
-// 352 us per call -- but the merge itself costs more than it saves: emit<1> 539 -> 740 us, emit<4> 754 -> 1333 us,
-// count 93 -> 250 us, the step 8.77 -> 9.51 ms.  LDS atomics on gfx950 retire about ONE LANE PER CLOCK and CU (32 K corner
-// terms x (ds_min + ds_read + F x ds_add_u64) = 95 us per workgroup and level at F = 4), not a full wave per few clocks;
-// the round-2 kernels spend one LDS atomic per RECORD (the queue rank) and are themselves ~60 % bound by it.  The merge is
-// therefore OPT-IN (NRHIP_BIN_DEDUPE=1: parity-tested like the default path) and the default stays the round-2 partition.
-template <int F>
-struct Dedup {
-  static constexpr int M = F == 1 ? 8192 : (F == 2 ? 4096 : (F == 4 ? 2048 : 1024));  // slots
-  static constexpr int kSub = M / 2;  // samples per table fill: 8 corner terms each -> 4 terms per slot
-  static constexpr size_t lds_bytes(int nb) {
-    return (size_t)M * 4 + (size_t)M * F * 8 + (size_t)(M * F / 32) * 4 + (size_t)2 * nb * 4 + 64;
-  }
-};
-constexpr uint32_t kEmptyKey = 0xffffffffu;
-
-__device__ __forceinline__ uint32_t dedup_slot(uint32_t key, uint32_t mmask) { return (key ^ (key >> 13)) & mmask; }
-
-bool dedupe_enabled() {  // opt-in: measured slower on the c3 step (see the note above `Dedup`)
-  const char* e = getenv("NRHIP_BIN_DEDUPE");
-  return e && e[0] == '1';
-}
-
-template <int F>
-__global__ __launch_bounds__(1024) void bin_count_dd_kernel(GridDev g, int log2TS, int nb, uint32_t* __restrict__ counts,
-                                                             const float4* __restrict__ gpos,
-                                                             const uint32_t* __restrict__ nlive) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dd_lds[];
-  constexpr int M = Dedup<F>::M, kSub = Dedup<F>::kSub;
-  uint32_t* skey = reinterpret_cast<uint32_t*>(dd_lds);
-  uint32_t* hist = skey + M;
-  const int tid = threadIdx.x;
-  constexpr int nt = 1024, nit = (kSub + nt - 1) / nt;
-  const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
-  const int nl = (int)nlive[blockIdx.x];  // block-uniform
-  const uint32_t mask = (1u << g.log2T) - 1u;
-  for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
-    const float sc = g.scal[l];
-    __syncthreads();  // previous level's histogram stored
-    for (int b = tid; b < nb; b += nt) hist[b] = 0;
-    for (int s0 = 0; s0 < nl; s0 += kSub) {
-      const int ns = nl - s0 < kSub ? nl - s0 : kSub;  // live samples of this table fill
-      __syncthreads();  // previous fill's slots counted
-      for (int k = tid; k < M; k += nt) skey[k] = kEmptyKey;
-      __syncthreads();
-      // pass A: the smallest entry of every slot
+            for (int j = 0; j < 2 * F; ++j) rec[1 + j] = v[j];
+          } else {  // the ceil corner lives in another slice: two records, each with a zero second half
+            float* rec = qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * (2 * F + 1);
+            rec[0] = __uint_as_float(kf & tsmask);
 #pragma unroll
-      for (int it = 0; it < nit; ++it) {
-        const int q = it * nt + tid;
-        if (q < ns) {
-          const float4 p = gpos[i_blk + s0 + q];
-          const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
+            for (int j = 0; j < F; ++j) rec[1 + j] = v[j], rec[1 + F + j] = 0.f;
+            const uint32_t b2 = kc >> log2TS;
+            rec = qrec + (size_t)(base[b2] + atomicAdd(&rank[b2], 1u)) * (2 * F + 1);
+            rec[0] = __uint_as_float(kc & tsmask);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) atomicMin(&skey[dedup_slot(c.idx[k], M - 1)], c.idx[k]);
-        }
-      }
-      __syncthreads();
-      // pass B: terms that do not own their slot go out on their own (run heads of equal entries in a 16-lane row)
-#pragma unroll
-      for (int it = 0; it < nit; ++it) {
-        const int q = it * nt + tid;
-        const bool live = q < ns;
-        if (__ballot(live) == 0ull) continue;  // wave-uniform
-        const float4 p = gpos[i_blk + s0 + (live ? q : 0)];
-        const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t key = c.idx[k];
-          const bool lone = live && skey[dedup_slot(key, M - 1)] != key;
-          const uint32_t ukey = lone ? key : 0xffffffffu;  // owners and dead lanes never join (or split into) a run
-          const uint32_t prev = dpp_row_shr<1>(ukey, ~ukey);
-          if (lone && prev != ukey) atomicAdd(&hist[key >> log2TS], 1u);
-        }
-      }
-      __syncthreads();
-      for (int k = tid; k < M; k += nt) {
-        const uint32_t key = skey[k];
-        if (key != kEmptyKey) atomicAdd(&hist[key >> log2TS], 1u);
-      }
-    }
-    __syncthreads();
-    uint32_t* row = counts + ((size_t)blockIdx.x * g.L + l) * nb;
-    for (int b = tid; b < nb; b += nt) row[b] = hist[b];
-  }
-}
-
-template <int F, class Src>
-__global__ __launch_bounds__(1024) void bin_emit_dd_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
-                                                            const uint32_t* __restrict__ bases,
-                                                            const uint32_t* __restrict__ segbase,
-                                                            const uint32_t* __restrict__ offsets,
-                                                            const float4* __restrict__ gpos,
-                                                            const uint16_t* __restrict__ gidx,
-                                                            const uint32_t* __restrict__ nlive, float* __restrict__ qrec,
-                                                            float* __restrict__ qmax, int nmax) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dd_lds[];
-  constexpr int M = Dedup<F>::M, kSub = Dedup<F>::kSub;
-  uint32_t* skey = reinterpret_cast<uint32_t*>(dd_lds);
-  unsigned long long* sval = reinterpret_cast<unsigned long long*>(dd_lds + (size_t)M * 4);
-  uint32_t* spoison = reinterpret_cast<uint32_t*>(dd_lds + (size_t)M * 4 + (size_t)M * F * 8);
-  uint32_t* rank = spoison + M * F / 32;
-  uint32_t* base = rank + nb;
-  uint32_t* s_gmax = base + nb;  // bits of max |per-sample gradient| of the fill
-  const int tid = threadIdx.x, lane = tid & 63;
-  constexpr int nt = 1024, nit = (kSub + nt - 1) / nt;
-  const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
-  const int nl = (int)nlive[blockIdx.x];  // block-uniform
-  const uint32_t mask = (1u << g.log2T) - 1u;
-  const uint32_t tsmask = (1u << log2TS) - 1u;
-  const uint32_t* seg = segbase ? segbase + (size_t)(blockIdx.x / kSegChunks) * g.L * nb : nullptr;
-  const float nan = __uint_as_float(0x7fc00000u);
-  for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
-    const float sc = g.scal[l];
-    __syncthreads();  // previous level's ranks consumed
-    for (int b = tid; b < nb; b += nt) {
-      rank[b] = 0;
-      base[b] = offsets[l * nb + b] + bases[((size_t)blockIdx.x * g.L + l) * nb + b] + (seg ? seg[l * nb + b] : 0u);
-    }
-    float vmax = 0.f;
-    for (int s0 = 0; s0 < nl; s0 += kSub) {
-      const int ns = nl - s0 < kSub ? nl - s0 : kSub;
-      __syncthreads();  // previous fill flushed
-      for (int k = tid; k < M; k += nt) skey[k] = kEmptyKey;
-      for (int k = tid; k < M * F; k += nt) sval[k] = 0ull;
-      for (int k = tid; k < M * F / 32; k += nt) spoison[k] = 0u;
-      if (tid == 0) *s_gmax = 0u;
-      __syncthreads();
-      // pass A: slot owners, and the largest finite |gradient| of the fill (sets the fixed-point scale)
-      float gmax = 0.f;
-#pragma unroll
-      for (int it = 0; it < nit; ++it) {
-        const int q = it * nt + tid;
-        if (q < ns) {
-          const float4 p = gpos[i_blk + s0 + q];
-          const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) atomicMin(&skey[dedup_slot(c.idx[k], M - 1)], c.idx[k]);
-          const int64_t si = i_off + i_blk + (int64_t)gidx[i_blk + s0 + q];
-          float gv[F];
-          src.template grad<F>(si, l, sc, p.w, src.pre(si), gv);
-#pragma unroll
-          for (int j = 0; j < F; ++j) {
-            const float av = fabsf(gv[j]);
-            if (av <= 3.402823466e38f) gmax = fmaxf(gmax, av);
+            for (int j = 0; j < F; ++j) rec[1 + j] = v[F + j], rec[1 + F + j] = 0.f;
           }
-        }
-      }
-#pragma unroll
-      for (int off = 32; off; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
-      if (lane == 0) atomicMax(s_gmax, __float_as_uint(gmax));  // non-negative floats order like their bits
-      __syncthreads();
-      // |w * g| <= gmax < 2^(e+1) (trilinear weights <= 1); <= 2^15 terms per slot -> |sum * 2^sh| < 2^61
-      const int e = (int)((*s_gmax >> 23) & 0xff) - 127;
-      const int sh = 61 - 16 - (e + 1);
-      // pass B
-#pragma unroll
-      for (int it = 0; it < nit; ++it) {
-        const int q = it * nt + tid;
-        const bool live = q < ns;
-        if (__ballot(live) == 0ull) continue;  // wave-uniform
-        const float4 p = gpos[i_blk + s0 + (live ? q : 0)];
-        const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
-        float w[8];
-        corner_weights(c, w);
-        const int64_t si = i_off + i_blk + (live ? (int64_t)gidx[i_blk + s0 + q] : 0);
-        float gv[F];
-        src.template grad<F>(si, l, sc, p.w, src.pre(si), gv);
-        if (!live) {
-#pragma unroll
-          for (int j = 0; j < F; ++j) gv[j] = 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t key = c.idx[k];
-          const uint32_t slot = dedup_slot(key, M - 1);
-          const bool owner = live && skey[slot] == key;
-          const bool lone = live && !owner;
-          float v[F];
-#pragma unroll
-          for (int j = 0; j < F; ++j) v[j] = w[k] * gv[j];
-          if (owner) {
-#pragma unroll
-            for (int j = 0; j < F; ++j) {
-              if (fabsf(v[j]) <= 3.402823466e38f) {
-                atomicAdd(sval + slot * F + j, (unsigned long long)__float2ll_rn(ldexpf(v[j], sh)));
-              } else {  // Inf / NaN poison their entry, as an atomic add of them would
-                atomicOr(&spoison[(slot * F + j) >> 5], 1u << ((slot * F + j) & 31));
-              }
-            }
-          }
-          const uint32_t ukey = lone ? key : 0xffffffffu;
-          const uint32_t prev = dpp_row_shr<1>(ukey, ~ukey);
-          const bool head = prev != ukey;
-          const unsigned long long hm = __ballot(head || !lone);
-          if (hm != ~0ull) {  // some run of lone terms is longer than 1: segmented suffix sum onto its head
-            const uint32_t run = (uint32_t)__popcll(__ballot(head) & ((2ull << lane) - 1ull));
-#define NR_SEG_STEP(OFF)                                                   \
-  {                                                                        \
-    const bool same = dpp_row_shl<OFF>(run, 0xffffffffu) == run;           \
-    _Pragma("unroll") for (int j = 0; j < F; ++j) {                        \
-      const float t = dpp_row_shl<OFF>(v[j], 0.f);                         \
-      if (same) v[j] += t;                                                 \
-    }                                                                      \
-  }
-            NR_SEG_STEP(1)
-            NR_SEG_STEP(2)
-            NR_SEG_STEP(4)
-            NR_SEG_STEP(8)
-#undef NR_SEG_STEP
-          }
-          if (lone && head) {
-            const uint32_t b = key >> log2TS;
-            const uint32_t at = base[b] + atomicAdd(&rank[b], 1u);
-            float* rec = qrec + (size_t)at * (F + 1);
-            rec[0] = __uint_as_float(key & tsmask);
-#pragma unroll
-            for (int j = 0; j < F; ++j) {
-              rec[1 + j] = v[j];
-              const float av = fabsf(v[j]);
-              if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);
-            }
-          }
-        }
-      }
-      __syncthreads();
-      // flush: one record per occupied slot
-      for (int k = tid; k < M; k += nt) {
-        const uint32_t key = skey[k];
-        if (key == kEmptyKey) continue;
-        const uint32_t b = key >> log2TS;
-        const uint32_t at = base[b] + atomicAdd(&rank[b], 1u);
-        float* rec = qrec + (size_t)at * (F + 1);
-        rec[0] = __uint_as_float(key & tsmask);
-#pragma unroll
-        for (int j = 0; j < F; ++j) {
-          float v = (float)ldexp((double)(long long)sval[k * F + j], -sh);
-          if ((spoison[(k * F + j) >> 5] >> ((k * F + j) & 31)) & 1u) v = nan;
-          rec[1 + j] = v;
-          const float av = fabsf(v);
-          if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);
         }
       }
     }
@@ -749,30 +514,33 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
 #pragma unroll
   for (int i = 1; i < 16; ++i) vmax = fmaxf(vmax, smax[i]);
   const int e = (int)((__float_as_uint(vmax) >> 23) & 0xff) - 127;
-  const int hb = 32 - __clz(cnt);
+  const int hb = 33 - __clz(cnt);  // a record adds up to two terms to an accumulator (xm = 0: both halves land on one entry)
   const int sh = 61 - hb - (e + 1);
-  const float* rec = qrec + (size_t)first * (F + 1);
+  constexpr int RW = 2 * F + 1;  // record: {entry-in-slice | xm << 16, F floor-corner values, F ceil-corner values}
+  const float* rec = qrec + (size_t)first * RW;
   // 4 records per thread in flight: the loads are independent, only the LDS adds follow them
   for (uint32_t e0 = 0; e0 < cnt; e0 += 4096) {
-    float q[4][F + 1];
+    float q[4][RW];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t i = e0 + u * 1024 + threadIdx.x;
-      const float* src = rec + (size_t)(i < cnt ? i : cnt - 1) * (F + 1);
+      const float* src = rec + (size_t)(i < cnt ? i : cnt - 1) * RW;
 #pragma unroll
-      for (int j = 0; j <= F; ++j) q[u][j] = src[j];
+      for (int j = 0; j < RW; ++j) q[u][j] = src[j];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (e0 + u * 1024 + threadIdx.x < cnt) {
-        const uint32_t key = __float_as_uint(q[u][0]);
+        const uint32_t w0 = __float_as_uint(q[u][0]);
+        const uint32_t key = w0 & 0xffffu, key2 = key ^ (w0 >> 16);
 #pragma unroll
-        for (int j = 0; j < F; ++j) {
+        for (int j = 0; j < 2 * F; ++j) {
           const float v = q[u][1 + j];
+          const uint32_t at = (j < F ? key : key2) * F + (j < F ? j : j - F);
           if (fabsf(v) <= 3.402823466e38f) {
-            atomicAdd(tile + key * F + j, (unsigned long long)__float2ll_rn(ldexpf(v, sh)));
+            atomicAdd(tile + at, (unsigned long long)__float2ll_rn(ldexpf(v, sh)));
           } else {
-            atomicOr(&pbits[(key * F + j) >> 5], 1u << ((key * F + j) & 31));
+            atomicOr(&pbits[at >> 5], 1u << (at & 31));
             poisoned = 1;
           }
         }
@@ -865,7 +633,6 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     count_configured = true;
   }
   const int64_t round = round_samples();
-  const bool dedupe = dedupe_enabled();
   for (int64_t i_off = 0; i_off < n; i_off += round) {
     const int64_t cnt = n - i_off < round ? n - i_off : round;
     const int chunks = (int)((cnt + kSamplesPerBlock - 1) / kSamplesPerBlock);
@@ -874,25 +641,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     // qmax slots of chunks this round does not have stay from an earlier round otherwise
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
     bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive);
-    if (dedupe) {
-#define CALL(F)                                                                                                     \
-  do {                                                                                                              \
-    static thread_local bool configured = false;                                                                    \
-    if (!configured) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)bin_count_dd_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                (int)Dedup<F>::lds_bytes(kMaxSlices));                                              \
-      (void)hipFuncSetAttribute((const void*)bin_emit_dd_kernel<F, Src>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)Dedup<F>::lds_bytes(kMaxSlices));                                              \
-      configured = true;                                                                                            \
-    }                                                                                                               \
-    bin_count_dd_kernel<F><<<grid_a, 1024, (size_t)Dedup<F>::M * 4 + (size_t)p.nb * 4, st>>>(gd, p.log2TS, p.nb,    \
-                                                                                          counts, gpos, nlive);    \
-  } while (0)
-      NR_DISPATCH_F(gd.F, CALL);
-#undef CALL
-    } else {
-      bin_count_kernel<<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
-    }
+    bin_count_kernel<<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     if (int e = check_launch(what)) return e;
     // one segment: its sums ARE the column totals and there is no second level
     bin_scan_chunks_kernel<<<dim3((cols + 255) / 256, nseg), 256, 0, st>>>(counts, chunks, cols, nseg > 1 ? segtot : totals);
@@ -909,14 +658,9 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
                                 kTileBytes + 4096);                                                                 \
       configured = true;                                                                                            \
     }                                                                                                               \
-    if (dedupe)                                                                                                     \
-      bin_emit_dd_kernel<F, Src><<<grid_a, 1024, Dedup<F>::lds_bytes(p.nb), st>>>(                                   \
-          gd, src, p.log2TS, p.nb, i_off, cnt, counts, nseg > 1 ? segtot : nullptr, offsets, gpos, gidx, nlive, qrec, \
-          qmax, p.nmax);                                                                                            \
-    else                                                                                                            \
-      bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,              \
-                                                           nseg > 1 ? segtot : nullptr, offsets, gpos,              \
-                                                           gidx, nlive, qrec, qmax, p.nmax);                        \
+    bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,                \
+                                                         nseg > 1 ? segtot : nullptr, offsets, gpos, gidx, nlive,   \
+                                                         qrec, qmax, p.nmax);                                       \
     bin_reduce_kernel<F><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,      \
                                                     p.nmax, (overwrite && i_off == 0) ? 1 : 0);                     \
   } while (0)

@@ -52,6 +52,14 @@ class SigmoidDensity(nn.Module):  # model_components/utils.py:21-41
         super().__init__()
         self.register_buffer("beta_min", torch.tensor(beta_min))
         self.register_parameter("beta", nn.Parameter(init_val * torch.ones(1), requires_grad=learnable_beta))
+        # the buffer's value on the host: read once here (and after a checkpoint load), never per training step -- a
+        # float(buffer) inside the step is a device->host sync between the queued sampler rounds and the field node
+        self.beta_min_value = float(beta_min)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        if prefix + "beta_min" in state_dict:
+            self.beta_min_value = float(state_dict[prefix + "beta_min"])
 
     def get_beta(self):
         return self.beta.abs() + self.beta_min
@@ -134,6 +142,9 @@ class NeuRADField(nn.Module):
         """a mode switch drops the cached host copy of beta: writes through ``beta.data`` (EMA / weight averaging, some
         optimizers) do not bump the version counter the cache is keyed on, and they happen between training and eval"""
         self._beta_cache = (None, 0.0)
+        # ... and the re-laid-out eval tables (NRHIP_EVAL_RELAYOUT=1): HashGridAdam updates fp32 tables through raw
+        # pointers, which does not bump the version the cache is keyed on -- train -> eval must rebuild them
+        ops.clear_eval_tables()
         return super().train(mode)
 
     def invalidate_caches(self) -> None:
@@ -208,7 +219,7 @@ class NeuRADField(nn.Module):
             ovr = self._actor_overrides(origins, directions, pixel_area.reshape(-1), edges, times.reshape(-1))
         sd = self.sdf_to_density
         return ag.NffRenderTrainFn.apply(
-            g.hash_table, g.spec, hg.static_scale, sd.beta, float(sd.beta_min), origins, directions,
+            g.hash_table, g.spec, hg.static_scale, sd.beta, sd.beta_min_value, origins, directions,
             pixel_area.reshape(-1), edges, emb, sensor, etimes, emb_cfg, order, *ovr,
             *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
             *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])

@@ -12,9 +12,10 @@ Nothing of neurad-studio is edited or re-typed: ``NeuRADHipModel`` IS the refere
   * ``sampler``, the renderers, ``lidar_decoder`` and the two sampler losses replaced by their HIP-backed namesakes
     after ``populate_modules``;
   * ``get_nff_outputs`` running the two fused kernels for eval chunks (FusedEvalMixin), the fused training nodes for
-    training steps of a static scene (FusedTrainMixin: sampler rounds, field + head + compositing + appearance as a
-    handful of autograd nodes, same output keys) and the reference's OWN ``get_nff_outputs`` (models/neurad.py:368-421)
-    otherwise (scenes with dynamic actors, ``fused_training=False``).
+    training steps (FusedTrainMixin: sampler rounds, field + head + compositing + appearance as a handful of autograd
+    nodes, same output keys; scenes with dynamic actors run on the same nodes with per-sample row overrides) and the
+    reference's OWN ``get_nff_outputs`` (models/neurad.py:368-421) otherwise (``fused_training=False``, options the fused
+    nodes do not cover).
 Per-actor 3-D grids are used (``use_4d_hashgrid=False``): the 4-D grid exists only inside tiny-cuda-nn.
 """
 from __future__ import annotations
@@ -28,7 +29,6 @@ from typing import Type
 import torch
 
 import nerfstudio.models.neurad as _ref_neurad
-from nerfstudio.configs.method_configs import method_configs
 from nerfstudio.field_components.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig
 from nerfstudio.fields.neurad_field import NeuRADFieldConfig, NeuRADProposalFieldConfig
 from nerfstudio.models.neurad import NeuRADModel, NeuRADModelConfig, SamplingSettings
@@ -40,7 +40,7 @@ from ..fields.neurad_field import NeuRADProposalField as HipNeuRADProposalField
 from ..model_components import losses as hip_losses
 from ..model_components import ray_samplers as hip_samplers
 from ..model_components import renderers as hip_renderers
-from ..models.neurad import FusedEvalMixin, FusedTrainMixin
+from ..models.neurad import FusedEvalMixin, FusedTrainMixin, warn_if_rays_need_grad
 from ..shims import nerfacc as hip_nerfacc
 
 
@@ -137,6 +137,7 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
     def get_nff_outputs(self, ray_bundle, calc_lidar_losses: bool = False):
         if self.fused_eval_possible():
             return self.fused_nff_outputs(ray_bundle)
+        warn_if_rays_need_grad(ray_bundle)
         if self.fused_training_possible():
             return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         return super().get_nff_outputs(ray_bundle, calc_lidar_losses)
@@ -160,6 +161,11 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
 
 
 def _trainer_config():
+    # imported here, not at module level: nerfstudio.configs.method_configs runs the plugin discovery at its end
+    # (plugins/registry.py:56-73), which imports THIS module -- at module level that is a cycle whenever this module is
+    # imported before the method table
+    from nerfstudio.configs.method_configs import method_configs
+
     cfg = deepcopy(method_configs["neurad"])  # optimizers, schedules, data manager: the reference's own
     cfg.method_name = "neurad-hip"
     ref_model = cfg.pipeline.model
@@ -168,5 +174,17 @@ def _trainer_config():
     return cfg
 
 
-neurad_hip = MethodSpecification(config=_trainer_config(),
-                                 description="NeuRAD with the volumetric hot path on MI355X HIP kernels (libneurad_hip.so)")
+_SPEC = None
+
+
+def __getattr__(name):
+    """``neurad_hip`` (the MethodSpecification the registry looks up) is built on first access"""
+    global _SPEC
+    if name != "neurad_hip":
+        raise AttributeError(name)
+    if _SPEC is None:
+        spec = MethodSpecification(config=_trainer_config(),
+                                   description="NeuRAD with the volumetric hot path on MI355X HIP kernels (libneurad_hip.so)")
+        if _SPEC is None:  # (building it may have run the discovery, which built it already)
+            _SPEC = spec
+    return _SPEC

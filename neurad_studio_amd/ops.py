@@ -1185,7 +1185,9 @@ def mask_compact(mask: Tensor, n_out: int):
         raise _lib.NeuradHipError("mask_compact: mask is on the CPU (no CPU fallback)")
     m = (m if m.dtype == torch.uint8 else (m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.ne(0).view(torch.uint8)))
     m = m.contiguous()
-    rows = torch.empty((n_out,), device=m.device, dtype=torch.int64)
+    # n_out is the caller's word for mask.sum(); should it be too large, the rows past the real count stay 0 (a valid
+    # gather index) instead of uninitialised memory
+    rows = torch.zeros((n_out,), device=m.device, dtype=torch.int64)
     inverse = torch.empty((m.shape[0],), device=m.device, dtype=torch.int32)
     call("nrhip_mask_compact", _ptr(m), m.shape[0], _ptr(rows), n_out, _ptr(inverse), _ptr(None), _stream())
     return rows, inverse

@@ -283,7 +283,11 @@ class RgbDecoderFn(torch.autograd.Function):
         rgb = torch.empty((b, 3 * ph, 3 * pw, 3), device=feats.device, dtype=torch.float32)
         call("nrhip_rgb_decoder_fwd", C.byref(d), _ptr(feats), _ptr(saved), _ptr(work), _ptr(rgb), _stream())
         ctx.training, ctx.dec, ctx.keep = training, d, keep
-        ctx.saved, ctx.sizes = (feats, saved, rgb), sizes
+        # through save_for_backward, not as attributes: `rgb` is this node's own output (an attribute would close the cycle
+        # rgb -> grad_fn -> ctx -> rgb that only the cyclic GC breaks, holding the activation buffer until then), the
+        # buffers are released when backward has run, and in-place edits of them are detected
+        ctx.save_for_backward(feats, saved, rgb)
+        ctx.sizes = sizes
         ctx.shapes = [t.shape for t in params]
         ctx.need = [features.requires_grad] + [t.requires_grad for t in params]
         return rgb
@@ -292,7 +296,7 @@ class RgbDecoderFn(torch.autograd.Function):
     def backward(ctx, grad_rgb):
         if not ctx.training:
             raise RuntimeError("decode_rgb: backward through the eval-mode decoder (running statistics) is not implemented")
-        feats, saved, rgb = ctx.saved
+        feats, saved, rgb = ctx.saved_tensors
         grad_rgb = _chk(grad_rgb.contiguous().float(), "grad_rgb")
         work = torch.empty((ctx.sizes[1].value,), device=feats.device, dtype=torch.uint8)
         gf = torch.empty_like(feats)

@@ -39,23 +39,34 @@ def shard_range(n_items: int, rank: int, world: int, granule: int = 1) -> Tuple[
     return min(start * granule, n_items), min(end * granule, n_items)
 
 
-_NO_REDUCE_SCATTER = set()  # (backend, device type) pairs whose reduce_scatter_tensor raised once
+def flat_collectives_supported(group, device: torch.device) -> bool:
+    """Does the group's backend implement reduce_scatter_tensor / all_gather_into_tensor for tensors on ``device``?
+    Decided from (backend, device type) alone -- the same answer on every rank, no exception probing: a rank-local
+    RuntimeError (a transport error, a bad shape) must surface, not silently switch ONE rank to a different collective.
+    The one unsupported pairing in use is gloo over GPU tensors (the one-GPU rehearsal of the N > 1 path)."""
+    return not (dist.get_backend(group) == "gloo" and device.type == "cuda")
 
 
 def reduce_scatter_flat(flat: Tensor, world: int, group=None, async_op: bool = False):
     """SUM-reduce-scatter of a flat buffer -> (work | None, this rank's shard).  A backend without reduce_scatter_tensor
-    for the buffer's device (gloo on GPU tensors: the one-GPU rehearsal of the N > 1 path) gets an all-reduce of the whole
-    buffer instead and the shard comes back as None: ``flat`` then already holds the full sum."""
-    key = (dist.get_backend(group), flat.device.type)
-    if key not in _NO_REDUCE_SCATTER:
+    for the buffer's device (``flat_collectives_supported``) gets an all-reduce of the whole buffer instead and the shard
+    comes back as None: ``flat`` then already holds the full sum."""
+    if flat_collectives_supported(group, flat.device):
         shard = flat.new_empty(flat.numel() // world)
-        try:
-            work = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-            return (work if async_op else None), shard
-        except (RuntimeError, NotImplementedError):
-            _NO_REDUCE_SCATTER.add(key)
+        work = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return (work if async_op else None), shard
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return (work if async_op else None), None
+
+
+def all_gather_flat(full: Tensor, shard: Tensor, world: int, group=None) -> None:
+    """all_gather_into_tensor, or -- where the backend lacks it for this device -- a list gather + copy"""
+    if flat_collectives_supported(group, full.device):
+        dist.all_gather_into_tensor(full, shard, group=group)
+        return
+    parts = [torch.empty_like(shard) for _ in range(world)]
+    dist.all_gather(parts, shard, group=group)
+    full.copy_(torch.cat(parts))
 
 
 class GradientSynchronizer:
@@ -145,12 +156,7 @@ class GradientSynchronizer:
             return
         if self.average:
             shard.div_(self.world_size())
-        try:
-            dist.all_gather_into_tensor(flat, shard, group=self.group)
-        except (RuntimeError, NotImplementedError):  # (gloo on GPU tensors: the rehearsal) gather into a list instead
-            parts = [torch.empty_like(shard) for _ in range(self.world_size())]
-            dist.all_gather(parts, shard, group=self.group)
-            flat.copy_(torch.cat(parts))
+        all_gather_flat(flat, shard, self.world_size(), self.group)
 
     # ---- level-sparse exchange ----------------------------------------------------------------------------------------
     @staticmethod

@@ -20,6 +20,8 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from .data_parallel import all_gather_flat
+
 
 def _hip_update(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float, beta1: float,
                 beta2: float, eps: float, weight_decay: float, grad_scale: float) -> None:
@@ -105,12 +107,7 @@ class ShardedTableAdam:
             if self.world > 1:
                 # in place (send buffer = this rank's slot of the receive buffer) where the backend supports it
                 src = p_shard if dist.get_backend(self.group) == "nccl" else p_shard.clone()
-                try:
-                    dist.all_gather_into_tensor(flat_p, src, group=self.group)
-                except (RuntimeError, NotImplementedError):  # (gloo on GPU tensors: the rehearsal) gather into a list
-                    parts = [torch.empty_like(src) for _ in range(self.world)]
-                    dist.all_gather(parts, src, group=self.group)
-                    flat_p.copy_(torch.cat(parts))
+                all_gather_flat(flat_p, src, self.world, self.group)
         return nbytes
 
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -125,7 +122,7 @@ class ShardedTableAdam:
         if self.world == 1:
             return shard.clone().view_as(like)
         full = shard.new_empty(like.numel())
-        dist.all_gather_into_tensor(full, shard.contiguous(), group=self.group)
+        all_gather_flat(full, shard.contiguous(), self.world, self.group)
         return full.view_as(like)
 
     def state_dict(self) -> Dict:

@@ -18,11 +18,32 @@ import sys
 import types
 from unittest import mock
 
-REFERENCE_ROOT = os.environ.get("NEURAD_REFERENCE_ROOT", "/root/reference")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SOURCE_ROOT = os.environ.get("NEURAD_REFERENCE_ROOT", "/root/reference")
+# the reference byte-compiled by oracle/make_ref.py (sourceless .pyc, gitignored, ships with the gpurun lease): what the
+# GPU box has in place of /root/reference
+_BYTECODE_ROOT = os.path.join(_HERE, "_ref")
+
+
+def _pick_root() -> str:
+    if os.path.isdir(os.path.join(_SOURCE_ROOT, "nerfstudio")):
+        return _SOURCE_ROOT
+    if os.path.exists(os.path.join(_BYTECODE_ROOT, "nerfstudio", "__init__.pyc")):
+        return _BYTECODE_ROOT
+    return _SOURCE_ROOT
+
+
+REFERENCE_ROOT = _pick_root()
 
 
 def reference_available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "nerfstudio"))
+    return (os.path.isdir(os.path.join(REFERENCE_ROOT, "nerfstudio"))
+            and any(os.path.exists(os.path.join(REFERENCE_ROOT, "nerfstudio", "__init__" + e)) for e in (".py", ".pyc")))
+
+
+def reference_kind() -> str:
+    """"source" (the build container's /root/reference) or "bytecode" (oracle/_ref on the GPU box)"""
+    return "bytecode" if REFERENCE_ROOT == _BYTECODE_ROOT else "source"
 
 
 class _Anno:
@@ -85,6 +106,9 @@ class _StubClass(metaclass=_StubMeta):
     def __class_getitem__(cls, item):
         return cls
 
+    def __call__(self, *args, **kwargs):  # metric objects of absent packages (torchmetrics' PSNR in get_metrics_dict)
+        return mock.MagicMock(name=f"{type(self).__name__}()")
+
     def __getattr__(self, item):
         if item.startswith("__"):
             raise AttributeError(item)
@@ -116,13 +140,14 @@ class _StubFinder:
 _FINDER = _StubFinder()
 
 
-def install() -> None:
-    """Make ``import nerfstudio...`` work from the read-only reference tree."""
+def install(allow_tcnn: bool = False) -> None:
+    """Make ``import nerfstudio...`` work from the read-only reference tree (``allow_tcnn``: the shim test wants the
+    ``tinycudann`` import-name package PRESENT; everything else needs it absent so that the torch branches run)."""
     if not reference_available():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
     sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
-    assert "tinycudann" not in sys.modules, "tinycudann must stay absent for the torch oracle"
+    assert allow_tcnn or "tinycudann" not in sys.modules, "tinycudann must stay absent for the torch oracle"
     if "jaxtyping" not in sys.modules:
         _stub("jaxtyping", **{k: _Anno for k in ("Float", "Int", "Shaped", "Bool", "UInt8", "Num", "Integer")})
     for name in (
@@ -149,5 +174,19 @@ def install() -> None:
         _FINDER.tops.add(name.split(".")[0])
     if _FINDER not in sys.meta_path:
         sys.meta_path.append(_FINDER)
+    if reference_kind() == "bytecode":
+        # TorchScript needs source text; the bytecode build has none.  The two scripted helpers of the reference
+        # (cameras/camera_utils.py:943,1032, fisheye projection) then run as the eager functions they decorate --
+        # same arithmetic.  Scoped to the reference's import: restored right after.
+        import torch
+
+        _script = torch.jit.script
+        torch.jit.script = lambda fn=None, *a, **k: fn
+        try:
+            if REFERENCE_ROOT not in sys.path:
+                sys.path.insert(0, REFERENCE_ROOT)
+            import nerfstudio.cameras.camera_utils  # noqa: F401
+        finally:
+            torch.jit.script = _script
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)

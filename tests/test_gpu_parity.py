@@ -395,15 +395,13 @@ def test_full_size_properties_config2(ops):
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 4096, 128), (8, 4, 16, 257, 33), (4, 8, 12, 64, 7), (6, 1, 20, 300, 48),
                                  (2, 4, 9, 5, 3), (6, 1, 14, 9001, 128),  # > 64 chunks: the two-level chunk prefix
                                  (6, 1, 14, 9001, 128, 18), (8, 4, 16, 2051, 33, 15)])  # rounds of 2^18 / 2^15 samples
-@pytest.mark.parametrize("dedupe", [False, True], ids=["partition", "partition+wg-merge"])
-def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, dedupe, monkeypatch):
+def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     """B1 table gradient: the owner-computes path (LDS slices, no memory-side atomics) against the atomic
     scatter-add, from BASELINE config 2 at full size down to ragged batches and tables smaller than one slice.
     Same terms, different summation order -> agreement to fp32 rounding; linearity in grad_out is exact-ish too.
     A sixth entry sets NRHIP_BIN_ROUND_LOG2: the batch then goes through in several rounds."""
     if len(cfg) == 6:
         monkeypatch.setenv("NRHIP_BIN_ROUND_LOG2", str(cfg[5]))
-    monkeypatch.setenv("NRHIP_BIN_DEDUPE", "1" if dedupe else "0")  # the opt-in workgroup-level merge of equal entries
     L, F, lg, R, S = cfg[:5]
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     o, d, area, s, e, eu = _sample_rays(R, S, seed=5)
@@ -432,14 +430,42 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, dedupe, monkeypatch):
     assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("F", [1, 4])
+def test_table_gradient_x_pairs_that_straddle_two_slices(ops, F, monkeypatch):
+    """The radix partition sends one record per (floor x, ceil x) corner pair.  The two entries differ by
+    floor x ^ ceil x, which reaches the slice bits only where floor x = k * 2^log2TS - 1: such a pair goes out as two
+    records.  Here most samples sit in exactly those cell columns of the finest levels (and the rest anywhere); the result
+    must equal the atomic scatter-add, bit-reproducibly."""
+    L, lg = 4, 14
+    spec = ops.GridSpec(L, F, lg, 256, 4096)  # slices of 2^9..2^12 entries < the finer levels' resolutions
+    n = 40000
+    g = np.random.default_rng(3)
+    x = g.uniform(0.02, 0.98, (n, 3)).astype(np.float32)
+    scal = spec.scalings.numpy()
+    for l in range(L):  # a quarter of the samples per level: floor(x * scale_l) = 2^k - 1 for a random k >= 9
+        rows = np.arange(l, n, 2 * L)
+        k = g.integers(9, 12, rows.size)
+        cell = (1 << k) - 1
+        cell = np.minimum(cell, int(scal[l]) - 2)
+        x[rows, 0] = ((cell + g.uniform(0.1, 0.9, rows.size)) / scal[l]).astype(np.float32)
+    xs, go = dev(x), dev(synth.normal((n, L * F), 17))
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
+    binned = ops.hashgrid_bwd(spec, None, xs, go)
+    again = ops.hashgrid_bwd(spec, None, xs, go)
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+    atomic = ops.hashgrid_bwd(spec, None, xs, go)
+    assert torch.equal(binned, again)
+    assert rel_l2(host(binned), host(atomic)) < 2e-6
+    assert (binned - atomic).abs().max() <= 1e-5 * atomic.abs().max()
+
+
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 2048, 64), (8, 4, 16, 257, 33), (6, 1, 14, 300, 48)])
-@pytest.mark.parametrize("dedupe", [False, True], ids=["partition", "partition+wg-merge"])
-def test_table_gradient_skips_exactly_zero_samples_exactly(ops, cfg, dedupe, monkeypatch):
+def test_table_gradient_skips_exactly_zero_samples_exactly(ops, cfg, monkeypatch):
     """Samples whose incoming gradient is exactly zero (the tail of a ray behind an opaque surface; scattered ones; whole
     rays) send no records.  The result must equal the atomic scatter-add of the same gradient, and -- integer
     accumulation -- must not change by a single bit when the silent samples' rows hold -0.0 instead of +0.0 or when
     silent samples sit between two samples of the same cell (they split a merged run, nothing else)."""
-    monkeypatch.setenv("NRHIP_BIN_DEDUPE", "1" if dedupe else "0")
     L, F, lg, R, S = cfg
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     o, d, area, s, e, eu = _sample_rays(R, S, seed=7)

@@ -1,0 +1,328 @@
+"""The REAL plugin on the MI355X against the REAL reference on the same box's CPU.
+
+``NeuRADHipModel`` (a subclass of the reference's NeuRADModel, nerfstudio/models/neurad.py:165-734) is resolved the way
+``ns-train`` resolves it -- ``NERFSTUDIO_METHOD_CONFIGS`` through plugins/registry.py:34-79 -- built on ``cuda:0``, its
+state_dict copied into the reference's own ``NeuRADModel(implementation="torch")`` on the CPU, and both are driven with the
+same rays:
+  * eval outputs of ``get_nff_outputs`` (models/neurad.py:368-421) within 1e-4 rel-L2;
+  * one training step -- ``get_outputs`` -> ``get_metrics_dict`` -> ``get_loss_dict`` -> backward (models/neurad.py:310-335,
+    462-561): every loss term and the gradients of the hash tables, the MLPs, beta, the appearance embedding, the lidar
+    head and (actor scene) the actor grids and the trajectory parameters;
+for a static scene and for a scene with 3 dynamic actors.
+
+The reference tree reaches the GPU box as sourceless bytecode (oracle/make_ref.py -> oracle/_ref, test infrastructure);
+in the build container the same file runs against /root/reference but has no GPU.  The only substitutions on the
+reference side are the ones every golden generator makes (oracle/make_golden_model.py): dense nerfacc 0.5.2 formulas in
+place of the CPU placeholder (models/neurad.py:713-715 returns 0.5 on CPU), no VGG network (torchvision weights absent,
+``vgg_mult = 0``), samplers and fields in eval mode inside the training-mode model (no jitter, no random actor flip).
+"""
+import os
+import sys
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_import  # noqa: E402
+import synth  # noqa: E402
+from conftest import rel_l2  # noqa: E402
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_import.reference_available(),
+                                 reason="no reference: run `python oracle/make_ref.py` in the build container "
+                                        "(oracle/_ref ships with the lease)")]
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32)))
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _dense_nerfacc():
+    import types
+
+    m = types.ModuleType("nerfacc")
+
+    def render_weight_from_alpha(alphas, **kw):
+        trans = torch.cumprod(torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas[..., :-1]], -1), -1)
+        return trans * alphas, trans
+
+    def accumulate_along_rays(weights, values=None, ray_indices=None, n_rays=None):
+        return weights.sum(-1, keepdim=True) if values is None else (weights[..., None] * values).sum(-2)
+
+    m.render_weight_from_alpha, m.accumulate_along_rays = render_weight_from_alpha, accumulate_along_rays
+    return m
+
+
+def _trajectories():
+    """3 actors moving along +x (the scene of oracle/make_golden_actors.py): actor 2 overlaps actor 1's box, actor 0 is
+    present early only"""
+    ts_all = torch.tensor([0.0, 1.0, 2.0, 3.0, 4.0])
+    out = []
+    for a, (y0, yaw, dims, ts) in enumerate([(8.0, 0.3, (2.0, 4.5, 1.6), ts_all[:3]), (-6.0, -0.2, (2.1, 4.8, 1.7), ts_all),
+                                             (-5.0, 0.1, (1.9, 4.2, 1.5), ts_all[1:])]):
+        poses = []
+        for t in ts:
+            c, s = np.cos(yaw + 0.05 * float(t)), np.sin(yaw + 0.05 * float(t))
+            p = torch.eye(4)
+            p[:3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+            p[:3, 3] = torch.tensor([12.0 + 2.0 * float(t) + a, y0, 0.5])
+            poses.append(p)
+        out.append({"timestamps": ts.clone(), "poses": torch.stack(poses), "dims": torch.tensor(dims),
+                    "symmetric": torch.tensor(True), "deformable": torch.tensor(False)})
+    return out
+
+
+def _fill(model):
+    """deterministic O(1)-feature parameters (tests/synth.py) so that densities, weights and every loss term are far from
+    their trivial values"""
+    for k, (name, p) in enumerate(model.named_parameters()):
+        if name.endswith("hash_table"):
+            scale = 1.0 if p.shape[1] == 4 else 2.5
+            p.data = T(synth.hash_table(p.shape[0], p.shape[1], seed=100 + k, scale=scale)).to(p.device)
+        elif name.startswith(("field.mlp", "proposal_fields", "lidar_decoder")) and name.endswith("weight") and p.dim() == 2:
+            w, _ = synth.linear(p.shape[0], p.shape[1], 100 + k)
+            p.data = T(w).to(p.device)
+        elif name.startswith(("field.mlp", "lidar_decoder")) and name.endswith("bias"):
+            p.data = T(synth.uniform(tuple(p.shape), -0.2, 0.2, 100 + k)).to(p.device)
+    # a translucent static scene (positive SDF offset): the rays reach the actors' corridor 10-25 m out, so that the actor
+    # grids and the trajectories receive gradients of the same order as the static table's
+    with torch.no_grad():
+        model.field.mlp_geo.layers[-1].bias[0] = 1.2
+    model.appearance_embedding.weight.data = T(synth.normal(tuple(model.appearance_embedding.weight.shape), seed=77)).to(
+        model.appearance_embedding.weight.device)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    ref_import.install()
+    import nerfstudio.model_components.renderers as ref_renderers
+    import nerfstudio.models.neurad as ref_neurad
+
+    saved = (ref_neurad.VGGPerceptualLossPix2Pix, ref_neurad.nerfacc, ref_renderers.nerfacc,
+             os.environ.get("NERFSTUDIO_METHOD_CONFIGS"))
+    ref_neurad.VGGPerceptualLossPix2Pix = torch.nn.Identity
+    os.environ["NERFSTUDIO_METHOD_CONFIGS"] = "neurad-hip=neurad_studio_amd.integration.neurad_hip:neurad_hip"
+    yield ref_neurad
+    ref_neurad.VGGPerceptualLossPix2Pix, ref_neurad.nerfacc, ref_renderers.nerfacc = saved[:3]
+    if saved[3] is None:
+        os.environ.pop("NERFSTUDIO_METHOD_CONFIGS", None)
+    else:
+        os.environ["NERFSTUDIO_METHOD_CONFIGS"] = saved[3]
+
+
+def _shrink(c):
+    c.field.grid.static.log2_hashmap_size = 12
+    c.field.grid.actor.log2_hashmap_size = 9
+    c.field.sdf_beta = 3.0
+    for pf in (c.sampling.proposal_field_1, c.sampling.proposal_field_2):
+        pf.grid.static.log2_hashmap_size = 10
+        pf.grid.actor.log2_hashmap_size = 8
+    c.loss.vgg_mult = 0.0
+    return c
+
+
+def _build_pair(ref_neurad, with_actors, fused_decoder=False):
+    """(the plugin on cuda:0, resolved through the registry; the reference's torch model on the CPU; same weights)"""
+    import nerfstudio.model_components.renderers as ref_renderers
+    from nerfstudio.data.scene_box import SceneBox
+    from nerfstudio.plugins.registry import discover_methods
+
+    # what ns-train does: importing the method table runs the plugin discovery (configs/method_configs.py ->
+    # plugins/registry.py:56-73, the NERFSTUDIO_METHOD_CONFIGS form)
+    import nerfstudio.configs.method_configs as ref_methods
+
+    methods = ref_methods.all_methods
+    if "neurad-hip" not in methods:  # the table was imported earlier in this process, before the variable was set
+        methods, _ = discover_methods()
+    mcfg = _shrink(deepcopy(methods["neurad-hip"].pipeline.model))
+    mcfg.fused_decoder = fused_decoder
+    from neurad_studio_amd.integration.neurad_hip import NeuRADHipModel
+
+
+    def kw():
+        return dict(scene_box=SceneBox(aabb=torch.tensor([[-100.0] * 3, [100.0] * 3])), num_train_data=2,
+                    metadata={"duration": 5.0, "sensor_idx_to_name": {0: "cam0", 1: "cam1", 2: "lidar"},
+                              "trajectories": _trajectories() if with_actors else []})
+
+    torch.manual_seed(0)
+    hip = mcfg.setup(**kw())
+    assert isinstance(hip, NeuRADHipModel) and isinstance(hip, ref_neurad.NeuRADModel)
+    ref_cfg = _shrink(ref_neurad.NeuRADModelConfig(implementation="torch"))
+    for c in (ref_cfg.field, ref_cfg.sampling.proposal_field_1, ref_cfg.sampling.proposal_field_2):
+        c.grid.actor.use_4d_hashgrid = False
+    refm = ref_cfg.setup(**kw())
+    assert sorted(hip.state_dict()) == sorted(refm.state_dict())
+    _fill(hip)
+    refm.load_state_dict(hip.state_dict())
+    hip = hip.to("cuda")
+    # the reference on the CPU: dense nerfacc formulas instead of its 0.5 placeholder (models/neurad.py:713-715)
+    na = _dense_nerfacc()
+    ref_neurad.nerfacc = na
+    ref_renderers.nerfacc = na
+    # (on the INSTANCE: the plugin class inherits from NeuRADModel and must keep the reference's method)
+    refm._render_weights = lambda outputs, rs: na.render_weight_from_alpha(
+        outputs[ref_neurad.FieldHeadNames.ALPHA].squeeze(-1))[0]
+    return hip, refm
+
+
+def _batch(with_actors, patch=4, n_patches=3, n_lidar=40):
+    """camera rays in ``patch`` x ``patch`` patches (the CNN decoder's unit) then lidar rays; with actors the rays are
+    aimed down the actors' corridor so that many samples fall inside boxes"""
+    Rc = n_patches * patch * patch
+    R = Rc + n_lidar
+    o = synth.normal((R, 3), 5) * np.array([1.5, 1.5, 0.3], np.float32)
+    if with_actors:
+        tgt = np.stack([synth.uniform((R,), 10, 24, 8),
+                        np.where(np.arange(R) % 2 == 0, 8.0, -5.5) + synth.uniform((R,), -1.5, 1.5, 9),
+                        synth.uniform((R,), 0.0, 1.0, 10)], -1).astype(np.float32)
+        d = tgt - o
+    else:
+        d = synth.normal((R, 3), 6)
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    is_lidar = np.arange(R) >= Rc
+    did_return = np.where(is_lidar, synth.uniform((R,), 0, 1, 7) < 0.75, True)
+    dist = synth.uniform((R,), 6.0, 40.0, 8)
+    area = np.where(is_lidar, 4.5e-6, 2.7e-7).astype(np.float32)
+    times = synth.uniform((R,), 0.2, 3.8, 9)
+    sensor = np.where(is_lidar, 2, (np.arange(R) // (patch * patch)) % 2).astype(np.int64)
+    up = 3 * patch
+    image = synth.uniform((n_patches, up, up, 3), 0.0, 1.0, 31)
+    lidar = np.concatenate([synth.normal((n_lidar, 3), 21), synth.uniform((n_lidar, 1), 0, 1, 22)], -1)
+    return dict(o=o, d=d, is_lidar=is_lidar, did_return=did_return, dist=dist, area=area, times=times, sensor=sensor,
+                image=image, lidar=lidar, patch=patch, Rc=Rc)
+
+
+def _bundle(b, device):
+    from nerfstudio.cameras.rays import RayBundle
+
+    t = lambda a: T(a).to(device)  # noqa: E731
+    return RayBundle(origins=t(b["o"]), directions=t(b["d"]), pixel_area=t(b["area"])[:, None], times=t(b["times"])[:, None],
+                     camera_indices=torch.zeros(len(b["o"]), 1, dtype=torch.long, device=device),
+                     metadata={"is_lidar": torch.from_numpy(b["is_lidar"])[:, None].to(device),
+                               "did_return": torch.from_numpy(b["did_return"])[:, None].to(device),
+                               "directions_norm": t(b["dist"])[:, None],
+                               "sensor_idxs": torch.from_numpy(b["sensor"])[:, None].to(device)})
+
+
+def _labels(b, device):
+    return {"image": T(b["image"]).to(device), "lidar": T(b["lidar"]).to(device),
+            "is_lidar": torch.from_numpy(b["is_lidar"])[:, None].to(device),
+            "did_return": torch.from_numpy(b["did_return"])[:, None].to(device),
+            "distance": T(b["dist"][b["is_lidar"]])[:, None].to(device)}
+
+
+def _deterministic(m, train):
+    m.train(train)
+    m.sampler.eval(), m.field.eval()
+    for p in m.proposal_fields:
+        p.eval()
+    return m
+
+
+@pytest.mark.parametrize("with_actors", [False, True], ids=["static", "actors3"])
+def test_plugin_eval_outputs_match_the_reference_torch_model(ref, with_actors):
+    hip, refm = _build_pair(ref, with_actors)
+    b = _batch(with_actors)
+    _deterministic(hip, False), _deterministic(refm, False)
+    with torch.no_grad():
+        got = hip.get_nff_outputs(_bundle(b, "cuda"))
+        want = refm.get_nff_outputs(_bundle(b, "cpu"))
+    assert set(got) == set(want)
+    for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+        assert got[k].shape == want[k].shape and got[k].is_cuda, k
+        assert rel_l2(N(got[k]), N(want[k])) < 1e-4, (k, rel_l2(N(got[k]), N(want[k])))
+    # the eval path really was the fused one (two kernels), not the reference's own orchestration
+    assert hip.fused_eval_possible.__func__ is not None and hip.fused_eval
+
+
+def _train_step(m, b, device):
+    m.zero_grad(set_to_none=True)
+    outputs = m.get_outputs(_bundle(b, device), patch_size=(b["patch"], b["patch"]), calc_lidar_losses=True)
+    labels = _labels(b, device)
+    metrics = m.get_metrics_dict(outputs, labels)
+    losses = m.get_loss_dict(outputs, labels, metrics)
+    sum(losses.values()).backward()
+    return outputs, metrics, losses
+
+
+# Parameter gradients: |got - want| <= tol * |want| in L2 over the tensor.  The tolerances are 3 x the measured
+# reference-vs-reference floor (the same torch model in fp64 vs fp32 on this batch: oracle/grad_noise_floor.py,
+# profiles/r04_grad_noise_floor.json) or 1e-4, whichever is larger.
+GRAD_TOL = {"table": 3e-4, "mlp": 3e-4, "beta": 1e-3, "embedding": 3e-4, "lidar_head": 3e-4, "decoder": 1e-3,
+            "actor_grid": 5e-4, "trajectory": 2e-3}
+
+
+def _kind(name):
+    if name.endswith("hash_table"):
+        return "actor_grid" if "actor_grids" in name else "table"
+    if name.startswith("dynamic_actors"):
+        return "trajectory"
+    if name.startswith("rgb_decoder"):
+        return "decoder"
+    if name.startswith("lidar_decoder"):
+        return "lidar_head"
+    if name.startswith("appearance_embedding"):
+        return "embedding"
+    if name.endswith("sdf_to_density.beta"):
+        return "beta"
+    return "mlp"
+
+
+@pytest.mark.parametrize("with_actors", [False, True], ids=["static", "actors3"])
+def test_plugin_training_step_matches_the_reference_torch_model(ref, with_actors):
+    hip, refm = _build_pair(ref, with_actors)
+    b = _batch(with_actors)
+    _deterministic(hip, True), _deterministic(refm, True)
+    assert hip.fused_training_possible()  # the fused nodes (static: ProposalRoundFn / NffRenderTrainFn; actors: OVR)
+    g_out, g_met, g_loss = _train_step(hip, b, "cuda")
+    w_out, w_met, w_loss = _train_step(refm, b, "cpu")
+    assert set(g_loss) == set(w_loss), (sorted(g_loss), sorted(w_loss))
+    for k in w_loss:
+        a, c = float(g_loss[k]), float(w_loss[k])
+        assert abs(a - c) <= 2e-4 * abs(c) + 1e-7, (k, a, c)
+    for k in ("rgb", "depth", "accumulation", "intensity", "ray_drop_logits", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(N(g_out[k]), N(w_out[k])) < 1e-4, (k, rel_l2(N(g_out[k]), N(w_out[k])))
+    want = dict(refm.named_parameters())
+    seen = set()
+    worst = {}
+    for name, p in hip.named_parameters():
+        wg = want[name].grad
+        if wg is None or float(wg.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-12, name
+            continue
+        assert p.grad is not None, f"{name}: the reference has a gradient, the plugin has none"
+        kind = _kind(name)
+        e = rel_l2(N(p.grad), N(wg))
+        worst[kind] = max(worst.get(kind, 0.0), e)
+        assert e < GRAD_TOL[kind], (name, kind, e)
+        seen.add(kind)
+    need = {"table", "mlp", "beta", "embedding", "lidar_head", "decoder"} | ({"actor_grid", "trajectory"} if with_actors
+                                                                             else set())
+    assert need <= seen, (need - seen, worst)
+    print("worst rel-L2 per parameter kind:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+
+
+def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
+    """the same step with decode_features' CNN on csrc/decoder.hip (fp16 operands, fp32 accumulation: the arithmetic of the
+    reference trainer's mixed precision) -- losses within the fp16 bound of the rgb term, hot-path gradients still tight
+    on everything the rgb loss does not dominate"""
+    hip, refm = _build_pair(ref, False, fused_decoder=True)
+    b = _batch(False)
+    _deterministic(hip, True), _deterministic(refm, True)
+    g_out, _, g_loss = _train_step(hip, b, "cuda")
+    w_out, _, w_loss = _train_step(refm, b, "cpu")
+    assert rel_l2(N(g_out["rgb"]), N(w_out["rgb"])) < 3e-3
+    for k in w_loss:
+        tol = 5e-3 if k == "rgb_loss" else 2e-4
+        assert abs(float(g_loss[k]) - float(w_loss[k])) <= tol * abs(float(w_loss[k])) + 1e-7, k
+    want = dict(refm.named_parameters())
+    for name, p in hip.named_parameters():
+        if name.startswith("rgb_decoder") and want[name].grad is not None and float(want[name].grad.abs().max()) > 0:
+            assert rel_l2(N(p.grad), N(want[name].grad)) < 2e-2, name

@@ -43,13 +43,7 @@ def test_reference_tcnn_components_construct_on_the_shim():
         import tinycudann, nerfacc                     # the import-name packages
         assert tinycudann.__file__.startswith({ROOT!r}) and nerfacc.__version__ == "0.5.2"
         import ref_import
-        ref_import.install = ref_import.install        # (same harness, tinycudann now present)
-        import types
-        orig_assert = ref_import.install
-        # the harness insists on tinycudann being absent for the TORCH oracle; this process wants it present
-        src = open(ref_import.__file__).read().replace('assert "tinycudann" not in sys.modules', 'assert True')
-        mod = types.ModuleType("ref_import_tcnn"); exec(compile(src, ref_import.__file__, "exec"), mod.__dict__)
-        mod.install()
+        ref_import.install(allow_tcnn=True)  # (same harness, tinycudann now present)
         from nerfstudio.utils.external import TCNN_EXISTS
         assert TCNN_EXISTS
         from nerfstudio.field_components.encodings import HashEncoding, SHEncoding
