@@ -20,7 +20,8 @@
 //             distribution (real scenes put most samples into a thin slab of the volume: a fixed per-slice capacity
 //             overflowed there, and the overflow went to the memory-side atomics this path exists to avoid).
 //   emit    : same walk as `count`; each record goes to base + LDS rank.  No global atomics.
-//             A record is an X-PAIR (round 4): the (floor x, ceil x) corners of one (y, z) hash to entries that differ
+//             At F = 1 a record is an X-PAIR (round 4; wider grids keep one corner term per record, see use_pairs): the
+//             (floor x, ceil x) corners of one (y, z) hash to entries that differ
 //             only by xm = (floor x ^ ceil x) & mask -- the same small value for all four pairs of a sample -- so they
 //             lie in the same slice and one record {entry-in-slice | xm << 16, F values for the floor corner, F values
 //             for the ceil corner} carries both: 4 records per (sample, level) instead of 8, half the LDS rank atomics
@@ -65,16 +66,69 @@ int64_t round_samples() {  // (read per call: a getenv is nothing next to seven 
   return (int64_t)1 << lg;
 }
 
+// X-pair records pay where the record is small: F = 1 (12 instead of 2 x 8 bytes per corner pair, half the LDS rank atomics:
+// emit<1> 539 -> 393 us per c3 call).  At F = 4 they were measured SLOWER (emit 754 -> 848, reduce 592 -> 858 us: 36-byte
+// records, 8 values per DPP chain), so wider grids keep one corner term per record.  NRHIP_BIN_PAIRS=all|none overrides (A/B).
+bool use_pairs(int F) {
+  if (const char* e = getenv("NRHIP_BIN_PAIRS")) {
+    if (e[0] == 'a') return true;
+    if (e[0] == 'n') return false;
+  }
+  return F == 1;
+}
+
 struct BinPlan {
   int log2TS, nb;        // entries per slice (log2), slices per level
   int chunks, lgroups;   // count/emit grid: sample chunks x level groups (levels dealt round-robin)
   int nmax;              // per-level partial maxima (one per emit wave)
   int nseg;              // segments of kSegChunks chunks (two-level prefix over the chunks)
-  int rec_slots;         // record slots per (sample, level): 4 x-pairs, 8 if pairs can straddle slices
+  bool pair;             // records carry x-pairs of corner terms (else one corner term each)
+  int rec_slots;         // record slots per (sample, level): 4 x-pairs (8 if pairs can straddle slices), or 8 corners
   size_t off_counts, off_seg, off_totals, off_offsets, off_qmax, off_pos, off_idx, off_live, off_rec, total_bytes;
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// A record is RW = 2F + 1 dwords at 4-byte alignment.  Moved as 12-byte vectors (global_load/store_dwordx3 and wider: gfx950
+// takes unaligned vector accesses) instead of RW dword accesses: a wave's strided record reads touch every cache line once
+// per INSTRUCTION, so nine dword loads of 36-byte records cost the L1 nine passes over the same lines (reduce<4> went from
+// 592 to 849 us when the records grew from 5 to 9 dwords), three 12-byte loads three.
+typedef float rec3 __attribute__((ext_vector_type(3)));
+typedef rec3 rec3u __attribute__((aligned(4)));
+typedef float rec2 __attribute__((ext_vector_type(2)));
+typedef rec2 rec2u __attribute__((aligned(4)));
+template <int RW>
+__device__ __forceinline__ void load_record(const float* __restrict__ p, float (&q)[RW]) {
+  constexpr int n3 = RW / 3, rem = RW - 3 * n3;
+#pragma unroll
+  for (int c = 0; c < n3; ++c) {
+    const rec3 v = *reinterpret_cast<const rec3u*>(p + 3 * c);
+    q[3 * c] = v.x, q[3 * c + 1] = v.y, q[3 * c + 2] = v.z;
+  }
+  if constexpr (rem == 2) {
+    const rec2 v = *reinterpret_cast<const rec2u*>(p + 3 * n3);
+    q[3 * n3] = v.x, q[3 * n3 + 1] = v.y;
+  } else if constexpr (rem == 1) {
+    q[3 * n3] = p[3 * n3];
+  }
+}
+template <int RW>
+__device__ __forceinline__ void store_record(float* __restrict__ p, const float (&q)[RW]) {
+  constexpr int n3 = RW / 3, rem = RW - 3 * n3;
+#pragma unroll
+  for (int c = 0; c < n3; ++c) {
+    rec3 v;
+    v.x = q[3 * c], v.y = q[3 * c + 1], v.z = q[3 * c + 2];
+    *reinterpret_cast<rec3u*>(p + 3 * c) = v;
+  }
+  if constexpr (rem == 2) {
+    rec2 v;
+    v.x = q[3 * n3], v.y = q[3 * n3 + 1];
+    *reinterpret_cast<rec2u*>(p + 3 * n3) = v;
+  } else if constexpr (rem == 1) {
+    p[3 * n3] = q[3 * n3];
+  }
+}
 
 // Returns false when the grid can not be binned (too many slices per level).
 bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
@@ -111,8 +165,9 @@ bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
   // resolution reaches the slice length: floor x ^ ceil x can then carry into the slice bits)
   float smax = 0.f;
   for (int l = 0; l < g.L; ++l) smax = g.scal[l] > smax ? g.scal[l] : smax;
-  p->rec_slots = (smax + 2.f < (float)(1 << log2TS)) ? 4 : 8;
-  p->off_rec = o, o += (size_t)n * p->rec_slots * g.L * (2 * g.F + 1) * sizeof(float);
+  p->pair = use_pairs(g.F);
+  p->rec_slots = (p->pair && smax + 2.f < (float)(1 << log2TS)) ? 4 : 8;
+  p->off_rec = o, o += (size_t)n * p->rec_slots * g.L * ((p->pair ? 2 : 1) * g.F + 1) * sizeof(float);
   p->total_bytes = o;
   return true;
 }
@@ -251,6 +306,7 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
 }
 
 // ---- count ---------------------------------------------------------------------------------------------------
+template <bool PAIR>
 __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, int nb, uint32_t* __restrict__ counts,
                                                           const float4* __restrict__ gpos,
                                                           const uint32_t* __restrict__ nlive) {
@@ -274,14 +330,14 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, 
       const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // a silent sample never joins a run of equal pairs
-        const uint32_t kf = live ? c.idx[kPairF[k]] : 0xffffffffu, kc = live ? c.idx[kPairC[k]] : 0xffffffffu;
-        // first lane of a 16-lane row always heads a run
-        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || dpp_row_shr<1>(kc, ~kc) != kc;
+      for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
+        // a silent sample never joins a run of equal entries; the first lane of a 16-lane row always heads a run
+        const uint32_t kf = live ? c.idx[PAIR ? kPairF[k] : k] : 0xffffffffu;
+        const uint32_t kc = PAIR ? (live ? c.idx[kPairC[k]] : 0xffffffffu) : kf;
+        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || (PAIR && dpp_row_shr<1>(kc, ~kc) != kc);
         if (live && head) {
           atomicAdd(&hist[kf >> log2TS], 1u);
-          if ((kf ^ kc) >> log2TS) atomicAdd(&hist[kc >> log2TS], 1u);  // the pair straddles two slices: two records
+          if (PAIR && ((kf ^ kc) >> log2TS)) atomicAdd(&hist[kc >> log2TS], 1u);  // the pair straddles two slices: two records
         }
       }
     }
@@ -362,7 +418,7 @@ __global__ __launch_bounds__(1024) void bin_scan_totals_kernel(const uint32_t* _
 }
 
 // ---- emit ----------------------------------------------------------------------------------------------------
-template <int F, class Src>
+template <int F, bool PAIR, class Src>
 __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int log2TS, int nb, int64_t i_off, int64_t n,
                                                          const uint32_t* __restrict__ bases,
                                                          const uint32_t* __restrict__ segbase,
@@ -414,14 +470,19 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 #pragma unroll
         for (int k = 0; k < F; ++k) gv[k] = 0.f;
       }
+      constexpr int NV = PAIR ? 2 * F : F, RW = NV + 1;  // values per record, record length in dwords
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t kf = live ? c.idx[kPairF[k]] : 0xffffffffu, kc = live ? c.idx[kPairC[k]] : 0xffffffffu;
-        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || dpp_row_shr<1>(kc, ~kc) != kc;
+      for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
+        const uint32_t kf = live ? c.idx[PAIR ? kPairF[k] : k] : 0xffffffffu;
+        const uint32_t kc = PAIR ? (live ? c.idx[kPairC[k]] : 0xffffffffu) : kf;
+        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || (PAIR && dpp_row_shr<1>(kc, ~kc) != kc);
         const unsigned long long hm = __ballot(head);
-        float v[2 * F];  // floor-corner terms, then ceil-corner terms
+        float v[NV];  // (floor-corner terms, then ceil-corner terms)
 #pragma unroll
-        for (int j = 0; j < F; ++j) v[j] = w[kPairF[k]] * gv[j], v[F + j] = w[kPairC[k]] * gv[j];
+        for (int j = 0; j < F; ++j) {
+          v[j] = w[PAIR ? kPairF[k] : k] * gv[j];
+          if constexpr (PAIR) v[F + j] = w[kPairC[k]] * gv[j];
+        }
         if (hm != ~0ull) {
           // some run is longer than 1: segmented suffix sum onto the run heads, inside each 16-lane row, on DPP
           // row shifts (VALU rate; a 64-lane __shfl version goes through the LDS crossbar 18x per corner)
@@ -429,7 +490,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 #define NR_SEG_STEP(OFF)                                                   \
   {                                                                        \
     const bool same = dpp_row_shl<OFF>(run, 0xffffffffu) == run;           \
-    _Pragma("unroll") for (int j = 0; j < 2 * F; ++j) {                    \
+    _Pragma("unroll") for (int j = 0; j < NV; ++j) {                       \
       const float t = dpp_row_shl<OFF>(v[j], 0.f);                         \
       if (same) v[j] += t;                                                 \
     }                                                                      \
@@ -442,27 +503,28 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
         }
         if (head && live) {
 #pragma unroll
-          for (int j = 0; j < 2 * F; ++j) {
+          for (int j = 0; j < NV; ++j) {
             const float av = fabsf(v[j]);
             if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);  // Inf/NaN do not set the scale; they poison in `reduce`
           }
-          const uint32_t xm = kf ^ kc;
+          const uint32_t xm = kf ^ kc;  // (0 without pairs)
           const uint32_t b = kf >> log2TS;
+          float out[RW];
           if ((xm >> log2TS) == 0) {  // (always, unless the level's resolution reaches the slice length)
-            float* rec = qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * (2 * F + 1);
-            rec[0] = __uint_as_float((kf & tsmask) | (xm << 16));
+            out[0] = __uint_as_float((kf & tsmask) | (xm << 16));
 #pragma unroll
-            for (int j = 0; j < 2 * F; ++j) rec[1 + j] = v[j];
-          } else {  // the ceil corner lives in another slice: two records, each with a zero second half
-            float* rec = qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * (2 * F + 1);
-            rec[0] = __uint_as_float(kf & tsmask);
+            for (int j = 0; j < NV; ++j) out[1 + j] = v[j];
+            store_record<RW>(qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * RW, out);
+          } else if constexpr (PAIR) {  // the ceil corner lives in another slice: two records, each with a zero second half
+            out[0] = __uint_as_float(kf & tsmask);
 #pragma unroll
-            for (int j = 0; j < F; ++j) rec[1 + j] = v[j], rec[1 + F + j] = 0.f;
+            for (int j = 0; j < F; ++j) out[1 + j] = v[j], out[1 + F + j] = 0.f;
+            store_record<RW>(qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * RW, out);
             const uint32_t b2 = kc >> log2TS;
-            rec = qrec + (size_t)(base[b2] + atomicAdd(&rank[b2], 1u)) * (2 * F + 1);
-            rec[0] = __uint_as_float(kc & tsmask);
+            out[0] = __uint_as_float(kc & tsmask);
 #pragma unroll
-            for (int j = 0; j < F; ++j) rec[1 + j] = v[F + j], rec[1 + F + j] = 0.f;
+            for (int j = 0; j < F; ++j) out[1 + j] = v[F + j];
+            store_record<RW>(qrec + (size_t)(base[b2] + atomicAdd(&rank[b2], 1u)) * RW, out);
           }
         }
       }
@@ -475,7 +537,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 }
 
 // ---- reduce --------------------------------------------------------------------------------------------------
-template <int F>
+template <int F, bool PAIR>
 __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ offsets,
                                                            const float* __restrict__ qrec,
                                                            const float* __restrict__ qmax_all, float* __restrict__ gt,
@@ -514,9 +576,10 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
 #pragma unroll
   for (int i = 1; i < 16; ++i) vmax = fmaxf(vmax, smax[i]);
   const int e = (int)((__float_as_uint(vmax) >> 23) & 0xff) - 127;
-  const int hb = 33 - __clz(cnt);  // a record adds up to two terms to an accumulator (xm = 0: both halves land on one entry)
+  const int hb = (PAIR ? 33 : 32) - __clz(cnt);  // a pair record adds up to two terms to one accumulator (xm = 0)
   const int sh = 61 - hb - (e + 1);
-  constexpr int RW = 2 * F + 1;  // record: {entry-in-slice | xm << 16, F floor-corner values, F ceil-corner values}
+  // record: {entry-in-slice | xm << 16, F floor-corner values, F ceil-corner values}; without pairs {entry, F values}
+  constexpr int NV = PAIR ? 2 * F : F, RW = NV + 1;
   const float* rec = qrec + (size_t)first * RW;
   // 4 records per thread in flight: the loads are independent, only the LDS adds follow them
   for (uint32_t e0 = 0; e0 < cnt; e0 += 4096) {
@@ -524,9 +587,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t i = e0 + u * 1024 + threadIdx.x;
-      const float* src = rec + (size_t)(i < cnt ? i : cnt - 1) * RW;
-#pragma unroll
-      for (int j = 0; j < RW; ++j) q[u][j] = src[j];
+      load_record<RW>(rec + (size_t)(i < cnt ? i : cnt - 1) * RW, q[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -534,7 +595,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
         const uint32_t w0 = __float_as_uint(q[u][0]);
         const uint32_t key = w0 & 0xffffu, key2 = key ^ (w0 >> 16);
 #pragma unroll
-        for (int j = 0; j < 2 * F; ++j) {
+        for (int j = 0; j < NV; ++j) {
           const float v = q[u][1 + j];
           const uint32_t at = (j < F ? key : key2) * F + (j < F ? j : j - F);
           if (fabsf(v) <= 3.402823466e38f) {
@@ -629,7 +690,8 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
   const size_t lds_b = (size_t)nacc * sizeof(unsigned long long) + (size_t)((nacc + 31) / 32) * sizeof(uint32_t);
   static thread_local bool count_configured = false;
   if (!count_configured) {
-    (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
     count_configured = true;
   }
   const int64_t round = round_samples();
@@ -641,31 +703,40 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     // qmax slots of chunks this round does not have stay from an earlier round otherwise
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
     bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive);
-    bin_count_kernel<<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
+    if (p.pair)
+      bin_count_kernel<true><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
+    else
+      bin_count_kernel<false><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     if (int e = check_launch(what)) return e;
     // one segment: its sums ARE the column totals and there is no second level
     bin_scan_chunks_kernel<<<dim3((cols + 255) / 256, nseg), 256, 0, st>>>(counts, chunks, cols, nseg > 1 ? segtot : totals);
     if (nseg > 1) bin_scan_segments_kernel<<<(cols + 255) / 256, 256, 0, st>>>(segtot, nseg, cols, totals);
     bin_scan_totals_kernel<<<1, 1024, 0, st>>>(totals, cols, offsets);
     if (int e = check_launch(what)) return e;
-#define CALL(F)                                                                                                     \
+#define CALL2(F, P)                                                                                                 \
   do {                                                                                                              \
     static thread_local bool configured = false;                                                                    \
     if (!configured) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)bin_emit_kernel<F, Src>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+      (void)hipFuncSetAttribute((const void*)bin_emit_kernel<F, P, Src>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 lds_a_max);                                                                         \
-      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+      (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<F, P>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 kTileBytes + 4096);                                                                 \
       configured = true;                                                                                            \
     }                                                                                                               \
-    bin_emit_kernel<F, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,                \
-                                                         nseg > 1 ? segtot : nullptr, offsets, gpos, gidx, nlive,   \
-                                                         qrec, qmax, p.nmax);                                       \
-    bin_reduce_kernel<F><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,      \
-                                                    p.nmax, (overwrite && i_off == 0) ? 1 : 0);                     \
+    bin_emit_kernel<F, P, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,             \
+                                                            nseg > 1 ? segtot : nullptr, offsets, gpos, gidx,       \
+                                                            nlive, qrec, qmax, p.nmax);                             \
+    bin_reduce_kernel<F, P><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,   \
+                                                       p.nmax, (overwrite && i_off == 0) ? 1 : 0);                  \
+  } while (0)
+#define CALL(F)              \
+  do {                       \
+    if (p.pair) CALL2(F, true);  \
+    else CALL2(F, false);    \
   } while (0)
     NR_DISPATCH_F(gd.F, CALL);
 #undef CALL
+#undef CALL2
     if (int e = check_launch(what)) return e;
   }
   return NRHIP_OK;

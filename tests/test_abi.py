@@ -115,8 +115,10 @@ def _grid(L, F, lg):
 
 
 def test_table_gradient_workspace_query_is_host_logic(lib):
-    """nrhip_encode_bwd_binned_workspace needs no GPU: one record slot per corner term + bookkeeping, flat beyond 2^23
-    samples (larger batches go through in rounds), 0 for grids with more than 2048 slices per level."""
+    """nrhip_encode_bwd_binned_workspace needs no GPU: one record slot per corner term ({entry, F values}, 8 per sample and level) --
+    at F = 1 per x-pair of corner terms ({entry | xm, 2 values}, 4 per sample and level; the scalings here stay below every
+    slice length, so no pair can straddle two slices) -- + bookkeeping, flat beyond 2^23 samples (larger batches go through in rounds), 0 for grids with more than 2048 slices per
+    level."""
     fn = lib.nrhip_encode_bwd_binned_workspace
     fn.restype = ctypes.c_int
 
@@ -126,7 +128,7 @@ def test_table_gradient_workspace_query_is_host_logic(lib):
         return out.value
 
     assert need(16, 2, 19, 0) == 0
-    records = lambda L, F, n: n * 8 * L * (F + 1) * 4  # noqa: E731
+    records = lambda L, F, n: n * L * (4 * 3 if F == 1 else 8 * (F + 1)) * 4  # noqa: E731
     for L, F, lg in [(16, 2, 19), (8, 4, 22), (6, 1, 20), (4, 4, 17)]:
         a, b = need(L, F, lg, 4096 * 128), need(L, F, lg, 2 * 4096 * 128)
         assert records(L, F, 4096 * 128) <= a <= records(L, F, 4096 * 128) + (64 << 20)

@@ -242,21 +242,12 @@ def test_plugin_eval_outputs_match_the_reference_torch_model(ref, with_actors):
     assert hip.fused_eval_possible.__func__ is not None and hip.fused_eval
 
 
-def _train_step(m, b, device):
+def _losses(m, b, device):
     m.zero_grad(set_to_none=True)
     outputs = m.get_outputs(_bundle(b, device), patch_size=(b["patch"], b["patch"]), calc_lidar_losses=True)
     labels = _labels(b, device)
     metrics = m.get_metrics_dict(outputs, labels)
-    losses = m.get_loss_dict(outputs, labels, metrics)
-    sum(losses.values()).backward()
-    return outputs, metrics, losses
-
-
-# Parameter gradients: |got - want| <= tol * |want| in L2 over the tensor.  The tolerances are 3 x the measured
-# reference-vs-reference floor (the same torch model in fp64 vs fp32 on this batch: oracle/grad_noise_floor.py,
-# profiles/r04_grad_noise_floor.json) or 1e-4, whichever is larger.
-GRAD_TOL = {"table": 3e-4, "mlp": 3e-4, "beta": 1e-3, "embedding": 3e-4, "lidar_head": 3e-4, "decoder": 1e-3,
-            "actor_grid": 5e-4, "trajectory": 2e-3}
+    return outputs, m.get_loss_dict(outputs, labels, metrics)
 
 
 def _kind(name):
@@ -275,38 +266,88 @@ def _kind(name):
     return "mlp"
 
 
+def _analytically_zero(name):
+    """convolution biases that feed a BatchNorm: their gradient is zero in exact arithmetic (rounding noise in fp32)"""
+    return name.startswith("rgb_decoder") and name.endswith((".main_branch.0.bias", ".main_branch.3.bias"))
+
+
+def per_loss_gradient_errors(got_model, got_losses, want_model, want_losses):
+    """{loss term: {parameter kind: worst rel-L2 over the kind's tensors of d loss / d parameter}} of ``got`` against
+    ``want``, one backward per term of get_loss_dict on either side (also used by oracle/grad_noise_floor.py: the
+    reference in fp32 against itself in fp64)"""
+    names = [n for n, p in want_model.named_parameters() if p.requires_grad and not _analytically_zero(n)]
+    gp, wp = dict(got_model.named_parameters()), dict(want_model.named_parameters())
+    res = {}
+    for term in want_losses:
+        gg = torch.autograd.grad(got_losses[term], [gp[n] for n in names], retain_graph=True, allow_unused=True)
+        wg = torch.autograd.grad(want_losses[term], [wp[n] for n in names], retain_graph=True, allow_unused=True)
+        tot = {}
+        for n, c in zip(names, wg):
+            if c is not None:
+                tot[_kind(n)] = max(tot.get(_kind(n), 0.0), float(c.double().norm()))
+        worst = {}
+        for n, a, c in zip(names, gg, wg):
+            k = _kind(n)
+            # a tensor this term barely reaches (1e-6 of its kind's largest gradient) carries rounding noise only
+            if c is None or float(c.double().norm()) <= 1e-6 * tot[k]:
+                continue
+            assert a is not None, f"{term}: {n} has a gradient on the reference side and none on the other"
+            e = float((a.detach().double().cpu() - c.detach().double().cpu()).norm() / c.detach().double().norm())
+            worst[k] = max(worst.get(k, 0.0), e)
+        res[term] = worst
+    return res
+
+
+def _floors(scene):
+    import json
+
+    f = os.path.join(ROOT, "profiles", "r04_grad_noise_floor.json")
+    return json.load(open(f))[scene]
+
+
 @pytest.mark.parametrize("with_actors", [False, True], ids=["static", "actors3"])
 def test_plugin_training_step_matches_the_reference_torch_model(ref, with_actors):
+    """losses and outputs to 1e-4 / 2e-4; gradients PER LOSS TERM of get_loss_dict and per kind of parameter, within 5x the
+    reference's own fp32-vs-fp64 noise floor for that kind (profiles/r04_grad_noise_floor.json, written by
+    oracle/grad_noise_floor.py; the largest floor over the terms), at least 1e-4.  Where the floor is high (hash tables and
+    MLPs: 5e-3) it is made of ReLU-kink flips of single hidden units -- see that script; the events are few and heavy-tailed,
+    which is why the bound is per kind and 5x -- and the SAME kernels are held to 2e-4 in absolute terms through rgb_loss
+    and interlevel_loss, which reach every parameter of the path and whose plugin-vs-reference difference is 2e-5.  beta,
+    embedding, lidar head, decoder: floors of 1e-6 .. 7e-5, so their bound is the 1e-4 .. 4e-4 one."""
     hip, refm = _build_pair(ref, with_actors)
     b = _batch(with_actors)
     _deterministic(hip, True), _deterministic(refm, True)
     assert hip.fused_training_possible()  # the fused nodes (static: ProposalRoundFn / NffRenderTrainFn; actors: OVR)
-    g_out, g_met, g_loss = _train_step(hip, b, "cuda")
-    w_out, w_met, w_loss = _train_step(refm, b, "cpu")
+    g_out, g_loss = _losses(hip, b, "cuda")
+    w_out, w_loss = _losses(refm, b, "cpu")
     assert set(g_loss) == set(w_loss), (sorted(g_loss), sorted(w_loss))
     for k in w_loss:
         a, c = float(g_loss[k]), float(w_loss[k])
         assert abs(a - c) <= 2e-4 * abs(c) + 1e-7, (k, a, c)
     for k in ("rgb", "depth", "accumulation", "intensity", "ray_drop_logits", "prop_depth_0", "prop_depth_1"):
         assert rel_l2(N(g_out[k]), N(w_out[k])) < 1e-4, (k, rel_l2(N(g_out[k]), N(w_out[k])))
-    want = dict(refm.named_parameters())
-    seen = set()
-    worst = {}
-    for name, p in hip.named_parameters():
-        wg = want[name].grad
-        if wg is None or float(wg.abs().max()) == 0.0:
-            assert p.grad is None or float(p.grad.abs().max()) < 1e-12, name
-            continue
-        assert p.grad is not None, f"{name}: the reference has a gradient, the plugin has none"
-        kind = _kind(name)
-        e = rel_l2(N(p.grad), N(wg))
-        worst[kind] = max(worst.get(kind, 0.0), e)
-        assert e < GRAD_TOL[kind], (name, kind, e)
-        seen.add(kind)
+    errs = per_loss_gradient_errors(hip, g_loss, refm, w_loss)
+    floors = _floors("actors3" if with_actors else "static")
+    seen, report = set(), {}
+    kind_floor = {}  # a kink flip moves every term that reaches the flipped sample: the kind's largest floor over the terms
+    for kinds in floors.values():
+        for kind, f in kinds.items():
+            kind_floor[kind] = max(kind_floor.get(kind, 0.0), f)
+    for term, kinds in errs.items():
+        for kind, e in kinds.items():
+            tol = max(5.0 * kind_floor.get(kind, 0.0), 1e-4)
+            report[f"{term}/{kind}"] = (float(f"{e:.1e}"), float(f"{tol:.1e}"))
+            assert e <= tol, (term, kind, e, tol)
+            seen.add(kind)
     need = {"table", "mlp", "beta", "embedding", "lidar_head", "decoder"} | ({"actor_grid", "trajectory"} if with_actors
                                                                              else set())
-    assert need <= seen, (need - seen, worst)
-    print("worst rel-L2 per parameter kind:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+    assert need <= seen, (need - seen)
+    # the terms that reach every parameter of the hot path are tight in absolute terms, whatever the floor file says
+    for term in ("rgb_loss", "interlevel_loss"):
+        for kind, e in errs[term].items():
+            if kind in ("table", "mlp", "embedding", "decoder"):
+                assert e < 2e-4, (term, kind, e)
+    print("rel-L2 (got, tolerance) per loss term / parameter kind:", report)
 
 
 def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
@@ -316,13 +357,14 @@ def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
     hip, refm = _build_pair(ref, False, fused_decoder=True)
     b = _batch(False)
     _deterministic(hip, True), _deterministic(refm, True)
-    g_out, _, g_loss = _train_step(hip, b, "cuda")
-    w_out, _, w_loss = _train_step(refm, b, "cpu")
+    g_out, g_loss = _losses(hip, b, "cuda")
+    w_out, w_loss = _losses(refm, b, "cpu")
+    sum(g_loss.values()).backward(), sum(w_loss.values()).backward()
     assert rel_l2(N(g_out["rgb"]), N(w_out["rgb"])) < 3e-3
     for k in w_loss:
         tol = 5e-3 if k == "rgb_loss" else 2e-4
         assert abs(float(g_loss[k]) - float(w_loss[k])) <= tol * abs(float(w_loss[k])) + 1e-7, k
     want = dict(refm.named_parameters())
     for name, p in hip.named_parameters():
-        if name.startswith("rgb_decoder") and want[name].grad is not None and float(want[name].grad.abs().max()) > 0:
+        if name.startswith("rgb_decoder") and not _analytically_zero(name) and want[name].grad is not None:
             assert rel_l2(N(p.grad), N(want[name].grad)) < 2e-2, name
