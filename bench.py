@@ -127,22 +127,45 @@ def timed(step, steps, warmup, world, device):
     return el
 
 
-class _Optimizers:
-    """the reference's two Adam groups (configs/method_configs.py:415-426): hash tables -> HashGridAdam (csrc/adam.hip,
-    torch.optim.Adam arithmetic, one streaming kernel per table), everything else -> torch's fused Adam"""
+def _fused(cls, params, **kw):
+    try:
+        return cls(params, fused=True, **kw)
+    except (RuntimeError, TypeError):
+        return cls(params, **kw)
 
-    def __init__(self, params):
+
+def _split_groups(params, groups):
+    """-> {"hashgrids": [...], "fields": [...], "cnn": [...]}: the reference's parameter groups (models/neurad.py:280-289,
+    get_param_groups).  Without an explicit assignment: the tables (>= 2^16 elements) are `hashgrids`, the rest `fields`."""
+    params = list(params)
+    if groups is None:
+        return {"hashgrids": [p for p in params if p.numel() >= 1 << 16], "fields": [p for p in params if p.numel() < 1 << 16],
+                "cnn": [], "trajectory_opt": []}
+    ids = {id(p) for p in params}
+    out = {k: [p for p in groups.get(k, []) if id(p) in ids and p.requires_grad] for k in ("hashgrids", "fields", "cnn")}
+    taken = {id(p) for v in out.values() for p in v}
+    # what no group names: the actor trajectories (the reference's `trajectory_opt`, Adam lr 1e-3: ad_model.py:75-79)
+    out["trajectory_opt"] = [p for p in params if id(p) not in taken]
+    assert sum(len(v) for v in out.values()) == len(params), "every trained parameter belongs to exactly one group"
+    return out
+
+
+class _Optimizers:
+    """the reference's optimizer groups (configs/method_configs.py:415-426): `hashgrids` Adam(lr=1e-2, eps=1e-15) ->
+    HashGridAdam (csrc/adam.hip, torch.optim.Adam arithmetic, one streaming kernel per table); `fields` AdamW(lr=1e-2,
+    eps=1e-15, weight_decay=1e-7) and `cnn` AdamW(lr=1e-3, eps=1e-15, weight_decay=1e-6) -> torch's fused AdamW"""
+
+    def __init__(self, params, groups=None):
         from neurad_studio_amd.optim import HashGridAdam
 
-        params = list(params)
-        tables = [p for p in params if p.numel() >= 1 << 16]
-        small = [p for p in params if p.numel() < 1 << 16]
-        self.opts = [HashGridAdam(tables, lr=1e-3, eps=1e-15)] if tables else []
-        if small:
-            try:
-                self.opts.append(torch.optim.Adam(small, lr=1e-3, eps=1e-15, fused=True))
-            except (RuntimeError, TypeError):
-                self.opts.append(torch.optim.Adam(small, lr=1e-3, eps=1e-15))
+        g = _split_groups(params, groups)
+        self.opts = [HashGridAdam(g["hashgrids"], lr=1e-2, eps=1e-15)] if g["hashgrids"] else []
+        if g["fields"]:
+            self.opts.append(_fused(torch.optim.AdamW, g["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7))
+        if g["cnn"]:
+            self.opts.append(_fused(torch.optim.AdamW, g["cnn"], lr=1e-3, eps=1e-15, weight_decay=1e-6))
+        if g["trajectory_opt"]:
+            self.opts.append(_fused(torch.optim.Adam, g["trajectory_opt"], lr=1e-3, eps=1e-15))
 
     def zero_grad(self, set_to_none=True):
         for o in self.opts:
@@ -157,27 +180,35 @@ class _ShardedOptimizers(_Optimizers):
     """--sharded-adam at N > 1: the hash tables on parallel/sharded_adam.py (their reduce-scatter IS the gradient exchange,
     Adam runs on 1/N of each table, the updated parameters are all-gathered); the GradientSynchronizer skips them"""
 
-    def __init__(self, params):
+    def __init__(self, params, groups=None):
         from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
 
-        params = list(params)
-        self.tables = [p for p in params if p.numel() >= 1 << 16]
-        small = [p for p in params if p.numel() < 1 << 16]
-        self.sharded = ShardedTableAdam(self.tables, lr=1e-3, eps=1e-15, usage="static")
+        g = _split_groups(params, groups)
+        self.tables = g["hashgrids"]
+        self.sharded = ShardedTableAdam(self.tables, lr=1e-2, eps=1e-15, usage="static")
         self.opts = [self.sharded]
-        if small:
-            self.opts.append(torch.optim.Adam(small, lr=1e-3, eps=1e-15, fused=True))
+        if g["fields"]:
+            self.opts.append(_fused(torch.optim.AdamW, g["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7))
+        if g["cnn"]:
+            self.opts.append(_fused(torch.optim.AdamW, g["cnn"], lr=1e-3, eps=1e-15, weight_decay=1e-6))
+        if g["trajectory_opt"]:
+            self.opts.append(_fused(torch.optim.Adam, g["trajectory_opt"], lr=1e-3, eps=1e-15))
 
     def owned_params(self):
         return self.tables
 
 
-def make_optimizer(params, sharded=False):
+_OPT_GROUPS = ("the reference's groups (configs/method_configs.py:415-426): hashgrids Adam(lr 1e-2, eps 1e-15), fields AdamW(lr 1e-2, "
+               "wd 1e-7), cnn AdamW(lr 1e-3, wd 1e-6); ")
+
+
+def make_optimizer(params, sharded=False, groups=None):
     if sharded:
-        return _ShardedOptimizers(params), ("Adam: hash tables on ShardedTableAdam (reduce-scatter of the gradient, Adam on the "
-                                            "rank's shard via nrhip_adam_step, all-gather of the parameters), MLPs on torch "
-                                            "fused Adam")
-    return _Optimizers(params), "Adam: hash tables on nrhip_adam_step (dense, torch.optim.Adam arithmetic), MLPs on torch fused Adam"
+        return _ShardedOptimizers(params, groups), (_OPT_GROUPS + "hash tables on ShardedTableAdam (reduce-scatter of the "
+                                                    "gradient, Adam on the rank's shard via nrhip_adam_step, all-gather of the "
+                                                    "parameters), the rest on torch's fused AdamW")
+    return _Optimizers(params, groups), (_OPT_GROUPS + "hash tables on nrhip_adam_step (dense, torch.optim.Adam arithmetic), the "
+                                         "rest on torch's fused AdamW")
 
 
 def train_section(device, rank, world, steps, warmup, beta=None, table_scale=None):
@@ -305,7 +336,8 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
         for p in m.proposal_fields:
             p.hashgrid.static_grid.hash_table.mul_(2000.0)
     params = [p for p in m.parameters() if p.requires_grad] + ([] if dec is None else list(dec.parameters()))
-    opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1)
+    groups = dict(m.get_param_groups(), cnn=[] if dec is None else list(dec.parameters()))
+    opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1, groups=groups)
     # static scene: the used-parameter set is agreed once (no per-step host read); the proposal tables' exchange starts
     # from their gradient hooks, under the field backward
     level_tables = None
@@ -313,7 +345,8 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
         grids = [m.field.hashgrid.static_grid] + [p.hashgrid.static_grid for p in m.proposal_fields]
         level_tables = {g.hash_table: g.num_levels for g in grids if g.hash_table.dtype == torch.float32}
     sync = GradientSynchronizer(params, average=True, usage="static", overlap=world > 1,
-                                skip=opt.owned_params() if hasattr(opt, "owned_params") else (), level_tables=level_tables)
+                                skip=opt.owned_params() if hasattr(opt, "owned_params") else (), level_tables=level_tables,
+                                profile=world > 1)
     o, d, area, times, md = joint_batch(device, rank, n_cam, n_lidar)
     R = n_cam + n_lidar
     g = torch.Generator(device=device)
@@ -422,6 +455,10 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
             "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
                               f"{sync.last_list_levels}") if level_tables else "dense reduce-scatter + all-gather",
+            # N > 1: what the exchange costs the step and how much of it the hooks hid (GradientSynchronizer.timing)
+            "grad_exchange_timing": dict(sync.timing(last=steps),
+                                         wire_bytes_by_table={("small" if i < 0 else f"param{i}:{tuple(sync.params[i].shape)}"): b
+                                                              for i, b in sync.last_wire_bytes_by_param.items()}) if world > 1 else None,
             "optimizer": opt_name,
             "rgb_decoder": ("CNN decoder (4 BasicBlocks of 7x7 convs + BatchNorm, 3x transposed conv) + rgb MSE in the step, "
                             + ("torch modules = MIOpen under fp16 autocast" if torch_decoder else
@@ -431,7 +468,29 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "rgb_decoder_fwd_bwd_ms": dec_ms,
             "what": "BASELINE config[3] shape per GPU: NeuRAD-default grids, sampler (2 rounds) + field + compositing + "
                     "appearance + lidar head" + (" + RGB CNN decoder" if dec is not None else "") +
-                    " + rgb/lidar/interlevel/distortion losses, backward, gradient exchange, Adam"}
+                    " + rgb/lidar/interlevel/distortion losses, backward, gradient exchange, optimizer step.  NOT in it: the "
+                    "VGG perceptual term of the reference's step (models/neurad.py:260,538: a torchvision network outside the hot "
+                    "path, SURVEY §8) -- so this figure must not be set beside the reference's it/s of its full trainer"}
+
+
+def device_state(device_index=0):
+    """clocks / power state of the GPU when the run starts (rocm-smi): the pool's boxes differ by ~10 % on the same kernel
+    (round 3: 169 us on the builder's best box, 185 us on the driver's) -- with this in the line the spread is attributable"""
+    import subprocess
+
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
+                            "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = d.get(f"card{device_index}", next(iter(d.values())))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level")):
+                keep[k] = v
+        return keep or {"raw": r.stdout[:400]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
 def cpu_baseline(fs, origins, dirs, area, edges, budget_s=12.0):
@@ -787,7 +846,8 @@ def bench_c4(args, device, rank, world):
     """BASELINE config[4]: 65 536 rays per GPU, appearance embedding (16-d), 32 dynamic actors, the main field's static and
     actor tables stored as fp16.  Step = one eval pass of get_outputs_for_ray_bundle (fused proposal sampler with per-sample
     actor select + fused field / compositing with per-sample table select + appearance); the line also carries one
-    training step of the same scene (operator-level actor path, fp16-storage tables on HashGridAdam's fp32 master copy)."""
+    training step of the same scene on all 65 536 rays (fused nodes with row overrides, fp16-storage static + actor tables
+    on HashGridAdam's fp32 master copies)."""
     from neurad_studio_amd import ops
     from neurad_studio_amd.cameras.rays import RayBundle
     from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
@@ -907,26 +967,35 @@ def bench_c4(args, device, rank, world):
                          "bytes_per_sample": "8 levels x 8 corners x 4 features x 2 B = 512 B (256 B for a sample inside an "
                                              "actor box: its 4-level grid) + 8 B interval + per-ray I/O / S"}}
         out["train_step"] = None
-    # ---- one training step of the same scene (operator-level path with actors) ----
+    # ---- the training step of the same scene, whole batch (fused nodes with per-sample row overrides for the in-box samples) ----
     del state["out"]
     torch.cuda.empty_cache()
     m.train()
-    with torch.no_grad():  # the operator-level actor path of TRAINING reads fp32 actor grids (the 537 MB static table, the one
-        for gr in m.field.hashgrid.actor_grids:  # that matters, stays fp16 with its fp32 master copy in the optimizer)
-            gr.hash_table.data = gr.hash_table.data.float()
     params = [p for p in m.parameters() if p.requires_grad]
-    opt, opt_name = make_optimizer(params)
+    opt, opt_name = make_optimizer(params, groups=m.get_param_groups())
     from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
 
     sync = GradientSynchronizer(params, average=True, usage="dynamic")
-    Rt = 16384
+    Rt = int(os.environ.get("NRHIP_C4_TRAIN_RAYS", R))  # the whole batch
     target = torch.rand((Rt, 48), device=device)
+    ev_t = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(16)]
+    real_field_train = ops.field_fwd_train
 
-    def tstep(_i=None):
+    def timed_field_train(*a, **k):  # HIP events around the step's largest kernel (fused training forward of the field)
+        e = state.get("ev_t")
+        if e is not None:
+            e[0].record()
+        r = real_field_train(*a, **k)
+        if e is not None:
+            e[1].record()
+        return r
+
+    def tstep(i=None):
+        state["ev_t"] = ev_t[i] if i is not None and i < len(ev_t) else None
         rb = RayBundle(origins=o[:Rt], directions=d[:Rt], pixel_area=area[:Rt].clone(), times=times[:Rt],
                        metadata={"sensor_idxs": sens[:Rt]})
         nff = m.get_nff_outputs(rb)
-        loss = (5.0 * (nff["features"] - target).square().mean()
+        loss = (5.0 * torch.nn.functional.mse_loss(nff["features"], target)
                 + 0.001 * zipnerf_interlevel_loss(nff["weights_list"], nff["ray_samples_list"])
                 + 0.002 * distortion_loss(nff["weights_list"], nff["ray_samples_list"]))
         opt.zero_grad(set_to_none=True)
@@ -936,14 +1005,32 @@ def bench_c4(args, device, rank, world):
         state["loss"] = loss
 
     tsteps = max(3, min(args.train_steps // 6, 10))
-    el = timed(tstep, tsteps, 3, world, device)
+    ops.field_fwd_train = timed_field_train
+    try:
+        el = timed(tstep, tsteps, 3, world, device)
+    finally:
+        ops.field_fwd_train = real_field_train
     if rank == 0:
+        f_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_t[:tsteps]]))
+        # the fused training forward moves, per field sample: fp16 table reads (8 levels x 8 corners x 4 features x 2 B; the
+        # in-box samples take their rows from the override list instead) + 8 B interval + saved activations + outputs
+        per = 8 * 8 * 4 * 2 + 8 + (32 + 32 + 48 + 64) * 4 + 34 * 4
+        t_alg = Rt * S * per
         out["train_step"] = {"ms_per_iter": el / tsteps * 1e3, "iters_per_sec": tsteps / el, "rays_per_gpu": Rt,
+                             "us_per_ray": el / tsteps * 1e6 / Rt,
                              "rays_per_sec": world * Rt * tsteps / el, "optimizer": opt_name, "loss_finite": bool(torch.isfinite(state["loss"])),
-                             "what": "16384 rays of the same scene: sampler + field with actors (operator-level actor path) + "
-                                     "compositing + appearance, feature / interlevel / distortion losses, backward, Adam "
-                                     "(fp16-storage static table on an fp32 master copy; the 32 actor grids, 8 MB each, in fp32 for "
-                                     "this step: the operator-level actor path reads fp32 actor grids)"}
+                             "roofline": {"kernel": "nrhip::render_kernel<8,4,32,fp16,train,OVR> (fused training forward of the field with "
+                                                    "row overrides; HIP events around nrhip_field_fwd_train_ovr in the timed steps)",
+                                          "bound": "hbm", "achieved": t_alg / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": t_alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": f_ms,
+                                          "algorithmic_bytes_per_launch": t_alg},
+                             "what": f"all {Rt} rays of the scene in one step: sampler rounds with the actor overlay (in-box "
+                                     "samples spliced in by nrhip_actor_density_splice_*), fused field + SDF head + compositing + "
+                                     "appearance with per-sample row overrides for the in-box samples, feature / interlevel / "
+                                     "distortion losses, backward (actor grids, trajectories), the reference's optimizer groups; the "
+                                     f"main field's static table and its {A} actor grids are fp16 storage (HashGridAdam: fp32 master "
+                                     "copies in the optimizer state, the fp16 gradient read and the fp16 table written inside the "
+                                     "kernel); the proposal fields' tables are fp32"}
     return out
 
 
@@ -983,13 +1070,37 @@ def main():
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dist_info = None
     if world > 1:
+        import socket
+
         import torch.distributed as dist
 
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        # fail loudly on a mis-launch instead of timing N replicas of one GPU: the group has --gpus ranks and (outside the
+        # gloo rehearsal) every rank of a host owns a different device
+        if dist.get_world_size() != args.gpus:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        try:
+            uuid = str(torch.cuda.get_device_properties(dev_index).uuid)
+        except Exception:  # noqa: BLE001
+            uuid = f"index{dev_index}"
+        mine = (socket.gethostname(), torch.cuda.current_device(), uuid)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if not rehearsal and len({(h, u) for h, _, u in everyone}) != world:
+            raise RuntimeError(f"ranks share a GPU: {everyone} (launch one rank per device, or set NRHIP_DIST_BACKEND=gloo for "
+                               "the labelled one-GPU rehearsal)")
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = None
+        dist_info = {"backend": backend, "rccl_version": rccl, "devices": [f"{h}:{i}" for h, i, _ in everyone],
+                     "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE"))}}
+    dev_state = device_state(dev_index) if rank == 0 else None
 
     if args.config == "c2":
         out = bench_c2(args, device, rank, world)
@@ -1084,6 +1195,9 @@ def main():
                                    "CPU (models/neurad.py:713-715); the oracle restates its dense formulas (DESIGN.md §3)",
                     "field": "oracle pinned to the reference's own outputs (tests/golden/, oracle/make_golden*.py)"}
     if rank == 0:
+        out["device_state"] = dev_state
+        if dist_info is not None:
+            out["dist"] = dist_info
         if rehearsal:
             out["rehearsal"] = (f"{world} ranks over {backend} on {n_dev} visible GPU(s): a run of the N > 1 code path (process "
                                 "group, gradient hooks, exchange, max-over-ranks timing), NOT a scaling measurement")

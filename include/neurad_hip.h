@@ -345,6 +345,25 @@ int nrhip_lidar_point_sample(const int64_t* shuffle, const double* draws, const 
 int nrhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, double lr,
                     double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
+/* The same update for MANY tensors in one launch per 24 tensors (the per-actor grids: 66 launches -> 3 on a 32-actor
+ * scene), with two extras per tensor: grad_dtype 1 = the gradient is fp16 (what autograd hands an fp16-storage table),
+ * converted in registers; image_fp16 != NULL = `param` is the fp32 MASTER copy of an fp16-storage table and the rounded
+ * new value is written to image_fp16 in the same pass (no .float() / copy_ passes over the table).  step is per tensor
+ * (a table no ray touched keeps its count: optim.py skips it, as torch.optim.Adam skips parameters without a gradient). */
+typedef struct nrhip_adam_tensor {
+  float* param;        /* [n] fp32: the tensor the update runs on                    */
+  const void* grad;    /* [n] fp32 or fp16 (grad_dtype)                               */
+  float* exp_avg;      /* [n] fp32                                                    */
+  float* exp_avg_sq;   /* [n] fp32                                                    */
+  void* image_fp16;    /* [n] fp16 or NULL                                            */
+  int64_t n;
+  int64_t step;        /* >= 1, this tensor's step count AFTER the increment          */
+  int32_t grad_dtype;  /* 0 fp32, 1 fp16                                              */
+  int32_t reserved;
+} nrhip_adam_tensor;
+int nrhip_adam_step_many(const nrhip_adam_tensor* tensors /* HOST array */, int32_t n_tensors, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, double grad_scale, void* stream);
+
 /* Processing order for cache locality (fills nrhip_rays.order): a permutation that groups rays looking at the same
  * region -- counting sort by the Morton code of the contracted position (ScaledSceneContraction, static_scale as in
  * nrhip_field) of the point origin + direction * t_ref, t_ref = a representative sample distance (the sampler's
@@ -460,6 +479,21 @@ int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip_rays* rays
                                    const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip,
                                    int64_t n_pairs, const float* grad_x01, const float* grad_cstd,
                                    float* grad_positions, float* grad_rotations_6d, void* stream);
+
+/* Proposal density of the in-box samples in TRAINING (fields/neurad_field.py:208-213 over neurad_encoding.py:150-187,
+ * index_put order :184-185): rows [P, row_dim] = rescaled actor features of the P (sample, actor) pairs, decoder_weight
+ * [row_dim], sample_idx [P] int64 flat sample index, winner [P] u8 (the pair whose actor the forward uses: the highest index
+ * containing the sample; exactly one per hit sample).
+ * fwd: density [N] IN/OUT -- the winners' trunc_exp(rows . w) overwrite the static density of their samples; logit [P] out.
+ * bwd: grad_density [N] IN/OUT = the caller's copy of grad_out, zeroed here at the hit samples; grad_rows [P, row_dim] out
+ *      (winners: through trunc_exp's backward exp(clamp(logit, +-15)), field_components/activations.py:37-41; shadowed pairs:
+ *      grad_out * merged density * w, the duplicate-index gradient of the reference's index_put); grad_decoder [row_dim]
+ *      ACCUMULATES (caller zeroes) and comes from the winners only.                                                        */
+int nrhip_actor_density_splice_fwd(const float* rows, int32_t row_dim, const float* decoder_weight, const int64_t* sample_idx,
+                                   const uint8_t* winner, int64_t n_pairs, float* density, float* logit, void* stream);
+int nrhip_actor_density_splice_bwd(const float* rows, int32_t row_dim, const float* decoder_weight, const int64_t* sample_idx,
+                                   const uint8_t* winner, const float* logit, const float* density_out, const float* grad_out,
+                                   int64_t n_pairs, float* grad_density, float* grad_rows, float* grad_decoder, void* stream);
 
 /* F1+C1+C2 with dynamic actors in ONE kernel (eval): nrhip_render_fwd_ex where a sample inside an actor's box reads
  * that actor's grid at its box-frame position and uses the box-frame view direction -- NeuRADHashEncoding.forward

@@ -64,6 +64,12 @@ class RgbDecoder(C.Structure):
                 ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
 
 
+class AdamTensor(C.Structure):  # nrhip_adam_tensor
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("image_fp16", C.c_void_p), ("n", C.c_int64), ("step", C.c_int64), ("grad_dtype", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class OccGrid(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
 
@@ -154,6 +160,8 @@ PROTOTYPES = {
     "nrhip_patch_sample": [P, P, I64, I32, I32, I32, I32, I32, I32, P, P, I32, P, P, P, P],
     "nrhip_lidar_point_sample": [P, P, P, P, P, I32, I32, I32, I64, P, P, P],
     "nrhip_adam_step": [P, P, P, P, I64, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P],
+    "nrhip_adam_step_many": [C.POINTER(AdamTensor), I32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                             P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],
@@ -168,6 +176,8 @@ PROTOTYPES = {
     "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],
     "nrhip_actor_pair_positions_fwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P],
     "nrhip_actor_pair_positions_bwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P, P, P],
+    "nrhip_actor_density_splice_fwd": [P, I32, P, P, P, I64, P, P, P],
+    "nrhip_actor_density_splice_bwd": [P, I32, P, P, P, P, P, P, I64, P, P, P, P],
     "nrhip_render_fwd_actors": [C.POINTER(Field), C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P, P, F32, P, P],
     "nrhip_occgrid_march": [C.POINTER(OccGrid), P, P, P, P, P, I64, F32, F32, F32, F32, I32, P, P, P, P, P, P],
     "nrhip_packed_visibility_from_alpha": [P, P, I64, F32, F32, P, P],

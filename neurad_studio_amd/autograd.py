@@ -80,10 +80,36 @@ class MultiHashGridFn(torch.autograd.Function):
     def backward(ctx, g):
         x, grid_id, *tables = ctx.saved_tensors
         g = g.contiguous()
-        gts = ops.hashgrid_multi_bwd(ctx.spec, len(tables), grid_id, x, g, present=ctx.present) \
+        gts = ops.hashgrid_multi_bwd(ctx.spec, len(tables), grid_id, x, g, present=ctx.present, out_dtype=tables[0].dtype) \
             if any(ctx.needs_input_grad[3:]) else [None] * len(tables)
         gx = ops.hashgrid_multi_bwd_input(ctx.spec, tables, grid_id, x, g) if ctx.needs_input_grad[0] else None
         return (gx, None, None, *gts)
+
+
+class ActorDensitySpliceFn(torch.autograd.Function):
+    """Proposal density with the in-box samples' values spliced in (fields/neurad_field.py:208-213 over
+    neurad_encoding.py:150-187): dens [N] static density, rows [P, La] rescaled actor features of the P (sample, actor)
+    pairs, weight [La] the decoder's first La columns, idx [P] flat sample index, winner [P] bool.  -> density [N].
+    One kernel each way (csrc/actors.hip actor_density_splice_*): winners through trunc_exp, shadowed pairs of overlapping
+    boxes with the reference's duplicate-index gradient, decoder gradient from the winners."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, dens, rows, weight, idx, winner):
+        out = dens.detach().reshape(-1).clone()
+        rows, weight = rows.detach().contiguous(), weight.detach().contiguous()
+        logit = ops.actor_density_splice_fwd(out, rows, weight, idx, winner)
+        ctx.save_for_backward(rows, weight, idx, winner, logit, out)
+        ctx.shape = dens.shape
+        return out.view(dens.shape)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        rows, weight, idx, winner, logit, out = ctx.saved_tensors
+        g_dens, g_rows, g_w = ops.actor_density_splice_bwd(rows, weight, idx, winner, logit, out, g.contiguous())
+        return (g_dens.view(ctx.shape) if ctx.needs_input_grad[0] else None, g_rows if ctx.needs_input_grad[1] else None,
+                g_w if ctx.needs_input_grad[2] else None, None, None)
 
 
 class EncodeFn(torch.autograd.Function):

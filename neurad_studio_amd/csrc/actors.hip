@@ -154,7 +154,7 @@ __device__ __forceinline__ ActorHit find_hit(const ActorsDev& a, const RaysDev& 
   return h;
 }
 
-template <int F>
+template <int F, bool HALF>
 __global__ __launch_bounds__(256) void actor_encode_kernel(ActorsDev a, RaysDev r,
                                                             const int32_t* __restrict__ cand_count,
                                                             const int32_t* __restrict__ cand_actor,
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void actor_encode_kernel(ActorsDev a, RaysDev 
   float* o = feat + i * out_dim;
   for (int l = 0; l < a.grid.L; ++l) {
     float v[F];
-    hash_level<F, false>(table, (uint32_t)l << a.grid.log2T, p.x, p.y, p.z, a.grid.scal[l], mask, v);
+    hash_level<F, HALF>(table, (uint32_t)l << a.grid.log2T, p.x, p.y, p.z, a.grid.scal[l], mask, v);
     const float w = rescale_weight(a.grid.scal[l], p.std);
 #pragma unroll
     for (int f = 0; f < F; ++f) o[l * F + f] = v[f] * w;
@@ -289,18 +289,25 @@ extern "C" int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays,
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(a->tables && a->actor_scale > 0.f && cand_count && cand_actor && cand_w2b && features,
              NRHIP_ERR_INVALID_ARG, "actor_encode: bad argument");
-  NR_REQUIRE(a->grid.param_dtype == 0, NRHIP_ERR_UNSUPPORTED, "actor grids: fp32 tables only");
   NR_REQUIRE(out_dim >= a->grid.num_levels * a->grid.n_features, NRHIP_ERR_INVALID_ARG,
              "actor_encode: out_dim %d < actor feature dim %d", out_dim, a->grid.num_levels * a->grid.n_features);
   const RaysDev rd = to_dev(*rays);
   const int blocks = grid_for(n, 256);
   const hipStream_t st = (hipStream_t)stream;
+#define CALL(F)                                                                                                              \
+  do {                                                                                                                       \
+    if (a->grid.param_dtype == 1)                                                                                            \
+      actor_encode_kernel<F, true><<<blocks, 256, 0, st>>>(d, rd, cand_count, cand_actor, cand_w2b, out_dim, features, directions, hit);  \
+    else                                                                                                                     \
+      actor_encode_kernel<F, false><<<blocks, 256, 0, st>>>(d, rd, cand_count, cand_actor, cand_w2b, out_dim, features, directions, hit); \
+  } while (0)
   switch (a->grid.n_features) {
-    case 1: actor_encode_kernel<1><<<blocks, 256, 0, st>>>(d, rd, cand_count, cand_actor, cand_w2b, out_dim, features, directions, hit); break;
-    case 2: actor_encode_kernel<2><<<blocks, 256, 0, st>>>(d, rd, cand_count, cand_actor, cand_w2b, out_dim, features, directions, hit); break;
-    case 4: actor_encode_kernel<4><<<blocks, 256, 0, st>>>(d, rd, cand_count, cand_actor, cand_w2b, out_dim, features, directions, hit); break;
-    default: actor_encode_kernel<8><<<blocks, 256, 0, st>>>(d, rd, cand_count, cand_actor, cand_w2b, out_dim, features, directions, hit); break;
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    default: CALL(8); break;
   }
+#undef CALL
   return check_launch("actor_encode");
 }
 
@@ -502,6 +509,57 @@ __global__ __launch_bounds__(256) void actor_pair_positions_bwd_kernel(
   }
 }
 
+// ---- proposal density of the in-box samples, training (fields/neurad_field.py:208-213 with neurad_encoding.py:150-187) ----
+// density = trunc_exp(decoder . actor features) replaces the static density of every sample inside a box; of several boxes
+// containing a sample the highest actor index wins (the reference's index_put order), the shadowed pairs keep a gradient
+// path into THEIR actor's features (the reference hands the merged row's gradient to every duplicate index).  One pass over
+// the P (sample, actor) pairs each way instead of ~25 torch launches (two of them rocblas gemv calls on a 4-wide dot
+// product: 1.7 ms each at 65 536 rays).
+__global__ __launch_bounds__(256) void actor_density_splice_fwd_kernel(const float* __restrict__ rows, int la,
+                                                                        const float* __restrict__ w,
+                                                                        const int64_t* __restrict__ idx,
+                                                                        const uint8_t* __restrict__ winner, int64_t n_pairs,
+                                                                        float* __restrict__ dens, float* __restrict__ logit) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_pairs) return;
+  float acc = 0.f;
+  for (int k = 0; k < la; ++k) acc = fmaf(rows[p * la + k], w[k], acc);
+  logit[p] = acc;
+  if (winner[p]) dens[idx[p]] = expf(acc);  // one winner per sample: no race
+}
+
+__global__ __launch_bounds__(256) void actor_density_splice_bwd_kernel(
+    const float* __restrict__ rows, int la, const float* __restrict__ w, const int64_t* __restrict__ idx,
+    const uint8_t* __restrict__ winner, const float* __restrict__ logit, const float* __restrict__ dens_out,
+    const float* __restrict__ g_out, int64_t n_pairs, float* __restrict__ g_dens, float* __restrict__ g_rows,
+    float* __restrict__ g_w) {
+  __shared__ float part[4][NRHIP_MAX_LEVELS];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gl = 0.f;  // d loss / d logit of a winner pair (the decoder's gradient comes from the winners only)
+  if (p < n_pairs) {
+    const int64_t s = idx[p];
+    const float go = g_out[s];
+    float f;
+    if (winner[p]) {
+      g_dens[s] = 0.f;  // the static density of a hit sample is not in the output
+      gl = go * expf(fminf(fmaxf(logit[p], -15.f), 15.f));  // trunc_exp's backward (field_components/activations.py:37-41)
+      f = gl;
+    } else {
+      f = go * dens_out[s];  // shadowed pair: (shadow - shadow.detach()) * merged value
+    }
+    for (int k = 0; k < la; ++k) g_rows[p * la + k] = f * w[k];
+  }
+  for (int k = 0; k < la; ++k) {
+    float v = p < n_pairs ? gl * rows[p * la + k] : 0.f;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < la) atomicAdd(g_w + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 }  // namespace nrhip
 
 extern "C" int nrhip_actor_pair_positions_fwd(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
@@ -533,4 +591,33 @@ extern "C" int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip
       d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, grad_x01, grad_cstd, grad_positions,
       grad_rotations_6d);
   return check_launch("actor_pair_positions_bwd");
+}
+
+extern "C" int nrhip_actor_density_splice_fwd(const float* rows, int32_t row_dim, const float* decoder_weight,
+                                              const int64_t* sample_idx, const uint8_t* winner, int64_t n_pairs,
+                                              float* density, float* logit, void* stream) {
+  NR_REQUIRE(n_pairs >= 0 && row_dim >= 1 && row_dim <= NRHIP_MAX_LEVELS, NRHIP_ERR_INVALID_ARG,
+             "actor_density_splice_fwd: bad argument");
+  if (n_pairs == 0) return NRHIP_OK;
+  NR_REQUIRE(rows && decoder_weight && sample_idx && winner && density && logit, NRHIP_ERR_INVALID_ARG,
+             "actor_density_splice_fwd: NULL pointer");
+  actor_density_splice_fwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
+      rows, row_dim, decoder_weight, sample_idx, winner, n_pairs, density, logit);
+  return check_launch("actor_density_splice_fwd");
+}
+
+extern "C" int nrhip_actor_density_splice_bwd(const float* rows, int32_t row_dim, const float* decoder_weight,
+                                              const int64_t* sample_idx, const uint8_t* winner, const float* logit,
+                                              const float* density_out, const float* grad_out, int64_t n_pairs,
+                                              float* grad_density, float* grad_rows, float* grad_decoder, void* stream) {
+  NR_REQUIRE(n_pairs >= 0 && row_dim >= 1 && row_dim <= NRHIP_MAX_LEVELS, NRHIP_ERR_INVALID_ARG,
+             "actor_density_splice_bwd: bad argument");
+  if (n_pairs == 0) return NRHIP_OK;
+  NR_REQUIRE(rows && decoder_weight && sample_idx && winner && logit && density_out && grad_out && grad_density && grad_rows &&
+                 grad_decoder,
+             NRHIP_ERR_INVALID_ARG, "actor_density_splice_bwd: NULL pointer");
+  actor_density_splice_bwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
+      rows, row_dim, decoder_weight, sample_idx, winner, logit, density_out, grad_out, n_pairs, grad_density, grad_rows,
+      grad_decoder);
+  return check_launch("actor_density_splice_bwd");
 }

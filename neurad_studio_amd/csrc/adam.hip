@@ -11,6 +11,8 @@
 // their hashed rows are never addressed) and sparsely observed scenes are mostly such rows.
 // 16-byte accesses, grid-stride, no atomics; the state (step, exp_avg, exp_avg_sq) stays in torch.optim.Adam's
 // state_dict layout (neurad_studio_amd/optim.py), so checkpoints interchange.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace nrhip {
@@ -33,61 +35,172 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
   p = p * a.decay - a.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, AdamArgs a) {
-  const int64_t n4 = n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<const float4*>(m)[i];
-    float4 vv = reinterpret_cast<const float4*>(v)[i];
+// One tensor of a launch.  param is the fp32 tensor the update runs on (an fp32 table itself, or the fp32 MASTER copy of an
+// fp16-storage table); image (optional) is the fp16 table: the rounded new value is written there in the same pass.  The
+// gradient is fp32 or fp16 (autograd hands an fp16 parameter an fp16 gradient): converted in registers, no .float() pass.
+struct AdamTensor {
+  float* p;
+  const void* g;
+  float* m;
+  float* v;
+  __half* image;
+  int64_t n;
+  AdamArgs a;        // per tensor: untouched tables keep their step count, so bias corrections differ
+  int32_t grad_half;
+  int32_t block0;    // first workgroup of this tensor in a multi-tensor launch
+};
+
+template <bool GH>
+__device__ __forceinline__ float4 load_grad4(const void* g, int64_t i) {
+  if constexpr (GH) {
+    const uint2 raw = reinterpret_cast<const uint2*>(g)[i];
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+    const float2 hi = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+  } else {
+    return reinterpret_cast<const float4*>(g)[i];
+  }
+}
+
+template <bool GH>
+__device__ __forceinline__ void adam_tensor(const AdamTensor& t, int64_t first, int64_t stride) {
+  const int64_t n4 = t.n >> 2;
+  for (int64_t i = first; i < n4; i += stride) {
+    const float4 gv = load_grad4<GH>(t.g, i);
+    float4 mv = reinterpret_cast<const float4*>(t.m)[i];
+    float4 vv = reinterpret_cast<const float4*>(t.v)[i];
     const bool dead = gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f && mv.x == 0.f && mv.y == 0.f &&
                       mv.z == 0.f && mv.w == 0.f && vv.x == 0.f && vv.y == 0.f && vv.z == 0.f && vv.w == 0.f;
-    if (dead && a.decay == 1.f) continue;  // exact no-op: never-touched rows cost three reads
-    float4 pv = reinterpret_cast<float4*>(p)[i];
-    adam_elem(pv.x, gv.x, mv.x, vv.x, a);
-    adam_elem(pv.y, gv.y, mv.y, vv.y, a);
-    adam_elem(pv.z, gv.z, mv.z, vv.z, a);
-    adam_elem(pv.w, gv.w, mv.w, vv.w, a);
-    reinterpret_cast<float4*>(p)[i] = pv;
-    reinterpret_cast<float4*>(m)[i] = mv;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    if (dead && t.a.decay == 1.f) continue;  // exact no-op: never-touched rows cost three reads
+    float4 pv = reinterpret_cast<float4*>(t.p)[i];
+    adam_elem(pv.x, gv.x, mv.x, vv.x, t.a);
+    adam_elem(pv.y, gv.y, mv.y, vv.y, t.a);
+    adam_elem(pv.z, gv.z, mv.z, vv.z, t.a);
+    adam_elem(pv.w, gv.w, mv.w, vv.w, t.a);
+    reinterpret_cast<float4*>(t.p)[i] = pv;
+    reinterpret_cast<float4*>(t.m)[i] = mv;
+    reinterpret_cast<float4*>(t.v)[i] = vv;
+    if (t.image) {  // the fp16 table = the rounded master copy (round to nearest even, like Tensor.copy_)
+      const __half2 lo = __floats2half2_rn(pv.x, pv.y), hi = __floats2half2_rn(pv.z, pv.w);
+      uint2 raw;
+      raw.x = *reinterpret_cast<const uint32_t*>(&lo), raw.y = *reinterpret_cast<const uint32_t*>(&hi);
+      reinterpret_cast<uint2*>(t.image)[i] = raw;
+    }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
-    const int64_t i = (n4 << 2) + threadIdx.x;
-    adam_elem(p[i], g[i], m[i], v[i], a);
+  if (first < (t.n & 3)) {  // tail elements, one lane each
+    const int64_t i = (n4 << 2) + first;
+    float g;
+    if constexpr (GH) g = __half2float(reinterpret_cast<const __half*>(t.g)[i]);
+    else g = reinterpret_cast<const float*>(t.g)[i];
+    adam_elem(t.p[i], g, t.m[i], t.v[i], t.a);
+    if (t.image) t.image[i] = __float2half_rn(t.p[i]);
   }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamTensor t) {
+  const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (t.grad_half) adam_tensor<true>(t, first, stride);
+  else adam_tensor<false>(t, first, stride);
+}
+
+// Many small tensors (the per-actor grids: 32 + 32 tables of 0.1 - 2 M elements) in ONE launch: the descriptors ride in the
+// kernel arguments, workgroup b serves the tensor whose [block0, next block0) range contains it.
+constexpr int kAdamMany = 24;  // descriptors per launch (24 x 104 B < the 4 KB kernel-argument limit)
+struct AdamMany {
+  AdamTensor t[kAdamMany];
+  int32_t count;
+  int32_t total_blocks;
+};
+
+__global__ __launch_bounds__(256) void adam_many_kernel(AdamMany many) {
+  int k = 0;
+  while (k + 1 < many.count && (int)blockIdx.x >= many.t[k + 1].block0) ++k;  // (block-uniform; <= 24 steps)
+  const AdamTensor& t = many.t[k];
+  const int nblk = (k + 1 < many.count ? many.t[k + 1].block0 : many.total_blocks) - t.block0;
+  const int64_t first = (int64_t)((int)blockIdx.x - t.block0) * 256 + threadIdx.x, stride = (int64_t)nblk * 256;
+  if (t.grad_half) adam_tensor<true>(t, first, stride);
+  else adam_tensor<false>(t, first, stride);
 }
 
 }  // namespace nrhip
 
 using namespace nrhip;
 
+namespace {
+
+int make_args(const char* what, int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
+              double grad_scale, AdamArgs* a) {
+  NR_REQUIRE(step >= 1, NRHIP_ERR_INVALID_ARG, "%s: step >= 1 required", what);
+  NR_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., NRHIP_ERR_INVALID_ARG,
+             "%s: bad hyper-parameter", what);
+  // hyper-parameters arrive as doubles and every derived scalar is formed in double, then rounded once -- exactly what
+  // torch does with its Python floats
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  a->step_size = (float)(lr / bc1);
+  a->b2 = (float)beta2;
+  a->omb1 = (float)(1.0 - beta1), a->omb2 = (float)(1.0 - beta2);
+  a->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  a->eps = (float)eps;
+  a->decay = (float)(1.0 - lr * weight_decay);
+  a->grad_scale = (float)grad_scale;
+  return NRHIP_OK;
+}
+
+int blocks_for(int64_t n) {
+  int64_t blocks = ((n >> 2) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride: 16 workgroups per CU
+  return (int)blocks;
+}
+
+int check_tensor(const char* what, const float* param, const void* grad, const float* m, const float* v, const void* image) {
+  NR_REQUIRE(param && grad && m && v, NRHIP_ERR_INVALID_ARG, "%s: NULL pointer", what);
+  NR_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
+               reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(image)) & 15) == 0,
+             NRHIP_ERR_INVALID_ARG, "%s: tensors must be 16-byte aligned", what);
+  return NRHIP_OK;
+}
+
+}  // namespace
+
 extern "C" int nrhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                                double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
                                void* stream) {
   NR_REQUIRE(n >= 0 && step >= 1, NRHIP_ERR_INVALID_ARG, "adam_step: n >= 0 and step >= 1 required");
   if (n == 0) return NRHIP_OK;
-  NR_REQUIRE(param && grad && exp_avg && exp_avg_sq, NRHIP_ERR_INVALID_ARG, "adam_step: NULL pointer");
-  NR_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
-               reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
-             NRHIP_ERR_INVALID_ARG, "adam_step: tensors must be 16-byte aligned");
-  NR_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., NRHIP_ERR_INVALID_ARG,
-             "adam_step: bad hyper-parameter");
-  // hyper-parameters arrive as doubles and every derived scalar is formed in double, then rounded once -- exactly what
-  // torch does with its Python floats
-  AdamArgs a;
-  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-  a.step_size = (float)(lr / bc1);
-  a.b2 = (float)beta2;
-  a.omb1 = (float)(1.0 - beta1), a.omb2 = (float)(1.0 - beta2);
-  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  a.eps = (float)eps;
-  a.decay = (float)(1.0 - lr * weight_decay);
-  a.grad_scale = (float)grad_scale;
-  int64_t blocks = ((n >> 2) + 255) / 256;
-  if (blocks < 1) blocks = 1;
-  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride: 16 workgroups per CU
-  adam_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, a);
+  if (int e = check_tensor("adam_step", param, grad, exp_avg, exp_avg_sq, nullptr)) return e;
+  AdamTensor t{param, grad, exp_avg, exp_avg_sq, nullptr, n, {}, 0, 0};
+  if (int e = make_args("adam_step", step, lr, beta1, beta2, eps, weight_decay, grad_scale, &t.a)) return e;
+  adam_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream>>>(t);
   return check_launch("adam_step");
+}
+
+extern "C" int nrhip_adam_step_many(const nrhip_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                                    double eps, double weight_decay, double grad_scale, void* stream) {
+  NR_REQUIRE(n_tensors >= 0 && (tensors || n_tensors == 0), NRHIP_ERR_INVALID_ARG, "adam_step_many: bad argument");
+  int k = 0;
+  while (k < n_tensors) {
+    AdamMany many;
+    many.count = 0;
+    int blocks = 0;
+    for (; k < n_tensors && many.count < kAdamMany; ++k) {
+      const nrhip_adam_tensor& in = tensors[k];
+      NR_REQUIRE(in.n >= 0 && (in.grad_dtype == 0 || in.grad_dtype == 1), NRHIP_ERR_INVALID_ARG,
+                 "adam_step_many: tensor %d: n >= 0, grad_dtype 0 (fp32) or 1 (fp16)", k);
+      if (in.n == 0) continue;
+      if (int e = check_tensor("adam_step_many", in.param, in.grad, in.exp_avg, in.exp_avg_sq, in.image_fp16)) return e;
+      AdamTensor& t = many.t[many.count++];
+      t = AdamTensor{in.param, in.grad, in.exp_avg, in.exp_avg_sq, reinterpret_cast<__half*>(in.image_fp16), in.n, {},
+                     in.grad_dtype, blocks};
+      if (int e = make_args("adam_step_many", in.step, lr, beta1, beta2, eps, weight_decay, grad_scale, &t.a)) return e;
+      int b = blocks_for(in.n);
+      if (b > 1024) b = 1024;  // many tensors share the machine: 4 workgroups per CU each at most
+      blocks += b;
+    }
+    if (many.count == 0) continue;
+    many.total_blocks = blocks;
+    adam_many_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(many);
+    if (int e = check_launch("adam_step_many")) return e;
+  }
+  return NRHIP_OK;
 }

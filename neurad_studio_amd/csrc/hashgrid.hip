@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_kernel(GridDev g, const floa
 
 // several grids of one shape (the per-actor grids, neurad_encoding.py:270-295): sample i looks into
 // tables[grid_id[i]] -- one launch instead of one lookup per actor id.
-template <int F>
+template <int F, bool HALF>
 __global__ __launch_bounds__(256) void hashgrid_multi_fwd_kernel(GridDev g, const void* const* __restrict__ tables,
                                                                   const int32_t* __restrict__ grid_id,
                                                                   const float* __restrict__ x, int64_t n,
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void hashgrid_multi_fwd_kernel(GridDev g, cons
   const int l = (int)(t - i * g.L);
   const uint32_t mask = (1u << g.log2T) - 1u;
   float v[F];
-  hash_level<F, false>(tables[grid_id[i]], (uint32_t)l << g.log2T, x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask,
-                       v);
+  hash_level<F, HALF>(tables[grid_id[i]], (uint32_t)l << g.log2T, x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask,
+                      v);
   float* o = out + t * F;
 #pragma unroll
   for (int k = 0; k < F; ++k) o[k] = v[k];
@@ -528,12 +528,17 @@ extern "C" int nrhip_hashgrid_multi_fwd(const nrhip_grid* g, const void* const* 
   NR_REQUIRE(n >= 0 && n_grids >= 1, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_fwd: bad argument");
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(tables && grid_id && x && out, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_fwd: null pointer");
-  NR_REQUIRE(g->param_dtype == 0, NRHIP_ERR_UNSUPPORTED, "hashgrid_multi_fwd: fp32 tables only");
   const GridDev gd = to_dev(*g);
   const int blocks = grid_for(n * gd.L, 256);
-#define CALL(F) hashgrid_multi_fwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, tables, grid_id, x, n, out)
-  DISPATCH_F(gd.F, CALL);
+  if (g->param_dtype == 1) {  // fp16-storage grids (all grids of one call share the dtype)
+#define CALL(F) hashgrid_multi_fwd_kernel<F, true><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, tables, grid_id, x, n, out)
+    DISPATCH_F(gd.F, CALL);
 #undef CALL
+  } else {
+#define CALL(F) hashgrid_multi_fwd_kernel<F, false><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, tables, grid_id, x, n, out)
+    DISPATCH_F(gd.F, CALL);
+#undef CALL
+  }
   return check_launch("hashgrid_multi_fwd");
 }
 

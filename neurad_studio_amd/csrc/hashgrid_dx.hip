@@ -6,7 +6,7 @@
 
 namespace nrhip {
 
-template <int F>
+template <int F, bool HALF>
 __device__ __forceinline__ void dx_of_sample(const GridDev& g, const void* __restrict__ table,
                                              const float* __restrict__ x, const float* __restrict__ go, int64_t i,
                                              float* __restrict__ gx) {
@@ -18,7 +18,7 @@ __device__ __forceinline__ void dx_of_sample(const GridDev& g, const void* __res
     const Corners c = hash_corners(px, py, pz, sc, mask);
     float f[8][F];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) Entry<F, false>::load(table, ((uint32_t)l << g.log2T) + c.idx[k], f[k]);
+    for (int k = 0; k < 8; ++k) Entry<F, HALF>::load(table, ((uint32_t)l << g.log2T) + c.idx[k], f[k]);
     const float ox = c.ox, oy = c.oy, oz = c.oz, mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
     float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
@@ -37,24 +37,24 @@ __device__ __forceinline__ void dx_of_sample(const GridDev& g, const void* __res
   gx[3 * i] = ax, gx[3 * i + 1] = ay, gx[3 * i + 2] = az;
 }
 
-template <int F>
+template <int F, bool HALF>
 __global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(GridDev g, const void* __restrict__ table,
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ go, int64_t n,
                                                                   float* __restrict__ gx) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dx_of_sample<F>(g, table, x, go, i, gx);
+  if (i < n) dx_of_sample<F, HALF>(g, table, x, go, i, gx);
 }
 
 // several grids of one shape (the per-actor grids): sample i looks into tables[grid_id[i]]
-template <int F>
+template <int F, bool HALF>
 __global__ __launch_bounds__(256) void hashgrid_multi_bwd_input_kernel(GridDev g, const void* const* __restrict__ tables,
                                                                         const int32_t* __restrict__ grid_id,
                                                                         const float* __restrict__ x,
                                                                         const float* __restrict__ go, int64_t n,
                                                                         float* __restrict__ gx) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dx_of_sample<F>(g, tables[grid_id[i]], x, go, i, gx);
+  if (i < n) dx_of_sample<F, HALF>(g, tables[grid_id[i]], x, go, i, gx);
 }
 
 }  // namespace nrhip
@@ -67,16 +67,21 @@ extern "C" int nrhip_hashgrid_bwd_input(const nrhip_grid* g, const void* table, 
   NR_REQUIRE(n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_input: negative n");
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(table && x && grad_out && grad_x, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_input: null pointer");
-  NR_REQUIRE(g->param_dtype == 0, NRHIP_ERR_UNSUPPORTED, "hashgrid_bwd_input: fp32 tables only");
   const GridDev gd = to_dev(*g);
   const int blocks = grid_for(n, 256);
   const hipStream_t st = (hipStream_t)stream;
+#define CALL(F)                                                                        \
+  do {                                                                                 \
+    if (g->param_dtype == 1) hashgrid_bwd_input_kernel<F, true><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x);   \
+    else hashgrid_bwd_input_kernel<F, false><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x);                      \
+  } while (0)
   switch (gd.F) {
-    case 1: hashgrid_bwd_input_kernel<1><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x); break;
-    case 2: hashgrid_bwd_input_kernel<2><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x); break;
-    case 4: hashgrid_bwd_input_kernel<4><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x); break;
-    default: hashgrid_bwd_input_kernel<8><<<blocks, 256, 0, st>>>(gd, table, x, grad_out, n, grad_x); break;
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    default: CALL(8); break;
   }
+#undef CALL
   return check_launch("hashgrid_bwd_input");
 }
 
@@ -87,15 +92,20 @@ extern "C" int nrhip_hashgrid_multi_bwd_input(const nrhip_grid* g, const void* c
   NR_REQUIRE(n >= 0 && n_grids >= 1, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd_input: bad argument");
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(tables && grid_id && x && grad_out && grad_x, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd_input: null pointer");
-  NR_REQUIRE(g->param_dtype == 0, NRHIP_ERR_UNSUPPORTED, "hashgrid_multi_bwd_input: fp32 tables only");
   const GridDev gd = to_dev(*g);
   const int blocks = grid_for(n, 256);
   const hipStream_t st = (hipStream_t)stream;
+#define CALL(F)                                                                        \
+  do {                                                                                 \
+    if (g->param_dtype == 1) hashgrid_multi_bwd_input_kernel<F, true><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x);   \
+    else hashgrid_multi_bwd_input_kernel<F, false><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x);                      \
+  } while (0)
   switch (gd.F) {
-    case 1: hashgrid_multi_bwd_input_kernel<1><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
-    case 2: hashgrid_multi_bwd_input_kernel<2><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
-    case 4: hashgrid_multi_bwd_input_kernel<4><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
-    default: hashgrid_multi_bwd_input_kernel<8><<<blocks, 256, 0, st>>>(gd, tables, grid_id, x, grad_out, n, grad_x); break;
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    default: CALL(8); break;
   }
+#undef CALL
   return check_launch("hashgrid_multi_bwd_input");
 }

@@ -363,45 +363,33 @@ class NeuRADProposalField(nn.Module):
             with torch.no_grad():  # geometry of the actor branch: never differentiated here (require_actor_grad=False)
                 spec, cand = hg.prepare_actors(o, d, a, starts, ends, times)
                 merged = dens.detach().clone()
-                hit = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged,
-                                        flip)
+                hit_actor = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged,
+                                              flip, return_actor=True)
             if hg.wants_actor_grad() or (need_graph and self.density_decoder.weight.requires_grad):
-                dens = self._splice_actor_density(dens, hit, spec, cand, o, d, a, starts, ends, times, flip)
+                dens = self._splice_actor_density(dens, hit_actor, spec, cand, o, d, a, starts, ends, times, flip)
             else:
-                dens = torch.where(hit, merged, dens)
+                dens = torch.where(hit_actor >= 0, merged, dens)
         return dens[..., None], None
 
-    def _splice_actor_density(self, dens, hit, spec, cand, o, d, a, starts, ends, times, flip):
+    def _splice_actor_density(self, dens, hit_actor, spec, cand, o, d, a, starts, ends, times, flip):
         """Differentiable actor rows of the proposal density.  ``require_actor_grad=False`` (neurad_field.py:177) only
         keeps the POSES out of the graph (neurad_encoding.py:174-176); the actor grids and the decoder are trained
         through the in-box samples exactly as through the static ones: density = trunc_exp(decoder(pad(actor_feat)))."""
         hg = self.hashgrid
         with torch.no_grad():
             hits = ops.actor_hits(spec, cand, o, d, a, starts, ends)
-            hit_actor = hits.max(dim=-1).values  # the actor the kernel used: the highest index containing the sample
-        pr = hg.actor_pair_rows(hit_actor, hits, o, d, a, starts, ends, times, flip)
+            # (hit_actor: the actor nrhip_actor_density used, the highest index containing the sample -- what
+            # hits.max(-1) would find again with a 0.25 ms reduction over [N, K])
+        pr = hg.actor_pair_rows(hit_actor.reshape(-1), hits, o, d, a, starts, ends, times, flip)
         if pr is None:
             return dens
         idx, winner, rows = pr
         w = self.density_decoder.weight[0, : rows.shape[1]]     # features are zero-padded up to the static width
-        logit = rows @ w
-        shape = dens.shape
-        # No boolean indexing and no `if winner.all()`: both are device->host reads in the middle of the step.  The winner of
-        # a sample writes its value, every other pair adds 0 to the value -- the winner rows through `where`, the losers
-        # through a factor 0 -- so one index_put with accumulate over ALL pairs does it: the base is zeroed at the hit
-        # samples first (each has exactly one winner).
-        is_hit = torch.zeros_like(dens.reshape(-1), dtype=torch.bool).index_fill_(0, idx, True)
-        base = torch.where(is_hit, torch.zeros_like(dens.reshape(-1)), dens.reshape(-1))
-        win_val = trunc_exp(logit)
-        # overlapping boxes: the reference's features[ray, sample] = ... hands the merged row's gradient to every duplicate
-        # (neurad_encoding.py:184-185), value unchanged: (shadow - shadow.detach()) * merged value.  Only the shadowed
-        # actors' FEATURES see that gradient (the decoder's own comes from the winner): the weight is detached there.
-        shadow = rows @ w.detach()
-        merged = torch.zeros_like(base).index_put((idx,), torch.where(winner, win_val.detach(), torch.zeros_like(win_val)),
-                                                   accumulate=True)
-        lose_val = (shadow - shadow.detach()) * merged.index_select(0, idx)
-        flat = base.index_put((idx,), torch.where(winner, win_val, lose_val), accumulate=True)
-        return flat.view(shape)
+        # One kernel each way (autograd.ActorDensitySpliceFn).  The winner of a sample writes trunc_exp(rows . w); overlapping
+        # boxes: the reference's features[ray, sample] = ... hands the merged row's gradient to every duplicate index
+        # (neurad_encoding.py:184-185) with the value unchanged -- only the shadowed actors' FEATURES see that gradient, the
+        # decoder's own comes from the winner.  No boolean indexing, no host read.
+        return ag.ActorDensitySpliceFn.apply(dens, rows, w, idx, winner)
 
     def get_outputs(self, ray_samples, density_embedding=None) -> dict:
         return {}

@@ -193,7 +193,7 @@ def _ptr_array(tensors: Sequence[Tensor]) -> Tensor:
 def hashgrid_multi_fwd(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor, x: Tensor) -> Tensor:
     """sample i -> tables[grid_id[i]]: all actor grids in one launch"""
     x, grid_id = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32)
-    tables = [_chk(t, "table") for t in tables]
+    tables = [_chk(t, "table", tables[0].dtype) for t in tables]  # fp32 or fp16 storage, one dtype per call
     out = torch.empty((x.shape[0], spec.out_dim), device=x.device, dtype=torch.float32)
     g = spec.c_grid(tables[0])
     ptrs = _ptr_array(tables)
@@ -205,11 +205,12 @@ def hashgrid_multi_fwd(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor
 def grids_present(grid_id: Tensor, n_grids: int) -> List[bool]:
     """which grids a batch of rows refers to, as a host list (ONE device->host read; callers do it in the forward, right
     behind the read that sized the batch, so that the backward needs none)"""
-    return torch.bincount(grid_id, minlength=n_grids).gt(0).tolist()
+    # (a scatter of ones, not torch.bincount: bincount first reduces max(grid_id) over all rows -- 0.25 ms at 0.5 M rows)
+    return torch.zeros(n_grids, device=grid_id.device, dtype=torch.uint8).index_fill_(0, grid_id.long(), 1).tolist()
 
 
 def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, grad_out: Tensor,
-                       present: Optional[List[bool]] = None):
+                       present: Optional[List[bool]] = None, out_dtype=torch.float32):
     """-> one gradient per grid, None for grids no sample refers to (like the reference's per-id loop, which never
     touches them: their optimizer state must not decay).  present: ``grids_present(grid_id, n_grids)`` when the caller
     already has it -- the backward then runs without a device->host read and without a host->device copy."""
@@ -229,6 +230,9 @@ def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor,
     ptrs = torch.where(slot >= 0, slot * (flat[0].numel() * 4) + flat.data_ptr(), torch.zeros_like(slot))
     call("nrhip_hashgrid_multi_bwd", C.byref(g), n_grids, _ptr(grid_id), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(ptrs),
          _stream())
+    if out_dtype != torch.float32:  # fp16-storage grids: autograd wants the parameter's dtype -- ONE cast of the block
+        views = iter(flat.to(out_dtype).unbind(0))
+        gts = [next(views) if p else None for p in present]
     return gts
 
 
@@ -253,7 +257,7 @@ def _present_slots(present: Tuple[bool, ...], device) -> Tensor:
 
 def hashgrid_multi_bwd_input(spec: GridSpec, tables: Sequence[Tensor], grid_id: Tensor, x: Tensor, grad_out: Tensor):
     x, grid_id, grad_out = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32), _chk(grad_out, "grad_out")
-    tables = [_chk(t, "table") for t in tables]
+    tables = [_chk(t, "table", tables[0].dtype) for t in tables]
     gx = torch.empty_like(x)
     g = spec.c_grid(tables[0])
     ptrs = _ptr_array(tables)
@@ -949,8 +953,9 @@ def actor_hits(spec: ActorSpec, cand, origins, directions, pixel_area, starts, e
 
 
 def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, decoder_weight: Tensor,
-                  density: Tensor, ray_flip: Optional[Tensor] = None):
-    """Overwrites density [R,S] (in place) where the sample lies inside an actor box.  -> hit [R,S] bool"""
+                  density: Tensor, ray_flip: Optional[Tensor] = None, return_actor: bool = False):
+    """Overwrites density [R,S] (in place) where the sample lies inside an actor box.  -> hit [R,S] bool (return_actor: the
+    int32 index of the actor the kernel used -- the highest index containing the sample -- or -1)"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
     cnt, act, w2b, _ = cand
@@ -960,7 +965,7 @@ def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts
     hit = torch.empty((r.n_rays, r.n_samples), dtype=torch.int32, device=dens.device)
     call("nrhip_actor_density", C.byref(a), C.byref(r), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(dw), dw.numel(),
          _ptr(dens), _ptr(hit), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), _stream())
-    return hit >= 0
+    return hit if return_actor else hit >= 0
 
 
 @dataclass
@@ -978,6 +983,34 @@ class OccGridSpec:
             g.aabb[i] = v
         g.resolution, g.binaries = b.shape[0], b8.data_ptr()
         return g, b8
+
+
+def actor_density_splice_fwd(density: Tensor, rows: Tensor, weight: Tensor, sample_idx: Tensor, winner: Tensor):
+    """density [N] is overwritten at the hit samples by trunc_exp(rows . weight) of their winning pair -> logit [P]"""
+    rows, weight = _chk(rows, "rows"), _chk(weight, "weight")
+    idx, win = _chk(sample_idx, "sample_idx", torch.int64), winner.contiguous().view(torch.uint8) if winner.dtype == torch.bool else _chk(winner, "winner", torch.uint8)
+    P, la = rows.shape
+    if weight.numel() != la or idx.shape[0] != P or win.shape[0] != P or density.dtype != torch.float32 or not density.is_contiguous():
+        raise ValueError("actor_density_splice_fwd: shapes")
+    logit = torch.empty((P,), device=rows.device, dtype=torch.float32)
+    call("nrhip_actor_density_splice_fwd", _ptr(rows), la, _ptr(weight), _ptr(idx), _ptr(win), P, _ptr(density), _ptr(logit),
+         _stream())
+    return logit
+
+
+def actor_density_splice_bwd(rows, weight, sample_idx, winner, logit, density_out, grad_out: Tensor):
+    """-> grad_density [N] (grad_out, zero at the hit samples), grad_rows [P, la], grad_weight [la]"""
+    rows, weight = _chk(rows, "rows"), _chk(weight, "weight")
+    idx = _chk(sample_idx, "sample_idx", torch.int64)
+    win = winner.contiguous().view(torch.uint8) if winner.dtype == torch.bool else _chk(winner, "winner", torch.uint8)
+    g = _chk(grad_out.reshape(-1), "grad_out")
+    P, la = rows.shape
+    g_dens = g.clone()
+    g_rows = torch.empty_like(rows)
+    g_w = torch.zeros((la,), device=rows.device, dtype=torch.float32)
+    call("nrhip_actor_density_splice_bwd", _ptr(rows), la, _ptr(weight), _ptr(idx), _ptr(win), _ptr(_chk(logit, "logit")),
+         _ptr(_chk(density_out.reshape(-1), "density_out")), _ptr(g), P, _ptr(g_dens), _ptr(g_rows), _ptr(g_w), _stream())
+    return g_dens, g_rows, g_w
 
 
 def occgrid_march(grid: OccGridSpec, origins, directions, render_step_size, near_plane=0.0, far_plane=1e10,
@@ -1022,6 +1055,31 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
             raise ValueError(f"adam_step: {n} must be a contiguous fp32 GPU tensor of the parameter's shape")
     call("nrhip_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step), float(lr),
          float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream())
+
+
+def adam_step_many(items, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15, weight_decay: float = 0.0,
+                   grad_scale: float = 1.0) -> None:
+    """torch.optim.Adam / AdamW update of MANY tensors in one launch per 24 (csrc/adam.hip).  items: (param fp32, grad fp32 |
+    fp16, exp_avg, exp_avg_sq, step, image | None) -- ``image``: the fp16 table whose fp32 master copy ``param`` is; it
+    receives the rounded new values in the same pass."""
+    items = list(items)
+    if not items:
+        return
+    arr = (_lib.AdamTensor * len(items))()
+    for k, (param, grad, m, v, step, image) in enumerate(items):
+        for t, n in ((param, "param"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            if _chk(t, n).data_ptr() != t.data_ptr() or t.shape != param.shape:
+                raise ValueError(f"adam_step_many: {n} must be a contiguous fp32 GPU tensor of the parameter's shape")
+        if grad.dtype not in (torch.float32, torch.float16) or not grad.is_contiguous() or not grad.is_cuda or grad.shape != param.shape:
+            raise ValueError("adam_step_many: grad must be a contiguous fp32 / fp16 GPU tensor of the parameter's shape")
+        if image is not None and (image.dtype != torch.float16 or not image.is_contiguous() or image.shape != param.shape):
+            raise ValueError("adam_step_many: image must be a contiguous fp16 tensor of the parameter's shape")
+        a = arr[k]
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq = param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.image_fp16 = image.data_ptr() if image is not None else None
+        a.n, a.step, a.grad_dtype = param.numel(), int(step), 1 if grad.dtype == torch.float16 else 0
+    call("nrhip_adam_step_many", arr, len(items), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+         float(grad_scale), _stream())
 
 
 def device_info():

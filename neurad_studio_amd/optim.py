@@ -2,8 +2,10 @@
 
 ``HashGridAdam`` is torch.optim.Adam / AdamW for large fp32 tables: same hyper-parameters, same arithmetic, same
 ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter -- checkpoints written by the reference's
-``Optimizers`` wrapper, engine/optimizers.py:168-181, load into it and vice versa), one streaming kernel per table that
-skips the rows whose update is provably a no-op (csrc/adam.hip).  The reference's settings for its ``hashgrids`` group
+``Optimizers`` wrapper, engine/optimizers.py:168-181, load into it and vice versa), one streaming kernel per large table and
+one launch per 24 small ones (the per-actor grids) that skips the rows whose update is provably a no-op (csrc/adam.hip).
+fp16-storage tables: the kernel reads the fp16 gradient, updates the fp32 master copy in the optimizer state and writes the
+rounded fp16 table in the same pass.  The reference's settings for its ``hashgrids`` group
 are ``AdamOptimizerConfig(lr=1e-2, eps=1e-15)`` (configs/method_configs.py:423-426)."""
 from __future__ import annotations
 
@@ -37,19 +39,25 @@ class HashGridAdam(torch.optim.Optimizer):
             if group.get("amsgrad") or group.get("maximize") or (group["weight_decay"] and not group.get("decoupled_weight_decay", True)):
                 raise NotImplementedError("HashGridAdam: amsgrad / maximize / L2-in-gradient weight decay")
             b1, b2 = group["betas"]
+            items = []
             for p in group["params"]:
                 if p.grad is None:
                     continue  # untouched tables (an actor no ray hit): state must not decay, as in torch
                 st = self.state[p]
                 if not st:
+                    # the step count is kept as a host int beside torch's 0-d tensor: no tensor arithmetic and no .item() per
+                    # table and step (66 tables on a 32-actor scene)
                     st["step"] = torch.tensor(0.0)  # host scalar, like torch.optim.Adam(capturable=False)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = st["step"] + 1  # (a new tensor: a state_dict loaded from a live optimizer shares this scalar)
-                target, grad = p, p.grad
+                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+                step = int(st["step"]) + 1
+                st["step"] = torch.tensor(float(step))  # (a new tensor: a state_dict loaded from a live optimizer shares this scalar)
+                image = None
+                target = p
                 if p.dtype != torch.float32:
                     # fp16-storage table (BASELINE config 5): the update runs on an fp32 master copy kept in the
-                    # optimizer state (what tiny-cuda-nn does for its fp16 parameters); the table is its rounded image.
+                    # optimizer state (what tiny-cuda-nn does for its fp16 parameters); the table is its rounded image,
+                    # written by the same kernel, which also reads the fp16 gradient as it is (no .float() / copy_ passes).
                     # Checked by DTYPE, not by key presence: a state that went through a generic load_state_dict may
                     # hold these tensors cast to the parameter's dtype (torch does that to floating-point state).
                     if "master" not in st or st["master"].dtype != torch.float32:
@@ -57,11 +65,19 @@ class HashGridAdam(torch.optim.Optimizer):
                     for k in ("exp_avg", "exp_avg_sq"):
                         if st[k].dtype != torch.float32:
                             st[k] = st[k].float()
-                    target, grad = st["master"], p.grad.float()
-                ops.adam_step(target, grad, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), group["lr"], b1, b2,
-                              group["eps"], group["weight_decay"], 1.0 if grad_scale is None else grad_scale)
-                if target is not p:
-                    p.copy_(target)
+                    target, image = st["master"], p.detach()
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if grad.dtype not in (torch.float32, torch.float16):
+                    grad = grad.float()
+                items.append((target, grad, st["exp_avg"], st["exp_avg_sq"], step, image))
+            # one launch per 24 tensors (csrc/adam.hip): the large tables get the machine to themselves in their own launch
+            big = [it for it in items if it[0].numel() >= 1 << 24]
+            small = [it for it in items if it[0].numel() < 1 << 24]
+            for it in big:
+                ops.adam_step_many([it], group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                   1.0 if grad_scale is None else grad_scale)
+            ops.adam_step_many(small, group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                               1.0 if grad_scale is None else grad_scale)
         return loss
 
     def load_state_dict(self, state_dict) -> None:

@@ -75,7 +75,7 @@ class GradientSynchronizer:
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, average: bool = True,
                  large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False,
                  skip: Iterable[torch.nn.Parameter] = (),
-                 level_tables: Optional[Dict[torch.nn.Parameter, int]] = None) -> None:
+                 level_tables: Optional[Dict[torch.nn.Parameter, int]] = None, profile: bool = False) -> None:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         if overlap and usage != "static":
@@ -102,7 +102,12 @@ class GradientSynchronizer:
                     raise ValueError("level_tables: contiguous [levels * T, F] tables only")
                 self._levels[i] = int(n_levels)
         self.last_wire_bytes = 0        # bytes this rank SENT in the last sync()
+        self.last_wire_bytes_by_param: Dict[int, int] = {}  # ... per parameter index (large / level tables), "small" = -1
         self.last_list_levels: Dict[int, List[int]] = {}
+        # profile=True: device events around sync() and at the first hook-started exchange of every step -> timing()
+        self.profile = profile
+        self._ev_first_hook = None
+        self._ev_steps: List[Tuple[object, object, object]] = []  # (first hook | None, sync entry, sync exit)
         if overlap:
             for i, p in enumerate(self.params):
                 if self._is_large(p) and i not in self._levels:  # level tables wait for the agreed row counts
@@ -253,6 +258,9 @@ class GradientSynchronizer:
         if i in self._inflight:
             raise RuntimeError("GradientSynchronizer(overlap=True): a second backward reached parameter "
                                f"{i} before sync(); call sync() after every backward (gradient accumulation: overlap=False)")
+        if self.profile and self._ev_first_hook is None:
+            self._ev_first_hook = torch.cuda.Event(enable_timing=True)
+            self._ev_first_hook.record()
         self._start_large(i, async_op=True)
 
     @torch.no_grad()
@@ -261,9 +269,13 @@ class GradientSynchronizer:
         world = self.world_size()
         if world == 1 or not self.params:
             return 0
+        ev_in = None
+        if self.profile and self.params[0].is_cuda:
+            ev_in = torch.cuda.Event(enable_timing=True)
+            ev_in.record()
         used = self._used_mask()
         small, nbytes, level_todo = [], 0, []
-        self.last_wire_bytes, self.last_list_levels = 0, {}
+        self.last_wire_bytes, self.last_list_levels, self.last_wire_bytes_by_param = 0, {}, {}
         self.overlapped_last_step = len(self._inflight)
         for i, (p, u) in enumerate(zip(self.params, used)):
             if not u:
@@ -276,7 +288,8 @@ class GradientSynchronizer:
                 level_todo.append(i)
                 continue
             if i in self._inflight or self._is_large(g):
-                self.last_wire_bytes += 2 * (world - 1) * g.numel() * g.element_size() // world
+                self.last_wire_bytes_by_param[i] = 2 * (world - 1) * g.numel() * g.element_size() // world
+                self.last_wire_bytes += self.last_wire_bytes_by_param[i]
             if i in self._inflight:  # started from the hook: wait for the scatter, finish with the gather
                 work, flat, shard = self._inflight.pop(i)
                 work.wait()
@@ -288,9 +301,12 @@ class GradientSynchronizer:
                 small.append(g)
         assert not self._inflight, "a hooked gradient was not consumed by sync()"
         if level_todo:
+            before = self.last_wire_bytes
             self._sync_level_tables(level_todo)
+            self.last_wire_bytes_by_param[level_todo[0]] = self.last_wire_bytes - before  # (all level tables together)
         if small:
             flat = torch.cat([g.reshape(-1) for g in small])
+            self.last_wire_bytes_by_param[-1] = 2 * (world - 1) * flat.numel() * flat.element_size() // world
             self.last_wire_bytes += 2 * (world - 1) * flat.numel() * flat.element_size() // world
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
@@ -299,7 +315,31 @@ class GradientSynchronizer:
             for g in small:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
+        if ev_in is not None:
+            ev_out = torch.cuda.Event(enable_timing=True)
+            ev_out.record()
+            self._ev_steps.append((self._ev_first_hook, ev_in, ev_out))
+            self._ev_first_hook = None
+            if len(self._ev_steps) > 64:
+                self._ev_steps = self._ev_steps[-64:]
         return nbytes
+
+    def timing(self, last: int = 0) -> Dict[str, float]:
+        """profile=True: means over the recorded steps (the last ``last`` of them; 0 = all), in ms of the compute stream's
+        timeline.  exposed = sync() entry -> exit (waiting for the hook-started exchanges + everything sync() itself
+        exchanges: what the step pays); overlap_window = first hook-started exchange -> sync() entry (the part of the
+        backward the early exchanges could hide under).  Synchronizes the device."""
+        steps = self._ev_steps[-last:] if last else self._ev_steps
+        if not steps:
+            return {}
+        torch.cuda.synchronize()
+        exposed = [a.elapsed_time(b) for _, a, b in steps]
+        window = [h.elapsed_time(a) for h, a, _ in steps if h is not None]
+        out = {"exchange_exposed_ms": sum(exposed) / len(exposed), "steps": len(exposed),
+               "hook_started_exchanges_per_step": self.overlapped_last_step}
+        if window:
+            out["exchange_overlap_window_ms"] = sum(window) / len(window)
+        return out
 
     def remove_hooks(self) -> None:
         for h in self._hooks:

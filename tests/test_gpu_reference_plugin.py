@@ -352,19 +352,51 @@ def test_plugin_training_step_matches_the_reference_torch_model(ref, with_actors
 
 def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
     """the same step with decode_features' CNN on csrc/decoder.hip (fp16 operands, fp32 accumulation: the arithmetic of the
-    reference trainer's mixed precision) -- losses within the fp16 bound of the rgb term, hot-path gradients still tight
-    on everything the rgb loss does not dominate"""
+    reference trainer's mixed precision, configs/method_configs.py:401).  The yardstick for that arithmetic is the trainer's
+    own path -- the SAME torch modules under torch.autocast(fp16) on the GPU: against the reference's fp32 CPU model the HIP
+    decoder may not be further off than 2 x what autocast is (+ a floor), output, loss and every decoder gradient
+    (both are fp16 noise of 1 - 5 % on three 24 x 24 patches: the ratio of two such numbers scatters)."""
     hip, refm = _build_pair(ref, False, fused_decoder=True)
-    b = _batch(False)
+    b = _batch(False, patch=8, n_patches=3, n_lidar=24)  # 24 x 24 px patches: BatchNorm statistics over > 1000 pixels
     _deterministic(hip, True), _deterministic(refm, True)
-    g_out, g_loss = _losses(hip, b, "cuda")
     w_out, w_loss = _losses(refm, b, "cpu")
-    sum(g_loss.values()).backward(), sum(w_loss.values()).backward()
-    assert rel_l2(N(g_out["rgb"]), N(w_out["rgb"])) < 3e-3
+    sum(w_loss.values()).backward()
+    want = {n: p.grad for n, p in refm.named_parameters() if n.startswith("rgb_decoder") and not _analytically_zero(n)}
+
+    def run():
+        out, loss = _losses(hip, b, "cuda")
+        sum(loss.values()).backward()
+        return out, loss
+
+    g_out, g_loss = run()
+    got = {n: p.grad.clone() for n, p in hip.named_parameters() if n in want}
+    # the yardstick: torch modules under fp16 autocast in place of the HIP decoder, everything else unchanged
+    dec = hip._modules["rgb_decoder"]
+
+    class _Autocast(torch.nn.Module):
+        def forward(self, x):
+            with torch.autocast("cuda", dtype=torch.float16):
+                return dec(x).float()
+
+    hip.config.fused_decoder = False
+    hip._modules["rgb_decoder"] = _Autocast()
+    try:
+        for p in dec.parameters():
+            p.grad = None
+        a_out, a_loss = run()
+    finally:
+        hip._modules["rgb_decoder"] = dec
+        hip.config.fused_decoder = True
+    auto = {"rgb_decoder." + n: p.grad for n, p in dec.named_parameters()}
+    e_rgb, y_rgb = rel_l2(N(g_out["rgb"]), N(w_out["rgb"])), rel_l2(N(a_out["rgb"]), N(w_out["rgb"]))
+    assert e_rgb <= max(2.0 * y_rgb, 3e-3), (e_rgb, y_rgb)
     for k in w_loss:
-        tol = 5e-3 if k == "rgb_loss" else 2e-4
-        assert abs(float(g_loss[k]) - float(w_loss[k])) <= tol * abs(float(w_loss[k])) + 1e-7, k
-    want = dict(refm.named_parameters())
-    for name, p in hip.named_parameters():
-        if name.startswith("rgb_decoder") and not _analytically_zero(name) and want[name].grad is not None:
-            assert rel_l2(N(p.grad), N(want[name].grad)) < 2e-2, name
+        c = float(w_loss[k])
+        tol = max(2.0 * abs(float(a_loss[k]) - c) / abs(c), 5e-3) if k == "rgb_loss" else 2e-4
+        assert abs(float(g_loss[k]) - c) <= tol * abs(c) + 1e-7, (k, float(g_loss[k]), c)
+    report = {}
+    for n, c in want.items():
+        e, y = rel_l2(N(got[n]), N(c)), rel_l2(N(auto[n]), N(c))
+        report[n] = (float(f"{e:.1e}"), float(f"{y:.1e}"))
+        assert e <= max(2.0 * y, 5e-3), (n, e, y)
+    print("decoder gradients vs the reference fp32 model: (HIP decoder, torch autocast fp16):", report)
