@@ -199,6 +199,8 @@ __device__ __forceinline__ bool rows_are_zero(const float* __restrict__ g, int w
 
 // Where the samples and their feature gradients come from (pass A is otherwise identical):
 //   position(i) -> (x, y, z in [0,1]^3, aux);  grad(i, l, level scale, aux, gv[F]) -> dL/d(level-l features of sample i)
+__device__ __forceinline__ int coherent_rays_of(const RaysDev& r, int64_t first_sample, int64_t count);  // (see `prep`)
+
 struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray samples, gradient of the rescaled features
   RaysDev r;
   float scale;
@@ -221,6 +223,7 @@ struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray sample
   }
   int width;  // L * F
   __device__ bool silent(int64_t w0, int64_t n_rows) const { return rows_are_zero(go, width, w0, n_rows); }
+  __device__ int coherent_rays(int64_t first, int64_t count) const { return coherent_rays_of(r, first, count); }
 };
 struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   const float* x;
@@ -235,6 +238,7 @@ struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   }
   int width;  // L * F
   __device__ bool silent(int64_t w0, int64_t n_rows) const { return rows_are_zero(go, width, w0, n_rows); }
+  __device__ int coherent_rays(int64_t, int64_t) const { return 0; }  // bare positions: no rays to compare
 };
 struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(decoder . rescaled features), F = 1
   RaysDev r;
@@ -263,6 +267,7 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
     const int64_t i = w0 + (threadIdx.x & 63);
     return i < n_rows ? gd[i] == 0.f : true;
   }
+  __device__ int coherent_rays(int64_t first, int64_t count) const { return coherent_rays_of(r, first, count); }
 };
 
 // ---- prep ----------------------------------------------------------------------------------------------------
@@ -270,20 +275,69 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
 // gradient is exactly zero sends no records and is dropped here.  Each 4096-sample chunk is compacted in order (so that
 // consecutive samples of a ray stay neighbours and their equal entries still merge): gpos / gidx [chunk][slot] = position
 // / index inside the chunk of the slot-th live sample, nlive[chunk] = their number.
+// Walk order inside a chunk (round 4).  `count` / `emit` merge equal entries of NEIGHBOURING LANES, so what the lanes of a
+// 16-lane row hold decides how many records go out.  Ray-major (a row = 16 consecutive samples of one ray) merges the runs of
+// one ray through a coarse cell.  When the chunk's rays are neighbours themselves -- the 32 rays of a pixel row of a camera
+// patch: one origin, directions a fraction of a degree apart -- walking the chunk SAMPLE-INDEX-major (a row = 16 neighbouring
+// rays at one sample index) merges far more: adjacent rays sit |jitter difference| x bin width apart along the ray, a third
+// of the distance between consecutive samples of one ray.  Measured on the c3 step (scripts/record_stats_probe.py,
+// profiles/r04_record_stats.txt): records per corner-pair term 0.78 -> 0.48 (first proposal round), 0.64 -> 0.49 (second),
+// 0.49 -> 0.35 (field) on the camera rays; lidar rays (unrelated neighbours) keep the ray-major walk.  Decided per chunk
+// from the rays themselves (coherent_rays); any order is correct -- `emit` finds its source sample through gidx.
+__device__ __forceinline__ int coherent_rays_of(const RaysDev& r, int64_t first_sample, int64_t count) {
+  const int S = r.S;
+  if (S < 16 || S > kSamplesPerBlock / 16 || kSamplesPerBlock % S != 0 || count < kSamplesPerBlock) return 0;
+  const int nr = kSamplesPerBlock / S;
+  const int64_t r0 = first_sample / S, r1 = r0 + 1, r2 = r0 + nr - 1;
+  const float ox = r.o[3 * r0], oy = r.o[3 * r0 + 1], oz = r.o[3 * r0 + 2];
+  const float tol = 1e-4f * (1.f + fabsf(ox) + fabsf(oy) + fabsf(oz));
+  const bool same_o = fabsf(r.o[3 * r1] - ox) + fabsf(r.o[3 * r1 + 1] - oy) + fabsf(r.o[3 * r1 + 2] - oz) <= tol &&
+                      fabsf(r.o[3 * r2] - ox) + fabsf(r.o[3 * r2 + 1] - oy) + fabsf(r.o[3 * r2 + 2] - oz) <= tol;
+  const float dx = r.d[3 * r0], dy = r.d[3 * r0 + 1], dz = r.d[3 * r0 + 2];
+  const float c1 = dx * r.d[3 * r1] + dy * r.d[3 * r1 + 1] + dz * r.d[3 * r1 + 2];
+  const float c2 = dx * r.d[3 * r2] + dy * r.d[3 * r2 + 1] + dz * r.d[3 * r2 + 2];
+  return (same_o && c1 > 0.9999f && c2 > 0.99f) ? nr : 0;  // (unit directions: < 0.8 deg to the next ray, < 8 deg across the chunk)
+}
+
+bool transposed_walk_enabled() {  // NRHIP_BIN_TRANSPOSE=0: ray-major everywhere (A/B)
+  const char* e = getenv("NRHIP_BIN_TRANSPOSE");
+  return !(e && e[0] == '0');
+}
+
 template <class Src>
 __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, int64_t n, int64_t n_total,
                                                          float4* __restrict__ gpos, uint16_t* __restrict__ gidx,
-                                                         uint32_t* __restrict__ nlive) {
+                                                         uint32_t* __restrict__ nlive, int allow_transpose) {
   __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t live_bits[kSamplesPerBlock / 32];
+  __shared__ int s_nr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
   const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;  // sample i of this round = sample i_off + i of the source
-  uint32_t base = 0;
+  // pass 1, source order (the gradient rows are tested the way they lie in memory): which samples are live
 #pragma unroll
   for (int it = 0; it < nit; ++it) {
     const int64_t i0 = i_blk + it * nt + tid;
-    const float4 p = src.position(i_off + (i0 < n ? i0 : n - 1));
     const bool live = !src.silent(i_off + i0 - lane, n_total) && i0 < n;
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) {
+      live_bits[(it * nt + tid) >> 5] = (uint32_t)m;
+      live_bits[((it * nt + tid) >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+  }
+  if (tid == 0) s_nr = allow_transpose ? src.coherent_rays(i_off + i_blk, n - i_blk) : 0;
+  __syncthreads();
+  const int nr = s_nr;                                  // rays of a sample-index-major chunk, 0: ray-major
+  const int spr = nr ? kSamplesPerBlock / nr : 1;       // samples per ray
+  // pass 2, walk order: positions of the live samples, compacted in that order
+  uint32_t base = 0;
+#pragma unroll
+  for (int it = 0; it < nit; ++it) {
+    const int p = it * nt + tid;
+    const int local = nr ? (p % nr) * spr + p / nr : p;  // slot p of the walk holds sample `local` of the chunk
+    const bool live = (live_bits[local >> 5] >> (local & 31)) & 1u;
+    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) pos = src.position(i_off + i_blk + local);
     const unsigned long long m = __ballot(live);
     if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -296,8 +350,8 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
     }
     if (live) {
       const uint32_t slot = base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      gpos[i_blk + slot] = p;
-      gidx[i_blk + slot] = (uint16_t)(it * nt + tid);
+      gpos[i_blk + slot] = pos;
+      gidx[i_blk + slot] = (uint16_t)local;
     }
     base += total;
     __syncthreads();  // wave_tot is reused by the next pass
@@ -502,24 +556,28 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
 #undef NR_SEG_STEP
         }
         if (head && live) {
+          const uint32_t b = kf >> log2TS;
+          // (one LDS atomic per record.  A wave-aggregated add -- one atomic for all lanes that share the first lane's slice --
+          //  was measured SLOWER: emit<1> 293 -> 341 us, emit<4> 693 -> 752 us; the hashed levels scatter a wave's records
+          //  over the slices, so the two ballots and the readlanes buy nothing there)
+          const uint32_t my_rank = atomicAdd(&rank[b], 1u);
 #pragma unroll
           for (int j = 0; j < NV; ++j) {
             const float av = fabsf(v[j]);
             if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);  // Inf/NaN do not set the scale; they poison in `reduce`
           }
           const uint32_t xm = kf ^ kc;  // (0 without pairs)
-          const uint32_t b = kf >> log2TS;
           float out[RW];
           if ((xm >> log2TS) == 0) {  // (always, unless the level's resolution reaches the slice length)
             out[0] = __uint_as_float((kf & tsmask) | (xm << 16));
 #pragma unroll
             for (int j = 0; j < NV; ++j) out[1 + j] = v[j];
-            store_record<RW>(qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * RW, out);
+            store_record<RW>(qrec + (size_t)(base[b] + my_rank) * RW, out);
           } else if constexpr (PAIR) {  // the ceil corner lives in another slice: two records, each with a zero second half
             out[0] = __uint_as_float(kf & tsmask);
 #pragma unroll
             for (int j = 0; j < F; ++j) out[1 + j] = v[j], out[1 + F + j] = 0.f;
-            store_record<RW>(qrec + (size_t)(base[b] + atomicAdd(&rank[b], 1u)) * RW, out);
+            store_record<RW>(qrec + (size_t)(base[b] + my_rank) * RW, out);
             const uint32_t b2 = kc >> log2TS;
             out[0] = __uint_as_float(kc & tsmask);
 #pragma unroll
@@ -702,7 +760,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     const dim3 grid_a((unsigned)chunks, (unsigned)p.lgroups);
     // qmax slots of chunks this round does not have stay from an earlier round otherwise
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
-    bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive);
+    bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive, transposed_walk_enabled() ? 1 : 0);
     if (p.pair)
       bin_count_kernel<true><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     else

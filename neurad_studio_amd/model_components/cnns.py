@@ -82,9 +82,8 @@ def decode_rgb(decoder: nn.Module, cam_features: Tensor, patch_size, fused: bool
             params, states, bns = args
             training = decoder.training
             rgb = RgbDecoderFn.apply(cam_features, tuple(patch_size), training, states, *params)
-            if training:
-                for bn in bns:
-                    bn.num_batches_tracked += 1
+            if training:  # (one multi-tensor launch for the eight counters)
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
             return rgb
     patches = cam_features.view(-1, *patch_size, cam_features.shape[-1]).permute(0, 3, 1, 2)
     return decoder(patches).permute(0, 2, 3, 1)

@@ -20,6 +20,9 @@ def main():
     res = {}
 
     def step(mode, d):
+        for p in d.parameters():  # as optimizer.zero_grad(set_to_none=True) does: without it every parameter gradient costs an
+            p.grad = None         # accumulation launch (36 torch adds per pass in round 3's trace: this script's artefact)
+        f.grad = None
         if mode == "hip":
             rgb = decode_rgb(d, f, (32, 32))
         else:

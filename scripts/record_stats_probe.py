@@ -68,6 +68,27 @@ for name, spec, scale, eu in calls:
                 h = (yy * PY) ^ (zz * PZ)
                 keys.append((((f[:, 0] ^ h) & (T - 1)) << 24) | ((f[:, 0] ^ c[:, 0]) & 0xffffff))  # pair id: floor entry + xm
         st = dict(terms=0, row16=0, wave64=0, ray=0, chunk=0)
+        # transposed mapping, camera rays only: a 16-lane row = 16 neighbouring rays at ONE sample index
+        nc = bench.C3_CAMERA_RAYS
+        tr = dict(cam_terms=0, cam_row16=0, cam_across16=0, cam_across32=0, lid_row16=0, lid_terms=0)
+        for k in keys:
+            k2 = k.view(R, S)
+            cam = k2[:nc]
+            tr["cam_terms"] += cam.numel()
+            same_a = torch.zeros_like(cam, dtype=torch.bool)
+            same_a[:, 1:] = cam[:, 1:] == cam[:, :-1]
+            col = torch.arange(S, device=dev)[None, :]
+            tr["cam_row16"] += int((~(same_a & (col % 16 != 0))).sum())
+            same_x = torch.zeros_like(cam, dtype=torch.bool)
+            same_x[1:] = cam[1:] == cam[:-1]
+            rr = torch.arange(nc, device=dev)[:, None]
+            tr["cam_across16"] += int((~(same_x & (rr % 16 != 0))).sum())
+            tr["cam_across32"] += int((~(same_x & (rr % 32 != 0))).sum())
+            lid = k2[nc:]
+            same_l = torch.zeros_like(lid, dtype=torch.bool)
+            same_l[:, 1:] = lid[:, 1:] == lid[:, :-1]
+            tr["lid_terms"] += lid.numel()
+            tr["lid_row16"] += int((~(same_l & (col % 16 != 0))).sum())
         for k in keys:
             same = torch.zeros_like(k, dtype=torch.bool)
             same[1:] = k[1:] == k[:-1]
@@ -87,6 +108,8 @@ for name, spec, scale, eu in calls:
         for kk in tot:
             tot[kk] += st[kk]
         print(f"  level {l} (res {sc:7.0f}): terms {st['terms']/1e6:7.2f} M | row16 {st['row16']/st['terms']:.3f} | wave64 "
-              f"{st['wave64']/st['terms']:.3f} | whole ray {st['ray']/st['terms']:.3f} | distinct per 4096-chunk {st['chunk']/st['terms']:.3f}")
+              f"{st['wave64']/st['terms']:.3f} | whole ray {st['ray']/st['terms']:.3f} | distinct per 4096-chunk {st['chunk']/st['terms']:.3f}"
+              f" || camera rays: along-ray row16 {tr['cam_row16']/tr['cam_terms']:.3f}, ACROSS 16 rays {tr['cam_across16']/tr['cam_terms']:.3f}, "
+              f"across 32 {tr['cam_across32']/tr['cam_terms']:.3f}; lidar along-ray {tr['lid_row16']/max(tr['lid_terms'],1):.3f}")
     print(f"  all levels: terms {tot['terms']/1e6:.1f} M | row16 {tot['row16']/tot['terms']:.3f} | wave64 {tot['wave64']/tot['terms']:.3f} | "
           f"whole ray {tot['ray']/tot['terms']:.3f} | distinct per chunk {tot['chunk']/tot['terms']:.3f}")
