@@ -474,21 +474,29 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
 
 
 def device_state(device_index=0):
-    """clocks / power state of the GPU when the run starts (rocm-smi): the pool's boxes differ by ~10 % on the same kernel
-    (round 3: 169 us on the builder's best box, 185 us on the driver's) -- with this in the line the spread is attributable"""
+    """clocks / power state of the GPU UNDER LOAD when the run starts (rocm-smi sampled while a matmul loop keeps the device
+    busy: the idle sclk says nothing): the pool's boxes differ by ~10 % on the same kernel (round 3: 169 us on the builder's
+    best box, 185 us on the driver's) -- with this in the line the spread is attributable"""
     import subprocess
 
     try:
-        r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
-                            "--json"], capture_output=True, text=True, timeout=20)
-        d = json.loads(r.stdout)
+        p = subprocess.Popen(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower",
+                              "--showperflevel", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        a = torch.randn((4096, 4096), device=f"cuda:{device_index}", dtype=torch.float16)
+        t0 = time.perf_counter()
+        while p.poll() is None and time.perf_counter() - t0 < 20:
+            for _ in range(20):
+                a @ a
+            torch.cuda.synchronize()
+        out = p.communicate(timeout=5)[0]
+        d = json.loads(out)
         card = d.get(f"card{device_index}", next(iter(d.values())))
-        keep = {}
+        keep = {"sampled": "under a matmul load"}
         for k, v in card.items():
             kl = k.lower()
-            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level")):
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "performance level")):
                 keep[k] = v
-        return keep or {"raw": r.stdout[:400]}
+        return keep
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 

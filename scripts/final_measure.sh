@@ -1,0 +1,40 @@
+#!/bin/bash
+# End-of-round measurements in one lease: GPU test suite, bench lines c1-c4, kernel traces, the PMC passes behind
+# roofline.traffic, the two-rank gloo rehearsal.  usage: scripts/final_measure.sh <tag>   (outputs under gpurun_out/<tag>_*)
+tag=${1:-r04}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT
+cd $R
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > $OUT/${tag}_gputests.txt
+cat $OUT/${tag}_gputests.txt
+timeout 600 python bench.py > $OUT/bench_${tag}_c1.json 2> $OUT/bench_${tag}_c1.err; echo "c1 rc=$?"
+for c in c2 c3 c4; do timeout 600 python bench.py --config $c > $OUT/bench_${tag}_$c.json 2> $OUT/bench_${tag}_$c.err; echo "$c rc=$?"; done
+NRHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 > $OUT/${tag}_rehearsal_n2_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2.err; echo "rehearsal rc=$?"
+cd /tmp
+prof() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_$name -o t -- "$@" > $OUT/prof_${tag}_$name.log 2>&1
+  python $R/scripts/prof_summary.py $(find $OUT/prof_${tag}_$name -name '*.db' | head -1) | head -64 > $OUT/${tag}_${name}_kernel_trace.txt; find $OUT/prof_${tag}_$name -name '*.db' -delete; }
+prof headline python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants
+prof train_full_c3 python $R/bench.py --config c3 --steps 10 --warmup 3
+prof c2 python $R/bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline
+prof c4 python $R/bench.py --config c4 --steps 4 --warmup 1 --train-steps 60
+NRHIP_BENCH_DECODER_MODES=hip prof decoder python $R/scripts/bench_decoder.py
+pmc() { name=$1; kern=$2; ctr=$3; shift; shift; shift; timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/pmc_${tag}_$name -o p -- "$@" > $OUT/pmc_${tag}_$name.log 2>&1
+  echo "== $name: $ctr ($kern)"; python $R/scripts/pmc_report.py "$kern" $(find $OUT/pmc_${tag}_$name -name '*.db' | head -1); rm -rf $OUT/pmc_${tag}_$name; }
+{
+C1="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants"
+pmc c1_fetch render_kernel FETCH_SIZE $C1
+pmc c1_write render_kernel WRITE_SIZE $C1
+pmc c1_tcc render_kernel "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" $C1
+pmc c1_mfma render_kernel "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" $C1
+C2="python $R/bench.py --config c2 --steps 10 --warmup 2 --no-cpu-baseline"
+pmc c2_fetch proposal_sampler_kernel FETCH_SIZE $C2
+pmc c2_write proposal_sampler_kernel WRITE_SIZE $C2
+C3="python $R/bench.py --config c3 --steps 3 --warmup 1 --no-rgb-decoder"
+pmc c3_fetch "render_kernel<8, 4, 32, false, false" FETCH_SIZE $C3
+pmc c3_write "render_kernel<8, 4, 32, false, false" WRITE_SIZE $C3
+C4="python $R/bench.py --config c4 --steps 5 --warmup 2 --train-steps 0"
+pmc c4_fetch "render_kernel<8, 4, 32, true, true, true" FETCH_SIZE $C4
+pmc c4_write "render_kernel<8, 4, 32, true, true, true" WRITE_SIZE $C4
+} > $OUT/${tag}_pmc_traffic.txt 2>&1
+cat $OUT/${tag}_pmc_traffic.txt
+cd $R; python scripts/show_bench.py $OUT/bench_${tag}_c1.json $OUT/bench_${tag}_c2.json $OUT/bench_${tag}_c3.json $OUT/bench_${tag}_c4.json 2>/dev/null | head -60
