@@ -750,7 +750,8 @@ int nrhip_rgb_decoder_sizes(const nrhip_rgb_decoder* d, int64_t* saved_bytes, in
 int nrhip_rgb_decoder_fwd(const nrhip_rgb_decoder* d, const float* features, void* saved, void* workspace, float* rgb,
                           void* stream);
 /* grad_params (written, not accumulated): conv_in (w, b), then per convolution i = 0..7 (w, b, gamma, beta), up (w, b),
- * out (w, b).  training mode only.                                                                                     */
+ * out (w, b).  training == 0: BatchNorm normalised with its running statistics in the forward, its backward is then the
+ * affine map gamma * rstd * g (round 4).                                                                               */
 int nrhip_rgb_decoder_bwd(const nrhip_rgb_decoder* d, const float* features, const void* saved, const float* rgb,
                           const float* grad_rgb, void* workspace, float* grad_features, float* grad_params, void* stream);
 

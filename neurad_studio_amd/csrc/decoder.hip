@@ -608,7 +608,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ coef, float* __restrict__ bcoef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              const float* __restrict__ gscale) {
+                                                              const float* __restrict__ gscale, int eval_mode) {
   __shared__ double red[16 * 64];
   __shared__ double tot[64];
   const double s = colsum64(partial, n, red);
@@ -620,10 +620,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const double sum_g = tot[c], sum_gc = tot[32 + c];
     const double dg = rstd * (sum_gc - mean * sum_g);  // sum g * xhat
     const double A = (double)gamma[c] * rstd;
-    const double B = -A * rstd * dg / count;
+    // eval mode: mean and rstd are the running statistics, constants of the step -- the gradient is A g alone
+    const double B = eval_mode ? 0.0 : -A * rstd * dg / count;
     bcoef[c] = (float)A;
     bcoef[32 + c] = (float)B;
-    bcoef[64 + c] = (float)(-A * sum_g / count - B * mean);
+    bcoef[64 + c] = eval_mode ? 0.f : (float)(-A * sum_g / count - B * mean);
     const double inv = gscale ? (double)gscale[1] : 1.0;
     if (dgamma) dgamma[c] += (float)(dg * inv);
     if (dbeta) dbeta[c] += (float)(sum_g * inv);
@@ -1173,9 +1174,22 @@ extern "C" int nrhip_dec_bn_act(const void* c, const float* coef, const void* sk
   return check_launch("dec_bn_act");
 }
 
+namespace {
+int bn_bwd_impl(const void* grad_out, const void* act, const void* c, const float* gamma, const float* coef, float* workspace,
+                float* grad_gamma, float* grad_beta, const float* grad_scale, void* grad_c, int64_t n_pixels, int eval_mode,
+                void* stream);
+}
+
 extern "C" int nrhip_dec_bn_bwd(const void* grad_out, const void* act, const void* c, const float* gamma,
                                 const float* coef, float* workspace, float* grad_gamma, float* grad_beta,
                                 const float* grad_scale, void* grad_c, int64_t n_pixels, void* stream) {
+  return bn_bwd_impl(grad_out, act, c, gamma, coef, workspace, grad_gamma, grad_beta, grad_scale, grad_c, n_pixels, 0, stream);
+}
+
+namespace {
+int bn_bwd_impl(const void* grad_out, const void* act, const void* c, const float* gamma, const float* coef, float* workspace,
+                float* grad_gamma, float* grad_beta, const float* grad_scale, void* grad_c, int64_t n_pixels, int eval_mode,
+                void* stream) {
   NR_REQUIRE(grad_out && act && c && gamma && coef && workspace && grad_c && n_pixels > 0, NRHIP_ERR_INVALID_ARG,
              "dec_bn_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -1184,11 +1198,12 @@ extern "C" int nrhip_dec_bn_bwd(const void* grad_out, const void* act, const voi
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, (const _Float16*)grad_out, (const _Float16*)act,
                      (const _Float16*)c, n_pixels * 4, workspace);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, (double)n_pixels, gamma, coef, bcoef,
-                     grad_gamma, grad_beta, grad_scale);
+                     grad_gamma, grad_beta, grad_scale, eval_mode);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n_pixels * 4)), dim3(256), 0, st, (const _Float16*)grad_out,
                      (const _Float16*)act, (const _Float16*)c, bcoef, 0, (_Float16*)grad_c, n_pixels * 4);
   return check_launch("dec_bn_bwd");
 }
+}  // namespace
 
 extern "C" int nrhip_dec_bn_bwd_workspace(int64_t n_pixels, int64_t* floats) {
   NR_REQUIRE(floats && n_pixels >= 0, NRHIP_ERR_INVALID_ARG, "dec_bn_bwd_workspace: bad argument");
@@ -1485,7 +1500,7 @@ extern "C" int nrhip_rgb_decoder_bwd(const nrhip_rgb_decoder* d, const float* fe
   DEC_TRY(dec_validate(d, "rgb_decoder_bwd"));
   NR_REQUIRE(features && saved && rgb && grad_rgb && workspace && grad_features && grad_params, NRHIP_ERR_INVALID_ARG,
              "rgb_decoder_bwd: null buffer");
-  NR_REQUIRE(d->training, NRHIP_ERR_UNSUPPORTED, "rgb_decoder_bwd: backward through running statistics is not implemented");
+  const int eval_mode = d->training ? 0 : 1;  // eval: BatchNorm normalises with its running statistics (constants)
   DecLayout L;
   dec_layout(d, &L);
   hipStream_t st = (hipStream_t)stream;
@@ -1528,13 +1543,13 @@ extern "C" int nrhip_rgb_decoder_bwd(const nrhip_rgb_decoder* d, const float* fe
     float* gb = g_blk + (2 * k + 1) * per_conv;
     const int ia = 2 * k, ib = 2 * k + 1;
     // dc2 -> t1; du1 = conv^T(dc2) -> t2; wgrad b
-    DEC_TRY(nrhip_dec_bn_bwd(dcur, out, c2, d->bn_gamma[ib], coef + 128 * ib, ws, gb + 32 * 32 * 49 + 32,
-                             gb + 32 * 32 * 49 + 64, gscale, t1, npix, stream));
+    DEC_TRY(bn_bwd_impl(dcur, out, c2, d->bn_gamma[ib], coef + 128 * ib, ws, gb + 32 * 32 * 49 + 32,
+                        gb + 32 * 32 * 49 + 64, gscale, t1, npix, eval_mode, stream));
     DEC_TRY(nrhip_conv7x7(t1, sv + L.packed + (int64_t)(2 * ib + 1) * kWfragBytes, nullptr, t2, nullptr, b, h, w, rows, stream));
     DEC_TRY(nrhip_conv7x7_wgrad(u1, t1, ws, gb, gb + 32 * 32 * 49, gscale, b, h, w, stream));
     // dc1 -> t1 (dc2 is dead); dx = conv^T(dc1) -> t2 (du1 is dead after bn_bwd); wgrad a
-    DEC_TRY(nrhip_dec_bn_bwd(t2, u1, c1, d->bn_gamma[ia], coef + 128 * ia, ws, ga + 32 * 32 * 49 + 32,
-                             ga + 32 * 32 * 49 + 64, gscale, t1, npix, stream));
+    DEC_TRY(bn_bwd_impl(t2, u1, c1, d->bn_gamma[ia], coef + 128 * ia, ws, ga + 32 * 32 * 49 + 32,
+                        ga + 32 * 32 * 49 + 64, gscale, t1, npix, eval_mode, stream));
     DEC_TRY(nrhip_conv7x7(t1, sv + L.packed + (int64_t)(2 * ia + 1) * kWfragBytes, nullptr, t2, nullptr, b, h, w, rows, stream));
     DEC_TRY(nrhip_conv7x7_wgrad(x, t1, ws, ga, ga + 32 * 32 * 49, gscale, b, h, w, stream));
     // block input gradient = convolution path + skip path -> t1

@@ -294,8 +294,6 @@ class RgbDecoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_rgb):
-        if not ctx.training:
-            raise RuntimeError("decode_rgb: backward through the eval-mode decoder (running statistics) is not implemented")
         feats, saved, rgb = ctx.saved_tensors
         grad_rgb = _chk(grad_rgb.contiguous().float(), "grad_rgb")
         work = torch.empty((ctx.sizes[1].value,), device=feats.device, dtype=torch.uint8)

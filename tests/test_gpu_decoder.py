@@ -261,3 +261,51 @@ def test_eval_mode_decoder_on_a_wide_chunk_matches_the_torch_modules():
         a = decode_rgb(dec, f, (6, 200))
         b = decode_rgb(dec, f, (6, 200), fused=False)
     assert a.shape == (2, 18, 600, 3) and (a - b).abs().max() <= 3e-3
+
+
+def test_decoder_backward_in_eval_mode_matches_the_torch_modules():
+    """eval mode (running statistics): BatchNorm is an affine map with constants, its backward A g alone.  Gradients of the
+    features and of every parameter against the same modules in fp32 torch, torch autocast(fp16) as the yardstick."""
+    import copy
+
+    from neurad_studio_amd.model_components.cnns import decode_rgb, make_rgb_decoder
+
+    torch.manual_seed(9)
+    dec = make_rgb_decoder(48, 32, 3).cuda()
+    with torch.no_grad():
+        for m in dec.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+    dec.eval()
+    f = torch.randn((2 * 1024, 48), device="cuda")
+    image = torch.rand((2, 96, 96, 3), device="cuda")
+
+    def run(mode):
+        d = copy.deepcopy(dec)
+        x = f.clone().requires_grad_()
+        if mode == "hip":
+            rgb = decode_rgb(d, x, (32, 32))
+        elif mode == "fp32":
+            rgb = decode_rgb(d, x, (32, 32), fused=False)
+        else:
+            with torch.autocast("cuda", dtype=torch.float16):
+                rgb = decode_rgb(d, x, (32, 32), fused=False)
+        torch.nn.functional.mse_loss(rgb.float(), image).backward()
+        return rgb.detach().float(), x.grad, {n: p.grad for n, p in d.named_parameters()}, dict(d.named_buffers())
+
+    rgb_h, gx_h, gp_h, buf_h = run("hip")
+    rgb_r, gx_r, gp_r, buf_r = run("fp32")
+    _, gx_a, gp_a, _ = run("autocast")
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-20))
+
+    assert rel(rgb_h, rgb_r) < 3e-3
+    assert rel(gx_h, gx_r) <= max(1.5 * rel(gx_a, gx_r), 5e-3)
+    for n in gp_r:  # (in eval mode the convolution biases in front of BatchNorm DO have a gradient)
+        assert rel(gp_h[n], gp_r[n]) <= max(1.5 * rel(gp_a[n], gp_r[n]), 5e-3), (n, rel(gp_h[n], gp_r[n]), rel(gp_a[n], gp_r[n]))
+    for n in buf_r:  # nothing is tracked in eval mode
+        assert torch.equal(buf_h[n], buf_r[n]), n
