@@ -243,14 +243,31 @@ __global__ __launch_bounds__(256) void proposal_levels_lp_kernel(GridDev g, cons
   __builtin_nontemporal_store(v[0] * rescale_weight(g.scal[l], p.std), lf + (size_t)l * n + i);
 }
 
+// VEC = 4: four consecutive samples per thread on 16-byte accesses (n % 4 == 0, 16-byte aligned buffers): the pass streams
+// L + 1 floats per sample and is worth what it keeps in flight (scalar form: 46 us per 57 344 x 128 call, ~3 TB/s)
+template <int VEC>
 __global__ __launch_bounds__(256) void proposal_density_from_levels_kernel(const float* __restrict__ lf,
                                                                             const float* __restrict__ dec, int64_t n,
                                                                             int L, float* __restrict__ dens) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
   if (i >= n) return;
-  float acc = 0.f;
-  for (int l = 0; l < L; ++l) acc += lf[(size_t)l * n + i] * dec[l];  // same order of operations as the fused kernel
-  dens[i] = expf(acc);
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  for (int l = 0; l < L; ++l) {  // same order of operations as the fused kernel
+    const float w = dec[l];
+    if constexpr (VEC == 4) {
+      const float4 f = *reinterpret_cast<const float4*>(lf + (size_t)l * n + i);
+      acc[0] += f.x * w, acc[1] += f.y * w, acc[2] += f.z * w, acc[3] += f.w * w;
+    } else {
+      acc[0] += lf[(size_t)l * n + i] * w;
+    }
+  }
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(dens + i) = make_float4(expf(acc[0]), expf(acc[1]), expf(acc[2]), expf(acc[3]));
+  } else {
+    dens[i] = expf(acc[0]);
+  }
 }
 
 // backward of S2 through trunc_exp (activations.py:37-41: g * exp(clamp(x,-15,15))) into the decoder
@@ -427,8 +444,12 @@ extern "C" int nrhip_proposal_density_fwd(const nrhip_proposal* p, const nrhip_r
       proposal_levels_lp_kernel<false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(
           gd, p->table, p->static_scale, rd, level_features, n, per_quarter, blocks_per_unit);
     if (int e = check_launch("proposal_density_fwd levels")) return e;
-    proposal_density_from_levels_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
-        level_features, p->decoder_weight, n, gd.L, density);
+    if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(level_features) | reinterpret_cast<uintptr_t>(density)) & 15) == 0)
+      proposal_density_from_levels_kernel<4><<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>(
+          level_features, p->decoder_weight, n, gd.L, density);
+    else
+      proposal_density_from_levels_kernel<1><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+          level_features, p->decoder_weight, n, gd.L, density);
     return check_launch("proposal_density_fwd");
   }
   if (gd.dtype == 1)
@@ -460,6 +481,7 @@ extern "C" int nrhip_proposal_density_bwd(const nrhip_proposal* p, const nrhip_r
 
 namespace nrhip {
 // decoder gradient from the per-level features the forward saved: d dec[l] = sum_i g_i * exp(clamp(x_i)) * f_il
+template <int VEC>
 __global__ __launch_bounds__(256) void proposal_decoder_grad_kernel(const float* __restrict__ lf,
                                                                      const float* __restrict__ dens,
                                                                      const float* __restrict__ gd, int64_t n, int L,
@@ -467,11 +489,29 @@ __global__ __launch_bounds__(256) void proposal_decoder_grad_kernel(const float*
   float gl[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) gl[l] = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gx = gd[i] * expf(fminf(fmaxf(logf(dens[i]), -15.f), 15.f));
+  const int64_t nv = n / VEC;  // (VEC == 4: n % 4 == 0, 16-byte aligned buffers -- checked by the launcher)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    float gx[VEC];
+    if constexpr (VEC == 4) {
+      const float4 g4 = reinterpret_cast<const float4*>(gd)[i], d4 = reinterpret_cast<const float4*>(dens)[i];
+      gx[0] = g4.x * expf(fminf(fmaxf(logf(d4.x), -15.f), 15.f));
+      gx[1] = g4.y * expf(fminf(fmaxf(logf(d4.y), -15.f), 15.f));
+      gx[2] = g4.z * expf(fminf(fmaxf(logf(d4.z), -15.f), 15.f));
+      gx[3] = g4.w * expf(fminf(fmaxf(logf(d4.w), -15.f), 15.f));
+    } else {
+      gx[0] = gd[i] * expf(fminf(fmaxf(logf(dens[i]), -15.f), 15.f));
+    }
 #pragma unroll
     for (int l = 0; l < 8; ++l)
-      if (l < L) gl[l] = fmaf(gx, lf[(size_t)l * n + i], gl[l]);  // level-major [L][N]
+      if (l < L) {  // level-major [L][N]
+        if constexpr (VEC == 4) {
+          const float4 f = reinterpret_cast<const float4*>(lf + (size_t)l * n)[i];
+          gl[l] = fmaf(gx[0], f.x, gl[l]), gl[l] = fmaf(gx[1], f.y, gl[l]);
+          gl[l] = fmaf(gx[2], f.z, gl[l]), gl[l] = fmaf(gx[3], f.w, gl[l]);
+        } else {
+          gl[l] = fmaf(gx[0], lf[(size_t)l * n + i], gl[l]);
+        }
+      }
   }
   __shared__ float red[4][8];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -510,8 +550,14 @@ extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const 
   if (level_features) {
     int blocks = grid_for(n, 256);
     if (blocks > 1024) blocks = 1024;
-    proposal_decoder_grad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(level_features, density, grad_density, n,
-                                                                        p->grid.num_levels, grad_decoder);
+    const bool vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(level_features) | reinterpret_cast<uintptr_t>(density) |
+                                     reinterpret_cast<uintptr_t>(grad_density)) & 15) == 0;
+    if (vec)
+      proposal_decoder_grad_kernel<4><<<blocks, 256, 0, (hipStream_t)stream>>>(level_features, density, grad_density, n,
+                                                                             p->grid.num_levels, grad_decoder);
+    else
+      proposal_decoder_grad_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>(level_features, density, grad_density, n,
+                                                                             p->grid.num_levels, grad_decoder);
   } else {  // forward did not save them: recompute the interpolated features
     proposal_density_bwd_kernel<false><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
         to_dev(p->grid), p->table, p->static_scale, p->decoder_weight, to_dev(*rays), density, grad_density,
