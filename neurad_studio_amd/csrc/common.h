@@ -173,6 +173,25 @@ __device__ __forceinline__ void lerp_corners(const Corners& c, const float (&f)[
 template <bool HALF>
 __device__ __forceinline__ void load_corners_f1(const void* table, uint32_t row0, const Corners& c, float (&f)[8][1]) {
   constexpr int kF[4] = {3, 2, 7, 6}, kC[4] = {0, 1, 4, 5};  // (f, c) corner of the pairs (y, z) = cc, fc, cf, ff
+  if constexpr (!HALF) {
+    // fp32 (round 4): ONE aligned 16-byte load per (y, z) where floor x ^ ceil x is 0, 1 or 3 -- three quarters of the
+    // samples: both entries then lie in one aligned 4-entry block.  5 line accesses per (sample, level) instead of 6; the L1
+    // charges per line, not per byte (scripts/probes/l1_coalesce_probe.hip).  row0 must be a multiple of 4.
+    const bool same = ((c.idx[3] ^ c.idx[0]) >> 2) == 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t rf = row0 + c.idx[kF[p]], rc = row0 + c.idx[kC[p]];
+      const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table) + (rf & ~3u) * 4u);
+      const uint32_t a = rf & 3u, b = rc & 3u;
+      f[kF[p]][0] = a == 0u ? t.x : (a == 1u ? t.y : (a == 2u ? t.z : t.w));
+      f[kC[p]][0] = b == 0u ? t.x : (b == 1u ? t.y : (b == 2u ? t.z : t.w));  // meaningful where `same`
+    }
+    if (!same) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) Entry<1, false>::load(table, row0 + c.idx[kC[p]], f[kC[p]]);
+    }
+    return;
+  }
   const bool same = ((c.idx[3] ^ c.idx[0]) >> 1) == 0;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
