@@ -5,7 +5,7 @@ tag=${1:-r04}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
-timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > $OUT/${tag}_gputests.txt
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > $OUT/${tag}_gputests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $OUT/${tag}_gputests.txt
 cat $OUT/${tag}_gputests.txt
 timeout 600 python bench.py > $OUT/bench_${tag}_c1.json 2> $OUT/bench_${tag}_c1.err; echo "c1 rc=$?"
 for c in c2 c3 c4; do timeout 600 python bench.py --config $c > $OUT/bench_${tag}_$c.json 2> $OUT/bench_${tag}_$c.err; echo "$c rc=$?"; done
