@@ -95,7 +95,12 @@ def test_training_outputs_with_lidar_metadata_and_appearance_vs_reference():
     losses["distortion_loss"] = float(lc[10]) * distortion_loss(out["weights_list"], out["ray_samples_list"])
     assert abs(float(losses["interlevel_loss"]) / float(g["loss_interlevel_loss"]) - 1) < 2e-3
     assert abs(float(losses["distortion_loss"]) / float(g["loss_distortion_loss"]) - 1) < 2e-3
-    # the whole chain backward: the gradients the reference's autograd produced for the same total loss
+    # the whole chain backward: the gradients the reference's autograd produced for the same total loss.  The bounds below
+    # (2e-3, 5e-3 for beta) are set by the REFERENCE's own fp32 noise on a batch of this size, not by these kernels: its
+    # model in fp32 differs from itself in fp64 by up to 5e-3 on the table / MLP gradients of the lidar terms -- a handful
+    # of hidden units within 5e-5 of the ReLU kink flip, each switching one sample's whole contribution -- while its loss
+    # values agree to 1e-7 (oracle/grad_noise_floor.py, profiles/r04_grad_noise_floor.json).  The tight statement about the
+    # same kernels is tests/test_gpu_reference_plugin.py: per loss term, rgb / interlevel gradients within 2e-4.
     sum(losses.values()).backward()
     assert rel_l2(host(m.lidar_decoder.layers[0].weight.grad), g["g_lidar_decoder_w0"]) < 2e-3
     assert rel_l2(host(m.appearance_embedding.weight.grad), g["g_embedding"]) < 2e-3
