@@ -444,6 +444,20 @@ typedef struct {
  * K = actors->max_candidates.  overflow (device int32, caller zeroes; may be NULL) is set if a ray has more than K. */
 int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const float* times /*[R]*/,
                         int32_t* cand_count, int32_t* cand_actor, float* cand_w2b, int32_t* overflow, void* stream);
+/* The same with the EVAL-time actor edit of DynamicActors.edit_boxes2world (model_components/dynamic_actors.py:181-249,
+ * applied by get_boxes2world when the module is not training, :261-265; set by the viewer sliders :58-104 and by the
+ * actor-shift FID evaluation, pipelines/ad_pipeline.py:476-480): after the pose interpolation the boxes of `index` (-1:
+ * all; clamped to the last actor) are moved by (lateral, longitudinal, height) in their own frame and yawed by `rotation`
+ * (radians, pre-multiplied: the translation stays).  Everything downstream -- line cull, in-box test, box-frame positions
+ * and directions -- sees the edited pose.  As in the reference nothing happens unless lateral, longitudinal or rotation is
+ * non-zero (a height-only edit is ignored, :182-187).  edit = NULL: nrhip_actor_prepare.                                    */
+typedef struct {
+  float lateral, longitudinal, height, rotation;
+  int32_t index;
+} nrhip_actor_edit;
+int nrhip_actor_prepare_edited(const nrhip_actors* a, const nrhip_rays* rays, const float* times /*[R]*/,
+                               const nrhip_actor_edit* edit, int32_t* cand_count, int32_t* cand_actor, float* cand_w2b,
+                               int32_t* overflow, void* stream);
 /* Field features: for every sample inside an actor box, OVERWRITE its feature row [out_dim] with the actor grid's
  * rescaled features zero-padded to out_dim, and write the per-sample direction (box frame, renormalised) -- ray
  * direction elsewhere.  hit [N] int32 = index of the actor whose grid was used, -1 elsewhere.                                         */

@@ -55,6 +55,11 @@ class Actors(C.Structure):
                 ("tables", C.c_void_p), ("actor_scale", C.c_float), ("max_candidates", C.c_int32)]
 
 
+class ActorEdit(C.Structure):  # nrhip_actor_edit
+    _fields_ = [("lateral", C.c_float), ("longitudinal", C.c_float), ("height", C.c_float), ("rotation", C.c_float),
+                ("index", C.c_int32)]
+
+
 class RgbDecoder(C.Structure):
     _fields_ = [("n_patches", C.c_int32), ("patch_h", C.c_int32), ("patch_w", C.c_int32), ("cin", C.c_int32),
                 ("training", C.c_int32), ("conv_in_w", C.c_void_p), ("conv_in_b", C.c_void_p),
@@ -171,6 +176,7 @@ PROTOTYPES = {
     "nrhip_power_sampler_ordered": [P, P, I64, I32, F32, F32, P, F32, P, P, P, P, F32, F32, I32, P, P],
     "nrhip_pdf_sample": [P, P, P, P, I64, I32, I32, F32, F32, F32, P, I32, P, P, P],
     "nrhip_actor_prepare": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P],
+    "nrhip_actor_prepare_edited": [C.POINTER(Actors), C.POINTER(Rays), P, C.POINTER(ActorEdit), P, P, P, P, P],
     "nrhip_actor_encode": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, I32, P, P, P, P, P],
     "nrhip_actor_hits": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],

@@ -20,6 +20,15 @@ struct ActorsDev {
   int K;              // row length of the per-ray candidate lists (nrhip_actors.max_candidates; == A: no ray overflows)
 };
 
+// Eval-time actor edit (DynamicActors.edit_boxes2world, model_components/dynamic_actors.py:181-249, the flatten=False branch the
+// hash encoding reads): the viewer's sliders and the actor-shift FID evaluation (pipelines/ad_pipeline.py:476-480) move /
+// yaw the boxes AFTER the pose interpolation.  on = 0: no edit.
+struct ActorEdit {
+  int on, index;           // index < 0: every actor, else that actor
+  int shift, turn;         // translate by (lateral, longitudinal, height) in the box frame; pre-multiply a yaw
+  float lat, lon, hgt, cs, sn;
+};
+
 constexpr int KH = NRHIP_MAX_SAMPLE_CONTAINMENTS;  // containing boxes recorded per SAMPLE by nrhip_actor_hits
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {  // F.normalize, eps 1e-12
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(256) void actor_prepare_kernel(ActorsDev a, RaysDev
                                                              int32_t* __restrict__ cand_count,
                                                              int32_t* __restrict__ cand_actor,
                                                              float* __restrict__ cand_w2b,
-                                                             int32_t* __restrict__ overflow) {
+                                                             int32_t* __restrict__ overflow, ActorEdit ed) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= r.R) return;
@@ -81,7 +90,19 @@ __global__ __launch_bounds__(256) void actor_prepare_kernel(ActorsDev a, RaysDev
       b2x -= dt * b1x, b2y -= dt * b1y, b2z -= dt * b1z;
       normalize3(b2x, b2y, b2z);
       const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
-      const float tx = ip[6], ty = ip[7], tz = ip[8];
+      float tx = ip[6], ty = ip[7], tz = ip[8];
+      if (ed.on && (ed.index < 0 || ed.index == act)) {
+        if (ed.shift) {  // t' = boxes2world @ (lateral, longitudinal, height, 1)   (dynamic_actors.py:205-227)
+          tx += b1x * ed.lat + b1y * ed.lon + b1z * ed.hgt;
+          ty += b2x * ed.lat + b2y * ed.lon + b2z * ed.hgt;
+          tz += b3x * ed.lat + b3y * ed.lon + b3z * ed.hgt;
+        }
+        if (ed.turn) {  // R' = yaw @ R: rows 0 and 1 mix, the translation stays   (dynamic_actors.py:229-249)
+          const float n1x = ed.cs * b1x - ed.sn * b2x, n1y = ed.cs * b1y - ed.sn * b2y, n1z = ed.cs * b1z - ed.sn * b2z;
+          const float n2x = ed.sn * b1x + ed.cs * b2x, n2y = ed.sn * b1y + ed.cs * b2y, n2z = ed.sn * b1z + ed.cs * b2z;
+          b1x = n1x, b1y = n1y, b1z = n1z, b2x = n2x, b2y = n2y, b2z = n2z;
+        }
+      }
       // boxes2world = [[b1],[b2],[b3] | t];  world2box = [R^T | -R^T t]  (utils/poses.py:42-55)
       w2b[0] = b1x, w2b[1] = b2x, w2b[2] = b3x, w2b[3] = -(b1x * tx + b2x * ty + b3x * tz);
       w2b[4] = b1y, w2b[5] = b2y, w2b[6] = b3y, w2b[7] = -(b1y * tx + b2y * ty + b3y * tz);
@@ -259,9 +280,9 @@ static int to_dev(const nrhip_actors* a, ActorsDev& d) {
 
 using namespace nrhip;
 
-extern "C" int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
-                                   int32_t* cand_count, int32_t* cand_actor, float* cand_w2b, int32_t* overflow,
-                                   void* stream) {
+extern "C" int nrhip_actor_prepare_edited(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                          const nrhip_actor_edit* edit, int32_t* cand_count, int32_t* cand_actor,
+                                          float* cand_w2b, int32_t* overflow, void* stream) {
   ActorsDev d;
   if (int e = to_dev(a, d)) return e;
   if (int e = validate_rays(rays)) return e;
@@ -271,10 +292,27 @@ extern "C" int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays
   NR_REQUIRE(overflow || d.K >= d.A, NRHIP_ERR_INVALID_ARG,
              "actor_prepare: without an overflow flag the candidate lists must hold all %d actors (max_candidates = %d)",
              d.A, d.K);
+  ActorEdit ed = {};
+  // the reference returns the poses untouched unless longitudinal, lateral or rotation is set -- a height-only edit does
+  // nothing (dynamic_actors.py:182-187); the index is clamped to the last actor (:192)
+  if (edit && (edit->longitudinal != 0.f || edit->lateral != 0.f || edit->rotation != 0.f)) {
+    ed.on = 1;
+    ed.index = edit->index < 0 ? -1 : (edit->index < d.A - 1 ? edit->index : d.A - 1);
+    ed.shift = edit->longitudinal != 0.f || edit->lateral != 0.f || edit->height != 0.f;
+    ed.turn = edit->rotation != 0.f;
+    ed.lat = edit->lateral, ed.lon = edit->longitudinal, ed.hgt = edit->height;
+    ed.cs = cosf(edit->rotation), ed.sn = sinf(edit->rotation);
+  }
   actor_prepare_kernel<<<(int)((rays->n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(d, to_dev(*rays), times,
                                                                                      cand_count, cand_actor, cand_w2b,
-                                                                                     overflow);
+                                                                                     overflow, ed);
   return check_launch("actor_prepare");
+}
+
+extern "C" int nrhip_actor_prepare(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                   int32_t* cand_count, int32_t* cand_actor, float* cand_w2b, int32_t* overflow,
+                                   void* stream) {
+  return nrhip_actor_prepare_edited(a, rays, times, nullptr, cand_count, cand_actor, cand_w2b, overflow, stream);
 }
 
 extern "C" int nrhip_actor_encode(const nrhip_actors* a, const nrhip_rays* rays, const int32_t* cand_count,

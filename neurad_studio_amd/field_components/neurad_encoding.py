@@ -152,10 +152,20 @@ class NeuRADHashEncoding(nn.Module):
                 [self.actor_grids[i].hash_table.detach() for i in ids], self.config.actor.actor_scale))
         return self._actor_spec[1]
 
+    def actor_edit(self) -> Optional[dict]:
+        """DynamicActors.actor_editing when it changes anything: only outside training (get_boxes2world,
+        dynamic_actors.py:261-265) and only if lateral, longitudinal or rotation is set (edit_boxes2world, :182-187)."""
+        ed = getattr(self.actors, "actor_editing", None)
+        if not ed or self.actors.training:
+            return None
+        if abs(ed.get("longitudinal", 0.0)) == 0.0 and abs(ed.get("lateral", 0.0)) == 0.0 and abs(ed.get("rotation", 0.0)) == 0.0:
+            return None
+        return ed
+
     def prepare_actors(self, origins, directions, pixel_area, starts, ends, times):
         """per-ray candidate lists (shared by every field evaluated on the same ray bundle)."""
         spec = self.actor_spec()
-        return spec, ops.actor_prepare(spec, origins, directions, pixel_area, starts, ends, times)
+        return spec, ops.actor_prepare(spec, origins, directions, pixel_area, starts, ends, times, edit=self.actor_edit())
 
     def sample_ray_flip(self, origins) -> Optional[Tensor]:
         """-1 with prob flip_prob else +1, per ray, training only (neurad_encoding.py:212-215)."""
@@ -204,6 +214,11 @@ class NeuRADHashEncoding(nn.Module):
         trajectories when ``require_actor_grad``), the actor grids through MultiHashGridFn (table scatter-add, and
         nrhip_hashgrid_bwd_input for dL/dx).  -> None, or (idx [P] flat sample index, winner [P] bool: the actor the
         forward kernels used for that sample (highest index), rows [P, La*Fa] rescaled actor features)."""
+        if self.actor_edit() is not None:
+            # the differentiable rows are recomputed from the trajectories themselves (nrhip_actor_pair_positions_*), which
+            # know nothing of the edit; the reference edits for rendering only (pipelines/ad_pipeline.py:476-480)
+            raise NotImplementedError("eval-time actor edits (DynamicActors.actor_editing) with gradients enabled: "
+                                      "render edited actors under torch.no_grad()")
         pair = (hits >= 0).nonzero()                  # every (sample, candidate slot) containment
         if pair.shape[0] == 0:
             return None

@@ -64,6 +64,10 @@ class DynamicActors(nn.Module):
         self.config = config
         self._populate_actors(trajectories)
         self.requires_grad_(config.optimize_trajectories)
+        # eval-time edit of the boxes (dynamic_actors.py:53-59, read by edit_boxes2world :181-249 outside training): the viewer's
+        # sliders and the actor-shift evaluation write it; the kernels apply it after the pose interpolation
+        # (nrhip_actor_prepare_edited)
+        self.actor_editing = {"lateral": 0.0, "longitudinal": 0.0, "rotation": 0.0, "index": -1.0, "height": 0.0}
 
     def actor_bounds(self) -> Tensor:
         return self.actor_sizes / 2 + self.actor_padding

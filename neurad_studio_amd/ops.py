@@ -880,9 +880,11 @@ class ActorSpec:
         return self._c_actors[1]
 
 
-def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times):
+def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times, edit: Optional[dict] = None):
     """-> (cand_count [R] i32, cand_actor [R,K] i32, cand_w2b [R,K,12], None) with K = the number of actors, so every
-    actor a ray passes fits (the reference has no limit either); R*K*52 bytes, e.g. 300 MB for 57 344 rays x 100 actors."""
+    actor a ray passes fits (the reference has no limit either); R*K*52 bytes, e.g. 300 MB for 57 344 rays x 100 actors.
+    edit: DynamicActors.actor_editing (lateral / longitudinal / height / rotation / index, dynamic_actors.py:53-59) for an
+    eval-time move of the boxes (nrhip_actor_prepare_edited), None: the trajectories as they are."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
     R, K, dev = r.n_rays, a.max_candidates, origins.device
@@ -890,7 +892,13 @@ def actor_prepare(spec: ActorSpec, origins, directions, pixel_area, starts, ends
     cnt = torch.empty((R,), dtype=torch.int32, device=dev)
     act = torch.empty((R, K), dtype=torch.int32, device=dev)  # only the first cnt[r] entries of a row are ever read
     w2b = torch.empty((R, K, 12), dtype=torch.float32, device=dev)
-    call("nrhip_actor_prepare", C.byref(a), C.byref(r), _ptr(t), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(None), _stream())
+    if edit is None:
+        call("nrhip_actor_prepare", C.byref(a), C.byref(r), _ptr(t), _ptr(cnt), _ptr(act), _ptr(w2b), _ptr(None), _stream())
+    else:
+        e = _lib.ActorEdit(float(edit.get("lateral", 0.0)), float(edit.get("longitudinal", 0.0)),
+                           float(edit.get("height", 0.0)), float(edit.get("rotation", 0.0)), int(edit.get("index", -1)))
+        call("nrhip_actor_prepare_edited", C.byref(a), C.byref(r), _ptr(t), C.byref(e), _ptr(cnt), _ptr(act), _ptr(w2b),
+             _ptr(None), _stream())
     return cnt, act, w2b, None
 
 

@@ -18,6 +18,7 @@ and is otherwise "parity unpinned" (see DESIGN.md).
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -554,9 +555,29 @@ class ActorParams:
         return (self.sizes / f32(2) + self.padding).astype(f32)  # dynamic_actors.py:106-107
 
 
-def actor_boxes2world(a: ActorParams, query_times):
+def edit_boxes2world(b2w, edit):
+    """DynamicActors.edit_boxes2world, the flatten=False branch (model_components/dynamic_actors.py:181-249), applied by
+    get_boxes2world outside training (:261-265).  b2w [R,A,4,4] (only the 3x4 part is read / written), edit = the
+    ``actor_editing`` dict (:53-59).  In place, like the reference."""
+    if abs(edit["longitudinal"]) == 0.0 and abs(edit["lateral"]) == 0.0 and abs(edit["rotation"]) == 0.0:
+        return b2w  # (:182-187: a height-only edit changes nothing)
+    A = b2w.shape[1]
+    idx = np.arange(A) if edit["index"] == -1.0 else np.array([int(min(edit["index"], A - 1))])  # (:189-193)
+    if abs(edit["longitudinal"]) > 0.0 or abs(edit["lateral"]) > 0.0 or abs(edit.get("height", 0.0)) > 0.0:
+        v = np.array([edit["lateral"], edit["longitudinal"], edit.get("height", 0.0), 1.0], f32)
+        for i in idx:
+            b2w[:, i, :3, 3] = (b2w[:, i, :3, :] @ v).astype(f32)  # (:216-227)
+    if abs(edit["rotation"]) > 0.0:
+        c, s = math.cos(edit["rotation"]), math.sin(edit["rotation"])
+        yaw = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], f32)
+        for i in idx:
+            b2w[:, i, :3, :3] = (yaw @ b2w[:, i, :3, :3]).astype(f32)  # (:238-249)
+    return b2w
+
+
+def actor_boxes2world(a: ActorParams, query_times, edit=None):
     """DynamicActors.get_boxes2world(flatten=False) -> (boxes2world [R,A,4,4], valid [R,A]);
-    interpolate_trajectories_6d (utils/poses.py:90-150)."""
+    interpolate_trajectories_6d (utils/poses.py:90-150).  edit: the eval-time ``actor_editing`` dict or None."""
     poses = np.concatenate([a.rotations_6d, a.positions], -1).astype(f32)  # [Tn,A,9]
     a1 = _normalize(poses[..., :3])
     a2 = poses[..., 3:6]
@@ -576,6 +597,8 @@ def actor_boxes2world(a: ActorParams, query_times):
     b2w[..., :3, :3] = rot
     b2w[..., :3, 3] = interp[..., 6:]
     b2w[..., 3, 3] = 1
+    if edit is not None:
+        b2w = edit_boxes2world(b2w, edit)
     return b2w, valid
 
 
@@ -614,7 +637,7 @@ def actor_hits(a: ActorParams, mean_pos, b2w, valid, w2b):
 
 
 def encode_with_actors(grid: GridParams, static_scale, a: ActorParams, origins, directions, pixel_area, starts, ends,
-                       times, ray_flip=None):
+                       times, ray_flip=None, edit=None):
     """NeuRADHashEncoding.forward (neurad_encoding.py:150-187), eval mode (no flip), per-actor 3-D grids.
     -> features [R*S, L*F], directions [R,S,3] (box frame + renormalised where a sample is inside an actor)."""
     R, S = np.asarray(starts).shape
@@ -623,7 +646,7 @@ def encode_with_actors(grid: GridParams, static_scale, a: ActorParams, origins, 
     dirs = np.broadcast_to(np.asarray(directions, f32)[:, None, :], (R, S, 3)).copy()
     if len(a.grids) == 0:
         return feats.reshape(R * S, -1), dirs
-    b2w, valid = actor_boxes2world(a, times)
+    b2w, valid = actor_boxes2world(a, times, edit)
     w2b = pose_inverse(b2w)
     r, s, k = actor_hits(a, mean, b2w, valid, w2b)
     if r.shape[0] == 0:
@@ -647,10 +670,11 @@ def encode_with_actors(grid: GridParams, static_scale, a: ActorParams, origins, 
     return feats.reshape(R * S, -1), dirs
 
 
-def field_fwd_actors(p: FieldParams, a: ActorParams, origins, directions, pixel_area, starts, ends, times):
+def field_fwd_actors(p: FieldParams, a: ActorParams, origins, directions, pixel_area, starts, ends, times, edit=None):
     """NeuRADField.forward with dynamic actors (fields/neurad_field.py:128-152)."""
     R, S = np.asarray(starts).shape
-    enc, dirs = encode_with_actors(p.grid, p.static_scale, a, origins, directions, pixel_area, starts, ends, times)
+    enc, dirs = encode_with_actors(p.grid, p.static_scale, a, origins, directions, pixel_area, starts, ends, times,
+                                   edit=edit)
     geo = mlp_fwd(enc, p.geo_w, p.geo_b)
     geo_out, geo_emb = geo[:, :1], geo[:, 1:]
     sh = sh_deg4(((dirs + f32(1)) / f32(2)).reshape(-1, 3))

@@ -419,3 +419,53 @@ def test_actor_pair_positions_kernel_vs_torch_autograd(scale):
     ((x * gx).sum() + (s * gs).sum()).backward()
     assert rel_l2(host(act.actor_positions.grad), host(want[0])) < 1e-4
     assert rel_l2(host(act.actor_rotations_6d.grad), host(want[1])) < 1e-4
+
+
+def test_actor_edits_vs_reference_golden():
+    """Eval-time actor edit (DynamicActors.actor_editing -> nrhip_actor_prepare_edited) against the REFERENCE's outputs for
+    the same edits (tests/golden/field_actors_edit.npz: a shift of every actor, a yaw of one, both on a clamped index, the
+    ignored height-only edit): hit set, per-sample field outputs (operator path) and the fused render kernel; the edit is
+    an eval-time thing -- the training mode ignores it, and asking for gradients of edited actors is refused."""
+    from neurad_studio_amd import ops
+    from neurad_studio_amd.cameras.rays import RayBundle
+    from neurad_studio_amd.field_components.field_heads import FieldHeadNames
+
+    g, ge = load_golden("field_actors"), load_golden("field_actors_edit")
+    fld = make_field()
+    R, S = g["starts"].shape
+    rb = RayBundle(origins=dev(g["o"]), directions=dev(g["d"]), pixel_area=dev(g["area"])[:, None],
+                   times=dev(g["times"])[:, None], nears=torch.zeros(R, 1, device="cuda"),
+                   fars=torch.full((R, 1), 60.0, device="cuda"))
+    rs = rb.get_ray_samples(dev(g["starts"])[..., None], dev(g["ends"])[..., None])
+    o, d, a = rs.frustums.per_ray()
+    act = fld.hashgrid.actors
+    for e, (lat, lon, hgt, rot, idx) in enumerate(ge["edits"].tolist()):
+        act.actor_editing.update(lateral=lat, longitudinal=lon, height=hgt, rotation=rot, index=idx)
+        spec, cand = fld.hashgrid.prepare_actors(o, d, a, dev(g["starts"]), dev(g["ends"]), dev(g["times"]))
+        _, hit = ops.actor_encode(spec, cand, o, d, a, dev(g["starts"]), dev(g["ends"]), torch.zeros((R * S, 32), device="cuda"))
+        want = np.zeros((R, S), bool)
+        want[ge[f"e{e}_hit_ray"], ge[f"e{e}_hit_sample"]] = True
+        np.testing.assert_array_equal(host(hit).reshape(R, S) >= 0, want)
+        with torch.no_grad():
+            out = fld(rs)
+            feats, depth, acc = fld.render(dev(g["o"]), dev(g["d"]), dev(g["area"]), dev(g["starts"]), dev(g["ends"]),
+                                           times=dev(g["times"]))
+        assert rel_l2(host(out[FieldHeadNames.ALPHA][..., 0]), ge[f"e{e}_alpha"]) < TOL
+        has_f = f"e{e}_feature" in ge
+        want_f, want_d, want_a = _composite_reference(ge[f"e{e}_feature"] if has_f else np.zeros((R, S, 32), np.float32),
+                                                      ge[f"e{e}_alpha"], g["starts"], g["ends"])
+        if has_f:
+            assert rel_l2(host(out[FieldHeadNames.FEATURE]), ge[f"e{e}_feature"]) < TOL
+            assert rel_l2(host(feats), want_f) < TOL
+        assert rel_l2(host(acc), want_a) < TOL and rel_l2(host(depth), want_d) < TOL
+    # a real edit moved something; in training mode the edit is not applied (dynamic_actors.py:261-265)
+    act.actor_editing.update(lateral=1.5, longitudinal=-2.0, height=0.3, rotation=0.0, index=-1.0)
+    assert not np.array_equal(ge["e0_alpha"], g["alpha"])
+    fld.hashgrid.config.actor.flip_prob = 0.0
+    fld.train()
+    with torch.no_grad():
+        out = fld(rs)
+    assert rel_l2(host(out[FieldHeadNames.ALPHA][..., 0]), g["alpha"]) < TOL
+    fld.eval()
+    with pytest.raises(NotImplementedError, match="actor edits"):
+        fld(rs)  # grad mode, eval, edited actors: the differentiable actor rows would ignore the edit

@@ -242,6 +242,28 @@ def test_plugin_eval_outputs_match_the_reference_torch_model(ref, with_actors):
     assert hip.fused_eval_possible.__func__ is not None and hip.fused_eval
 
 
+def test_plugin_eval_with_actor_edits_matches_the_reference_torch_model(ref):
+    """the viewer's actor sliders / the actor-shift FID evaluation (pipelines/ad_pipeline.py:476-480) write
+    ``model.dynamic_actors.actor_editing``; the reference applies it in get_boxes2world outside training
+    (model_components/dynamic_actors.py:181-249,261-265), the plugin in nrhip_actor_prepare_edited"""
+    hip, refm = _build_pair(ref, True)
+    b = _batch(True)
+    _deterministic(hip, False), _deterministic(refm, False)
+    with torch.no_grad():
+        base = hip.get_nff_outputs(_bundle(b, "cuda"))["features"].clone()
+    for edit in (dict(lateral=1.0, longitudinal=-1.5, height=0.2, rotation=0.0, index=-1.0),
+                 dict(lateral=0.0, longitudinal=0.0, height=0.0, rotation=0.5, index=1.0),
+                 dict(lateral=-0.7, longitudinal=0.0, height=0.0, rotation=-0.3, index=9.0)):
+        hip.dynamic_actors.actor_editing.update(edit), refm.dynamic_actors.actor_editing.update(edit)
+        with torch.no_grad():
+            got = hip.get_nff_outputs(_bundle(b, "cuda"))
+            want = refm.get_nff_outputs(_bundle(b, "cpu"))
+        for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1"):
+            assert rel_l2(N(got[k]), N(want[k])) < 1e-4, (edit, k, rel_l2(N(got[k]), N(want[k])))
+        # the edit really moved something: the unedited output is much farther from the edited reference than the plugin is
+        assert rel_l2(N(base), N(want["features"])) > 10 * rel_l2(N(got["features"]), N(want["features"])) + 1e-5, edit
+
+
 def _losses(m, b, device):
     m.zero_grad(set_to_none=True)
     outputs = m.get_outputs(_bundle(b, device), patch_size=(b["patch"], b["patch"]), calc_lidar_losses=True)
