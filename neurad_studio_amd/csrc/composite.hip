@@ -3,41 +3,18 @@
 // wave-level shuffle scan in chunks of 64 samples with a carried transmittance, reductions are wave
 // shuffles.  Nothing here needs LDS or atomics.
 #include "common.h"
+#include "wave_scan.h"
 
 namespace nrhip {
 
 constexpr int kRaysPerBlock = 4;  // 4 waves / block
 
-__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_up(v, off, 64);
-    if (lane >= off) v *= u;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// wave-wide scans on DPP row shifts + readlane (wave_scan.h), not on ds_bpermute shuffles
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) { return wscan::incl<wscan::Mul>(v, lane); }
+__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) { return wscan::incl<wscan::Add>(v, lane); }
+__device__ __forceinline__ float wave_sum(float v) { return wscan::reduce<wscan::Add>(v); }
 // suffix (reverse) inclusive scan
-__device__ __forceinline__ float wave_incl_rscan_add(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_down(v, off, 64);
-    if (lane + off < 64) v += u;
-  }
-  return v;
-}
+__device__ __forceinline__ float wave_incl_rscan_add(float v, int lane) { return wscan::rincl<wscan::Add>(v, lane); }
 
 __device__ __forceinline__ float nan_to_num(float v) {
   if (v != v) return 0.f;
@@ -76,16 +53,14 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void weights_fwd_kernel(const f
     float T;
     if (MODE == 0) {
       const float incl = wave_incl_scan_mul(step, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 1.f;
+      const float excl = wscan::shift_up1(incl, 1.f, lane);
       T = carry * excl;
-      carry *= __shfl(incl, 63, 64);
+      carry *= wscan::last(incl);
     } else {
       const float incl = wave_incl_scan_add(step, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 0.f;
+      const float excl = wscan::shift_up1(incl, 0.f, lane);
       T = expf(-(carry + excl));
-      carry += __shfl(incl, 63, 64);
+      carry += wscan::last(incl);
     }
     if (live) {
       float w = alpha * T;
@@ -125,10 +100,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void weights_bwd_kernel(const f
       else if (MODE == 1) step = c[i] * (b[i] - a[i]);
       else step = a[i] * b[i];
       if (MODE == 0) {
-        float v = step;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
-        carry *= v;
+        carry *= wscan::reduce<wscan::Mul>(step);
       } else {
         carry += wave_sum(step);
       }
@@ -152,13 +124,11 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void weights_bwd_kernel(const f
     float T;
     if (MODE == 0) {
       const float incl = wave_incl_scan_mul(step, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 1.f;
+      const float excl = wscan::shift_up1(incl, 1.f, lane);
       T = carry * excl;
     } else {
       const float incl = wave_incl_scan_add(step, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 0.f;
+      const float excl = wscan::shift_up1(incl, 0.f, lane);
       T = expf(-(carry + excl));
     }
     const float gwi = live ? gw[i] : 0.f;
@@ -175,7 +145,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void weights_bwd_kernel(const f
       }
       gout[i] = g;
     }
-    suffix += __shfl(incl_r, 0, 64);
+    suffix += wscan::first(incl_r);
   }
 }
 

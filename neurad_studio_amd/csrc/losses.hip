@@ -8,6 +8,7 @@
 // The prefix sums accumulate in fp64 and round every prefix to fp32, exactly what torch's CPU cumsum does for fp32
 // (at::acc_type<float> = double); a plain fp32 scan lands 1e-4 away after the division by (w_p + 1e-5).
 #include "common.h"
+#include "wave_scan.h"
 
 namespace nrhip {
 namespace {
@@ -26,30 +27,19 @@ struct RayLds {
   float v[kMaxProp + 1];   // cdf interpolated at the proposal edges
 };
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// wave-wide sums / scans on DPP row shifts + readlane (wave_scan.h): the fp64 scans below were six dependent pairs of
+// ds_bpermute each as shuffles, three times per ray and chunk
+__device__ __forceinline__ double wave_sum_d(double v) { return wscan::reduce<wscan::Add>(v); }
+__device__ __forceinline__ float wave_sum_f(float v) { return wscan::reduce<wscan::Add>(v); }
 // inclusive prefix sum of arr[0..n) in place: fp64 accumulation, every prefix rounded to fp32 (see header)
 __device__ __forceinline__ void scan_inplace(float* arr, int n, int lane) {
   double carry = 0.0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
-    double v = i < n ? (double)arr[i] : 0.0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
-    }
+    double v = wscan::incl<wscan::Add>(i < n ? (double)arr[i] : 0.0, lane);
     v += carry;
     if (i < n) arr[i] = (float)v;
-    carry = __shfl(v, 63, 64);
+    carry = wscan::last(v);
   }
 }
 __device__ __forceinline__ void wave_fence() {
@@ -207,8 +197,7 @@ __global__ __launch_bounds__(256) void lidar_carving_kernel(const float* __restr
     }
   }
   if (loss_ray) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    acc = wave_sum_f(acc);
     if (lane == 0) loss_ray[ray] = acc;
   }
 }

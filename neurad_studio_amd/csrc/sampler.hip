@@ -3,6 +3,7 @@
 // slab, the exclusive sum scans are wave shuffles, the inverse-CDF lookups are per-lane binary searches
 // in LDS (the 65 / 33 query points of a round fit one / two passes of the 64 lanes).
 #include "rayorder.h"
+#include "wave_scan.h"
 
 namespace nrhip {
 
@@ -112,19 +113,9 @@ __global__ __launch_bounds__(kOrderThreads) void power_sampler_order_kernel(
   if (t < R * (S + 1)) power_sampler_bin(nears, fars, t, S, lam, scaling, t_rand, last_edge, sp, eu);
 }
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ float wscan_add(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
-  return v;
-}
+// wave-wide sum / scan on DPP row shifts + readlane (wave_scan.h), not on ds_bpermute shuffles
+__device__ __forceinline__ float wsum(float v) { return wscan::reduce<wscan::Add>(v); }
+__device__ __forceinline__ float wscan_add(float v, int lane) { return wscan::incl<wscan::Add>(v, lane); }
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -148,7 +139,7 @@ __device__ __forceinline__ void pdf_build_cdf(const float* w_lds, float* cdf_lds
     const float pdf = k < Sp ? ((w_lds[k] + pad) + add) / tot : 0.f;
     const float incl = wscan_add(pdf, lane);
     if (k < Sp) cdf_lds[k + 1] = fminf(1.f, carry + incl);
-    carry += __shfl(incl, 63, 64);
+    carry += wscan::last(incl);
   }
   if (lane == 0) cdf_lds[0] = 0.f;
 }
@@ -415,7 +406,7 @@ __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, co
           wl[k] = w;
           sd.w_out[rd][ray * S + k] = w;
         }
-        carry += __shfl(incl, 63, 64);
+        carry += wscan::last(incl);
       }
       wave_fence();
       // S4: resample into the next round's bins

@@ -15,41 +15,18 @@
 //                     intensity, ray-drop BCE -- a per-ray pass + one single-workgroup pass; gradients in one scatter
 // One wavefront per ray for the per-ray scans, exactly like composite.hip.
 #include "common.h"
+#include "wave_scan.h"
 
 namespace nrhip {
 namespace {
 
 constexpr int kRaysPerBlock = 4;  // 4 waves / block
 
-__device__ __forceinline__ float tf_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_up(v, off, 64);
-    if (lane >= off) v *= u;
-  }
-  return v;
-}
-__device__ __forceinline__ float tf_scan_add(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
-  return v;
-}
-__device__ __forceinline__ float tf_rscan_add(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float u = __shfl_down(v, off, 64);
-    if (lane + off < 64) v += u;
-  }
-  return v;
-}
-__device__ __forceinline__ float tf_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// wave-wide scans on DPP row shifts + readlane (wave_scan.h), not on ds_bpermute shuffles
+__device__ __forceinline__ float tf_scan_mul(float v, int lane) { return wscan::incl<wscan::Mul>(v, lane); }
+__device__ __forceinline__ float tf_scan_add(float v, int lane) { return wscan::incl<wscan::Add>(v, lane); }
+__device__ __forceinline__ float tf_rscan_add(float v, int lane) { return wscan::rincl<wscan::Add>(v, lane); }
+__device__ __forceinline__ float tf_sum(float v) { return wscan::reduce<wscan::Add>(v); }
 __device__ __forceinline__ float tf_nan_to_num(float v) {
   if (v != v) return 0.f;
   if (v == INFINITY) return 3.4028234663852886e38f;
@@ -74,10 +51,9 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void prop_weights_fwd_kernel(co
     const float step = live ? (e1 - e0) * dens[ray * S + s] : 0.f;  // delta_density = deltas * densities
     const float alpha = 1.f - expf(-step);
     const float incl = tf_scan_add(step, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0.f;
+    const float excl = wscan::shift_up1(incl, 0.f, lane);
     const float T = expf(-(carry + excl));
-    carry += __shfl(incl, 63, 64);
+    carry += wscan::last(incl);
     if (live) {
       const float w = tf_nan_to_num(alpha * T);
       weights[ray * S + s] = w;
@@ -116,8 +92,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void prop_weights_bwd_kernel(co
     const float step = live ? delta * dens[ray * S + s] : 0.f;
     const float alpha = 1.f - expf(-step);
     const float incl = tf_scan_add(step, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0.f;
+    const float excl = wscan::shift_up1(incl, 0.f, lane);
     const float T = expf(-(carry + excl));
     float G = 0.f;
     if (live) G = (gw ? gw[ray * S + s] : 0.f) + gd * ((e0 + e1) / 2.f);
@@ -125,7 +100,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void prop_weights_bwd_kernel(co
     const float incl_r = tf_rscan_add(term, lane);
     const float after = incl_r - term + suffix;
     if (live) gdens[ray * S + s] = (G * T * expf(-step) - after) * delta;
-    suffix += __shfl(incl_r, 0, 64);
+    suffix += wscan::first(incl_r);
   }
 }
 
@@ -148,10 +123,9 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_fwd_kernel(
     const bool live = s < S;
     const float a = live ? sigmoidf_(-sdf[ray * S + s] * beta) : 0.f;
     const float incl = tf_scan_mul(1.f - a, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.f;
+    const float excl = wscan::shift_up1(incl, 1.f, lane);
     const float w = a * (carry * excl);
-    carry *= __shfl(incl, 63, 64);
+    carry *= wscan::last(incl);
     if (live) {
       alpha_out[ray * S + s] = a;
       wsh[s] = w;
@@ -231,10 +205,9 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_bwd_kernel(
       const bool live = s < S;
       const float a = live ? ar[s] : 0.f;
       const float incl = tf_scan_mul(1.f - a, lane);
-      float excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = 1.f;
+      const float excl = wscan::shift_up1(incl, 1.f, lane);
       const float T = carry * excl;
-      carry *= __shfl(incl, 63, 64);
+      carry *= wscan::last(incl);
       if (live) {
         Tsh[s] = T;
         w2[s] = a * T;
@@ -313,7 +286,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_bwd_kernel(
         gsdf[ray * S + s] = -ds * beta;
         gb -= ds * x;
       }
-      suffix += __shfl(incl_r, 0, 64);
+      suffix += wscan::first(incl_r);
     }
     gb = tf_sum(gb);
   }
@@ -441,12 +414,7 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* __res
         if (i0 + k < R && mask[i0 + k]) bits |= 1u << k;
     }
     const uint32_t c = (uint32_t)__popc(bits);
-    uint32_t incl = c;  // inclusive prefix over the wave's lanes
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t u = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += u;
-    }
+    const uint32_t incl = wscan::incl<wscan::Add>(c, lane);  // inclusive prefix over the wave's lanes
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     uint32_t before = 0, total = 0;
