@@ -18,14 +18,18 @@ constexpr int kMaxProp = 512;                   // proposal samples per ray
 constexpr int kKnots = 2 * (kMaxFine + 1) + 2;  // blurred knots incl. the 0 / 1 padding
 constexpr int kRaysPerBlock = 4;
 
+// One ray's scratch, carved out of dynamic LDS for the launch's actual sample counts: sized for the maxima (6.2 KB per ray)
+// the four rays of a workgroup held the CU at 6 workgroups = 24 of its 32 waves; NeuRAD's 32 fine / 128 proposal samples
+// need 1.6 KB.
 struct RayLds {
-  float c[kMaxFine + 1];
-  float wn[kMaxFine + 1];  // w / (c[i+1] - c[i]), then y1
-  float x[kKnots];         // c_  (padded knots)
-  float y[kKnots];         // w_  (padded blurred pdf)
-  float cdf[kKnots];       // padded cdf
-  float v[kMaxProp + 1];   // cdf interpolated at the proposal edges
+  float* c;    // [sf + 1]
+  float* wn;   // [sf + 1]      w / (c[i+1] - c[i]), then y1
+  float* x;    // [2 sf + 4]    c_  (padded knots)
+  float* y;    // [2 sf + 4]    w_  (padded blurred pdf)
+  float* cdf;  // [2 sf + 4]    padded cdf
+  float* v;    // [sp + 1]      cdf interpolated at the proposal edges
 };
+__host__ __device__ constexpr int ray_lds_floats(int sf, int sp) { return 2 * (sf + 1) + 3 * (2 * sf + 4) + (sp + 1); }
 
 // wave-wide sums / scans on DPP row shifts + readlane (wave_scan.h): the fp64 scans below were six dependent pairs of
 // ds_bpermute each as shuffles, three times per ray and chunk
@@ -50,11 +54,17 @@ __device__ __forceinline__ void wave_fence() {
 __global__ __launch_bounds__(64 * kRaysPerBlock) void interlevel_loss_kernel(
     const float* __restrict__ c_all, const float* __restrict__ w_all, int sf, const float* __restrict__ cp_all,
     const float* __restrict__ wp_all, int sp, float r, int64_t R, float* __restrict__ loss, float* __restrict__ gwp) {
-  __shared__ RayLds lds_all[kRaysPerBlock];
+  extern __shared__ float lds_dyn[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wid;
   if (ray >= R) return;
-  RayLds& L = lds_all[wid];
+  RayLds L;
+  L.c = lds_dyn + wid * ray_lds_floats(sf, sp);
+  L.wn = L.c + (sf + 1);
+  L.x = L.wn + (sf + 1);
+  L.y = L.x + (2 * sf + 4);
+  L.cdf = L.y + (2 * sf + 4);
+  L.v = L.cdf + (2 * sf + 4);
   const float* c = c_all + ray * (sf + 1);
   const float* w = w_all + ray * sf;
   // ---- fine histogram: last weight absorbs the missing mass, heights = weight / width (losses.py:680-683) ------
@@ -215,8 +225,8 @@ extern "C" int nrhip_interlevel_loss(const float* c, const float* w, int32_t n_f
              "interlevel_loss: %d fine / %d proposal samples per ray exceed %d / %d", n_fine, n_prop, kMaxFine, kMaxProp);
   if (r == 0) return NRHIP_OK;
   NR_REQUIRE(c && w && cp && wp && loss_per_ray, NRHIP_ERR_INVALID_ARG, "interlevel_loss: null pointer");
-  interlevel_loss_kernel<<<(unsigned)((r + kRaysPerBlock - 1) / kRaysPerBlock), 64 * kRaysPerBlock, 0,
-                           (hipStream_t)stream>>>(c, w, n_fine, cp, wp, n_prop, pulse_width, r, loss_per_ray, grad_wp);
+  interlevel_loss_kernel<<<(unsigned)((r + kRaysPerBlock - 1) / kRaysPerBlock), 64 * kRaysPerBlock,
+                           (size_t)kRaysPerBlock * ray_lds_floats(n_fine, n_prop) * sizeof(float), (hipStream_t)stream>>>(c, w, n_fine, cp, wp, n_prop, pulse_width, r, loss_per_ray, grad_wp);
   return check_launch("interlevel_loss");
 }
 

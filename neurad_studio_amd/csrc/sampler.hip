@@ -192,16 +192,19 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
                                                           float lam, float scaling, float pad,
                                                           const float* __restrict__ rand, int rand_stride,
                                                           float* __restrict__ new_sp, float* __restrict__ new_eu) {
-  __shared__ float slab[4][3 * (kSMax + 1)];
+  // three arrays of Sp + 1 floats per ray, sized for THIS launch: at the kSMax the four slabs (24 KB) held the CU at 6
+  // workgroups = 24 of its 32 waves
+  extern __shared__ float slab_dyn[];
+  const int slab_len = 3 * (Sp + 1);
   __shared__ float s_near[4], s_far[4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t ray0 = (int64_t)blockIdx.x * 4;
   const int n_rays = (int)min((int64_t)4, R - ray0);
   if (wid < n_rays) {
     const int64_t ray = ray0 + wid;
-    float* w_lds = slab[wid];
-    float* b_lds = w_lds + kSMax + 1;
-    float* c_lds = b_lds + kSMax + 1;
+    float* w_lds = slab_dyn + wid * slab_len;
+    float* b_lds = w_lds + Sp + 1;
+    float* c_lds = b_lds + Sp + 1;
     for (int k = lane; k < Sp; k += 64) w_lds[k] = weights[ray * Sp + k];
     for (int k = lane; k <= Sp; k += 64) b_lds[k] = bins[ray * (Sp + 1) + k];
     wave_fence();
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
   const int nb = Sn + 1;
   for (int j = threadIdx.x; j < n_rays * nb; j += 256) {
     const int r = j / nb, i = j - r * nb;
-    const float* w_lds = slab[r];
-    const float* b_lds = w_lds + kSMax + 1;
-    const float* c_lds = b_lds + kSMax + 1;
+    const float* w_lds = slab_dyn + r * slab_len;
+    const float* b_lds = w_lds + Sp + 1;
+    const float* c_lds = b_lds + Sp + 1;
     const int64_t ray = ray0 + r;
     const float nbv = pdf_sample_bin(c_lds, b_lds, Sp, nb, i, rand ? rand + ray * (rand_stride ? rand_stride : 1) : nullptr,
                                      rand_stride);
@@ -477,7 +480,7 @@ extern "C" int nrhip_pdf_sample(const float* weights, const float* spacing_bins,
   NR_REQUIRE(rand_stride == 0 || rand_stride == s_new + 1, NRHIP_ERR_INVALID_ARG,
              "pdf_sample: rand_stride must be 0 (single jitter) or s_new+1");
   if (r == 0) return NRHIP_OK;
-  pdf_sample_kernel<<<(int)((r + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+  pdf_sample_kernel<<<(int)((r + 3) / 4), 256, (size_t)4 * 3 * (s_prev + 1) * sizeof(float), (hipStream_t)stream>>>(
       weights, spacing_bins, nears, fars, r, s_prev, s_new, lam, scaling, histogram_padding, rand, rand_stride,
       new_spacing_bins, new_euclid_bins);
   return check_launch("pdf_sample");
