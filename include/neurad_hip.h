@@ -660,6 +660,26 @@ int nrhip_lidar_losses_bwd(const float* unit_grads, const float* scratch, const 
                            const float* upstream, int32_t n_levels, int64_t r, int64_t n, float* const* grad_depths,
                            float* grad_intensity, float* grad_logits, void* stream);
 
+/* ---- the level-sparse gradient exchange (opt-in; the reference's DDP all-reduce, pipelines/base_pipeline.py:304-307,
+ *      sends every level of a hash table densely).  grad [n_levels * rows_per_level, f] fp32, 16-byte aligned.
+ * count  : block_counts [n_levels, ceil(rows_per_level / NRHIP_GRAD_ROWS_PER_BLOCK)] = non-zero rows per block, turned into their
+ *          exclusive prefix per level before the call returns; level_counts [n_levels] int64 = non-zero rows per level.
+ * compact: the levels `levels[i]` (i < n_list_levels <= 32) as ordered lists: entries [sum caps[<i], + caps[i]) of rows (int32,
+ *          level-local, ascending; the CALLER pre-fills -1: padding up to the capacity agreed between the ranks) and of vals
+ *          [., f] = grad * scale.  block_offsets = count's block_counts.
+ * apply  : mode 0: grad[level, row] = 0; mode 1: grad[level, row] += vals -- for the entries with row >= 0 of a list laid out
+ *          the same way.  The rows of one list are distinct: no atomics, and lists applied in a fixed order give every rank
+ *          bit-identical sums.                                                                                              */
+#define NRHIP_GRAD_ROWS_PER_BLOCK 256 /* blocks per level = ceil(rows_per_level / 256) */
+int nrhip_grad_rows_count(const float* grad, int32_t n_levels, int64_t rows_per_level, int32_t f, uint32_t* block_counts,
+                          int64_t* level_counts, void* stream);
+int nrhip_grad_rows_compact(const float* grad, int32_t n_levels, int64_t rows_per_level, int32_t f,
+                            const uint32_t* block_offsets, const int32_t* levels /*host*/, const int64_t* caps /*host*/,
+                            int32_t n_list_levels, float scale, int32_t* rows, float* vals, void* stream);
+int nrhip_grad_rows_apply(float* grad, int32_t n_levels, int64_t rows_per_level, int32_t f, const int32_t* levels /*host*/,
+                          const int64_t* caps /*host*/, int32_t n_list_levels, const int32_t* rows, const float* vals,
+                          int32_t mode, void* stream);
+
 /* ---- (f)-1: RGB CNN decoder (models/neurad.py:198-216,359-366; model_components/cnns.py:20-46) on fp16 operands with
  *          fp32 accumulation -- the arithmetic of the reference's mixed-precision trainer.  Activations are NHWC fp16:
  *          [B, H, W, 32].                                                                                              */

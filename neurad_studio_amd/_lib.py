@@ -93,6 +93,7 @@ class LidarTable(C.Structure):
 
 
 MAX_SAMPLE_CONTAINMENTS = 8  # NRHIP_MAX_SAMPLE_CONTAINMENTS
+GRAD_ROWS_PER_BLOCK = 256   # NRHIP_GRAD_ROWS_PER_BLOCK
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes : exactly the prototypes of include/neurad_hip.h (tests/test_abi.py cross-checks this
@@ -201,6 +202,9 @@ PROTOTYPES = {
     "nrhip_appearance_fwd": [P, P, P, F32, I32, I32, I64, I32, I32, P, I32, P],
     "nrhip_appearance_bwd": [P, I32, P, P, F32, I32, I32, I64, I32, I32, P, P],
     "nrhip_mask_compact": [P, I64, P, I64, P, P, P],
+    "nrhip_grad_rows_count": [P, I32, I64, I32, P, P, P],
+    "nrhip_grad_rows_compact": [P, I32, I64, I32, P, C.POINTER(I32), C.POINTER(I64), I32, F32, P, P, P],
+    "nrhip_grad_rows_apply": [P, I32, I64, I32, C.POINTER(I32), C.POINTER(I64), I32, P, P, I32, P],
     "nrhip_lidar_losses": [C.POINTER(P), I32, P, P, P, P, P, P, I64, F32, F32, F32, P, P, P, P],
     "nrhip_lidar_losses_workspace": [I64, C.POINTER(I64)],
     "nrhip_lidar_losses_bwd": [P, P, P, P, P, I32, I64, I64, C.POINTER(P), P, P, P],

@@ -1302,3 +1302,51 @@ def lidar_losses_bwd(saved, inverse: Tensor, upstream: Tensor, n_levels: int, n_
     call("nrhip_lidar_losses_bwd", _ptr(unit), _ptr(scratch), _ptr(ret), _ptr(inv), _ptr(up), n_levels, n_rays, n,
          C.cast(pg, C.POINTER(C.c_void_p)), _ptr(gi), _ptr(gl), _stream())
     return gds, gi, gl
+
+
+# ---- the level-sparse gradient exchange's device side (csrc/grad_rows.hip; parallel/data_parallel.py) ----------
+def grad_rows_count(grad: Tensor, n_levels: int):
+    """grad [n_levels * T, F] fp32 -> (level_counts [n_levels] int64 = non-zero rows per level, block_offsets [n_levels, nblk]
+    uint32 as int32 storage: the per-block exclusive prefix ``grad_rows_compact`` needs)"""
+    g = _chk(grad, "grad")
+    T, F = g.shape[0] // n_levels, g.shape[1]
+    nblk = (T + _lib.GRAD_ROWS_PER_BLOCK - 1) // _lib.GRAD_ROWS_PER_BLOCK
+    blocks = torch.empty((n_levels, nblk), dtype=torch.int32, device=g.device)
+    counts = torch.empty((n_levels,), dtype=torch.int64, device=g.device)
+    call("nrhip_grad_rows_count", _ptr(g), n_levels, T, F, _ptr(blocks), _ptr(counts), _stream())
+    return counts, blocks
+
+
+def _list_args(levels: Sequence[int], caps: Sequence[int]):
+    n = len(levels)
+    return (C.c_int32 * n)(*levels), (C.c_int64 * n)(*caps), n
+
+
+def grad_rows_compact(grad: Tensor, n_levels: int, block_offsets: Tensor, levels: Sequence[int], caps: Sequence[int],
+                      scale: float = 1.0):
+    """the levels ``levels`` of grad as ordered (row, values) lists, level i padded to caps[i] entries with row -1 / zeros
+    -> (rows [sum caps] int32, vals [sum caps, F] fp32 = grad * scale)"""
+    g = _chk(grad, "grad")
+    T, F = g.shape[0] // n_levels, g.shape[1]
+    total = int(sum(caps))
+    rows = torch.full((total,), -1, dtype=torch.int32, device=g.device)
+    vals = torch.zeros((total, F), dtype=torch.float32, device=g.device)
+    if total:
+        lv, cp, n = _list_args(levels, caps)
+        call("nrhip_grad_rows_compact", _ptr(g), n_levels, T, F, _ptr(_chk(block_offsets, "block_offsets", torch.int32)), lv, cp, n,
+             float(scale), _ptr(rows), _ptr(vals), _stream())
+    return rows, vals
+
+
+def grad_rows_apply(grad: Tensor, n_levels: int, levels: Sequence[int], caps: Sequence[int], rows: Tensor,
+                    vals: Optional[Tensor], add: bool) -> None:
+    """in place on grad: rows of the list -> 0 (add=False) or += vals (add=True); entries with row -1 are padding"""
+    if not grad.is_contiguous():
+        raise ValueError("grad_rows_apply: contiguous gradient only (it is updated in place)")
+    g = _chk(grad, "grad")
+    T, F = g.shape[0] // n_levels, g.shape[1]
+    if int(sum(caps)) == 0:
+        return
+    lv, cp, n = _list_args(levels, caps)
+    call("nrhip_grad_rows_apply", _ptr(g), n_levels, T, F, lv, cp, n, _ptr(_chk(rows, "rows", torch.int32)),
+         _ptr(None if vals is None else _chk(vals, "vals")), 1 if add else 0, _stream())

@@ -19,6 +19,9 @@ MI355X-first choices (xGMI is point-to-point, 7 links x ~153 GB/s per GPU; a rin
     levels), so those levels travel as (row, values) lists in one all-gather and every rank adds the lists in rank order
     (bit-identical replicas); the fine levels stay dense.  Which levels go as lists is decided per step from the agreed
     maximum row count: a list pays while (N-1) * rows * (4 + 4F) bytes < the 2 (N-1)/N * T * 4F of the dense pair.
+    On the GPU the counting, the ordered compaction and the merge are csrc/grad_rows.hip (no torch op chains); with
+    ``overlap=True`` the table's hook starts the count agreement and the reduce-scatter of the levels that went densely in the
+    previous step -- the bulk of the bytes -- under the rest of the backward; sync() only sizes and sends the lists.
 Backend-agnostic (``"nccl"`` == RCCL on ROCm, ``"gloo"`` in the CPU tests)."""
 from __future__ import annotations
 
@@ -91,6 +94,9 @@ class GradientSynchronizer:
         self._agreed_all: Optional[List[bool]] = None  # ... and the parameters EVERY rank holds a local gradient for
         self._local_at_agreement: Optional[List[bool]] = None
         self._inflight: Dict[int, Tuple[object, Tensor, Tensor]] = {}  # param index -> (work, flat grad, shard)
+        self._inflight_levels: Dict[int, tuple] = {}   # level table -> (counts, count all-reduce, compaction aux, dense runs)
+        self._dense_prev: Dict[int, set] = {}          # level table -> the levels that went densely in the previous step
+        self.overlapped_level_runs_last_step = 0       # dense level runs whose exchange a hook started (last sync())
         self._hooks = []
         self.overlapped_last_step = 0
         # level-sparse exchange (opt-in): parameter index -> number of levels of a [levels * T, F] hash table
@@ -110,7 +116,9 @@ class GradientSynchronizer:
         self._ev_steps: List[Tuple[object, object, object]] = []  # (first hook | None, sync entry, sync exit)
         if overlap:
             for i, p in enumerate(self.params):
-                if self._is_large(p) and i not in self._levels:  # level tables wait for the agreed row counts
+                if i in self._levels:  # counts + the previously dense levels start from the hook (_start_level_table)
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda param, i=i: self._on_level_grad_ready(i)))
+                elif self._is_large(p):
                     self._hooks.append(p.register_post_accumulate_grad_hook(lambda param, i=i: self._on_grad_ready(i)))
 
     def world_size(self) -> int:
@@ -168,30 +176,93 @@ class GradientSynchronizer:
     def _row_mask(g: Tensor, n_levels: int) -> Tensor:
         return (g.view(n_levels, -1, g.shape[-1]) != 0).any(-1)  # [levels, T]
 
-    def _sync_level_tables(self, todo: List[int]) -> None:
-        """Hash-table gradients whose coarse levels go as (row, values) lists.  One MAX all-reduce of the per-level row counts
-        and ONE host read size the lists for every table; lists are padded to the agreed count with row -1."""
+    def _level_counts(self, g: Tensor, n_levels: int):
+        """-> (non-zero rows per level, int64 [levels] on g's device; what the compaction needs later).  GPU gradients: two
+        launches of csrc/grad_rows.hip (count + per-block prefix); CPU tensors (the gloo tests): torch ops."""
+        if g.is_cuda:
+            from .. import ops
+
+            return ops.grad_rows_count(g, n_levels)
+        mask = self._row_mask(g, n_levels)
+        return mask.sum(1).to(torch.int64), mask
+
+    def _start_level_table(self, i: int, early: bool) -> None:
+        """Count the rows, start the MAX all-reduce of the counts (tiny, async) and -- ``early``: called from the gradient's
+        hook -- the dense reduce-scatter of the levels that went densely in the PREVIOUS step (that set is agreed: it was
+        derived from all-reduced counts), so that the bulk of a table's exchange runs under the rest of the backward exactly
+        as for a plain large gradient.  Which of the remaining levels go as lists is decided in sync(), from this step's counts."""
+        g, L = self.params[i].grad, self._levels[i]
+        T, F = g.shape[0] // L, g.shape[1]
         world = self.world_size()
-        masks = {i: self._row_mask(self.params[i].grad, self._levels[i]) for i in todo}
-        counts = torch.cat([masks[i].sum(1) for i in todo]).to(torch.int64)
-        dist.all_reduce(counts, op=dist.ReduceOp.MAX, group=self.group)
-        counts, off = counts.tolist(), 0
-        for i in todo:
-            g, L = self.params[i].grad, self._levels[i]
-            T, F = g.shape[0] // L, g.shape[1]
-            cap = counts[off:off + L]
-            off += L
-            # a list costs (N-1) * cap * (4 + 4F) bytes per rank, the dense pair 2 (N-1)/N * T * 4F
-            lists = [l for l in range(L) if cap[l] * (1 + F) * world < 2 * T * F and (T * F) % world == 0]
-            self.last_list_levels[i] = lists
-            flat = g.view(-1)
-            l = 0
-            while l < L:  # maximal runs of dense levels: reduce-scatter + all-gather in place, as for any large gradient
-                if l in lists:
+        counts, aux = self._level_counts(g, L)
+        cw = dist.all_reduce(counts, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        runs = []
+        prev = self._dense_prev.get(i) if early else None
+        if prev and (T * F) % world == 0:
+            flat, l = g.view(-1), 0
+            while l < L:  # maximal runs of previously dense levels
+                if l not in prev:
                     l += 1
                     continue
                 e = l
-                while e < L and e not in lists:
+                while e < L and e in prev:
+                    e += 1
+                run = flat[l * T * F:e * T * F]
+                work, shard = reduce_scatter_flat(run, world, self.group, async_op=True)
+                runs.append((l, e, work, run, shard))
+                l = e
+        self._inflight_levels[i] = (counts, cw, aux, runs)
+
+    def _on_level_grad_ready(self, i: int) -> None:
+        """post-accumulate-grad hook of a level table (overlap): same conditions as ``_on_grad_ready``"""
+        if self._agreed is None or not self._agreed_all[i] or self.world_size() == 1:
+            return
+        g = self.params[i].grad
+        if g.dtype != torch.float32 or not g.is_contiguous():  # (sync() sends such a table like any other gradient)
+            return
+        if i in self._inflight_levels:
+            raise RuntimeError("GradientSynchronizer(overlap=True): a second backward reached level table "
+                               f"{i} before sync(); call sync() after every backward (gradient accumulation: overlap=False)")
+        if self.profile and self._ev_first_hook is None and self.params[i].is_cuda:
+            self._ev_first_hook = torch.cuda.Event(enable_timing=True)
+            self._ev_first_hook.record()
+        self._start_level_table(i, early=True)
+
+    def _sync_level_tables(self, todo: List[int]) -> None:
+        """Hash-table gradients whose coarse levels go as (row, values) lists.  One MAX all-reduce of the per-level row counts
+        per table and ONE host read for all of them size the lists; lists are padded to the agreed count with row -1."""
+        world = self.world_size()
+        for i in todo:  # tables whose hook did not run (first step, overlap off): the same collectives, issued now
+            if i not in self._inflight_levels:
+                self._start_level_table(i, early=False)
+        state = {i: self._inflight_levels.pop(i) for i in todo}
+        for i in todo:
+            state[i][1].wait()
+        counts, off = torch.cat([state[i][0] for i in todo]).tolist(), 0
+        for i in todo:
+            g, L = self.params[i].grad, self._levels[i]
+            T, F = g.shape[0] // L, g.shape[1]
+            _, _, aux, runs = state[i]
+            cap = counts[off:off + L]
+            off += L
+            started = {l for (a, e, _, _, _) in runs for l in range(a, e)}
+            # a list costs (N-1) * cap * (4 + 4F) bytes per rank, the dense pair 2 (N-1)/N * T * 4F
+            lists = [l for l in range(L) if l not in started and cap[l] * (1 + F) * world < 2 * T * F and (T * F) % world == 0]
+            self.last_list_levels[i] = lists
+            self._dense_prev[i] = set(range(L)) - set(lists)
+            for (a, e, work, run, shard) in runs:  # started from the hook: wait for the scatter, finish with the gather
+                work.wait()
+                self._finish_large(run, shard)
+                self.last_wire_bytes += 2 * (world - 1) * run.numel() * 4 // world
+            self.overlapped_level_runs_last_step += len(runs)
+            flat = g.view(-1)
+            l = 0
+            while l < L:  # maximal runs of the remaining dense levels: reduce-scatter + all-gather in place
+                if l in lists or l in started:
+                    l += 1
+                    continue
+                e = l
+                while e < L and e not in lists and e not in started:
                     e += 1
                 run = flat[l * T * F:e * T * F]
                 if run.numel() % world:
@@ -203,9 +274,24 @@ class GradientSynchronizer:
                     self._finish_large(run, shard)
                 self.last_wire_bytes += 2 * (world - 1) * run.numel() * 4 // world
                 l = e
-            if not lists or sum(cap[l] for l in lists) == 0:
+            caps = [cap[l] for l in lists]
+            total = sum(caps)
+            if not lists or total == 0:
                 continue
-            total = sum(cap[l] for l in lists)
+            self.last_wire_bytes += (world - 1) * total * (4 + 4 * F)
+            if g.is_cuda:  # csrc/grad_rows.hip: ordered compaction, then every rank's list applied in RANK order
+                from .. import ops
+
+                rows, vals = ops.grad_rows_compact(g, L, aux, lists, caps, scale=1.0 / world if self.average else 1.0)
+                all_rows, all_vals = rows.new_empty((world * total,)), vals.new_empty((world * total, F))
+                all_gather_flat(all_rows, rows, world, self.group)
+                all_gather_flat(all_vals.view(-1), vals.view(-1), world, self.group)
+                ops.grad_rows_apply(g, L, lists, caps, rows, None, add=False)  # own rows -> 0, then the sums in rank order
+                for k in range(world):
+                    ops.grad_rows_apply(g, L, lists, caps, all_rows[k * total:(k + 1) * total],
+                                        all_vals[k * total:(k + 1) * total], add=True)
+                continue
+            masks = aux
             rows = torch.full((total,), -1, device=g.device, dtype=torch.int32)
             vals = torch.zeros((total, F), device=g.device, dtype=g.dtype)
             ar = torch.arange(T, device=g.device, dtype=torch.int32)
@@ -213,7 +299,7 @@ class GradientSynchronizer:
             for l in lists:  # ordered compaction without a host read: the capacity is known, a dump slot takes the rest
                 c = cap[l]
                 if c:
-                    m = masks[i][l]
+                    m = masks[l]
                     slot = torch.where(m, m.cumsum(0) - 1, c)
                     buf = torch.full((c + 1,), -1, device=g.device, dtype=torch.int32)
                     buf.scatter_(0, slot, ar)
@@ -233,7 +319,6 @@ class GradientSynchronizer:
             all_vals = [torch.empty_like(vals) for _ in range(world)]
             dist.all_gather(all_rows, rows, group=self.group)
             dist.all_gather(all_vals, vals, group=self.group)
-            self.last_wire_bytes += (world - 1) * total * (4 + 4 * F)
             o = 0
             for l in lists:
                 c = cap[l]
@@ -277,6 +362,7 @@ class GradientSynchronizer:
         small, nbytes, level_todo = [], 0, []
         self.last_wire_bytes, self.last_list_levels, self.last_wire_bytes_by_param = 0, {}, {}
         self.overlapped_last_step = len(self._inflight)
+        self.overlapped_level_runs_last_step = 0
         for i, (p, u) in enumerate(zip(self.params, used)):
             if not u:
                 continue
@@ -300,6 +386,7 @@ class GradientSynchronizer:
             else:
                 small.append(g)
         assert not self._inflight, "a hooked gradient was not consumed by sync()"
+        assert all(i in level_todo for i in self._inflight_levels), "a hooked level table was not consumed by sync()"
         if level_todo:
             before = self.last_wire_bytes
             self._sync_level_tables(level_todo)
@@ -336,7 +423,8 @@ class GradientSynchronizer:
         exposed = [a.elapsed_time(b) for _, a, b in steps]
         window = [h.elapsed_time(a) for h, a, _ in steps if h is not None]
         out = {"exchange_exposed_ms": sum(exposed) / len(exposed), "steps": len(exposed),
-               "hook_started_exchanges_per_step": self.overlapped_last_step}
+               "hook_started_exchanges_per_step": self.overlapped_last_step,
+               "hook_started_level_runs_per_step": self.overlapped_level_runs_last_step}
         if window:
             out["exchange_overlap_window_ms"] = sum(window) / len(window)
         return out

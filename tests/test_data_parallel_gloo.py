@@ -333,3 +333,50 @@ def test_level_sparse_exchange_equals_the_dense_exchange_world2_gloo():
         ret = mgr.dict()
         mp.spawn(_worker_levels, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert all(ret[r][0] for r in range(world)), dict(ret)
+
+
+def _worker_levels_overlap(rank, world, port, ret):
+    """the level-sparse exchange with overlap=True: from the second step on the table's hook starts the count agreement and
+    the dense levels' reduce-scatter; every step must still equal the plain dense exchange, on both ranks"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L, T, F = 4, 1024, 4
+    g = torch.Generator().manual_seed(177 + rank)
+
+    def grads(step):
+        a = torch.zeros(L, T, F)
+        for lvl, frac in enumerate((3 / T, 0.05, 0.4 if step < 3 else 0.9, 1.0)):  # level 2 turns dense in the last step
+            rows = torch.randperm(T, generator=g)[:max(int(frac * T), 1)]
+            a[lvl, rows] = torch.randn(len(rows), F, generator=g)
+        return a.reshape(L * T, F)
+
+    ok, runs, lists = True, [], []
+    ta = torch.nn.Parameter(torch.zeros(L * T, F))
+    tb = torch.nn.Parameter(torch.zeros(L * T, F))  # the same gradients through the dense exchange
+    small = torch.nn.Parameter(torch.zeros(5))
+    sync_l = GradientSynchronizer([ta, small], average=True, large_threshold_bytes=1 << 10, usage="static", overlap=True,
+                                  level_tables={ta: L})
+    sync_d = GradientSynchronizer([tb], average=True, large_threshold_bytes=1 << 10, usage="static", overlap=True)
+    for step in range(4):
+        ga = grads(step)
+        ta.grad = tb.grad = small.grad = None
+        ((ta * ga).sum() + (tb * ga).sum() + small.sum() * (1.0 + rank)).backward()  # fires the post-accumulate hooks
+        sync_l.sync(), sync_d.sync()
+        ok = ok and torch.equal(ta.grad, tb.grad) and torch.equal(small.grad, torch.full((5,), 1.5))
+        runs.append(sync_l.overlapped_level_runs_last_step)
+        lists.append(list(sync_l.last_list_levels[0]))
+    # step 0 agrees on the usage set (no hooks) and leaves its split behind: level 3 went densely, so from step 1 on its
+    # reduce-scatter starts from the hook; in step 3 level 2 has turned dense too
+    ok = ok and runs[0] == 0 and runs[1] == 1 and runs[2] == 1 and lists[0] == [0, 1, 2] and lists[2] == [0, 1, 2]
+    ok = ok and lists[3] == [0, 1] and runs[3] == 1  # level 2 goes densely from sync() in step 3 (hook: only level 3)
+    ret[rank] = (bool(ok), runs, lists)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_sparse_exchange_with_hook_started_overlap_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_levels_overlap, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret[r][0] for r in range(world)), dict(ret)

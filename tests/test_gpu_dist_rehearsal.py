@@ -89,6 +89,7 @@ def _worker(rank, world, port, mode, ret):
                                 skip=tables if sharded else (), level_tables=levels)
     lists = []
     overlapped = []
+    level_runs = []
     for step in range(3):
         for o in (topt, sopt):
             o.zero_grad(set_to_none=True)
@@ -96,11 +97,13 @@ def _worker(rank, world, port, mode, ret):
         sync.sync()
         overlapped.append(sync.overlapped_last_step)
         lists.append(sum(len(v) for v in sync.last_list_levels.values()))
+        level_runs.append(sync.overlapped_level_runs_last_step)
         topt.step(), sopt.step()
     torch.cuda.synchronize()
     if rank == 0:
         ret["overlapped"] = overlapped
         ret["lists"] = lists
+        ret["level_runs"] = level_runs
         ret["params"] = {n: p.detach().cpu() for n, p in m.named_parameters()}
     ret[f"done{rank}"] = True
     dist.barrier()
@@ -118,6 +121,7 @@ def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean
         mp.spawn(_worker, args=(world, _free_port(), mode, ret), nprocs=world, join=True)
         assert ret.get("done0") and ret.get("done1")
         got, overlapped, lists = dict(ret["params"]), list(ret["overlapped"]), list(ret["lists"])
+        level_runs = list(ret["level_runs"])
     # one process, the mean loss of both shards
     m = _model()
     params, tables, topt, sopt = _optimizers(m, False)
@@ -137,3 +141,6 @@ def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean
     assert overlapped[0] == 0 and overlapped[1] == overlapped[2] == (2 if mode == "allreduce" else 0), overlapped
     if mode == "level-sparse":  # 256 rays x 32 samples into 2^14-row levels: the coarse levels of both tables go as lists
         assert min(lists) >= 2, lists
+        # ... through csrc/grad_rows.hip (GPU gradients), and the levels that went densely in the previous step start their
+        # reduce-scatter from the table's hook (20 levels in the three tables; the never-evaluated proposal table has none)
+        assert level_runs[0] == 0 and (lists[0] >= 14 or min(level_runs[1:]) >= 1), (lists, level_runs)
