@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round measurements in one lease: GPU test suite, bench lines c1-c4, kernel traces, the PMC passes behind
 # roofline.traffic, the two-rank gloo rehearsal.  usage: scripts/final_measure.sh <tag>   (outputs under gpurun_out/<tag>_*)
-tag=${1:-r04}
+tag=${1:-r04f}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
@@ -18,6 +18,7 @@ prof train_full_c3 python $R/bench.py --config c3 --steps 10 --warmup 3
 prof c2 python $R/bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline
 prof c4 python $R/bench.py --config c4 --steps 4 --warmup 1 --train-steps 60
 NRHIP_BENCH_DECODER_MODES=hip prof decoder python $R/scripts/bench_decoder.py
+if [ -n "$SKIP_PMC" ]; then cd $R; python scripts/show_bench.py $OUT/bench_${tag}_c1.json $OUT/bench_${tag}_c2.json $OUT/bench_${tag}_c3.json $OUT/bench_${tag}_c4.json 2>/dev/null | head -60; exit 0; fi
 pmc() { name=$1; kern=$2; ctr=$3; shift; shift; shift; timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/pmc_${tag}_$name -o p -- "$@" > $OUT/pmc_${tag}_$name.log 2>&1
   echo "== $name: $ctr ($kern)"; python $R/scripts/pmc_report.py "$kern" $(find $OUT/pmc_${tag}_$name -name '*.db' | head -1); rm -rf $OUT/pmc_${tag}_$name; }
 {
