@@ -94,8 +94,12 @@ class NeuRADField(nn.Module):
     def __init__(self, config: NeuRADFieldConfig, actors=None, static_scale: float = 1.0,
                  implementation: str = "hip") -> None:
         super().__init__()
-        if config.num_multisamples != 1:
-            raise NotImplementedError("num_multisamples != 1 is not used by any NeuRAD config (neurad_field.py:67)")
+        if config.num_multisamples < 1:
+            raise ValueError("num_multisamples >= 1")
+        if config.num_multisamples != 1 and actors is not None and int(getattr(actors, "n_actors", 0)) > 0 \
+                and not config.grid.disable_actors:
+            raise NotImplementedError("num_multisamples != 1 with dynamic actors (no NeuRAD config uses it, neurad_field.py:67): "
+                                      "the multisampled frustum is implemented for the static scene")
         self.config, self.implementation = config, implementation
         self.order_rays = False
         """Training forward: walk the batch in the cache-coherent order of ops.ray_order (computed per call).  Pays for
@@ -129,6 +133,8 @@ class NeuRADField(nn.Module):
         with dynamic actors (per-sample table select, nrhip_render_fwd_actors) when the actor grids share the static
         grid's features per level (the reference's defaults); the other fused kernels cover the static scene only."""
         c, g = self.config, self.hashgrid.static_grid
+        if c.num_multisamples != 1:  # M probes per frustum: the operator-level path (forward) averages their encodings
+            return False
         if self.hashgrid.has_actors():
             ag_ = self.hashgrid.actor_grids[0]
             if not (with_actors and ag_.features_per_level == g.features_per_level and ag_.num_levels <= g.num_levels
@@ -273,7 +279,22 @@ class NeuRADField(nn.Module):
                 *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)],
                 *([ops.ray_order(o, d, self.hashgrid.static_scale)] if self.order_rays else []))
             return self._heads(feature.view(R, S, self.config.nff_out_dim), geo_out.view(R, S, 1))
-        features, sample_dirs = self.hashgrid.forward_rays(o, d, a, starts, ends, sample_times(ray_samples))
+        M = self.config.num_multisamples
+        if M == 1:
+            features, sample_dirs = self.hashgrid.forward_rays(o, d, a, starts, ends, sample_times(ray_samples))
+        else:
+            # get_fast_isotropic_gaussian(M) (cameras/rays.py:109-124): probes at t_k = start + k step, step = (end - start) /
+            # (M + 1), each with std_k = (area t_k^2 step)^(1/3) -- exactly the M = 1 gaussian of the interval (t_k - step,
+            # t_k + step), which is what the encode kernel computes from an interval; the rescaled features are averaged
+            # over k (neurad_encoding.py:297-304, mean(dim=-3)).  M launches of the M = 1 kernels, autograd through each.
+            step = (ends - starts) / (M + 1)
+            features, sample_dirs = None, None
+            for k in range(1, M + 1):
+                tk = starts + k * step
+                fk, _ = self.hashgrid.forward_rays(o, d, a, (tk - step).contiguous(), (tk + step).contiguous(),
+                                                   sample_times(ray_samples))
+                features = fk if features is None else features + fk
+            features = features / M
         geo = self.mlp_geo(features)
         geo_out, geo_embedding = geo[:, :1], geo[:, 1:]
         if sample_dirs is None:

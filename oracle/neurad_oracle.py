@@ -268,8 +268,21 @@ class ProposalParams:
     decoder_w: np.ndarray  # [1, L*F], no bias
 
 
-def encode_static(grid: GridParams, static_scale, origins, directions, pixel_area, starts, ends):
-    """H2 -> H3 -> H1 -> H4 (neurad_encoding.py:164-169,265-268).  -> [R*S, L*F]"""
+def encode_static(grid: GridParams, static_scale, origins, directions, pixel_area, starts, ends, num_multisamples: int = 1):
+    """H2 -> H3 -> H1 -> H4 (neurad_encoding.py:164-169,265-268).  -> [R*S, L*F]
+    num_multisamples = M > 1 (NeuRADFieldConfig.num_multisamples, fields/neurad_field.py:67,134): the frustum is probed at
+    t_k = start + k (end - start) / (M + 1), k = 1..M, each with std_k = (area t_k^2 (end - start) / (M + 1))^(1/3)
+    (cameras/rays.py:109-124), and the RESCALED features are averaged over k (neurad_encoding.py:302: mean(dim=-3)).  Sub-sample
+    k is exactly the M = 1 gaussian of the interval (t_k - step, t_k + step)."""
+    if num_multisamples > 1:
+        st, en = np.asarray(starts, f32), np.asarray(ends, f32)
+        step = ((en - st) / f32(num_multisamples + 1)).astype(f32)
+        acc = None
+        for k in range(1, num_multisamples + 1):
+            tk = (st + f32(k) * step).astype(f32)
+            fk = encode_static(grid, static_scale, origins, directions, pixel_area, (tk - step).astype(f32), (tk + step).astype(f32))
+            acc = fk if acc is None else acc + fk
+        return (acc / f32(num_multisamples)).astype(f32)
     mean, std = fast_isotropic_gaussian(origins, directions, pixel_area, starts, ends)
     pos, cstd = contract_gaussian(mean, std, static_scale)
     feat = hashgrid_fwd(pos.reshape(-1, 3), grid.table, grid.scalings, grid.table_size)
@@ -284,10 +297,10 @@ def sigmoid(x):
 # --------------------------------------------------------------------------------------
 # F1/F4  NeuRADField.forward (fields/neurad_field.py:128-152), SigmoidDensity (model_components/utils.py:21-41)
 # --------------------------------------------------------------------------------------
-def field_fwd(p: FieldParams, origins, directions, pixel_area, starts, ends) -> Dict[str, np.ndarray]:
+def field_fwd(p: FieldParams, origins, directions, pixel_area, starts, ends, num_multisamples: int = 1) -> Dict[str, np.ndarray]:
     """-> {"feature" [R,S,C], "sdf" [R,S], "alpha" [R,S]}  (or "density" when use_sdf=False)."""
     R, S = np.asarray(starts).shape
-    enc = encode_static(p.grid, p.static_scale, origins, directions, pixel_area, starts, ends)
+    enc = encode_static(p.grid, p.static_scale, origins, directions, pixel_area, starts, ends, num_multisamples)
     geo = mlp_fwd(enc, p.geo_w, p.geo_b)
     geo_out, geo_emb = geo[:, :1], geo[:, 1:]
     d01 = (np.asarray(directions, f32) + f32(1)) / f32(2)  # base_field.py:136-142

@@ -20,10 +20,10 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def make_field(use_sdf, lg=11):
+def make_field(use_sdf, lg=11, num_multisamples=1):
     from neurad_studio_amd.fields.neurad_field import NeuRADField, NeuRADFieldConfig
 
-    cfg = NeuRADFieldConfig(use_sdf=use_sdf)
+    cfg = NeuRADFieldConfig(use_sdf=use_sdf, num_multisamples=num_multisamples)
     cfg.grid.static.log2_hashmap_size = lg
     f = NeuRADField(cfg, actors=None, static_scale=100.0).cuda()
     with torch.no_grad():
@@ -79,6 +79,38 @@ def test_field_forward_backward_vs_reference_autograd(tag, fused_training):
         assert rel_l2(host(l.weight.grad), g[f"feat_dw{k}"]) < TOL and rel_l2(host(l.bias.grad), g[f"feat_db{k}"]) < TOL
     if tag == "sdf":
         assert rel_l2(host(fld.sdf_to_density.beta.grad), g["dbeta"]) < TOL
+
+
+def test_field_multisampled_vs_reference_golden():
+    """NeuRADFieldConfig.num_multisamples = 3 (fields/neurad_field.py:67,134): forward (no-grad and training path) and the table /
+    MLP gradients against the reference's own outputs for the same field and rays (oracle/make_golden_multisample.py)"""
+    from neurad_studio_amd.field_components.field_heads import FieldHeadNames
+    from neurad_studio_amd.model_components.ray_samplers import PowerSampler
+
+    g, gm = load_golden("field_sdf"), load_golden("field_multisample")
+    fld = make_field(True, num_multisamples=int(gm["num_multisamples"])).eval()
+    assert not fld.fused_supported()  # M probes per frustum: not what the fused kernels compute
+    rs = PowerSampler(num_samples=12, lambda_=-1.0, scaling=0.1).eval()(bundle(g["o"], g["d"], g["area"]))
+    with torch.no_grad():
+        out_e = fld(rs)
+    out = fld(rs)
+    for o_ in (out_e, out):
+        assert rel_l2(host(o_[FieldHeadNames.FEATURE]), gm["feature"]) < TOL
+        assert rel_l2(host(o_[FieldHeadNames.ALPHA][..., 0]), gm["alpha"]) < TOL
+        assert rel_l2(host(o_[FieldHeadNames.SDF][..., 0]), gm["sdf"]) < TOL
+    ((out[FieldHeadNames.FEATURE] * dev(g["g_feature"])).sum() + (out[FieldHeadNames.ALPHA][..., 0] * dev(g["g_head"])).sum()).backward()
+    tg = np.zeros((8 * 2**11, 4), np.float32)
+    tg[gm["tg_idx"]] = gm["tg_val"]
+    assert rel_l2(host(fld.hashgrid.static_grid.hash_table.grad), tg) < TOL
+    assert rel_l2(host(fld.mlp_geo.layers[0].weight.grad), gm["geo_dw0"]) < TOL
+    # dynamic actors + multisampling is refused at construction
+    from neurad_studio_amd.fields.neurad_field import NeuRADField, NeuRADFieldConfig
+    from neurad_studio_amd.model_components.dynamic_actors import DynamicActors, DynamicActorsConfig
+    from test_gpu_actors import trajectories
+
+    with pytest.raises(NotImplementedError, match="num_multisamples"):
+        NeuRADField(NeuRADFieldConfig(num_multisamples=2), actors=DynamicActors(DynamicActorsConfig(), trajectories=trajectories()),
+                    static_scale=100.0)
 
 
 def make_prop(seed, lg=11):

@@ -107,6 +107,25 @@ def test_field_forward(tag):
         assert rel_l2(out["density"], g["density"]) < TOL
 
 
+def test_field_forward_multisampled():
+    """NeuRADFieldConfig.num_multisamples = 3 against the reference's own outputs (oracle/make_golden_multisample.py): the
+    sub-sample gaussians, the averaged rescaled encoding, the field heads"""
+    g, gm = load_golden("field_sdf"), load_golden("field_multisample")
+    M = int(gm["num_multisamples"])
+    st, en = g["starts"], g["ends"]
+    step = ((en - st) / np.float32(M + 1)).astype(np.float32)
+    for k in range(1, M + 1):  # sub-sample k IS the M = 1 gaussian of (t_k - step, t_k + step)
+        tk = (st + np.float32(k) * step).astype(np.float32)
+        mean, std = O.fast_isotropic_gaussian(g["o"], g["d"], g["area"], tk - step, tk + step)
+        assert rel_l2(mean, gm["gmean"][:, :, k - 1]) < 1e-6 and rel_l2(std, gm["gstd"][:, :, k - 1]) < 1e-5
+    p = field_params(use_sdf=True)
+    enc = O.encode_static(p.grid, p.static_scale, g["o"], g["d"], g["area"], st, en, num_multisamples=M)
+    assert rel_l2(enc, gm["enc"]) < TOL
+    out = O.field_fwd(p, g["o"], g["d"], g["area"], st, en, num_multisamples=M)
+    assert rel_l2(out["feature"], gm["feature"]) < TOL and rel_l2(out["sdf"], gm["sdf"]) < TOL
+    assert rel_l2(out["alpha"], gm["alpha"]) < TOL and rel_l2(gm["alpha"], g["alpha"]) > 1e-3
+
+
 def prop_params(seed, lg=11):
     w, _ = synth.linear(1, 6, seed + 1, bias=False)
     return O.ProposalParams(O.GridParams(synth.hash_table(6 * 2**lg, 1, seed=seed, scale=2.0), 6, 128, 4096, lg),
