@@ -653,10 +653,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const _Float16* __res
   store8(out + idx * 8, v);
 }
 
-// the first `cols` columns of partial [n][k] -> out [cols] (= or +=), fixed order; 256 threads = 32 columns x 8 slices
+// the first `cols` columns of partial [n][k] -> out [cols] (= or +=), fixed order; 256 threads = 32 columns x 8 slices.
+// Columns >= cols0 go to out1 [cols - cols0] (a layer's bias gradient behind its weight gradient: one launch for both).
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ partial, int n, int k, int cols,
                                                          float* __restrict__ out, int accumulate,
-                                                         const float* __restrict__ gscale) {
+                                                         const float* __restrict__ gscale, int cols0 = 0x7fffffff,
+                                                         float* __restrict__ out1 = nullptr) {
   __shared__ float red[8][32];
   const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + o;
@@ -676,7 +678,8 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += red[q][o];
     if (gscale) s *= gscale[1];
-    out[col] = accumulate ? out[col] + s : s;
+    float* dst = col < cols0 ? out + col : out1 + (col - cols0);
+    *dst = accumulate ? *dst + s : s;
   }
 }
 
@@ -1250,8 +1253,8 @@ extern "C" int nrhip_dec_conv1x1_in_bwd(const float* features, const void* h, co
   hipLaunchKernelGGL(conv1x1_in_bwd_kernel, dim3(nb), dim3(256), 0, st, features, (const _Float16*)h,
                      (const _Float16*)grad_h, weight, grad_features, workspace, grad_scale, n, cin);
   // columns [0, 32 cin) -> grad_weight, [32 cin, +32) -> grad_bias (accumulated)
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(cin), dim3(256), 0, st, workspace, nb, k, 32 * cin, grad_weight, 1, grad_scale);
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 32 * cin, nb, k, 32, grad_bias, 1, grad_scale);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(cin + 1), dim3(256), 0, st, workspace, nb, k, 32 * cin + 32, grad_weight, 1,
+                     grad_scale, 32 * cin, grad_bias);  // weight columns, then the 32 bias columns
   return check_launch("dec_conv1x1_in_bwd");
 }
 
@@ -1298,10 +1301,8 @@ extern "C" int nrhip_dec_upsample_bwd(const void* h, const void* grad_out, const
                      (const _Float16*)grad_out, (const uint4*)wup + 9 * 2 * 64, (_Float16*)grad_h, hh, w, npix);
   hipLaunchKernelGGL(upsample_bwd_weight_kernel, dim3(kUpWgs), dim3(256), 0, st, (const _Float16*)h,
                      (const _Float16*)grad_out, workspace, hh, w, npix);
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(9 * 32), dim3(256), 0, st, workspace, kUpWgs * 4, k, 9 * 1024, grad_weight, 1,
-                     grad_scale);
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 9 * 1024, kUpWgs * 4, k, 32, grad_bias, 1,
-                     grad_scale);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(9 * 32 + 1), dim3(256), 0, st, workspace, kUpWgs * 4, k, 9 * 1024 + 32, grad_weight,
+                     1, grad_scale, 9 * 1024, grad_bias);
   return check_launch("dec_upsample_bwd");
 }
 
@@ -1345,8 +1346,8 @@ extern "C" int nrhip_dec_rgb_bwd(const void* h, const float* rgb, const float* g
   const int nb = (int)((n_pixels + 256 * kRgbChunks - 1) / (256 * kRgbChunks));
   hipLaunchKernelGGL(rgb_bwd_kernel, dim3(nb), dim3(256), 0, st, (const _Float16*)h, rgb, grad_rgb, weight,
                      (_Float16*)grad_h, workspace, grad_scale, n_pixels);
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(3), dim3(256), 0, st, workspace, nb, 99, 96, grad_weight, 1, grad_scale);
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(256), 0, st, workspace + 96, nb, 99, 3, grad_bias, 1, grad_scale);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(4), dim3(256), 0, st, workspace, nb, 99, 99, grad_weight, 1, grad_scale, 96,
+                     grad_bias);
   return check_launch("dec_rgb_bwd");
 }
 
