@@ -308,7 +308,7 @@ template <class Src>
 __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, int64_t n, int64_t n_total,
                                                          float4* __restrict__ gpos, uint16_t* __restrict__ gidx,
                                                          uint32_t* __restrict__ nlive, int allow_transpose) {
-  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t wave_tot[16 * (kSamplesPerBlock / 1024)];
   __shared__ uint32_t live_bits[kSamplesPerBlock / 32];
   __shared__ int s_nr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -329,32 +329,36 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
   __syncthreads();
   const int nr = s_nr;                                  // rays of a sample-index-major chunk, 0: ray-major
   const int spr = nr ? kSamplesPerBlock / nr : 1;       // samples per ray
-  // pass 2, walk order: positions of the live samples, compacted in that order
-  uint32_t base = 0;
+  // pass 2, walk order: positions of the live samples, compacted in that order.  All four passes' wave counts go to LDS
+  // first and ONE barrier orders them (a barrier pair per pass was eight workgroup syncs for 4096 samples).
+  bool live_it[nit];
+  int local_it[nit];
+  unsigned long long m_it[nit];
 #pragma unroll
   for (int it = 0; it < nit; ++it) {
     const int p = it * nt + tid;
-    const int local = nr ? (p % nr) * spr + p / nr : p;  // slot p of the walk holds sample `local` of the chunk
-    const bool live = (live_bits[local >> 5] >> (local & 31)) & 1u;
-    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) pos = src.position(i_off + i_blk + local);
-    const unsigned long long m = __ballot(live);
-    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
+    local_it[it] = nr ? (p % nr) * spr + p / nr : p;  // slot p of the walk holds sample `local` of the chunk
+    live_it[it] = (live_bits[local_it[it] >> 5] >> (local_it[it] & 31)) & 1u;
+    m_it[it] = __ballot(live_it[it]);
+    if (lane == 0) wave_tot[it * 16 + wave] = (uint32_t)__popcll(m_it[it]);
+  }
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int it = 0; it < nit; ++it) {
     uint32_t before = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-      const uint32_t c = wave_tot[w];
+      const uint32_t c = wave_tot[it * 16 + w];
       before += w < wave ? c : 0u;
       total += c;
     }
-    if (live) {
-      const uint32_t slot = base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      gpos[i_blk + slot] = pos;
-      gidx[i_blk + slot] = (uint16_t)local;
+    if (live_it[it]) {
+      const uint32_t slot = base + before + (uint32_t)__popcll(m_it[it] & ((1ull << lane) - 1ull));
+      gpos[i_blk + slot] = src.position(i_off + i_blk + local_it[it]);
+      gidx[i_blk + slot] = (uint16_t)local_it[it];
     }
     base += total;
-    __syncthreads();  // wave_tot is reused by the next pass
   }
   if (tid == 0) nlive[blockIdx.x] = base;
 }
