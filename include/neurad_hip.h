@@ -148,6 +148,13 @@ int nrhip_encode_fwd(const nrhip_grid* g, const void* table, float static_scale,
                      float* out /*[N,L*F]*/, void* stream);
 int nrhip_encode_bwd(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
                      const float* grad_out /*[N,L*F]*/, float* grad_table, void* stream);
+/* dL/d(origins) [R,3] and dL/d(directions) [R,3] (both WRITTEN) of the same path given grad_out [N,L*F] = dL/d(rescaled
+ * features): what autograd hands a camera optimizer that moves the rays (cameras/camera_optimizers.py:173-182,
+ * apply_to_raybundle; the `*-scaleopt` methods, configs/method_configs.py:438-447) -- mean = o + d t (cameras/rays.py:119,
+ * t constant: bins are detached, ray_samplers.py:363-364) -> contraction of mean AND std (spatial_distortions.py:126-141)
+ * -> trilinear offsets (encodings.py:425-464) and the std-dependent rescale (neurad_encoding.py:297-304).  No atomics. */
+int nrhip_encode_bwd_rays(const nrhip_grid* g, const void* table, float static_scale, const nrhip_rays* rays,
+                          const float* grad_out /*[N,L*F]*/, float* grad_origins, float* grad_directions, void* stream);
 /* Same result without memory-side atomics (every table entry gets one owning workgroup; see
  * csrc/encode_bwd_binned.hip).  Needs scratch: ask _workspace for the size (0 = this grid can not be binned, use
  * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  overwrite = 0: grad_table
@@ -493,6 +500,14 @@ int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip_rays* rays
                                    const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip,
                                    int64_t n_pairs, const float* grad_x01, const float* grad_cstd,
                                    float* grad_positions, float* grad_rotations_6d, void* stream);
+/* The same backward, additionally ACCUMULATING dL/d(origins) [R,3] and dL/d(directions) [R,3] of the pairs' rays (caller
+ * zeroes or pre-fills): the in-box samples' share of the pose gradient of a camera optimizer that moves the rays
+ * (cameras/camera_optimizers.py:173-182; `require_actor_grad`, neurad_encoding.py:174-176 keeps positions.mean in the graph). */
+int nrhip_actor_pair_positions_bwd_rays(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                        const int64_t* sample_idx, const int32_t* actor_idx, const float* ray_flip,
+                                        int64_t n_pairs, const float* grad_x01, const float* grad_cstd,
+                                        float* grad_positions, float* grad_rotations_6d, float* grad_origins,
+                                        float* grad_directions, void* stream);
 
 /* Proposal density of the in-box samples in TRAINING (fields/neurad_field.py:208-213 over neurad_encoding.py:150-187,
  * index_put order :184-185): rows [P, row_dim] = rescaled actor features of the P (sample, actor) pairs, decoder_weight

@@ -136,6 +136,7 @@ PROTOTYPES = {
     "nrhip_hashgrid_multi_bwd_input": [C.POINTER(Grid), P, I32, P, P, P, I64, P, P],
     "nrhip_encode_fwd": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P],
     "nrhip_encode_bwd": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P],
+    "nrhip_encode_bwd_rays": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P, P, P],
     "nrhip_encode_bwd_binned_workspace": [C.POINTER(Grid), I64, C.POINTER(I64)],
     "nrhip_encode_bwd_binned": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, I32, P, I64, P],
     "nrhip_hashgrid_bwd_binned": [C.POINTER(Grid), P, P, I64, P, I32, P, I64, P],
@@ -183,6 +184,7 @@ PROTOTYPES = {
     "nrhip_actor_density": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I32, P, P, P, P],
     "nrhip_actor_pair_positions_fwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P],
     "nrhip_actor_pair_positions_bwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P, P, P],
+    "nrhip_actor_pair_positions_bwd_rays": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P, P, P, P, P],
     "nrhip_actor_density_splice_fwd": [P, I32, P, P, P, I64, P, P, P],
     "nrhip_actor_density_splice_bwd": [P, I32, P, P, P, P, P, P, I64, P, P, P, P],
     "nrhip_render_fwd_actors": [C.POINTER(Field), C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P, P, F32, P, P],

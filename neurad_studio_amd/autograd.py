@@ -3,8 +3,10 @@
 Every Function runs under ``custom_fwd(cast_inputs=float32)`` like the reference's ``trunc_exp``
 (field_components/activations.py:31-41), because the trainer runs under autocast + GradScaler
 (engine/trainer.py:550-553).  Gradients flow to hash tables, MLP weights/biases, the proposal decoder,
-densities/alphas and features; positions get no gradient (static samples carry none while
-camera_optimizer.mode == "off"; actor-pose gradients are a later row).
+densities/alphas and features, to the actor trajectories, and -- when the ray bundle's origins / directions require grad
+(a camera optimizer moved them, cameras/camera_optimizers.py:173-182) -- to the rays: `_ray_grads` below, one kernel per
+hash grid the rays were encoded with (nrhip_encode_bwd_rays; view directions carry none: SHEncoding.pytorch_fwd is
+@torch.no_grad in the parity target, encodings.py:797).
 """
 from __future__ import annotations
 
@@ -12,6 +14,23 @@ import torch
 from torch.amp import custom_bwd, custom_fwd
 
 from . import ops
+
+
+_E15, _EM15 = 3269017.3724721107, 3.0590232050182579e-07  # exp(+-15): trunc_exp's backward clamp (activations.py:37-41)
+
+
+def _ray_grads(need_o: bool, need_d: bool, spec, table, scale, o, d, a, starts, ends, genc):
+    """(dL/d origins, dL/d directions) of a static encoding from dL/d(rescaled features), None where not needed"""
+    if not (need_o or need_d):
+        return None, None
+    go, gd = ops.encode_bwd_rays(spec, table, scale, o, d, a, starts, ends, genc)
+    return (go if need_o else None), (gd if need_d else None)
+
+
+def _proposal_genc(dens, gdens, decoder_weight):
+    """dL/d(rescaled level features) [N, L] of density = trunc_exp(features . decoder) from dL/d density"""
+    gl = gdens.reshape(-1) * dens.reshape(-1).clamp(_EM15, _E15)
+    return gl[:, None] * decoder_weight.reshape(1, -1)
 
 
 class HashGridFn(torch.autograd.Function):
@@ -52,6 +71,11 @@ class ActorPairPositionsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_x01, g_cstd):
         o, d, a, s, e, times, si, ai = ctx.saved_tensors
+        need_o, need_d = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        if need_o or need_d:  # the rays move with a camera optimizer: the in-box samples' share of its gradient
+            gp, gr, go, gd = ops.actor_pair_positions_bwd(ctx.spec, o, d, a, s, e, times, si, ai, ctx.flip,
+                                                          g_x01.contiguous(), g_cstd.contiguous(), ray_grads=True)
+            return (gp, gr, None, go if need_o else None, gd if need_d else None) + (None,) * 7
         gp, gr = ops.actor_pair_positions_bwd(ctx.spec, o, d, a, s, e, times, si, ai, ctx.flip, g_x01.contiguous(),
                                               g_cstd.contiguous())
         return (gp, gr) + (None,) * 10
@@ -119,15 +143,19 @@ class EncodeFn(torch.autograd.Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, table, spec, static_scale, origins, directions, pixel_area, starts, ends):
         ctx.spec, ctx.scale, ctx.table_dtype = spec, static_scale, table.dtype
-        ctx.save_for_backward(origins, directions, pixel_area, starts, ends)
+        ctx.rays = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, *([table] if ctx.rays else []))
         return ops.encode_fwd(spec, table, static_scale, origins, directions, pixel_area, starts, ends)
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        o, d, a, s, e = ctx.saved_tensors
-        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, g.contiguous())
-        return _like_param(gt, ctx.table_dtype), None, None, None, None, None, None, None
+        o, d, a, s, e, *tab = ctx.saved_tensors
+        g = g.contiguous()
+        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, g) if ctx.needs_input_grad[0] else None
+        go, gd = (None, None) if not ctx.rays else _ray_grads(ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.spec,
+                                                              tab[0], ctx.scale, o, d, a, s, e, g)
+        return _like_param(gt, ctx.table_dtype), None, None, go, gd, None, None, None
 
 
 class FieldTrainFn(torch.autograd.Function):
@@ -148,25 +176,33 @@ class FieldTrainFn(torch.autograd.Function):
                                                                            order=order)
         ctx.has_order, ctx.table_dtype = order is not None, table.dtype
         ctx.spec, ctx.scale = spec, static_scale
-        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, enc, hg, xf, hf, *params)
+        ctx.rays = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        ctx.save_for_backward(origins, directions, pixel_area, starts, ends, enc, hg, xf, hf, *params,
+                              *([table] if ctx.rays else []))
         return feature, geo_out[:, None]
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, g_feature, g_geo_out):
         o, d, a, s, e, enc, hg, xf, hf, *params = ctx.saved_tensors
-        gt, grads = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, s, e, enc, hg, xf,
-                                    hf, params, g_feature.contiguous(), g_geo_out)
-        return (gt, None, None, None, None, None, None, None, None, None, *grads, *([None] if ctx.has_order else []))
+        rays = None
+        if ctx.rays:
+            params, rays = params[:-1], (params[-1], ctx.needs_input_grad[5], ctx.needs_input_grad[6])
+        gt, grads, _, (go, gd) = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, s, e,
+                                                 enc, hg, xf, hf, params, g_feature.contiguous(), g_geo_out, rays=rays)
+        return (gt, None, None, None, None, go, gd, None, None, None, *grads, *([None] if ctx.has_order else []))
 
 
 def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends, enc, hg, xf, hf, params, g_feature, g_geo_out,
-                    override=None):
+                    override=None, rays=None):
     """Backward of the fused field forward from (dL/dfeature [N,32], dL/dgeo_out [N]): feature-MLP gradients -> residual ->
-    geometry-MLP gradients -> table gradient.  -> (grad table or None, the ten MLP parameter gradients in argument order
-    [, gradient of the override rows]).  override = (ovr_row [N], pair_idx [P]): samples whose encoding row came from the
-    caller (actor boxes) hand dL/d enc to those rows -- every (sample, actor) pair gets its sample's row, as the reference's
-    index_put does (neurad_encoding.py:184-185) -- and send nothing to the static table."""
+    geometry-MLP gradients -> table gradient.  -> (grad table or None, the ten MLP parameter gradients in argument order,
+    gradient of the override rows or None, (dL/d origins, dL/d directions) or Nones).  override = (ovr_row [N], pair_idx
+    [P]): samples whose encoding row came from the caller (actor boxes) hand dL/d enc to those rows -- every (sample, actor)
+    pair gets its sample's row, as the reference's index_put does (neurad_encoding.py:184-185) -- and send nothing to the
+    static table.  rays = (table, need_o, need_d): the bundle's rays require grad (camera optimizer) -> the static samples'
+    dL/d enc also goes back to the ray through the positions (`_ray_grads`; the overridden rows are zero by then: their
+    share comes through ActorPairPositionsFn)."""
     gw, gb, fw, fb = list(params[0:4:2]), list(params[1:4:2]), list(params[4:10:2]), list(params[5:10:2])
     # feature = embedding + mlp_feature([embedding | sh])
     if ops.field_feature_bwd_supported(fw, fb):
@@ -185,7 +221,8 @@ def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends,
         genc.masked_fill_((ovr_row >= 0)[:, None], 0.0)  # exactly-zero rows send no records (encode_bwd_binned: prep)
     gt = _like_param(ops.encode_bwd(spec, scale, o, d, a, starts, ends, genc), table_dtype) if need_table else None
     grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
-    return (gt, grads) if override is None else (gt, grads, g_rows)
+    god = (None, None) if rays is None else _ray_grads(rays[1], rays[2], spec, rays[0], scale, o, d, a, starts, ends, genc)
+    return gt, grads, g_rows, god
 
 
 class MLPFn(torch.autograd.Function):
@@ -356,7 +393,7 @@ class ProposalDensityFn(torch.autograd.Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, table, decoder_weight, spec, static_scale, origins, directions, pixel_area, starts, ends):
         ps = ops.ProposalSpec(spec, table, static_scale, decoder_weight)
-        if not (table.requires_grad or decoder_weight.requires_grad):  # eval / frozen: nothing to save
+        if not any(ctx.needs_input_grad):  # eval / frozen, rays fixed: nothing to save
             return ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends)
         dens, lf = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends, save_features=True)
         ctx.ps = ps
@@ -367,8 +404,13 @@ class ProposalDensityFn(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, g):
         o, d, a, s, e, dens, lf = ctx.saved_tensors
-        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g.contiguous(), level_features=lf)
-        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None, None
+        g = g.contiguous()
+        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g, level_features=lf)
+        go, gd = (None, None)
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            go, gd = _ray_grads(ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.ps.grid, ctx.ps.table,
+                                ctx.ps.static_scale, o, d, a, s, e, _proposal_genc(dens, g, ctx.ps.decoder_weight))
+        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None, None
 
 
 class InterlevelLossFn(torch.autograd.Function):
@@ -423,7 +465,7 @@ class ProposalRoundFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ps = ops.ProposalSpec(spec, table, static_scale, decoder_weight)
         starts, ends = edges[:, :-1], edges[:, 1:]
-        if table.requires_grad or decoder_weight.requires_grad:
+        if any(ctx.needs_input_grad):
             dens, lf = ops.proposal_density_fwd(ps, origins, directions, pixel_area, starts, ends, save_features=True)
             ctx.ps = ps
             ctx.save_for_backward(origins, directions, pixel_area, edges, dens, lf)
@@ -438,8 +480,13 @@ class ProposalRoundFn(torch.autograd.Function):
         if gw is None and gdepth is None:
             return (None,) * 8
         gdens = ops.prop_weights_bwd(edges, dens, None if gw is None else gw.contiguous(), gdepth)
-        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, edges[:, :-1], edges[:, 1:], dens, gdens, level_features=lf)
-        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, None, None, None, None
+        starts, ends = edges[:, :-1], edges[:, 1:]
+        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, starts, ends, dens, gdens, level_features=lf)
+        go, gd = (None, None)
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:  # the rays moved with a camera optimizer
+            go, gd = _ray_grads(ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.ps.grid, ctx.ps.table,
+                                ctx.ps.static_scale, o, d, a, starts, ends, _proposal_genc(dens, gdens, ctx.ps.decoder_weight))
+        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None
 
 
 class PropWeightsFn(torch.autograd.Function):
@@ -494,7 +541,9 @@ class NffRenderTrainFn(torch.autograd.Function):
         ctx.spec, ctx.scale, ctx.table_dtype, ctx.beta_min, ctx.emb_cfg = spec, static_scale, table.dtype, beta_min, emb_cfg
         ctx.n_embed, ctx.A = (0 if emb_weight is None else emb_weight.shape[0]), A
         ctx.has = (sensor_idx is not None, times is not None)
-        opt = [t for t in (sensor_idx, times) if t is not None] + ([ovr_row, pair_idx] if ctx.has_ovr else [])
+        ctx.rays = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]  # a camera optimizer moved the rays
+        opt = ([t for t in (sensor_idx, times) if t is not None] + ([ovr_row, pair_idx] if ctx.has_ovr else [])
+               + ([table] if ctx.rays else []))
         ctx.save_for_backward(origins, directions, pixel_area, edges, enc, hg, xf, hf, feature, sdf, alpha, beta, *params, *opt)
         return out, depth, acc, w_ns
 
@@ -515,19 +564,15 @@ class NffRenderTrainFn(torch.autograd.Function):
         if ctx.A and ctx.needs_input_grad[9]:
             g_emb = ops.appearance_bwd(g_out[:, C_:], sensor_idx, times, ctx.emb_cfg[0], ctx.emb_cfg[1], ctx.emb_cfg[2],
                                        ctx.n_embed)
-        g_rows = None
-        if ctx.has_ovr:
-            ovr_row, pair_idx = opt.pop(0), opt.pop(0)
-            gt, grads, g_rows = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a,
-                                                edges[:, :-1], edges[:, 1:], enc, hg, xf, hf, params, gfeat.view(R * S, C_),
-                                                gsdf.view(-1), override=(ovr_row, pair_idx))
-            if not ctx.needs_input_grad[15]:
-                g_rows = None
-        else:
-            gt, grads = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a, edges[:, :-1],
-                                        edges[:, 1:], enc, hg, xf, hf, params, gfeat.view(R * S, C_), gsdf.view(-1))
+        override = (opt.pop(0), opt.pop(0)) if ctx.has_ovr else None
+        rays = (opt.pop(0), ctx.needs_input_grad[5], ctx.needs_input_grad[6]) if ctx.rays else None
+        gt, grads, g_rows, (go, gd) = _field_backward(ctx.spec, ctx.scale, ctx.table_dtype, ctx.needs_input_grad[0], o, d, a,
+                                                      edges[:, :-1], edges[:, 1:], enc, hg, xf, hf, params,
+                                                      gfeat.view(R * S, C_), gsdf.view(-1), override=override, rays=rays)
+        if not ctx.needs_input_grad[15]:
+            g_rows = None
         g_beta = gbeta.reshape(beta.shape) if ctx.needs_input_grad[3] else None
-        return (gt, None, None, g_beta, None, None, None, None, None, g_emb, None, None, None, None, None, g_rows, None, None,
+        return (gt, None, None, g_beta, None, go, gd, None, None, g_emb, None, None, None, None, None, g_rows, None, None,
                 *grads)
 
 

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void actor_pair_positions_bwd_kernel(
     ActorsDev a, RaysDev r, const float* __restrict__ times, const int64_t* __restrict__ sample_idx,
     const int32_t* __restrict__ actor_idx, const float* __restrict__ ray_flip, int64_t n_pairs,
     const float* __restrict__ g_x01, const float* __restrict__ g_cstd, float* __restrict__ g_positions,
-    float* __restrict__ g_rot6) {
+    float* __restrict__ g_rot6, float* __restrict__ g_origins, float* __restrict__ g_directions) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n_pairs) return;
   const int64_t i = sample_idx[p], ray = i / r.S;
@@ -518,6 +518,16 @@ __global__ __launch_bounds__(256) void actor_pair_positions_bwd_kernel(
   float gb1[3], gb2[3], gb3[3], gt[3];
   for (int c = 0; c < 3; ++c) gb1[c] = v[0] * gpos[c], gb2[c] = v[1] * gpos[c], gb3[c] = v[2] * gpos[c];
   gt[0] = -dot3(f.b1, gpos), gt[1] = -dot3(f.b2, gpos), gt[2] = -dot3(f.b3, gpos);
+  if (g_origins) {
+    // d pos / d mean = -d pos / d t: the sample's world position moves with the ray (camera optimizer,
+    // cameras/camera_optimizers.py:173-182); mean = o + d t_mid with t_mid a constant (detached bins)
+    const float t0 = r.starts[ray * r.stride + s], t1 = r.ends[ray * r.stride + s];
+    const float tm = t0 + (t1 - t0) / 2.f;
+    for (int c = 0; c < 3; ++c) {
+      atomicAdd(g_origins + 3 * ray + c, -gt[c]);
+      atomicAdd(g_directions + 3 * ray + c, -gt[c] * tm);
+    }
+  }
   // b3 = b1 x b2:  g_b1 += b2 x g_b3,  g_b2 += g_b3 x b1
   gb1[0] += f.b2[1] * gb3[2] - f.b2[2] * gb3[1];
   gb1[1] += f.b2[2] * gb3[0] - f.b2[0] * gb3[2];
@@ -627,8 +637,28 @@ extern "C" int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip
              NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd: NULL pointer");
   actor_pair_positions_bwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
       d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, grad_x01, grad_cstd, grad_positions,
-      grad_rotations_6d);
+      grad_rotations_6d, nullptr, nullptr);
   return check_launch("actor_pair_positions_bwd");
+}
+
+extern "C" int nrhip_actor_pair_positions_bwd_rays(const nrhip_actors* a, const nrhip_rays* rays, const float* times,
+                                                   const int64_t* sample_idx, const int32_t* actor_idx,
+                                                   const float* ray_flip, int64_t n_pairs, const float* grad_x01,
+                                                   const float* grad_cstd, float* grad_positions,
+                                                   float* grad_rotations_6d, float* grad_origins,
+                                                   float* grad_directions, void* stream) {
+  ActorsDev d;
+  if (int e = to_dev(a, d)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(n_pairs >= 0 && a->actor_scale > 0.f, NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd_rays: bad argument");
+  if (n_pairs == 0) return NRHIP_OK;
+  NR_REQUIRE(times && sample_idx && actor_idx && grad_x01 && grad_cstd && grad_positions && grad_rotations_6d &&
+                 grad_origins && grad_directions,
+             NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd_rays: NULL pointer");
+  actor_pair_positions_bwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
+      d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, grad_x01, grad_cstd, grad_positions,
+      grad_rotations_6d, grad_origins, grad_directions);
+  return check_launch("actor_pair_positions_bwd_rays");
 }
 
 extern "C" int nrhip_actor_density_splice_fwd(const float* rows, int32_t row_dim, const float* decoder_weight,

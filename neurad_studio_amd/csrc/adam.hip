@@ -183,6 +183,8 @@ extern "C" int nrhip_adam_step_many(const nrhip_adam_tensor* tensors, int32_t n_
     AdamMany many;
     many.count = 0;
     int blocks = 0;
+    int live = 0;  // non-empty tensors this launch will hold
+    for (int j = k; j < n_tensors && live < kAdamMany; ++j) live += tensors[j].n > 0 ? 1 : 0;
     for (; k < n_tensors && many.count < kAdamMany; ++k) {
       const nrhip_adam_tensor& in = tensors[k];
       NR_REQUIRE(in.n >= 0 && (in.grad_dtype == 0 || in.grad_dtype == 1), NRHIP_ERR_INVALID_ARG,
@@ -194,7 +196,9 @@ extern "C" int nrhip_adam_step_many(const nrhip_adam_tensor* tensors, int32_t n_
                      in.grad_dtype, blocks};
       if (int e = make_args("adam_step_many", in.step, lr, beta1, beta2, eps, weight_decay, grad_scale, &t.a)) return e;
       int b = blocks_for(in.n);
-      if (b > 1024) b = 1024;  // many tensors share the machine: 4 workgroups per CU each at most
+      // many tensors share the machine: 4 workgroups per CU each at most; a tensor alone in its launch (the large tables
+      // HashGridAdam sends one by one) keeps nrhip_adam_step's 16 per CU
+      if (b > 1024 && live > 1) b = 1024;
       blocks += b;
     }
     if (many.count == 0) continue;

@@ -55,7 +55,7 @@ int validate_rays(const nrhip_rays* r) {
 extern "C" const char* nrhip_last_error(void) { return nrhip::g_err; }
 // 200: nrhip_rays.order, render_fwd_ex, ray_order.  300: nrhip_field grew eval_table / eval_layout (trailing), the training
 // glue of train_fused.hip, nrhip_field_fwd_train_ovr, nrhip_eval_layout_*.
-extern "C" int nrhip_version(void) { return 401; }
+extern "C" int nrhip_version(void) { return 500; }
 
 extern "C" int nrhip_device_info(int32_t* n_cus, int32_t* n_xcds, int64_t* hbm_bytes) {
   int dev = 0;

@@ -40,7 +40,7 @@ from ..fields.neurad_field import NeuRADProposalField as HipNeuRADProposalField
 from ..model_components import losses as hip_losses
 from ..model_components import ray_samplers as hip_samplers
 from ..model_components import renderers as hip_renderers
-from ..models.neurad import FusedEvalMixin, FusedTrainMixin, warn_if_rays_need_grad
+from ..models.neurad import FusedEvalMixin, FusedTrainMixin
 from ..shims import nerfacc as hip_nerfacc
 
 
@@ -137,7 +137,6 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
     def get_nff_outputs(self, ray_bundle, calc_lidar_losses: bool = False):
         if self.fused_eval_possible():
             return self.fused_nff_outputs(ray_bundle)
-        warn_if_rays_need_grad(ray_bundle)
         if self.fused_training_possible():
             return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         return super().get_nff_outputs(ray_bundle, calc_lidar_losses)

@@ -235,27 +235,6 @@ class FusedTrainMixin:
         return nff
 
 
-_POSE_GRAD_WARNED = False
-
-
-def warn_if_rays_need_grad(ray_bundle) -> None:
-    """The HIP field nodes (fused and operator level alike) return no gradient for ray origins / directions: a camera
-    optimizer that moves the rays (cameras/camera_optimizers.py apply_to_raybundle, mode SO3xR3 -- NOT the ``neurad``
-    default, configs/method_configs.py:404 uses mode="off") gets its pose gradient from its own regulariser only.  Say so
-    once instead of training silently with frozen poses ("what is not covered")."""
-    global _POSE_GRAD_WARNED
-    if _POSE_GRAD_WARNED or not torch.is_grad_enabled():
-        return
-    if getattr(ray_bundle.origins, "requires_grad", False) or getattr(ray_bundle.directions, "requires_grad", False):
-        import warnings
-
-        _POSE_GRAD_WARNED = True
-        warnings.warn("neurad-hip: ray origins/directions require grad (camera optimizer), but the HIP field kernels do not "
-                      "propagate gradients to the rays: camera poses receive no rendering-loss gradient.  Use "
-                      "camera_optimizer.mode='off' (the neurad default) or the reference's torch field for pose refinement.",
-                      RuntimeWarning, stacklevel=3)
-
-
 def _light_samples(rb: RayBundle, sp: Tensor, eu: Tensor, fn) -> RaySamples:
     """RaySamples of the fused training path: S samples from S+1 edges, every field a VIEW (per-ray fields stride-0 like
     rays.py:336-355, starts / ends two views of the edge tensor); no deltas, no metadata -- nothing is launched"""
@@ -479,7 +458,6 @@ class NeuRADHotPath(FusedEvalMixin, FusedTrainMixin, nn.Module):
     def get_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool = False) -> Dict[str, Tensor]:
         if self.fused_eval_possible():
             return self.fused_nff_outputs(ray_bundle)
-        warn_if_rays_need_grad(ray_bundle)
         if self.fused_training_possible():
             return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         self._scale_pixel_area(ray_bundle)

@@ -313,6 +313,22 @@ def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_a
     return gt
 
 
+def encode_bwd_rays(spec: GridSpec, table: Tensor, static_scale: float, origins, directions, pixel_area, starts, ends,
+                    grad_out) -> Tuple[Tensor, Tensor]:
+    """dL/d(origins), dL/d(directions) [R,3] of the static encoding path from dL/d(rescaled features) [N, L*F]: the
+    gradient a camera optimizer that moves the rays receives (cameras/camera_optimizers.py:173-182).  One kernel, no
+    atomics (csrc/hashgrid_dx.hip)."""
+    r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
+    grad_out = _chk(grad_out, "grad_out")
+    if grad_out.numel() != r.n_rays * r.n_samples * spec.out_dim:
+        raise ValueError(f"grad_out has {grad_out.numel()} elements, expected {r.n_rays * r.n_samples * spec.out_dim}")
+    g = spec.c_grid(table)
+    out = torch.empty((2, r.n_rays, 3), device=origins.device, dtype=torch.float32)
+    call("nrhip_encode_bwd_rays", C.byref(g), _ptr(_chk(table, "table", table.dtype)), float(static_scale), C.byref(r),
+         _ptr(grad_out), _ptr(out[0]), _ptr(out[1]), _stream())
+    return out[0], out[1]
+
+
 def sh4_fwd(dirs01: Tensor) -> Tensor:
     d = _chk(dirs01, "dirs")
     out = torch.empty((d.shape[0], 16), device=d.device, dtype=torch.float32)
@@ -936,18 +952,24 @@ def actor_pair_positions(spec: ActorSpec, origins, directions, pixel_area, start
 
 
 def actor_pair_positions_bwd(spec: ActorSpec, origins, directions, pixel_area, starts, ends, times, sample_idx, actor_idx,
-                             ray_flip, grad_x01: Tensor, grad_cstd: Tensor):
-    """-> (grad actor_positions [Tn,A,3], grad actor_rotations_6d [Tn,A,6])"""
+                             ray_flip, grad_x01: Tensor, grad_cstd: Tensor, ray_grads: bool = False):
+    """-> (grad actor_positions [Tn,A,3], grad actor_rotations_6d [Tn,A,6]); with ``ray_grads`` also (grad origins [R,3],
+    grad directions [R,3]): the in-box samples' world positions move with the ray (camera optimizer)"""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     a, keep2 = spec.c_actors()
     si, ai = _chk(sample_idx, "sample_idx", torch.int64), _chk(actor_idx, "actor_idx", torch.int32)
     flat = torch.zeros((a.n_times * a.n_actors * 9,), dtype=torch.float32, device=si.device)
     gp = flat[: a.n_times * a.n_actors * 3].view(a.n_times, a.n_actors, 3)
     gr = flat[a.n_times * a.n_actors * 3:].view(a.n_times, a.n_actors, 6)
-    call("nrhip_actor_pair_positions_bwd", C.byref(a), C.byref(r), _ptr(_chk(times.reshape(-1), "times")), _ptr(si),
-         _ptr(ai), _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), si.shape[0],
-         _ptr(_chk(grad_x01, "grad_x01")), _ptr(_chk(grad_cstd, "grad_cstd")), _ptr(gp), _ptr(gr), _stream())
-    return gp, gr
+    common = (C.byref(a), C.byref(r), _ptr(_chk(times.reshape(-1), "times")), _ptr(si), _ptr(ai),
+              _ptr(None if ray_flip is None else _chk(ray_flip.reshape(-1), "ray_flip")), si.shape[0],
+              _ptr(_chk(grad_x01, "grad_x01")), _ptr(_chk(grad_cstd, "grad_cstd")), _ptr(gp), _ptr(gr))
+    if not ray_grads:
+        call("nrhip_actor_pair_positions_bwd", *common, _stream())
+        return gp, gr
+    god = torch.zeros((2, r.n_rays, 3), dtype=torch.float32, device=si.device)
+    call("nrhip_actor_pair_positions_bwd_rays", *common, _ptr(god[0]), _ptr(god[1]), _stream())
+    return gp, gr, god[0], god[1]
 
 
 def actor_hits(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends) -> Tensor:
@@ -1317,6 +1339,9 @@ def grad_rows_count(grad: Tensor, n_levels: int):
     return counts, blocks
 
 
+_MAX_LIST_LEVELS = 32  # kMaxListLevels of csrc/grad_rows.hip
+
+
 def _list_args(levels: Sequence[int], caps: Sequence[int]):
     n = len(levels)
     return (C.c_int32 * n)(*levels), (C.c_int64 * n)(*caps), n
@@ -1331,10 +1356,16 @@ def grad_rows_compact(grad: Tensor, n_levels: int, block_offsets: Tensor, levels
     total = int(sum(caps))
     rows = torch.full((total,), -1, dtype=torch.int32, device=g.device)
     vals = torch.zeros((total, F), dtype=torch.float32, device=g.device)
-    if total:
-        lv, cp, n = _list_args(levels, caps)
-        call("nrhip_grad_rows_compact", _ptr(g), n_levels, T, F, _ptr(_chk(block_offsets, "block_offsets", torch.int32)), lv, cp, n,
-             float(scale), _ptr(rows), _ptr(vals), _stream())
+    bo = _chk(block_offsets, "block_offsets", torch.int32)
+    off = 0
+    for k in range(0, len(levels), _MAX_LIST_LEVELS):  # the kernel takes at most 32 list levels per launch
+        lvk, cpk = list(levels[k:k + _MAX_LIST_LEVELS]), list(caps[k:k + _MAX_LIST_LEVELS])
+        tk = int(sum(cpk))
+        if tk:
+            lv, cp, n = _list_args(lvk, cpk)
+            call("nrhip_grad_rows_compact", _ptr(g), n_levels, T, F, _ptr(bo), lv, cp, n, float(scale), _ptr(rows[off:]),
+                 _ptr(vals[off:]), _stream())
+        off += tk
     return rows, vals
 
 
@@ -1347,6 +1378,14 @@ def grad_rows_apply(grad: Tensor, n_levels: int, levels: Sequence[int], caps: Se
     T, F = g.shape[0] // n_levels, g.shape[1]
     if int(sum(caps)) == 0:
         return
-    lv, cp, n = _list_args(levels, caps)
-    call("nrhip_grad_rows_apply", _ptr(g), n_levels, T, F, lv, cp, n, _ptr(_chk(rows, "rows", torch.int32)),
-         _ptr(None if vals is None else _chk(vals, "vals")), 1 if add else 0, _stream())
+    rows = _chk(rows, "rows", torch.int32)
+    vals = None if vals is None else _chk(vals, "vals")
+    off = 0
+    for k in range(0, len(levels), _MAX_LIST_LEVELS):
+        lvk, cpk = list(levels[k:k + _MAX_LIST_LEVELS]), list(caps[k:k + _MAX_LIST_LEVELS])
+        tk = int(sum(cpk))
+        if tk:
+            lv, cp, n = _list_args(lvk, cpk)
+            call("nrhip_grad_rows_apply", _ptr(g), n_levels, T, F, lv, cp, n, _ptr(rows[off:]),
+                 _ptr(None if vals is None else vals[off:]), 1 if add else 0, _stream())
+        off += tk

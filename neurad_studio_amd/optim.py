@@ -78,6 +78,11 @@ class HashGridAdam(torch.optim.Optimizer):
                                    1.0 if grad_scale is None else grad_scale)
             ops.adam_step_many(small, group["lr"], b1, b2, group["eps"], group["weight_decay"],
                                1.0 if grad_scale is None else grad_scale)
+            # the kernel wrote the tables through raw pointers: the parameters' version counters did not move.  Caches keyed
+            # on a table's version (ops.eval_table under NRHIP_EVAL_RELAYOUT=1: the re-laid-out coarse levels) would serve
+            # the old values to an eval that stays in train mode; dropping them here costs nothing when none exist.
+            if items:
+                ops.clear_eval_tables()
         return loss
 
     def load_state_dict(self, state_dict) -> None:

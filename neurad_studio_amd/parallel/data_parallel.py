@@ -18,7 +18,8 @@ MI355X-first choices (xGMI is point-to-point, 7 links x ~153 GB/s per GPU; a rin
     (config[3] step, scripts/grad_density.py: 0.3 / 1 / 3 / 8 / 17 / 33 / 52 / 67 % of the rows of the field table's eight
     levels), so those levels travel as (row, values) lists in one all-gather and every rank adds the lists in rank order
     (bit-identical replicas); the fine levels stay dense.  Which levels go as lists is decided per step from the agreed
-    maximum row count: a list pays while (N-1) * rows * (4 + 4F) bytes < the 2 (N-1)/N * T * 4F of the dense pair.
+    maximum row count: a list pays while (N-1) * rows * (4 + 4F) bytes < the 2 (N-1)/N * T * 4F of the dense pair (a level the
+    hook already started densely finishes densely this step and is re-decided, from this step's counts, for the next).
     On the GPU the counting, the ordered compaction and the merge are csrc/grad_rows.hip (no torch op chains); with
     ``overlap=True`` the table's hook starts the count agreement and the reduce-scatter of the levels that went densely in the
     previous step -- the bulk of the bytes -- under the rest of the backward; sync() only sizes and sends the lists.
@@ -247,9 +248,12 @@ class GradientSynchronizer:
             off += L
             started = {l for (a, e, _, _, _) in runs for l in range(a, e)}
             # a list costs (N-1) * cap * (4 + 4F) bytes per rank, the dense pair 2 (N-1)/N * T * 4F
-            lists = [l for l in range(L) if l not in started and cap[l] * (1 + F) * world < 2 * T * F and (T * F) % world == 0]
+            pays = [cap[l] * (1 + F) * world < 2 * T * F and (T * F) % world == 0 for l in range(L)]
+            lists = [l for l in range(L) if pays[l] and l not in started]
             self.last_list_levels[i] = lists
-            self._dense_prev[i] = set(range(L)) - set(lists)
+            # next step's early-started dense set from THIS step's agreed counts alone -- not from what was started: a level
+            # that went dense once (a spike step) returns to the list exchange as soon as its row count says so
+            self._dense_prev[i] = {l for l in range(L) if not pays[l]}
             for (a, e, work, run, shard) in runs:  # started from the hook: wait for the scatter, finish with the gather
                 work.wait()
                 self._finish_large(run, shard)
@@ -343,7 +347,7 @@ class GradientSynchronizer:
         if i in self._inflight:
             raise RuntimeError("GradientSynchronizer(overlap=True): a second backward reached parameter "
                                f"{i} before sync(); call sync() after every backward (gradient accumulation: overlap=False)")
-        if self.profile and self._ev_first_hook is None:
+        if self.profile and self._ev_first_hook is None and self.params[i].is_cuda:
             self._ev_first_hook = torch.cuda.Event(enable_timing=True)
             self._ev_first_hook.record()
         self._start_large(i, async_op=True)

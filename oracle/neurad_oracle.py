@@ -289,6 +289,77 @@ def encode_static(grid: GridParams, static_scale, origins, directions, pixel_are
     return rescale_grid_features(feat, cstd.reshape(-1), grid.scalings, grid.n_feat)
 
 
+def encode_static_ray_grads(grid: GridParams, static_scale, origins, directions, pixel_area, starts, ends, grad_enc):
+    """dL/d(origins), dL/d(directions) [R,3] of :func:`encode_static` (M = 1) given dL/d(rescaled features) [R*S, L*F]:
+    what autograd does for a camera optimizer that moves the rays (cameras/camera_optimizers.py:173-182).  The chain, every
+    link the derivative of the reference line it names (sample midpoints t are constants: bins are detached,
+    ray_samplers.py:363-364):
+      enc_l = w_l(s) * lerp_l(x)            neurad_encoding.py:297-304, w_l = 1 / max(1, 2 scal_l s)
+      lerp_l: trilinear in offset = x scal_l - floor(x scal_l)          encodings.py:425-464 (floor / ceil carry no gradient)
+      x = (c + 2) / 4, s = std' / 4;  |u|_inf >= 1: c = (2 - 1/m) u / m, std' = (std/scale) ((2m - 1)^(1/3) / m)^2, m = |u|_inf
+                                                                        spatial_distortions.py:126-141,  u = mean / scale
+      mean = o + d t                                                    cameras/rays.py:119
+    Primal quantities (cells, offsets, masks) in fp32 exactly as the forward restatement, derivative arithmetic in fp64."""
+    f64 = np.float64
+    mean, std = fast_isotropic_gaussian(origins, directions, pixel_area, starts, ends)
+    R, S = np.asarray(starts).shape
+    pos, cstd = contract_gaussian(mean, std, static_scale)
+    x = pos.reshape(-1, 3)
+    N = x.shape[0]
+    sc = grid.scalings.astype(f32)
+    L, F = sc.shape[0], grid.n_feat
+    idx, off = hashgrid_corner_indices(x, sc, grid.table_size)
+    t = np.asarray(grid.table, f64)
+    fc = [t[idx[..., k]] for k in range(8)]  # [N,L,F]; corner order 0 ccc 1 cfc 2 ffc 3 fcc 4 ccf 5 cff 6 fff 7 fcf
+    ox, oy, oz = (off[..., k:k + 1].astype(f64) for k in range(3))
+    mx, my, mz = 1 - ox, 1 - oy, 1 - oz
+    f03, f12 = fc[0] * ox + fc[3] * mx, fc[1] * ox + fc[2] * mx
+    f56, f47 = fc[5] * ox + fc[6] * mx, fc[4] * ox + fc[7] * mx
+    val = (f03 * oy + f12 * my) * oz + (f47 * oy + f56 * my) * mz
+    d03, d12, d56, d47 = fc[0] - fc[3], fc[1] - fc[2], fc[5] - fc[6], fc[4] - fc[7]
+    dvx = (d03 * oy + d12 * my) * oz + (d47 * oy + d56 * my) * mz
+    dvy = (f03 - f12) * oz + (f47 - f56) * mz
+    dvz = (f03 * oy + f12 * my) - (f47 * oy + f56 * my)
+    g = np.asarray(grad_enc, f64).reshape(N, L, F)
+    s = cstd.reshape(-1, 1).astype(f64)
+    a = sc[None, :].astype(f64) * 2.0 * s                     # [N,L]
+    w = 1.0 / np.maximum(a, 1.0)
+    dw = np.where(a > 1.0, -2.0 * sc[None, :].astype(f64) * w * w, 0.0)
+    scw = (sc[None, :].astype(f64) * w)[..., None]
+    gx = np.stack([(g * dvx * scw).sum((1, 2)), (g * dvy * scw).sum((1, 2)), (g * dvz * scw).sum((1, 2))], -1)  # dL/dx01
+    gs = ((g * val).sum(-1) * dw).sum(-1)                    # dL/d cstd
+    # contraction backward
+    u = (mean.reshape(-1, 3) / f32(static_scale)).astype(f32).astype(f64)
+    sd = (std.reshape(-1) / f32(static_scale)).astype(f32).astype(f64)
+    au = np.abs(u)
+    kmax = np.argmax(au, -1)
+    m = au[np.arange(N), kmax]
+    gc = gx / 4.0
+    outside = ~(m < 1.0)
+    mm = np.where(outside, m, 1.0)
+    k = 2.0 / mm - 1.0 / mm**2
+    dk = -2.0 / mm**2 + 2.0 / mm**3
+    cr = np.cbrt(2.0 * mm - 1.0)
+    dq = 2.0 * (cr / mm) * ((2.0 / 3.0) / (cr * cr * mm) - cr / mm**2)      # d/dm of ((2m-1)^(1/3)/m)^2
+    g_mag = (gc * u).sum(-1) * dk + (gs / 4.0) * sd * dq
+    gu = np.where(outside[:, None], gc * k[:, None], gc)
+    gu[np.arange(N), kmax] += np.where(outside, g_mag * np.sign(u[np.arange(N), kmax]), 0.0)
+    gmean = (gu / f64(static_scale)).reshape(R, S, 3)
+    st, en = np.asarray(starts, f32), np.asarray(ends, f32)
+    tm = (st + f32(1) * ((en - st) / f32(2))).astype(f64)
+    return gmean.sum(1).astype(f32), (gmean * tm[..., None]).sum(1).astype(f32)
+
+
+def proposal_density_ray_grads(p: "ProposalParams", origins, directions, pixel_area, starts, ends, grad_density):
+    """dL/d(origins, directions) of :func:`proposal_density`: trunc_exp's backward g * exp(clamp(x, -15, 15))
+    (field_components/activations.py:27-41) -> the decoder row -> :func:`encode_static_ray_grads`."""
+    enc = encode_static(p.grid, p.static_scale, origins, directions, pixel_area, starts, ends)
+    logit = enc.astype(np.float64) @ np.asarray(p.decoder_w, np.float64).T           # [N,1]
+    gl = np.asarray(grad_density, np.float64).reshape(-1, 1) * np.exp(np.clip(logit, -15.0, 15.0))
+    genc = gl * np.asarray(p.decoder_w, np.float64).reshape(1, -1)
+    return encode_static_ray_grads(p.grid, p.static_scale, origins, directions, pixel_area, starts, ends, genc)
+
+
 def sigmoid(x):
     x = np.asarray(x, f32)
     return (f32(1) / (f32(1) + np.exp(-x))).astype(f32)

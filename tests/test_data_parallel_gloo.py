@@ -345,7 +345,8 @@ def _worker_levels_overlap(rank, world, port, ret):
 
     def grads(step):
         a = torch.zeros(L, T, F)
-        for lvl, frac in enumerate((3 / T, 0.05, 0.4 if step < 3 else 0.9, 1.0)):  # level 2 turns dense in the last step
+        # level 2 turns dense in steps 3 and 4 (a spike) and collapses again from step 5 on
+        for lvl, frac in enumerate((3 / T, 0.05, 0.9 if step in (3, 4) else (0.4 if step < 3 else 0.05), 1.0)):
             rows = torch.randperm(T, generator=g)[:max(int(frac * T), 1)]
             a[lvl, rows] = torch.randn(len(rows), F, generator=g)
         return a.reshape(L * T, F)
@@ -357,7 +358,7 @@ def _worker_levels_overlap(rank, world, port, ret):
     sync_l = GradientSynchronizer([ta, small], average=True, large_threshold_bytes=1 << 10, usage="static", overlap=True,
                                   level_tables={ta: L})
     sync_d = GradientSynchronizer([tb], average=True, large_threshold_bytes=1 << 10, usage="static", overlap=True)
-    for step in range(4):
+    for step in range(7):
         ga = grads(step)
         ta.grad = tb.grad = small.grad = None
         ((ta * ga).sum() + (tb * ga).sum() + small.sum() * (1.0 + rank)).backward()  # fires the post-accumulate hooks
@@ -369,6 +370,11 @@ def _worker_levels_overlap(rank, world, port, ret):
     # reduce-scatter starts from the hook; in step 3 level 2 has turned dense too
     ok = ok and runs[0] == 0 and runs[1] == 1 and runs[2] == 1 and lists[0] == [0, 1, 2] and lists[2] == [0, 1, 2]
     ok = ok and lists[3] == [0, 1] and runs[3] == 1  # level 2 goes densely from sync() in step 3 (hook: only level 3)
+    # step 4: the hook starts levels 2 + 3 as one dense run; step 5: level 2's count has collapsed, but its hook-started dense
+    # exchange (decided from step 4's counts) is already on the wire -- it finishes densely and the NEXT step's dense set
+    # is re-derived from step 5's counts alone; step 6: level 2 travels as a list again (dense -> list, not only list -> dense)
+    ok = ok and lists[4] == [0, 1] and runs[4] == 1 and lists[5] == [0, 1] and runs[5] == 1
+    ok = ok and lists[6] == [0, 1, 2] and runs[6] == 1
     ret[rank] = (bool(ok), runs, lists)
     dist.barrier()
     dist.destroy_process_group()

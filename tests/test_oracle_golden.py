@@ -132,6 +132,25 @@ def prop_params(seed, lg=11):
                             100.0, w + np.float32(0.3))
 
 
+def test_ray_gradients_vs_reference_autograd():
+    """dL/d(origins, directions) -- what a camera optimizer that moves the rays receives (cameras/camera_optimizers.py:173-182)
+    -- of the static encoding and of a proposal density: the oracle's analytic chain against the reference's autograd
+    (oracle/make_golden_raygrads.py)"""
+    g = load_golden("ray_grads")
+    p = field_params(use_sdf=True)
+    go, gd = O.encode_static_ray_grads(p.grid, p.static_scale, g["o"], g["d"], g["area"], g["starts"], g["ends"], g["g_enc"])
+    assert rel_l2(go, g["enc_go"]) < TOL and rel_l2(gd, g["enc_gd"]) < TOL
+    pp = prop_params(91)
+    assert rel_l2(O.proposal_density(pp, g["o"], g["d"], g["area"], g["starts"], g["ends"]), g["prop_dens"]) < TOL
+    go, gd = O.proposal_density_ray_grads(pp, g["o"], g["d"], g["area"], g["starts"], g["ends"], g["prop_g_dens"])
+    assert rel_l2(go, g["prop_go"]) < TOL and rel_l2(gd, g["prop_gd"]) < TOL
+    # both regimes of the contraction are in the fixture, and the inf-norm's arg-max coordinate changes along some rays
+    mean, _ = O.fast_isotropic_gaussian(g["o"], g["d"], g["area"], g["starts"], g["ends"])
+    mag = np.abs(mean / np.float32(100.0)).max(-1)
+    assert (mag < 1).any() and (mag > 1).any()
+    assert (np.abs(mean).argmax(-1).max(1) != np.abs(mean).argmax(-1).min(1)).any()
+
+
 def test_sampler_parts():
     g = load_golden("sampler_parts")
     R = g["o"].shape[0]
