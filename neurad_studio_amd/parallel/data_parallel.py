@@ -63,6 +63,29 @@ def reduce_scatter_flat(flat: Tensor, world: int, group=None, async_op: bool = F
     return (work if async_op else None), None
 
 
+def scatter_16bit_start(flat: Tensor, world: int, group=None, async_op: bool = False, wire_dtype=torch.bfloat16):
+    """16-bit wire format of the reduce-scatter leg (opt-in; SURVEY §8e prices the table exchange at half the bytes): every
+    rank rounds its gradient to ``wire_dtype`` ONCE and sends chunk j straight to its owner j (an all-to-all: on xGMI's
+    point-to-point links every pair has its own link, no ring hops, no re-rounding per hop); ``scatter_16bit_finish`` sums
+    the N received chunks in fp32, in rank order.  -> (work | None, receive buffer [world, m] as int16 bits).
+    The 16-bit payload travels as raw bytes so that any backend's all-to-all carries it (gloo has neither bf16 nor int16)."""
+    m = flat.numel() // world
+    send = flat.view(world, m).to(wire_dtype).view(torch.int16)
+    recv = torch.empty_like(send)
+    work = dist.all_to_all_single(recv.view(torch.uint8).view(-1), send.view(torch.uint8).view(-1), group=group,
+                                  async_op=async_op)
+    return (work if async_op else None), recv
+
+
+def scatter_16bit_finish(recv: Tensor, wire_dtype=torch.bfloat16) -> Tensor:
+    """fp32 sum over the ranks' 16-bit chunks, in rank order (one owner per shard: whatever the order, the all-gather that
+    follows hands every replica the same bits) -> this rank's fp32 shard of the SUM"""
+    acc = recv[0].view(wire_dtype).float()
+    for k in range(1, recv.shape[0]):
+        acc += recv[k].view(wire_dtype)
+    return acc
+
+
 def all_gather_flat(full: Tensor, shard: Tensor, world: int, group=None) -> None:
     """all_gather_into_tensor, or -- where the backend lacks it for this device -- a list gather + copy"""
     if flat_collectives_supported(group, full.device):
@@ -79,7 +102,8 @@ class GradientSynchronizer:
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, average: bool = True,
                  large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False,
                  skip: Iterable[torch.nn.Parameter] = (),
-                 level_tables: Optional[Dict[torch.nn.Parameter, int]] = None, profile: bool = False) -> None:
+                 level_tables: Optional[Dict[torch.nn.Parameter, int]] = None, profile: bool = False,
+                 wire_dtype: Optional[torch.dtype] = None) -> None:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         if overlap and usage != "static":
@@ -91,6 +115,12 @@ class GradientSynchronizer:
         self.large_threshold = large_threshold_bytes
         self.usage = usage
         self.overlap = overlap
+        if wire_dtype not in (None, torch.bfloat16, torch.float16):
+            raise ValueError("wire_dtype: None (fp32), torch.bfloat16 or torch.float16")
+        # 16-bit reduce-scatter leg of the LARGE fp32 gradients (scatter_16bit_*): rounded once per rank, summed in fp32 on
+        # the owning rank, the fp32 mean all-gathered -- replicas stay bit-identical, 6 instead of 8 bytes per element on
+        # the wire.  Level tables and small gradients keep fp32.
+        self.wire_dtype = wire_dtype
         self._agreed: Optional[List[bool]] = None      # usage == "static": the set agreed at the first sync
         self._agreed_all: Optional[List[bool]] = None  # ... and the parameters EVERY rank holds a local gradient for
         self._local_at_agreement: Optional[List[bool]] = None
@@ -157,13 +187,25 @@ class GradientSynchronizer:
     def _start_large(self, i: int, async_op: bool):
         g = self.params[i].grad
         flat = g.view(-1)
+        if self._wire16(g):
+            work, recv = scatter_16bit_start(flat, self.world_size(), self.group, async_op, self.wire_dtype)
+            if not async_op:
+                self._finish_large(flat, scatter_16bit_finish(recv, self.wire_dtype))
+                return
+            self._inflight[i] = (work, flat, recv)
+            return
         work, shard = reduce_scatter_flat(flat, self.world_size(), self.group, async_op)
         if not async_op:
             self._finish_large(flat, shard)
             return
         self._inflight[i] = (work, flat, shard)
 
+    def _wire16(self, g: Tensor) -> bool:
+        return self.wire_dtype is not None and g.dtype == torch.float32
+
     def _finish_large(self, flat: Tensor, shard: Optional[Tensor]) -> None:
+        if shard is not None and shard.dtype == torch.int16:  # hook-started 16-bit scatter: the owner's fp32 sum first
+            shard = scatter_16bit_finish(shard, self.wire_dtype)
         if shard is None:  # the backend had no reduce-scatter for this device: `flat` already holds the full sum
             if self.average:
                 flat.div_(self.world_size())
@@ -378,7 +420,8 @@ class GradientSynchronizer:
                 level_todo.append(i)
                 continue
             if i in self._inflight or self._is_large(g):
-                self.last_wire_bytes_by_param[i] = 2 * (world - 1) * g.numel() * g.element_size() // world
+                per_elt = (2 + g.element_size()) if self._wire16(g) else 2 * g.element_size()  # scatter leg + gather leg
+                self.last_wire_bytes_by_param[i] = (world - 1) * g.numel() * per_elt // world
                 self.last_wire_bytes += self.last_wire_bytes_by_param[i]
             if i in self._inflight:  # started from the hook: wait for the scatter, finish with the gather
                 work, flat, shard = self._inflight.pop(i)

@@ -39,10 +39,16 @@ class ShardedTableAdam:
 
     def __init__(self, tables: Iterable[torch.nn.Parameter], lr: float = 1e-2, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-15, weight_decay: float = 0.0, process_group=None, average: bool = True,
-                 update_fn: Optional[Callable] = None, usage: str = "dynamic") -> None:
+                 update_fn: Optional[Callable] = None, usage: str = "dynamic",
+                 wire_dtype: Optional[torch.dtype] = None) -> None:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         self.usage = usage
+        if wire_dtype not in (None, torch.bfloat16, torch.float16):
+            raise ValueError("wire_dtype: None (fp32), torch.bfloat16 or torch.float16")
+        # 16-bit gradient leg (data_parallel.scatter_16bit_*): rounded once per rank, summed in fp32 on the owning rank, whose
+        # Adam step then runs on that fp32 sum; the parameters come back in fp32: 6 instead of 8 bytes per element per step
+        self.wire_dtype = wire_dtype
         self._agreed: Optional[List[bool]] = None
         self._local_at_agreement: Optional[List[bool]] = None
         self.tables: List[torch.nn.Parameter] = list(tables)
@@ -92,7 +98,13 @@ class ShardedTableAdam:
             flat_p = p.data.view(-1)
             grad = p.grad if p.grad is not None else torch.zeros_like(p)
             flat_g = grad.contiguous().view(-1)
-            if self.world > 1:
+            if self.world > 1 and self.wire_dtype is not None:
+                from .data_parallel import scatter_16bit_finish, scatter_16bit_start
+
+                _, recv = scatter_16bit_start(flat_g, self.world, self.group, False, self.wire_dtype)
+                g_shard = scatter_16bit_finish(recv, self.wire_dtype)
+                nbytes += flat_g.numel() * (2 + 4) * (self.world - 1) // self.world
+            elif self.world > 1:
                 from .data_parallel import reduce_scatter_flat
 
                 _, g_shard = reduce_scatter_flat(flat_g, self.world, self.group)

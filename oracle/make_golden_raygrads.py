@@ -91,6 +91,21 @@ def main():
     ((out[FieldHeadNames.FEATURE] * gf).sum() + (out[FieldHeadNames.ALPHA] * ga).sum()).backward()
     kw.update(field_g_feature=gf, field_g_alpha=ga[..., 0], field_go=ot.grad.clone(), field_gd=dt.grad.clone(),
               field_feature=out[FieldHeadNames.FEATURE].detach())
+    # the same functional with the reference in fp64: its own fp32 noise floor on these gradients (a hidden unit of the
+    # MLPs within rounding of the ReLU kink flips between the precisions and switches one sample's contribution; the
+    # direction gradient weighs every sample with its distance t, up to 2e4 m)
+    fld64 = fld.double()
+    rb, ot64, dt64, _ = bundle(R, 161)
+    rb.origins, rb.directions = ot64.double(), dt64.double()
+    rb.pixel_area, rb.times, rb.nears, rb.fars = rb.pixel_area.double(), rb.times.double(), rb.nears.double(), rb.fars.double()
+    out = fld64(smp(rb))
+    ((out[FieldHeadNames.FEATURE] * gf.double()).sum() + (out[FieldHeadNames.ALPHA] * ga.double()).sum()).backward()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
+    per_ray = ((kw["field_gd"].double() - dt64.grad.double()).norm(dim=-1) / dt64.grad.double().norm(dim=-1))
+    kw.update(field_floor=np.array([rel(kw["field_go"], ot64.grad), rel(kw["field_gd"], dt64.grad)]),
+              field_gd_rays_off_fp64=np.array(int((per_ray > 1e-4).sum())))
+    print("fp32 vs fp64 floor of the field's ray gradients (origins, directions):", kw["field_floor"],
+          "rays further than 1e-4:", int((per_ray > 1e-4).sum()))
     save("ray_grads", **kw)
 
 

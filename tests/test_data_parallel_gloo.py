@@ -386,3 +386,70 @@ def test_level_sparse_exchange_with_hook_started_overlap_world2_gloo():
         ret = mgr.dict()
         mp.spawn(_worker_levels_overlap, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert all(ret[r][0] for r in range(world)), dict(ret)
+
+
+def _wire16_worker(rank, world, port, ret):
+    """wire_dtype=bf16: (a) GradientSynchronizer, direct and hook-started -- the exchanged gradient is bit-identical on both
+    ranks, equals the fp32 mean of the ranks' bf16-ROUNDED gradients exactly, and is within bf16 rounding of the fp32
+    exchange; (b) ShardedTableAdam -- parameters bit-identical across ranks and equal to one process stepping on that mean."""
+    from neurad_studio_amd.parallel.sharded_adam import ShardedTableAdam
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    shape = (2048, 4)
+
+    def grad_of(r, it):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(500 + 10 * it + r))
+
+    def gathered(t):
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous())
+        return parts
+
+    for overlap in (False, True):
+        ta, tb = torch.nn.Parameter(torch.zeros(shape)), torch.nn.Parameter(torch.zeros(shape))
+        small = torch.nn.Parameter(torch.zeros(7))
+        kw = dict(average=True, large_threshold_bytes=1 << 10, usage="static", overlap=overlap)
+        s16 = GradientSynchronizer([ta, small], wire_dtype=torch.bfloat16, **kw)
+        s32 = GradientSynchronizer([tb], **kw)
+        for it in range(3):  # step 0 agrees on the usage set; with overlap the hooks start the exchange from step 1 on
+            g = grad_of(rank, it)
+            ta.grad = tb.grad = small.grad = None
+            ((ta * g).sum() + (tb * g).sum() + small.sum() * (1.0 + rank)).backward()
+            s16.sync(), s32.sync()
+            want16 = sum(grad_of(r, it).bfloat16().float() for r in range(world)) / world
+            ok = ok and torch.equal(ta.grad, want16)                       # fp32 sum of the once-rounded gradients
+            ok = ok and all(torch.equal(p, ta.grad) for p in gathered(ta.grad))  # replicas bit-identical
+            bound = sum(grad_of(r, it).abs() for r in range(world)) / world * 2.0**-8
+            ok = ok and bool(((ta.grad - tb.grad).abs() <= bound + 1e-12).all())  # within bf16 rounding of the fp32 exchange
+            ok = ok and torch.equal(small.grad, torch.full((7,), 1.5))      # small gradients keep fp32
+            if overlap and it >= 1:
+                ok = ok and s16.overlapped_last_step == 1
+        ok = ok and s16.last_wire_bytes_by_param[0] == (world - 1) * ta.numel() * 6 // world
+        ok = ok and s32.last_wire_bytes_by_param[0] == (world - 1) * tb.numel() * 8 // world
+    # (b) the sharded optimizer on the 16-bit gradient leg
+    torch.manual_seed(0)
+    tables = [torch.nn.Parameter(torch.randn(1024, 4) * 0.1)]
+    ref_tables = [torch.nn.Parameter(t.detach().clone()) for t in tables]
+    ref_opt = torch.optim.Adam(ref_tables, lr=1e-2, eps=1e-15)
+    opt = ShardedTableAdam(tables, lr=1e-2, eps=1e-15, update_fn=_torch_adam_update, wire_dtype=torch.bfloat16)
+    for it in range(3):
+        gs = [torch.randn(tables[0].shape, generator=torch.Generator().manual_seed(900 + 10 * it + r)) for r in range(world)]
+        tables[0].grad = gs[rank].clone()
+        nbytes = opt.step()
+        ref_tables[0].grad = sum(g.bfloat16().float() for g in gs) / world
+        ref_opt.step()
+    ok = ok and torch.allclose(tables[0], ref_tables[0], atol=1e-6, rtol=1e-5)
+    ok = ok and all(torch.equal(p, tables[0].data) for p in gathered(tables[0].data))
+    ok = ok and nbytes == tables[0].numel() * 6 * (world - 1) // world
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_format_keeps_replicas_identical_world2_gloo():
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_wire16_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
