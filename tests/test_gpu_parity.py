@@ -430,6 +430,52 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"], ids=["ray-major", "sample-index-major", "quads"])
+@pytest.mark.parametrize("cfg", [(6, 1, 14, 128), (6, 1, 14, 64), (8, 4, 15, 32), (8, 4, 15, 16), (16, 2, 14, 64)])
+def test_table_gradient_on_coherent_chunks_every_walk(ops, cfg, mode, monkeypatch):
+    """Camera-patch rays (one origin, directions a fraction of a degree apart): `prep` then walks a 4096-sample chunk
+    sample-index-major or, round 5, as QUADS -- four consecutive samples of a ray per thread, neighbouring rays in
+    neighbouring lanes, equal entries merged first inside the thread and then across the row (NRHIP_BIN_TRANSPOSE = 0 / 1 / 2).
+    Every walk sends the same terms: the result equals the atomic scatter-add, with silent samples (opaque tails, scattered
+    zeros, whole silent quads and rays) and a ragged last chunk, for the encode path and the proposal-density path."""
+    L, F, lg, S = cfg
+    monkeypatch.setenv("NRHIP_BIN_TRANSPOSE", mode)
+    spec = ops.GridSpec(L, F, lg, 16, 2048)
+    R = 4096 // S * 5 + 7  # five coherent chunks and a ragged one
+    o = np.tile(np.array([[1.5, -2.0, 0.7]], np.float32), (R, 1))
+    ang = (np.arange(R, dtype=np.float32) * 2e-4)[:, None]
+    d = np.concatenate([np.cos(ang), np.sin(ang), 0.05 + 0.3 * ang], -1)
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    area = np.full((R,), 2.4e-6, np.float32)
+    _, eu, _ = O.power_sampler(np.zeros(R), np.full(R, 60.0, np.float32), S)
+    g = synth.normal((R, S, L * F), 23)
+    cut = (S * (0.35 + 0.6 * synth.uniform((R,), 0, 1, 24))).astype(np.int64)  # opaque from sample cut[r] on: whole silent quads
+    g[np.arange(S)[None, :] >= cut[:, None]] = 0.0
+    g[synth.uniform((R, S), 0, 1, 25) < 0.15] = 0.0  # scattered silent samples inside live quads
+    g[5::11] = 0.0  # whole rays
+    do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
+    st, en = edges[:, :-1], edges[:, 1:]
+    go = dev(g.reshape(R * S, L * F))
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
+    binned = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    assert torch.equal(binned, ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go))  # bit-reproducible
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+    atomic = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    assert float(atomic.abs().max()) > 0
+    assert rel_l2(host(binned), host(atomic)) < 2e-6
+    assert (binned - atomic).abs().max() <= 1e-5 * atomic.abs().max()
+    if F == 1:
+        ps = ops.ProposalSpec(spec, dev(synth.hash_table(L << lg, 1, seed=3, scale=0.5)), 1.0, dev(synth.normal((1, L), 5)))
+        dens = ops.proposal_density_fwd(ps, do, dd, da, st, en)
+        gd = dev(g[..., 0].copy())
+        monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+        gt, gdec = ops.proposal_density_bwd(ps, do, dd, da, st, en, dens, gd)
+        monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", True)
+        gt2, gdec2 = ops.proposal_density_bwd(ps, do, dd, da, st, en, dens, gd)
+        assert rel_l2(host(gt), host(gt2)) < 2e-6 and rel_l2(host(gdec), host(gdec2)) < 1e-5
+
+
 @pytest.mark.parametrize("F", [1, 4])
 def test_table_gradient_x_pairs_that_straddle_two_slices(ops, F, monkeypatch):
     """The radix partition sends one record per (floor x, ceil x) corner pair.  The two entries differ by

@@ -162,8 +162,8 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False):
     ref_cfg = _shrink(ref_neurad.NeuRADModelConfig(implementation="torch"))
     for c in (ref_cfg.field, ref_cfg.sampling.proposal_field_1, ref_cfg.sampling.proposal_field_2):
         c.grid.actor.use_4d_hashgrid = False
-    if pose_opt:
-        ref_cfg.camera_optimizer.mode = "SO3xR3"
+    if pose_opt:  # (the method table's camera optimizer carries its own penalties: the same object on both sides)
+        ref_cfg.camera_optimizer = deepcopy(mcfg.camera_optimizer)
     refm = ref_cfg.setup(**kw())
     assert sorted(hip.state_dict()) == sorted(refm.state_dict())
     _fill(hip)
