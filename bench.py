@@ -837,6 +837,57 @@ def c3_parity(device, n_cam=1024, n_lidar=512):
             "compositing": "unpinned against nerfacc itself (DESIGN.md §3)"}
 
 
+def c4_parity(m, o, d, area_scaled, times, n=160):
+    """Both fused eval kernels of the config[4] scene -- 32 actors, fp16 static + actor tables, THIS model's parameters --
+    on the first ``n`` rays of the batch against the numpy oracle's actor path (oracle/neurad_oracle.py: encode_with_actors /
+    field_fwd_actors, pinned to the reference's goldens field_actors / proposal_actors): the first proposal round's
+    weights (static density with the in-box samples' actor densities spliced in) and, at the sampler's final samples,
+    features / depth / accumulation."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import neurad_oracle as O
+
+    h = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    sky = m.config.sampling.sky_distance
+    o, d, a, t = o[:n].contiguous(), d[:n].contiguous(), area_scaled[:n].reshape(-1).contiguous(), times[:n].reshape(-1).contiguous()
+    from neurad_studio_amd.cameras.rays import RayBundle
+
+    with torch.no_grad():
+        z = torch.zeros(n, device=o.device)
+        _, cand = m.field.hashgrid.prepare_actors(o, d, a, torch.stack([z, z + 1], -1), torch.stack([z + 1, z + 2], -1), t)
+        rb = RayBundle(origins=o, directions=d, pixel_area=a[:, None], times=t[:, None], nears=z[:, None].clone(),
+                       fars=torch.full((n, 1), sky, device=o.device), metadata={})
+        pf = m.proposal_fields[-1]
+        rs, pw, prs = m.sampler.generate_fused(rb, [pf, pf], sky, actor_cand=cand)
+        st = rs.frustums.starts[..., 0].contiguous()
+        en = rs.frustums.ends[..., 0].clone()
+        en[:, -1] = sky
+        feats, depth, acc = m.field.render(o, d, a, st, en, times=t, actor_cand=cand)[:3]
+    act = m.field.hashgrid.actors
+
+    def actor_params(hg):
+        c = hg.config.actor
+        return O.ActorParams(h(act.unique_timestamps), h(act.actor_positions), h(act.actor_rotations_6d),
+                             act.actor_present_at_time.cpu().numpy().astype(bool), h(act.actor_sizes), h(act.actor_padding),
+                             [O.GridParams(h(g.hash_table), c.num_levels, c.base_res, c.max_res, c.log2_hashmap_size)
+                              for g in hg.actor_grids], actor_scale=c.actor_scale)
+
+    props, fp = _oracle_params(m, O)
+    rl2 = lambda x, y: float(np.linalg.norm(x - y) / np.linalg.norm(y))  # noqa: E731
+    on, dn, an, tn = h(o), h(d), h(a), h(t)
+    s0, e0 = h(prs[0].frustums.starts[..., 0]), h(prs[0].frustums.ends[..., 0])
+    enc, _ = O.encode_with_actors(props[-1].grid, STATIC_SCALE, actor_params(pf.hashgrid), on, dn, an, s0, e0, tn)
+    dens = np.exp(enc @ props[-1].decoder_w.T).reshape(s0.shape).astype(np.float32)
+    w0 = O.weights_from_density(e0 - s0, dens)
+    ref = O.field_fwd_actors(fp, actor_params(m.field.hashgrid), on, dn, an, h(st), h(en), tn)
+    w, _ = O.render_weight_from_alpha(ref["alpha"])
+    rf, rd, ra = O.composite(w, ref["feature"], h(st), h(en))
+    return {"sampler_round0_weights": rl2(h(pw[0][..., 0]), w0), "eval_features": rl2(h(feats), rf),
+            "eval_depth": rl2(h(depth), rd), "eval_accumulation": rl2(h(acc), ra), "tolerance": 1e-4,
+            "sample": f"the first {n} rays of the batch, {len(m.field.hashgrid.actor_grids)} actors, fp16 static + actor tables: "
+                      "nrhip_proposal_sampler_fwd_actors and nrhip_render_fwd_actors vs oracle/neurad_oracle.py (actor path)",
+            "compositing": "unpinned against nerfacc itself (DESIGN.md §3)"}
+
+
 def actor_scene(n_actors, seed=21):
     """n parked / slowly moving boxes (2 x 4.6 x 1.6 m) on a 60 m square, 9 poses over 4 s each"""
     ts = torch.linspace(0.0, 4.0, 9)
@@ -941,6 +992,7 @@ def bench_c4(args, device, rank, world):
         hits = ops.actor_hits(spec, cand, o, d, rb.pixel_area.reshape(-1), st_, en_)
         frac_hit = float((hits[:, 0] >= 0).float().mean())
         rays_with_cand = float((cand[0] > 0).float().mean())
+        parity = c4_parity(m, o, d, rb.pixel_area, times) if rank == 0 else None
     per_sample = algorithmic_bytes_per_sample(8, 4, 2, S)
     alg = n_field * (per_sample - frac_hit * 256.0)
     out = None
@@ -978,6 +1030,7 @@ def bench_c4(args, device, rank, world):
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
                          "bytes_per_sample": "8 levels x 8 corners x 4 features x 2 B = 512 B (256 B for a sample inside an "
                                              "actor box: its 4-level grid) + 8 B interval + per-ray I/O / S"}}
+        out["parity_rel_l2_vs_oracle"] = parity
         out["train_step"] = None
     # ---- the training step of the same scene, whole batch (fused nodes with per-sample row overrides for the in-box samples) ----
     del state["out"]

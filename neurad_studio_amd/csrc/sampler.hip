@@ -302,6 +302,71 @@ __device__ __forceinline__ float actor_density_override(const PropDev& p, const 
   return dens;
 }
 
+// Round 5: the in-box samples of a ray's round as a SEPARATE, dense pass.  `actor_density_override` above (kept for
+// NRHIP_SAMPLER_ACTOR_INLINE=1, A/B) looks an actor grid up inside the 64-sample chunk that met it: one wave-uniform pass per
+// distinct winning actor, a handful of lanes busy, four dependent gather round trips each -- for the 5 % of the samples
+// that lie in a box, on the 75 % of the rays that have a candidate.  Here the chunk loop only finds WHICH candidate
+// contains a sample (`actor_slot_of`) and appends (sample, slot) to a per-wave list in LDS; after the last chunk the list is
+// walked 64 entries at a time with every lane busy -- per-lane world->box rows and table base, all corner gathers of up
+// to four levels in flight together -- and the densities land in the round's density slab before the weights are formed.
+// Same arithmetic, same summation order: bit-identical densities.
+__device__ __forceinline__ int actor_slot_of(int K, int64_t ray, int ncand, float ox, float oy, float oz, float dx, float dy,
+                                             float dz, float area, float t0, float t1,
+                                             const int32_t* __restrict__ cand_actor, const float* __restrict__ cand_w2b,
+                                             const float* __restrict__ bounds) {
+  const SamplePos gs = sample_gaussian(ox, oy, oz, dx, dy, dz, area, t0, t1);
+  const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)ray * (uint32_t)K));
+  int slot = -1;
+  for (int c = 0; c < ncand; ++c) {  // ascending actor index: the last containing box wins (neurad_encoding.py:184-185)
+    const float* w = cand_w2b + (row + (uint32_t)c) * 12u;
+    const int act = cand_actor[row + (uint32_t)c];
+    const float bx = w[0] * gs.x + w[1] * gs.y + w[2] * gs.z + w[3];
+    const float by = w[4] * gs.x + w[5] * gs.y + w[6] * gs.z + w[7];
+    const float bz = w[8] * gs.x + w[9] * gs.y + w[10] * gs.z + w[11];
+    if (fabsf(bx) < bounds[3 * act] && fabsf(by) < bounds[3 * act + 1] && fabsf(bz) < bounds[3 * act + 2]) slot = c;
+  }
+  return slot;
+}
+
+// density of one in-box sample from its actor's grid (per-lane table base and world->box rows)
+__device__ __forceinline__ float actor_density_of(const PropDev& p, const PropActorDev& pa, const float* __restrict__ w,
+                                                  const void* tb, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                  float area, float t0, float t1) {
+  const SamplePos gs = sample_gaussian(ox, oy, oz, dx, dy, dz, area, t0, t1);
+  const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4),
+               w2 = *reinterpret_cast<const float4*>(w + 8);
+  const float bx = w0.x * gs.x + w0.y * gs.y + w0.z * gs.z + w0.w;
+  const float by = w1.x * gs.x + w1.y * gs.y + w1.z * gs.z + w1.w;
+  const float bz = w2.x * gs.x + w2.y * gs.y + w2.z * gs.z + w2.w;
+  const SamplePos q = contract_gaussian(bx, by, bz, gs.std, pa.scale);
+  const uint32_t amask = (1u << pa.grid.log2T) - 1u;
+  float acc = 0.f;
+  for (int l0 = 0; l0 < pa.grid.L; l0 += 4) {  // up to four levels' 32 gathers in flight, then their blends in level order
+    float fv[4][8][1];
+    float off[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (l0 + u < pa.grid.L) {  // wave-uniform
+        const Corners cs = hash_corners(q.x, q.y, q.z, pa.grid.scal[l0 + u], amask);
+        off[u][0] = cs.ox, off[u][1] = cs.oy, off[u][2] = cs.oz;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Entry<1, false>::load(tb, ((uint32_t)(l0 + u) << pa.grid.log2T) + cs.idx[k], fv[u][k]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (l0 + u < pa.grid.L) {
+        Corners cs;
+        cs.ox = off[u][0], cs.oy = off[u][1], cs.oz = off[u][2];
+        float v[1];
+        lerp_corners<1>(cs, fv[u], v);
+        acc += (v[0] * rescale_weight(pa.grid.scal[l0 + u], q.std)) * p.dec[l0 + u];
+      }
+    }
+  }
+  return expf(acc);
+}
+
 // S2 for one sample.  LT > 0: the grid has exactly LT levels and ALL 8*LT corner loads are issued before the first
 // blend -- one memory round trip per sample instead of one per level (the kernel is latency bound: 4-byte entries, a few
 // waves per SIMD).  LT == 0: any level count, level after level.  Same arithmetic and summation order either way.
@@ -351,7 +416,7 @@ __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, co
                                                                 const int32_t* __restrict__ cand_count,
                                                                 const int32_t* __restrict__ cand_actor,
                                                                 const float* __restrict__ cand_w2b,
-                                                                const float* __restrict__ bounds) {
+                                                                const float* __restrict__ bounds, int inline_actors) {
   // per wave: spacing bins (2 buffers), euclid bins, weights, cdf
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -389,16 +454,56 @@ __global__ __launch_bounds__(256) void proposal_sampler_kernel(SamplerDev sd, co
     for (int rd = 0; rd < sd.n_rounds; ++rd) {
       // S2 + S3: density -> delta*density -> exclusive-sum transmittance -> weights
       float carry = 0.f;
+      bool staged = false;  // ACT: the round's densities already lie in wl[] (static pass + dense in-box pass)
+      if constexpr (ACT) {
+        const int ncand = __builtin_amdgcn_readfirstlane(cand_count[ray]);
+        if (ncand > 0 && !inline_actors) {
+          staged = true;
+          uint32_t* list = reinterpret_cast<uint32_t*>(cdf);  // (cdf is free until the resampling below)
+          int nin = 0;                                         // wave-uniform: in-box samples of this round so far
+          for (int k0 = 0; k0 < S; k0 += 64) {
+            const int k = k0 + lane;
+            const bool live = k < S;
+            const float t0 = eu[live ? k : 0], t1 = eu[live ? k + 1 : 1];
+            // (the candidate walk first: it ends in one integer, the 48 gathers of the static lookup then have the registers)
+            const int slot = actor_slot_of(sd.K, ray, ncand, ox, oy, oz, dx, dy, dz, ar, t0, t1, cand_actor, cand_w2b, bounds);
+            const bool inb = live && slot >= 0;
+            const unsigned long long m = __ballot(inb);
+            if (inb) list[nin + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)k | ((uint32_t)slot << 16);
+            nin += __popcll(m);
+            const float dens = prop_density<HALF, LT>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
+            if (live) wl[k] = dens;
+          }
+          wave_fence();
+          const uint32_t row = (uint32_t)ray * (uint32_t)sd.K;
+          for (int i0 = 0; i0 < nin; i0 += 64) {
+            const bool on = i0 + lane < nin;
+            const uint32_t e = list[on ? i0 + lane : 0];
+            const int k = (int)(e & 0xffffu);
+            const uint32_t c = e >> 16;
+            const float dens = actor_density_of(sd.prop[rd], sd.pact[rd], cand_w2b + (size_t)(row + c) * 12u,
+                                                sd.pact[rd].tables[cand_actor[row + c]], ox, oy, oz, dx, dy, dz, ar, eu[k],
+                                                eu[k + 1]);
+            if (on) wl[k] = dens;
+          }
+          wave_fence();
+        }
+      }
       for (int k0 = 0; k0 < S; k0 += 64) {
         const int k = k0 + lane;
         const bool live = k < S;
         const float t0 = eu[live ? k : 0], t1 = eu[live ? k + 1 : 1];
-        float dens = prop_density<HALF, LT>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
-        if constexpr (ACT) {
-          const int ncand = __builtin_amdgcn_readfirstlane(cand_count[ray]);
-          if (ncand > 0)
-            dens = actor_density_override(sd.prop[rd], sd.pact[rd], sd.K, ray, ncand, dens, live, ox, oy, oz, dx, dy, dz, ar,
-                                          t0, t1, cand_actor, cand_w2b, bounds);
+        float dens;
+        if (staged) {
+          dens = wl[live ? k : 0];
+        } else {
+          dens = prop_density<HALF, LT>(sd.prop[rd], ox, oy, oz, dx, dy, dz, ar, t0, t1);
+          if constexpr (ACT) {
+            const int ncand = __builtin_amdgcn_readfirstlane(cand_count[ray]);
+            if (ncand > 0)
+              dens = actor_density_override(sd.prop[rd], sd.pact[rd], sd.K, ray, ncand, dens, live, ox, oy, oz, dx, dy, dz, ar,
+                                            t0, t1, cand_actor, cand_w2b, bounds);
+          }
         }
         const float dd = live ? (t1 - t0) * dens : 0.f;
         const float incl = wscan_add(dd, lane);
@@ -550,16 +655,18 @@ static int sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props
   const hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(HALF_, LT_)                                                                                              \
   proposal_sampler_kernel<HALF_, LT_><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars, r, \
-                                                                     slab_len, nullptr, nullptr, nullptr, nullptr)
+                                                                     slab_len, nullptr, nullptr, nullptr, nullptr, 0)
   if (actors) {
+    const char* ia = getenv("NRHIP_SAMPLER_ACTOR_INLINE");  // 1: the round-2..4 per-chunk lookup (A/B against the dense pass)
+    const int inline_actors = (ia && ia[0] == '1') ? 1 : 0;
     if (lt == 6)
       proposal_sampler_kernel<false, 6, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
                                                                             r, slab_len, cand_count, cand_actor, cand_w2b,
-                                                                            bounds);
+                                                                            bounds, inline_actors);
     else
       proposal_sampler_kernel<false, 0, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
                                                                             r, slab_len, cand_count, cand_actor, cand_w2b,
-                                                                            bounds);
+                                                                            bounds, inline_actors);
   } else if (half) {
     if (lt == 6) LAUNCH(true, 6);
     else LAUNCH(true, 0);

@@ -219,10 +219,9 @@ class NeuRADHashEncoding(nn.Module):
             # know nothing of the edit; the reference edits for rendering only (pipelines/ad_pipeline.py:476-480)
             raise NotImplementedError("eval-time actor edits (DynamicActors.actor_editing) with gradients enabled: "
                                       "render edited actors under torch.no_grad()")
-        pair = (hits >= 0).nonzero()                  # every (sample, candidate slot) containment
-        if pair.shape[0] == 0:
+        idx, act = ops.actor_pairs(hits)              # every (sample, containing actor), in (sample, slot) order
+        if idx.shape[0] == 0:
             return None
-        idx, act = pair[:, 0], hits[pair[:, 0], pair[:, 1]]
         winner = act == hit[idx]                      # the row the forward actually used (highest actor index)
         # box-frame position + contraction of every pair in one kernel; its backward hands the trajectory parameters
         # their gradient (require_actor_grad governs exactly that: neurad_encoding.py:174-176)
@@ -231,7 +230,7 @@ class NeuRADHashEncoding(nn.Module):
         with torch.set_grad_enabled(pose_grad):
             x01, cstd = ag.ActorPairPositionsFn.apply(self.actors.actor_positions, self.actors.actor_rotations_6d, spec,
                                                       origins, directions, pixel_area.reshape(-1), starts, ends, times, idx,
-                                                      act.int(), flip)
+                                                      act, flip)
         act = act.long()
         ids = self.actors.actor_to_id[act]
         # _get_actor_features_slow loops over the actor ids; all actor grids share one shape, so one multi-grid

@@ -982,6 +982,24 @@ def actor_hits(spec: ActorSpec, cand, origins, directions, pixel_area, starts, e
     return hits
 
 
+def actor_pairs(hits: Tensor) -> Tuple[Tensor, Tensor]:
+    """-> (sample_idx int64 [P], actor_idx int32 [P]): every (sample, containing actor) of a hits table in (sample, slot)
+    order -- `(hits >= 0).nonzero()` + `hits[idx, slot]` without the rocprim partition, the gather and the casts (one host
+    read of P, which nonzero needs as well)"""
+    h = _chk(hits, "hits", torch.int32)
+    n = h.shape[0]
+    nblk = (n + 1023) // 1024
+    off = torch.empty((max(nblk, 1),), dtype=torch.int32, device=h.device)
+    total = torch.empty((1,), dtype=torch.int64, device=h.device)
+    call("nrhip_actor_pairs_count", _ptr(h), n, _ptr(off), _ptr(total), _stream())
+    P_ = int(total.item())
+    si = torch.empty((P_,), dtype=torch.int64, device=h.device)
+    ai = torch.empty((P_,), dtype=torch.int32, device=h.device)
+    if P_:
+        call("nrhip_actor_pairs_write", _ptr(h), n, _ptr(off), _ptr(si), _ptr(ai), _stream())
+    return si, ai
+
+
 def actor_density(spec: ActorSpec, cand, origins, directions, pixel_area, starts, ends, decoder_weight: Tensor,
                   density: Tensor, ray_flip: Optional[Tensor] = None, return_actor: bool = False):
     """Overwrites density [R,S] (in place) where the sample lies inside an actor box.  -> hit [R,S] bool (return_actor: the

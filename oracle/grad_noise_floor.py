@@ -15,7 +15,8 @@ level-8192 features by that much), flip between the two runs, and each flip swit
 off: few units far off (outlier_frac), the others close (rest_rel_l2 1e-5 .. 6e-4: flips of low-gradient samples stay under
 the 1e-4 outlier threshold).  The plugin-vs-reference test on the GPU
 holds the HIP path to the same picture (check_gradients_against_floor) instead of to a widened rel-L2.
-Scenes: static, actors3, and both with camera_optimizer.mode = "SO3xR3" (*_pose: also the floor of the ray gradients).
+Scenes: static, actors3, both with camera_optimizer.mode = "SO3xR3" (*_pose: also the floor of the ray gradients), and
+actors32 (config[4] at test size: 32 actors, tables holding fp16-representable values).
 TEST INFRASTRUCTURE.   python oracle/grad_noise_floor.py  ->  profiles/r05_grad_noise_floor.json"""
 import json
 import os
@@ -69,13 +70,16 @@ def merge_max(acc, new):
 
 def main():
     out = {}
-    for wa in (False, True):
-        for pose in (False, True):
-            scene = ("actors3" if wa else "static") + ("_pose" if pose else "")
-            _, m32 = t._build_pair(ref_neurad, wa, pose_opt=pose)
-            _, m64 = t._build_pair(ref_neurad, wa, pose_opt=pose)
+    for wa, pose, na in ((False, False, 3), (False, True, 3), (True, False, 3), (True, True, 3), (True, False, 32)):
+        scene = ("actors%d" % na if wa else "static") + ("_pose" if pose else "")
+        if os.environ.get("NRHIP_FLOOR_SCENES") and scene not in os.environ["NRHIP_FLOOR_SCENES"].split(","):
+            continue
+        if True:
+            kw = dict(pose_opt=pose, n_actors=na, fp16_tables=na == 32)  # (actors32: tables hold fp16-representable values)
+            _, m32 = t._build_pair(ref_neurad, wa, **kw)
+            _, m64 = t._build_pair(ref_neurad, wa, **kw)
             m64 = m64.double()
-            b = t._batch(wa)
+            b = t._batch(wa, n_actors=na)
             t._deterministic(m32, True), t._deterministic(m64, True)
             rb32, l32 = step(m32, b, torch.float32)
             rb64, l64 = step(m64, b, torch.float64)
@@ -84,7 +88,7 @@ def main():
                 f64["__ray_grads__"] = [t.rel_l2(t.N(a), t.N(c)) for a, c in zip(ray_grads(rb32, l32), ray_grads(rb64, l64))]
             pert = {}
             for trial in range(PERTURBED_TRIALS):
-                _, mp = t._build_pair(ref_neurad, wa, pose_opt=pose)
+                _, mp = t._build_pair(ref_neurad, wa, **kw)
                 t._deterministic(mp, True)
                 g = torch.Generator().manual_seed(1000 + trial)
                 with torch.no_grad():
@@ -100,7 +104,10 @@ def main():
             print(scene, "perturbed_max", json.dumps({k: {a: (float(f"{s['rel_l2']:.1e}"), s["n_outliers"],
                                                              float(f"{s['rest_rel_l2']:.1e}")) for a, s in v.items()}
                                                       for k, v in pert.items()}), flush=True)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r05_grad_noise_floor.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "r05_grad_noise_floor.json")
+    if os.environ.get("NRHIP_FLOOR_SCENES") and os.path.exists(path):  # a partial run updates its scenes only
+        out = dict(json.load(open(path)), **out)
+    json.dump(out, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -469,3 +469,23 @@ def test_actor_edits_vs_reference_golden():
     fld.eval()
     with pytest.raises(NotImplementedError, match="actor edits"):
         fld(rs)  # grad mode, eval, edited actors: the differentiable actor rows would ignore the edit
+
+
+@pytest.mark.parametrize("n", [0, 1, 1023, 1024, 70001])
+def test_actor_pairs_equal_nonzero_of_the_hits_table(n):
+    """ops.actor_pairs: the (sample, containing actor) pairs in (sample, slot) order -- exactly what
+    `(hits >= 0).nonzero()` followed by `hits[idx, slot]` gives, empty tables and ragged last blocks included"""
+    from neurad_studio_amd import ops
+
+    g = np.random.default_rng(n)
+    hits = np.full((n, 8), -1, np.int32)
+    for i in np.flatnonzero(g.uniform(size=n) < 0.07):  # ascending actors, compacted to the front (nrhip_actor_hits' layout)
+        k = int(g.integers(1, 4))
+        hits[i, :k] = np.sort(g.choice(32, k, replace=False))
+    if n > 10:
+        hits[n - 1, :8] = np.arange(8)  # a full row at the very end
+    h = torch.from_numpy(hits).cuda()
+    si, ai = ops.actor_pairs(h)
+    pair = (h >= 0).nonzero()
+    assert si.dtype == torch.int64 and ai.dtype == torch.int32
+    assert torch.equal(si, pair[:, 0]) and torch.equal(ai, h[pair[:, 0], pair[:, 1]])

@@ -119,12 +119,12 @@ def test_field_ray_gradients_vs_reference_autograd(fused_training):
         assert rel_l2(a, c) < 0.1 * floor, (key, rel_l2(a, c), floor, np.sort(per_ray)[-5:])
         assert np.median(per_ray) < 1e-3, (key, np.sort(per_ray))  # (measured: median 1.1e-4, worst ray 1.2e-3)
     tg = host(fld.hashgrid.static_grid.hash_table.grad).copy()
-    # same step with fixed rays: identical parameter gradients, and no ray-gradient kernel is launched
+    # same step with fixed rays: the same parameter gradients, and no ray-gradient kernel is launched
     fld.zero_grad()
     rb2 = bundle(g["o"], g["d"], g["area"])
     rs2 = PowerSampler(num_samples=g["starts"].shape[1], lambda_=-1.0, scaling=0.1).eval()(rb2)
     out2 = fld(rs2)
     ((out2[FieldHeadNames.FEATURE] * dev(g["field_g_feature"])).sum()
      + (out2[FieldHeadNames.ALPHA][..., 0] * dev(g["field_g_alpha"])).sum()).backward()
-    assert np.array_equal(host(fld.hashgrid.static_grid.hash_table.grad), tg)
+    assert rel_l2(host(fld.hashgrid.static_grid.hash_table.grad), tg) < 1e-6  # (a batch this small takes the atomic scatter)
     assert rb2.origins.grad is None

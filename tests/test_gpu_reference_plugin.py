@@ -79,6 +79,27 @@ def _trajectories():
     return out
 
 
+def _many_trajectories(n):
+    """n actors in two lanes along +x, staggered every 3 m, each present over its own part of the scene's 4 s (config[4]'s 32
+    actors at test size: several boxes along every ray, neighbours overlapping at the lane changes)"""
+    ts_all = torch.tensor([0.0, 1.0, 2.0, 3.0, 4.0])
+    out = []
+    for a in range(n):
+        ts = ts_all[a % 2:] if a % 3 else ts_all[:4]
+        yaw = 0.25 * ((a * 7) % 5 - 2) / 2
+        poses = []
+        for t in ts:
+            c, s = np.cos(yaw + 0.04 * float(t)), np.sin(yaw + 0.04 * float(t))
+            p = torch.eye(4)
+            p[:3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+            p[:3, 3] = torch.tensor([8.0 + 3.0 * a + 1.5 * float(t), 6.5 if a % 2 == 0 else -5.5, 0.5])
+            poses.append(p)
+        out.append({"timestamps": ts.clone(), "poses": torch.stack(poses),
+                    "dims": torch.tensor([1.9 + 0.01 * a, 4.2 + 0.02 * a, 1.5 + 0.01 * a]),
+                    "symmetric": torch.tensor(True), "deformable": torch.tensor(False)})
+    return out
+
+
 def _fill(model):
     """deterministic O(1)-feature parameters (tests/synth.py) so that densities, weights and every loss term are far from
     their trivial values"""
@@ -128,10 +149,12 @@ def _shrink(c):
     return c
 
 
-def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False):
+def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_actors=3, fp16_tables=False):
     """(the plugin on cuda:0, resolved through the registry; the reference's torch model on the CPU; same weights).
     pose_opt: camera_optimizer.mode = "SO3xR3" on both (the `*-scaleopt` methods, configs/method_configs.py:438-447), with
-    non-zero pose adjustments so that the rays really move"""
+    non-zero pose adjustments so that the rays really move.  n_actors > 3: `_many_trajectories`.  fp16_tables: the plugin's
+    main-field static table and actor grids in fp16 STORAGE (BASELINE config[4]); the reference's fp32 tables then hold exactly
+    those rounded values"""
     import nerfstudio.model_components.renderers as ref_renderers
     from nerfstudio.data.scene_box import SceneBox
     from nerfstudio.plugins.registry import discover_methods
@@ -154,7 +177,8 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False):
     def kw():
         return dict(scene_box=SceneBox(aabb=torch.tensor([[-100.0] * 3, [100.0] * 3])), num_train_data=2,
                     metadata={"duration": 5.0, "sensor_idx_to_name": {0: "cam0", 1: "cam1", 2: "lidar"},
-                              "trajectories": _trajectories() if with_actors else []})
+                              "trajectories": (_trajectories() if n_actors == 3 else _many_trajectories(n_actors))
+                              if with_actors else []})
 
     torch.manual_seed(0)
     hip = mcfg.setup(**kw())
@@ -170,7 +194,10 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False):
     if pose_opt:
         pa = hip.camera_optimizer.pose_adjustment
         pa.data = T(synth.normal(tuple(pa.shape), seed=55) * np.float32(0.02)).to(pa.device)
-    refm.load_state_dict(hip.state_dict())
+    if fp16_tables:
+        for gr in [hip.field.hashgrid.static_grid, *hip.field.hashgrid.actor_grids]:
+            gr.hash_table.data = gr.hash_table.data.half()
+    refm.load_state_dict({k: (v.float() if v.dtype == torch.float16 else v) for k, v in hip.state_dict().items()})
     hip = hip.to("cuda")
     # the reference on the CPU: dense nerfacc formulas instead of its 0.5 placeholder (models/neurad.py:713-715)
     na = _dense_nerfacc()
@@ -182,16 +209,21 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False):
     return hip, refm
 
 
-def _batch(with_actors, patch=4, n_patches=3, n_lidar=40):
+def _batch(with_actors, patch=4, n_patches=3, n_lidar=40, n_actors=3):
     """camera rays in ``patch`` x ``patch`` patches (the CNN decoder's unit) then lidar rays; with actors the rays are
     aimed down the actors' corridor so that many samples fall inside boxes"""
     Rc = n_patches * patch * patch
     R = Rc + n_lidar
     o = synth.normal((R, 3), 5) * np.array([1.5, 1.5, 0.3], np.float32)
     if with_actors:
-        tgt = np.stack([synth.uniform((R,), 10, 24, 8),
-                        np.where(np.arange(R) % 2 == 0, 8.0, -5.5) + synth.uniform((R,), -1.5, 1.5, 9),
-                        synth.uniform((R,), 0.0, 1.0, 10)], -1).astype(np.float32)
+        if n_actors == 3:
+            tgt = np.stack([synth.uniform((R,), 10, 24, 8),
+                            np.where(np.arange(R) % 2 == 0, 8.0, -5.5) + synth.uniform((R,), -1.5, 1.5, 9),
+                            synth.uniform((R,), 0.0, 1.0, 10)], -1).astype(np.float32)
+        else:  # down the two lanes of `_many_trajectories`: shallow angles, several boxes along a ray
+            tgt = np.stack([synth.uniform((R,), 12, 8.0 + 3.0 * n_actors, 28),
+                            np.where(np.arange(R) % 2 == 0, 6.5, -5.5) + synth.uniform((R,), -1.0, 1.0, 9),
+                            synth.uniform((R,), 0.1, 0.9, 10)], -1).astype(np.float32)
         d = tgt - o
     else:
         d = synth.normal((R, 3), 6)
@@ -346,6 +378,8 @@ def per_loss_gradient_errors(got_model, got_losses, want_model, want_losses, det
             if c is None or float(c.double().norm()) <= 1e-6 * tot[k]:
                 continue
             assert a is not None, f"{term}: {n} has a gradient on the reference side and none on the other"
+            if a.dtype == torch.float16:  # fp16-storage table: autograd hands the parameter an fp16 gradient -- held to
+                c = c.half().float()       # the fp16 ROUNDING of the reference's gradient (what that storage can express)
             e = float((a.detach().double().cpu() - c.detach().double().cpu()).norm() / c.detach().double().norm())
             worst[k] = max(worst.get(k, 0.0), e)
             if detail:
@@ -488,6 +522,37 @@ def test_plugin_pose_gradients_match_the_reference_torch_model(ref, with_actors)
           "pose:", {k: (v["rel_l2"], v["bound"]) for k, v in report.items() if k.endswith("/pose")})
     for e, f in zip(ray_err, fl):
         assert e <= max(3.0 * f, 1e-4), (ray_err, fl)
+
+
+def test_plugin_training_step_32_actors_fp16_tables_matches_the_reference_torch_model(ref):
+    """BASELINE config[4]'s training mode against the reference itself (round 4 pinned it HIP-vs-HIP only): 32 dynamic actors,
+    the main field's static table and its 32 actor grids in fp16 storage on the plugin, the reference's fp32 tables holding
+    the same (rounded) values -- outputs, every loss term, every parameter gradient per loss term (actor grids and
+    trajectories included; fp16 gradients against the fp16 rounding of the reference's)."""
+    hip, refm = _build_pair(ref, True, n_actors=32, fp16_tables=True)
+    b = _batch(True, n_actors=32)
+    _deterministic(hip, True), _deterministic(refm, True)
+    assert hip.fused_training_possible()
+    assert hip.field.hashgrid.static_grid.hash_table.dtype == torch.float16 and len(hip.field.hashgrid.actor_grids) == 32
+    g_out, g_loss = _losses(hip, b, "cuda")
+    w_out, w_loss = _losses(refm, b, "cpu")
+    assert set(g_loss) == set(w_loss)
+    for k in w_loss:
+        a, c = float(g_loss[k]), float(w_loss[k])
+        assert abs(a - c) <= 2e-4 * abs(c) + 1e-7, (k, a, c)
+    for k in ("rgb", "depth", "accumulation", "intensity", "ray_drop_logits", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(N(g_out[k]), N(w_out[k])) < 1e-4, (k, rel_l2(N(g_out[k]), N(w_out[k])))
+    errs = per_loss_gradient_errors(hip, g_loss, refm, w_loss, detail=True)
+    report = check_gradients_against_floor(errs, _floors("actors32"), "r05_grad_outliers_actors32_fp16.json")
+    seen = {k for kinds in errs.values() for k in kinds}
+    assert {"table", "mlp", "actor_grid", "trajectory", "beta", "embedding"} <= seen, seen
+    # many actors really take part (this batch: 10 of the 32 grids receive a gradient, several boxes along most rays)
+    sum(g_loss.values()).backward()
+    hit = sum(1 for gr in hip.field.hashgrid.actor_grids
+              if gr.hash_table.grad is not None and float(gr.hash_table.grad.float().abs().max()) > 0)
+    assert hit >= 8, hit
+    print("32 actors, fp16 tables:", {k: (v["rel_l2"], v["bound"]) for k, v in report.items()
+                                      if k.split("/")[1] in ("actor_grid", "trajectory", "table")})
 
 
 def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
