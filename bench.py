@@ -176,6 +176,54 @@ class _Optimizers:
             o.step()
 
 
+def adam_live_report(opt):
+    """csrc/adam.hip reads 12 instead of 28 bytes for elements whose gradient and both moments are exactly zero (rows no ray
+    has touched yet -- exact, but a short bench from zero state flatters the kernel: after thousands of steps few rows are
+    still untouched).  -> what the timed steps saw and what the kernel costs with EVERY row live: the fraction of table
+    elements with a non-zero moment after the run, and the table optimizer's time on copies of the same tensors whose
+    moments are all non-zero (HIP events, best of 3)."""
+    from neurad_studio_amd import ops
+    from neurad_studio_amd.optim import HashGridAdam
+
+    hg = next((o for o in getattr(opt, "opts", []) if isinstance(o, HashGridAdam)), None)
+    if hg is None:
+        return None
+    items, live, total = [], 0, 0
+    for group in hg.param_groups:
+        for p in group["params"]:
+            st = hg.state.get(p)
+            if not st:
+                continue
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            live += int(((m != 0) | (v != 0)).sum())
+            total += m.numel()
+            tgt = st.get("master", p.detach())
+            grad = p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)  # (cleared after the timed steps)
+            items.append((tgt.clone(), grad, torch.full_like(m, 1e-30), torch.full_like(v, 1e-30),
+                          int(st["step"]) + 1, None if p.dtype == torch.float32 else p.detach().clone()))
+    if not items:
+        return None
+    g = hg.param_groups[0]
+    best = float("inf")
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        big = [it for it in items if it[0].numel() >= 1 << 24]
+        for it in big:
+            ops.adam_step_many([it], g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
+        ops.adam_step_many([it for it in items if it[0].numel() < 1 << 24], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                           g["weight_decay"])
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    nbytes = sum(it[0].numel() * (4 + it[1].element_size() + 4 + 4 + 4 + 4 + (2 if it[5] is not None else 0)) for it in items)
+    return {"live_fraction_after_the_timed_steps": live / max(total, 1), "table_elements": total,
+            "table_optimizer_ms_all_rows_live": best, "all_live_bytes": nbytes, "all_live_gb_per_s": nbytes / best / 1e6,
+            "what": "hash-table Adam (csrc/adam.hip): elements with g = m = v = 0 cost 12 B instead of 28 B; the timed steps start "
+                    "from zero state, so most rows are still untouched -- `table_optimizer_ms_all_rows_live` is the same "
+                    "launches on the same tables with every moment non-zero (the long-run cost)"}
+
+
 class _ShardedOptimizers(_Optimizers):
     """--sharded-adam at N > 1: the hash tables on parallel/sharded_adam.py (their reduce-scatter IS the gradient exchange,
     Adam runs on 1/N of each table, the updated parameters are all-gathered); the GradientSynchronizer skips them"""
@@ -463,7 +511,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "grad_exchange_timing": dict(sync.timing(last=steps),
                                          wire_bytes_by_table={("small" if i < 0 else f"param{i}:{tuple(sync.params[i].shape)}"): b
                                                               for i, b in sync.last_wire_bytes_by_param.items()}) if world > 1 else None,
-            "optimizer": opt_name,
+            "optimizer": opt_name, "table_optimizer_live_rows": adam_live_report(opt),
             "rgb_decoder": ("CNN decoder (4 BasicBlocks of 7x7 convs + BatchNorm, 3x transposed conv) + rgb MSE in the step, "
                             + ("torch modules = MIOpen under fp16 autocast" if torch_decoder else
                                "HIP kernels (csrc/decoder.hip: fp16 operands, fp32 accumulation, v_mfma_f32_32x32x16_f16)")
@@ -1018,7 +1066,8 @@ def bench_c4(args, device, rank, world):
             "roofline": {"kernel": "nrhip::proposal_sampler_kernel<ACT> (both rounds on chip, one wave per ray, per-sample actor "
                                    "select; HIP events around nrhip_proposal_sampler_fwd_actors in the timed steps)",
                          "bound": "l1", "achieved": gathers / (s_ms * 1e-3) / 1e9, "peak": L1_ACCESS_PEAK_G,
-                         "unit": "Gaccess/s", "frac": gathers / (s_ms * 1e-3) / 1e9 / L1_ACCESS_PEAK_G, "traffic": None,
+                         "unit": "Gaccess/s", "frac": gathers / (s_ms * 1e-3) / 1e9 / L1_ACCESS_PEAK_G,
+                         "traffic": recorded_traffic("proposal_sampler_actors"),
                          "kernel_ms": s_ms, "accesses_per_launch": gathers,
                          "what": "algorithmic 4-byte gathers of the STATIC proposal grid (48 per proposal evaluation, "
                                  f"{n_prop} evaluations per launch) per second against the vector L1's access rate; config[2]'s "
@@ -1087,7 +1136,8 @@ def bench_c4(args, device, rank, world):
                              "roofline": {"kernel": "nrhip::render_kernel<8,4,32,fp16,train,OVR> (fused training forward of the field with "
                                                     "row overrides; HIP events around nrhip_field_fwd_train_ovr in the timed steps)",
                                           "bound": "hbm", "achieved": t_alg / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": t_alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": f_ms,
+                                          "frac": t_alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "traffic": recorded_traffic("field_fwd_train_ovr_fp16"), "kernel_ms": f_ms,
                                           "algorithmic_bytes_per_launch": t_alg},
                              "what": f"all {Rt} rays of the scene in one step: sampler rounds with the actor overlay (in-box "
                                      "samples spliced in by nrhip_actor_density_splice_*), fused field + SDF head + compositing + "
