@@ -978,6 +978,9 @@ def bench_c4(args, device, rank, world):
             p.hashgrid.static_grid.hash_table.mul_(500.0)
         for gr in [m.field.hashgrid.static_grid, *m.field.hashgrid.actor_grids]:
             gr.hash_table.data = gr.hash_table.data.half()
+    # the batch is incoherent (random origins and directions): the render stage walks it in the cache-coherent order of
+    # ops.ray_order, like the c1 step does (NRHIP_C4_ORDER_RAYS=0: data-loader order, A/B)
+    m.order_rays = os.environ.get("NRHIP_C4_ORDER_RAYS", "1") != "0"
     gen.manual_seed(31 + rank)
     o = (torch.randn(R, 3, generator=gen) * torch.tensor([20.0, 20.0, 0.3]) + torch.tensor([0.0, 0.0, 1.5])).to(device)
     d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.1]), dim=-1).to(device)

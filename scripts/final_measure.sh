@@ -1,26 +1,17 @@
 #!/bin/bash
-# End-of-round measurements in one lease: GPU test suite, bench lines c1-c4, kernel traces, the PMC passes behind
-# roofline.traffic, the two-rank gloo rehearsal.  usage: scripts/final_measure.sh <tag>   (outputs under gpurun_out/<tag>_*)
-tag=${1:-r04f}
+# End-of-round measurements in one lease: GPU test suite, the PMC passes behind roofline.traffic (written to profiles/traffic_*.json
+# BEFORE the bench lines read them), bench lines c1-c4, kernel traces, the two-rank gloo rehearsals, the round's A/B re-measurements.
+# usage: scripts/final_measure.sh <tag>   (outputs under gpurun_out/<tag>_*)
+tag=${1:-r05}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
-timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > $OUT/${tag}_gputests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $OUT/${tag}_gputests.txt
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/${tag}_gputests.txt; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $OUT/${tag}_gputests.txt
 cat $OUT/${tag}_gputests.txt
-timeout 600 python bench.py > $OUT/bench_${tag}_c1.json 2> $OUT/bench_${tag}_c1.err; echo "c1 rc=$?"
-for c in c2 c3 c4; do timeout 600 python bench.py --config $c > $OUT/bench_${tag}_$c.json 2> $OUT/bench_${tag}_$c.err; echo "$c rc=$?"; done
-NRHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 > $OUT/${tag}_rehearsal_n2_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2.err; echo "rehearsal rc=$?"
 cd /tmp
-prof() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_$name -o t -- "$@" > $OUT/prof_${tag}_$name.log 2>&1
-  python $R/scripts/prof_summary.py $(find $OUT/prof_${tag}_$name -name '*.db' | head -1) | head -64 > $OUT/${tag}_${name}_kernel_trace.txt; find $OUT/prof_${tag}_$name -name '*.db' -delete; }
-prof headline python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants
-prof train_full_c3 python $R/bench.py --config c3 --steps 10 --warmup 3
-prof c2 python $R/bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline
-prof c4 python $R/bench.py --config c4 --steps 4 --warmup 1 --train-steps 60
-NRHIP_BENCH_DECODER_MODES=hip prof decoder python $R/scripts/bench_decoder.py
-if [ -n "$SKIP_PMC" ]; then cd $R; python scripts/show_bench.py $OUT/bench_${tag}_c1.json $OUT/bench_${tag}_c2.json $OUT/bench_${tag}_c3.json $OUT/bench_${tag}_c4.json 2>/dev/null | head -60; exit 0; fi
 pmc() { name=$1; kern=$2; ctr=$3; shift; shift; shift; timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/pmc_${tag}_$name -o p -- "$@" > $OUT/pmc_${tag}_$name.log 2>&1
   echo "== $name: $ctr ($kern)"; python $R/scripts/pmc_report.py "$kern" $(find $OUT/pmc_${tag}_$name -name '*.db' | head -1); rm -rf $OUT/pmc_${tag}_$name; }
+if [ -z "$SKIP_PMC" ]; then
 {
 C1="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants"
 pmc c1_fetch render_kernel FETCH_SIZE $C1
@@ -36,6 +27,41 @@ pmc c3_write "render_kernel<8, 4, 32, false, false" WRITE_SIZE $C3
 C4="python $R/bench.py --config c4 --steps 5 --warmup 2 --train-steps 0"
 pmc c4_fetch "render_kernel<8, 4, 32, true, true, true" FETCH_SIZE $C4
 pmc c4_write "render_kernel<8, 4, 32, true, true, true" WRITE_SIZE $C4
+pmc c4static_fetch "render_kernel<8, 4, 32, true, true, false" FETCH_SIZE $C4
+pmc c4s_fetch "proposal_sampler_kernel" FETCH_SIZE $C4
+pmc c4s_write "proposal_sampler_kernel" WRITE_SIZE $C4
+C4T="python $R/bench.py --config c4 --steps 2 --warmup 1 --train-steps 36"
+pmc c4t_fetch "render_kernel<8, 4, 32, true, false, false, false, false, true" FETCH_SIZE $C4T
+pmc c4t_write "render_kernel<8, 4, 32, true, false, false, false, false, true" WRITE_SIZE $C4T
 } > $OUT/${tag}_pmc_traffic.txt 2>&1
 cat $OUT/${tag}_pmc_traffic.txt
-cd $R; python scripts/show_bench.py $OUT/bench_${tag}_c1.json $OUT/bench_${tag}_c2.json $OUT/bench_${tag}_c3.json $OUT/bench_${tag}_c4.json 2>/dev/null | head -60
+python $R/scripts/traffic_from_pmc.py $OUT/${tag}_pmc_traffic.txt $tag; cp $R/profiles/traffic_*.json $OUT/
+fi
+cd $R
+timeout 600 python bench.py > $OUT/bench_${tag}_c1.json 2> $OUT/bench_${tag}_c1.err; echo "c1 rc=$?"
+for c in c2 c3 c4; do timeout 600 python bench.py --config $c > $OUT/bench_${tag}_$c.json 2> $OUT/bench_${tag}_$c.err; echo "$c rc=$?"; done
+NRHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 > $OUT/${tag}_rehearsal_n2_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2.err; echo "rehearsal rc=$?"
+NRHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 --wire-bf16 > $OUT/${tag}_rehearsal_n2_wire_bf16_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2_wire_bf16.err; echo "rehearsal wire-bf16 rc=$?"
+cd /tmp
+prof() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_$name -o t -- "$@" > $OUT/prof_${tag}_$name.log 2>&1
+  python $R/scripts/prof_summary.py $(find $OUT/prof_${tag}_$name -name '*.db' | head -1) | head -64 > $OUT/${tag}_${name}_kernel_trace.txt; find $OUT/prof_${tag}_$name -name '*.db' -delete; }
+prof headline python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants
+prof train_full_c3 python $R/bench.py --config c3 --steps 10 --warmup 3
+prof c2 python $R/bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline
+prof c4 python $R/bench.py --config c4 --steps 4 --warmup 1 --train-steps 60
+NRHIP_BENCH_DECODER_MODES=hip prof decoder python $R/scripts/bench_decoder.py
+cd $R
+# the round's A/B re-measurements on this box
+{
+echo "== split-bf16 MLP products in the headline kernel (NRHIP_MLP_SPLIT_BF16=1) vs the fp32 MFMA default"
+for v in 0 1; do if [ $v = 1 ]; then export NRHIP_MLP_SPLIT_BF16=1; else unset NRHIP_MLP_SPLIT_BF16; fi
+  timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants 2>/dev/null | python -c "
+import sys, json
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('split_bf16=$v', 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline'].get('kernel_ms'), 'frac', d['roofline']['frac'], 'parity', d.get('parity_rel_l2_vs_oracle'))"; done; unset NRHIP_MLP_SPLIT_BF16
+echo "== c4 eval: render stage in ray_order (default) vs data-loader order; fused sampler's in-box pass dense (default) vs inline"
+for e in "NRHIP_C4_ORDER_RAYS=1" "NRHIP_C4_ORDER_RAYS=0" "NRHIP_SAMPLER_ACTOR_INLINE=1"; do env $e timeout 300 python bench.py --config c4 --steps 8 --warmup 2 --train-steps 0 2>/dev/null | python -c "
+import sys, json
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$e', 'eval ms', d['ms_per_step'], 'sampler ms', d['roofline']['kernel_ms'], 'render ms', d['render_roofline']['kernel_ms'])"; done
+} > $OUT/${tag}_ab.txt 2>&1
+cat $OUT/${tag}_ab.txt
+python scripts/show_bench.py $OUT/bench_${tag}_c1.json $OUT/bench_${tag}_c2.json $OUT/bench_${tag}_c3.json $OUT/bench_${tag}_c4.json 2>/dev/null | head -70
