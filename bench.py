@@ -978,9 +978,16 @@ def bench_c4(args, device, rank, world):
             p.hashgrid.static_grid.hash_table.mul_(500.0)
         for gr in [m.field.hashgrid.static_grid, *m.field.hashgrid.actor_grids]:
             gr.hash_table.data = gr.hash_table.data.half()
-    # the batch is incoherent (random origins and directions): the render stage walks it in the cache-coherent order of
-    # ops.ray_order, like the c1 step does (NRHIP_C4_ORDER_RAYS=0: data-loader order, A/B)
-    m.order_rays = os.environ.get("NRHIP_C4_ORDER_RAYS", "1") != "0"
+        # round 5: the proposal fields' STATIC tables in fp16 storage as well (their small actor grids stay fp32).  On this
+        # incoherent batch the fused sampler runs against the L2 <-> fabric bandwidth (fp32 tables: 15.7 GB per launch,
+        # profiles/r05_pmc_traffic.txt), and half the footprint is half the misses.  NRHIP_C4_PROP_FP32=1: the round-4 setup.
+        if os.environ.get("NRHIP_C4_PROP_FP32", "0") != "1":
+            for p in m.proposal_fields:
+                p.hashgrid.static_grid.hash_table.data = p.hashgrid.static_grid.hash_table.data.half()
+    # NRHIP_C4_ORDER_RAYS=1: the render stage walks the (incoherent) batch in the order of ops.ray_order.  Measured round 5:
+    # traffic 1.73 -> 1.59 GB per launch but the single-workgroup ordering pass costs more at 65 536 rays than it returns
+    # (render stage 0.62 -> 0.69 ms, profiles/r05_ab.txt): off
+    m.order_rays = os.environ.get("NRHIP_C4_ORDER_RAYS", "0") == "1"
     gen.manual_seed(31 + rank)
     o = (torch.randn(R, 3, generator=gen) * torch.tensor([20.0, 20.0, 0.3]) + torch.tensor([0.0, 0.0, 1.5])).to(device)
     d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen) * torch.tensor([1.0, 1.0, 0.1]), dim=-1).to(device)
@@ -1072,6 +1079,11 @@ def bench_c4(args, device, rank, world):
                          "unit": "Gaccess/s", "frac": gathers / (s_ms * 1e-3) / 1e9 / L1_ACCESS_PEAK_G,
                          "traffic": recorded_traffic("proposal_sampler_actors"),
                          "kernel_ms": s_ms, "accesses_per_launch": gathers,
+                         "fabric_rate_gb_s": (recorded_traffic("proposal_sampler_actors") or 0) / (s_ms * 1e-3) / 1e9 or None,
+                         "fabric_note": "on this incoherent batch (random origins / directions) the proposal table's lines miss the "
+                                        "per-XCD L2s: `traffic` / kernel time is the L2 <-> fabric (MALL / HBM) rate the kernel "
+                                        "actually runs against (round-5 PMC passes: 15.7 GB per launch at 7.3 TB/s with fp32 "
+                                        "tables) -- the L1 figure below is what the same kernel reaches on camera patches (c2)",
                          "what": "algorithmic 4-byte gathers of the STATIC proposal grid (48 per proposal evaluation, "
                                  f"{n_prop} evaluations per launch) per second against the vector L1's access rate; config[2]'s "
                                  "sampler without actors reaches 0.8 of it"},
@@ -1148,7 +1160,7 @@ def bench_c4(args, device, rank, world):
                                      "distortion losses, backward (actor grids, trajectories), the reference's optimizer groups; the "
                                      f"main field's static table and its {A} actor grids are fp16 storage (HashGridAdam: fp32 master "
                                      "copies in the optimizer state, the fp16 gradient read and the fp16 table written inside the "
-                                     "kernel); the proposal fields' tables are fp32"}
+                                     "kernel); the proposal fields' static tables are fp16 storage too (NRHIP_C4_PROP_FP32=1: fp32), their actor grids fp32"}
     return out
 
 

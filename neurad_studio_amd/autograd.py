@@ -410,7 +410,8 @@ class ProposalDensityFn(torch.autograd.Function):
         if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
             go, gd = _ray_grads(ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.ps.grid, ctx.ps.table,
                                 ctx.ps.static_scale, o, d, a, s, e, _proposal_genc(dens, g, ctx.ps.decoder_weight))
-        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None, None
+        return (_like_param(gt, ctx.ps.table.dtype), gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None,
+                None)
 
 
 class InterlevelLossFn(torch.autograd.Function):
@@ -486,7 +487,7 @@ class ProposalRoundFn(torch.autograd.Function):
         if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:  # the rays moved with a camera optimizer
             go, gd = _ray_grads(ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.ps.grid, ctx.ps.table,
                                 ctx.ps.static_scale, o, d, a, starts, ends, _proposal_genc(dens, gdens, ctx.ps.decoder_weight))
-        return gt, gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None
+        return _like_param(gt, ctx.ps.table.dtype), gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None
 
 
 class PropWeightsFn(torch.autograd.Function):

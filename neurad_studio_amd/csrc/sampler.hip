@@ -627,8 +627,10 @@ static int sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props
       if (int e = validate_grid(&a.grid)) return e;
       NR_REQUIRE(a.tables && a.bounds && a.actor_scale > 0.f && a.n_actors >= 1, NRHIP_ERR_INVALID_ARG,
                  "proposal_sampler_fwd_actors: bad actor descriptor %d", i);
-      NR_REQUIRE(a.grid.n_features == 1 && a.grid.param_dtype == 0 && props[i].grid.param_dtype == 0 &&
-                     a.grid.num_levels <= props[i].grid.num_levels,
+      // (the STATIC proposal table may be fp16 storage -- round 5: on incoherent rays the kernel runs against the L2 <-> fabric
+      //  bandwidth, 15.7 GB per 65 536-ray launch with fp32 tables, and half the footprint is half the misses; the small actor
+      //  grids stay fp32)
+      NR_REQUIRE(a.grid.n_features == 1 && a.grid.param_dtype == 0 && a.grid.num_levels <= props[i].grid.num_levels,
                  NRHIP_ERR_UNSUPPORTED,
                  "proposal_sampler_fwd_actors: actor grids need 1 feature per level, fp32 tables and at most the static "
                  "grid's levels; use the unfused ops");
@@ -656,7 +658,16 @@ static int sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props
 #define LAUNCH(HALF_, LT_)                                                                                              \
   proposal_sampler_kernel<HALF_, LT_><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars, r, \
                                                                      slab_len, nullptr, nullptr, nullptr, nullptr, 0)
-  if (actors) {
+  if (actors && half) {
+    if (lt == 6)
+      proposal_sampler_kernel<true, 6, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
+                                                                           r, slab_len, cand_count, cand_actor, cand_w2b,
+                                                                           bounds, 0);
+    else
+      proposal_sampler_kernel<true, 0, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
+                                                                           r, slab_len, cand_count, cand_actor, cand_w2b,
+                                                                           bounds, 0);
+  } else if (actors) {
     const char* ia = getenv("NRHIP_SAMPLER_ACTOR_INLINE");  // 1: the round-2..4 per-chunk lookup (A/B against the dense pass)
     const int inline_actors = (ia && ia[0] == '1') ? 1 : 0;
     if (lt == 6)

@@ -350,12 +350,13 @@ class NeuRADProposalField(nn.Module):
 
     def fused_sampler_supported(self) -> bool:
         """Can the fused proposal sampler evaluate this field?  Always for the static scene; with dynamic actors when their
-        grids have one feature per level, fp32 tables and at most the static grid's levels (the reference's defaults)."""
+        grids have one feature per level, fp32 tables and at most the static grid's levels (the reference's defaults).  The
+        static table may be fp32 or fp16 storage."""
         hg = self.hashgrid
         if not hg.has_actors():
             return True
         g, a = hg.static_grid, hg.actor_grids[0]
-        return (a.features_per_level == 1 and a.num_levels <= g.num_levels and g.hash_table.dtype == torch.float32
+        return (a.features_per_level == 1 and a.num_levels <= g.num_levels
                 and all(t.hash_table.dtype == torch.float32 for t in hg.actor_grids))
 
     def proposal_spec(self) -> ops.ProposalSpec:

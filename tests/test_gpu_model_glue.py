@@ -457,3 +457,17 @@ def test_config4_shape_actors_fp16_field_tables_appearance_65536_rays_chunked():
     assert in_box > 0.005, f"the slice must contain actor samples ({in_box:.4f})"
     assert rel_l2(host(feats), rf) < 1e-4 and rel_l2(host(acc), ra) < 1e-4 and rel_l2(host(depth), rd) < 1e-4
     assert torch.equal(out["features"][a0:a1, :32], feats)  # the chunked entry rendered exactly this
+    # ---- round 5: the proposal fields' STATIC tables in fp16 storage too (bench.py --config c4; actor grids stay fp32).  The
+    # fused sampler with the per-sample actor select takes them, and places the samples of the same model whose fp32 proposal
+    # tables hold the rounded values
+    for mm, half in ((m16, True), (m32, False)):
+        for pfield in mm.proposal_fields:
+            t = pfield.hashgrid.static_grid.hash_table
+            t.data = t.data.half() if half else t.data.half().float()
+    assert all(pfield.fused_sampler_supported() for pfield in m16.proposal_fields)
+    with torch.no_grad():
+        got = m16.sampler.generate_fused(sl, [m16.proposal_fields[-1]] * 2, m16.config.sampling.sky_distance, actor_cand=cand)
+        want = m32.sampler.generate_fused(sl, [m32.proposal_fields[-1]] * 2, m32.config.sampling.sky_distance, actor_cand=cand)
+    for k in range(2):
+        assert rel_l2(host(got[1][k]), host(want[1][k])) < 1e-5, k
+    assert rel_l2(host(got[0].frustums.starts), host(want[0].frustums.starts)) < 1e-5
