@@ -541,8 +541,10 @@ extern "C" int nrhip_proposal_density_bwd_binned(const nrhip_proposal* p, const 
   NR_REQUIRE(p, NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null descriptor");
   if (int e = validate_grid(&p->grid)) return e;
   if (int e = validate_rays(rays)) return e;
-  NR_REQUIRE(p->grid.n_features == 1 && p->grid.num_levels <= 8 && p->grid.param_dtype == 0, NRHIP_ERR_UNSUPPORTED,
-             "proposal_density_bwd_binned: needs F=1, L<=8, fp32 table");
+  // (with the forward's per-level features at hand the table itself is never read: fp16-storage tables are fine then)
+  NR_REQUIRE(p->grid.n_features == 1 && p->grid.num_levels <= 8 && (p->grid.param_dtype == 0 || level_features),
+             NRHIP_ERR_UNSUPPORTED,
+             "proposal_density_bwd_binned: needs F=1, L<=8, and an fp32 table unless the forward's level features are passed");
   NR_REQUIRE(p->table && p->decoder_weight && density && grad_density && grad_table && grad_decoder,
              NRHIP_ERR_INVALID_ARG, "proposal_density_bwd_binned: null pointer");
   const int64_t n = rays->n_rays * rays->n_samples;

@@ -736,6 +736,9 @@ def proposal_density_bwd(ps: ProposalSpec, origins, directions, pixel_area, star
              _ptr(level_features), _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), 1, _ptr(ws),
              ws.numel(), _stream())
     else:
+        if ps.table.dtype != torch.float32:  # the atomic kernel recomputes the features from an fp32 table: small batches only
+            ps32 = ProposalSpec(ps.grid, ps.table.float(), ps.static_scale, ps.decoder_weight)  # (alive until the launch)
+            p, keep2 = ps32.c_prop()
         gt = torch.zeros((ps.grid.table_rows, 1), device=origins.device, dtype=torch.float32)
         call("nrhip_proposal_density_bwd", C.byref(p), C.byref(r), _ptr(_chk(density, "density")),
              _ptr(_chk(grad_density, "grad_density")), _ptr(gt), _ptr(gdec), _stream())
