@@ -1,6 +1,6 @@
 """profiles/traffic_<name>.json from the text of the PMC passes (scripts/final_measure.sh: `== <pass>: <counter> (<kernel>)`
 headers followed by scripts/pmc_report.py lines), stamped with the sha1 of the kernel sources of THIS tree so that bench.py
-can tell a measured roofline.traffic from a stale one.  usage: python scripts/traffic_from_pmc.py <pmc text> <round tag>
+can tell a measured roofline.traffic from a stale one.  usage: python scripts/traffic_from_pmc.py <pmc text> <round tag> [name,name,...]
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB (median per launch): MI355X_MICROARCH.md, HBM section -- FETCH_SIZE tallies
 gfx950's 128-byte fabric requests at 64 B, WRITE_SIZE is taken as reported."""
 import hashlib
@@ -44,7 +44,10 @@ def main():
         m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+).*median=\s*([0-9.]+)", line)
         if m and cur:
             passes[cur] = (m.group(1), int(m.group(2)), float(m.group(3)))
+    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None  # optional: restrict to these traffic names
     for name, (pf, pw, kernel, srcs, cmd) in ENTRIES.items():
+        if only is not None and name not in only:
+            continue
         if pf not in passes or pw not in passes:
             print("missing passes for", name)
             continue
