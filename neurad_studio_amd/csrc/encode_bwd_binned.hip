@@ -285,6 +285,11 @@ struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(de
 // profiles/r04_record_stats.txt): records per corner-pair term 0.78 -> 0.48 (first proposal round), 0.64 -> 0.49 (second),
 // 0.49 -> 0.35 (field) on the camera rays; lidar rays (unrelated neighbours) keep the ray-major walk.  Decided per chunk
 // from the rays themselves (coherent_rays); any order is correct -- `emit` finds its source sample through gidx.
+// Round 5 built a third walk -- QUADS: a thread owns four consecutive samples of a ray, neighbouring lanes are neighbouring
+// rays, equal entries merge first inside the thread and then across the row (the "2-D merge") -- and measured it: records
+// -3.4 % (field) / -5.6 % (proposal rounds) on the c3 step, but the count / emit structure it needs (four slots' corners live at
+// once) is slower than this loop: c1 train 1.42 -> 1.48 ms, c3 step 9.11 -> 9.21 ms on one box.  Reverted; the patch and
+// the numbers: profiles/r05_quad_walk_rejected.diff, r05_record_stats_walks.txt, r05_ab_table_gradient_r04_vs_r05.txt.
 __device__ __forceinline__ int coherent_rays_of(const RaysDev& r, int64_t first_sample, int64_t count) {
   const int S = r.S;
   if (S < 16 || S > kSamplesPerBlock / 16 || kSamplesPerBlock % S != 0 || count < kSamplesPerBlock) return 0;
@@ -300,22 +305,9 @@ __device__ __forceinline__ int coherent_rays_of(const RaysDev& r, int64_t first_
   return (same_o && c1 > 0.9999f && c2 > 0.99f) ? nr : 0;  // (unit directions: < 0.8 deg to the next ray, < 8 deg across the chunk)
 }
 
-// Walk of a COHERENT chunk (NRHIP_BIN_TRANSPOSE, A/B): 0 = ray-major everywhere; 1 = sample-index-major (round 4: slot p of
-// the compacted walk = the p-th live sample in (sample index, ray) order); 2 (default, round 5) = QUADS: thread t owns four
-// CONSECUTIVE samples 4q..4q+3 of ray r (t = q * rays + r), so that neighbouring lanes are neighbouring rays at the same four
-// sample indices.  `count` / `emit` first merge equal entries among a thread's own four slots (registers, no cross-lane
-// traffic: consecutive samples of a ray in one coarse cell), then the surviving run heads across the 16 lanes of a row
-// (neighbouring rays) -- the 2-D merge profiles/r04_record_stats.txt priced at -10 / -30 / -35 % of the records of the c3
-// step's three calls.  A quad is dropped when all four of its samples are silent; a silent sample inside a live quad keeps
-// its slot (position x = NaN) and neither sends nor joins anything.
-constexpr uint32_t kQuadLayout = 0x80000000u;  // flag in nlive[chunk]: the chunk's slots are quads (low bits: live quads)
-
-int coherent_walk_mode() {
-  if (const char* e = getenv("NRHIP_BIN_TRANSPOSE")) {
-    if (e[0] == '0') return 0;
-    if (e[0] == '1') return 1;
-  }
-  return 2;
+bool transposed_walk_enabled() {  // NRHIP_BIN_TRANSPOSE=0: ray-major everywhere (A/B)
+  const char* e = getenv("NRHIP_BIN_TRANSPOSE");
+  return !(e && e[0] == '0');
 }
 
 template <class Src>
@@ -343,41 +335,6 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
   __syncthreads();
   const int nr = s_nr;                                  // rays of a sample-index-major chunk, 0: ray-major
   const int spr = nr ? kSamplesPerBlock / nr : 1;       // samples per ray
-  if (nr && allow_transpose == 2) {
-    // QUADS: thread t = q * nr + r owns samples 4q .. 4q+3 of ray r; live quads are compacted in that order, slot j of quad
-    // `slot` lies at [j * 1024 + slot] (what thread `slot` of count / emit reads as its j-th slot)
-    const int q = tid / nr, r = tid - q * nr;
-    int loc[4];
-    bool lv[4], any = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      loc[j] = r * spr + 4 * q + j;
-      lv[j] = (live_bits[loc[j] >> 5] >> (loc[j] & 31)) & 1u;
-      any = any || lv[j];
-    }
-    const unsigned long long m = __ballot(any);
-    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const uint32_t c = wave_tot[w];
-      before += w < wave ? c : 0u;
-      total += c;
-    }
-    if (any) {
-      const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float4 p = make_float4(__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f);  // silent sample of a live quad: x = NaN
-        if (lv[j]) p = src.position(i_off + i_blk + loc[j]);
-        gpos[i_blk + j * nt + slot] = p;
-        gidx[i_blk + j * nt + slot] = (uint16_t)loc[j];
-      }
-    }
-    if (tid == 0) nlive[blockIdx.x] = total | kQuadLayout;
-    return;
-  }
   // pass 2, walk order: positions of the live samples, compacted in that order.  All four passes' wave counts go to LDS
   // first and ONE barrier orders them (a barrier pair per pass was eight workgroup syncs for 4096 samples).
   bool live_it[nit];
@@ -413,18 +370,6 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
 }
 
 // ---- count ---------------------------------------------------------------------------------------------------
-// Slots of a thread: j = 0..3.  Compacted-sample layout (ray-major / sample-index-major chunks): slot j = live sample
-// j * 1024 + tid of the walk, valid while that is < nl.  Quad layout: slot j = sample 4q + j of the thread's quad, valid for
-// tid < nl, live unless its position is marked (x = NaN).  Merge, identically in `count` and `emit`: a slot whose entry
-// equals the previous slot's of the SAME thread joins it (quads: consecutive samples of one ray; elsewhere the slots lie 1024
-// samples apart and an equality is a harmless coincidence); of the remaining slots, equal entries in neighbouring lanes of
-// a 16-lane row form a run, headed by its first lane.  One record per run head.
-struct SlotState {
-  bool quad;
-  int nl;
-  __device__ __forceinline__ bool valid(int j, int tid) const { return quad ? tid < nl : j * 1024 + tid < nl; }
-};
-
 template <bool PAIR>
 __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, int nb, uint32_t* __restrict__ counts,
                                                           const float4* __restrict__ gpos,
@@ -434,52 +379,29 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, 
   const int tid = threadIdx.x;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
   const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
-  const uint32_t nlw = nlive[blockIdx.x];
-  const SlotState ss{(nlw & kQuadLayout) != 0u, (int)(nlw & ~kQuadLayout)};  // block-uniform
-  bool live[nit];
-#pragma unroll
-  for (int j = 0; j < nit; ++j) {
-    live[j] = false;
-    if (ss.valid(j, tid)) {
-      const float4 p = gpos[i_blk + j * nt + tid];
-      pos[j * nt + tid] = p;  // (read back by this thread only)
-      live[j] = p.x == p.x;
-    }
-  }
+  const int nl = (int)nlive[blockIdx.x], nit_live = (nl + nt - 1) / nt;  // block-uniform
+  for (int it = 0; it < nit_live; ++it)
+    if (it * nt + tid < nl) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
   const uint32_t mask = (1u << g.log2T) - 1u;
   for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
     const float sc = g.scal[l];
-    __syncthreads();  // previous level's histogram stored
+    __syncthreads();  // pos[] written / previous level's histogram stored
     for (int b = tid; b < nb; b += nt) hist[b] = 0;
     __syncthreads();
-    Corners c[nit];
+    for (int it = 0; it < nit_live; ++it) {
+      const bool live = it * nt + tid < nl;
+      if (__ballot(live) == 0ull) continue;  // wave-uniform
+      const float4 p = pos[live ? it * nt + tid : 0];
+      const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
 #pragma unroll
-    for (int j = 0; j < nit; ++j) {
-      c[j] = Corners{};
-      if (__ballot(live[j]) != 0ull) {  // wave-uniform: a slot no lane of the wave fills costs nothing
-        const float4 p = pos[live[j] ? j * nt + tid : tid];
-        c[j] = hash_corners(p.x, p.y, p.z, sc, mask);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
-      uint32_t kf[nit], kc[nit];
-#pragma unroll
-      for (int j = 0; j < nit; ++j) {
-        kf[j] = c[j].idx[PAIR ? kPairF[k] : k];
-        kc[j] = PAIR ? c[j].idx[kPairC[k]] : kf[j];
-      }
-#pragma unroll
-      for (int j = 0; j < nit; ++j) {
-        // own previous slot first, then the previous lane of the row; a slot that joined its thread's previous one shows
-        // its neighbours the sentinel (entries are < 2^24: never equal to it), so nothing joins IT across lanes
-        const bool th = live[j] && !(j > 0 && live[j > 0 ? j - 1 : 0] && kf[j] == kf[j > 0 ? j - 1 : 0] &&
-                                     kc[j] == kc[j > 0 ? j - 1 : 0]);
-        const uint32_t ef = th ? kf[j] : 0xffffffffu, ec = th ? kc[j] : 0xffffffffu;
-        const bool head = th && (dpp_row_shr<1>(ef, ~ef) != ef || (PAIR && dpp_row_shr<1>(ec, ~ec) != ec));
-        if (head) {
-          atomicAdd(&hist[kf[j] >> log2TS], 1u);
-          if (PAIR && ((kf[j] ^ kc[j]) >> log2TS)) atomicAdd(&hist[kc[j] >> log2TS], 1u);  // the pair straddles two slices: two records
+      for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
+        // a silent sample never joins a run of equal entries; the first lane of a 16-lane row always heads a run
+        const uint32_t kf = live ? c.idx[PAIR ? kPairF[k] : k] : 0xffffffffu;
+        const uint32_t kc = PAIR ? (live ? c.idx[kPairC[k]] : 0xffffffffu) : kf;
+        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || (PAIR && dpp_row_shr<1>(kc, ~kc) != kc);
+        if (live && head) {
+          atomicAdd(&hist[kf >> log2TS], 1u);
+          if (PAIR && ((kf ^ kc) >> log2TS)) atomicAdd(&hist[kc >> log2TS], 1u);  // the pair straddles two slices: two records
         }
       }
     }
@@ -575,109 +497,66 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
   const int64_t i_blk = (int64_t)blockIdx.x * kSamplesPerBlock;
-  const uint32_t nlw = nlive[blockIdx.x];
-  const SlotState ss{(nlw & kQuadLayout) != 0u, (int)(nlw & ~kQuadLayout)};  // block-uniform
-  bool live[nit];
+  const int nl = (int)nlive[blockIdx.x], nit_live = (nl + nt - 1) / nt;  // block-uniform
   int64_t src_i[nit];  // the source sample behind each of this thread's live slots
   float pre[nit];      // its level-independent gradient factor
 #pragma unroll
-  for (int j = 0; j < nit; ++j) {
-    live[j] = false;
-    if (ss.valid(j, tid)) {
-      const float4 p = gpos[i_blk + j * nt + tid];
-      pos[j * nt + tid] = p;  // (read back by this thread only)
-      live[j] = p.x == p.x;
-    }
-    src_i[j] = i_off + i_blk + (live[j] ? (int64_t)gidx[i_blk + j * nt + tid] : 0);
-    pre[j] = live[j] ? src.pre(src_i[j]) : 0.f;
+  for (int it = 0; it < nit; ++it) {
+    const bool live = it * nt + tid < nl;
+    if (live) pos[it * nt + tid] = gpos[i_blk + it * nt + tid];
+    src_i[it] = i_off + i_blk + (live ? (int64_t)gidx[i_blk + it * nt + tid] : 0);
+    pre[it] = live ? src.pre(src_i[it]) : 0.f;
   }
   const uint32_t* seg = segbase ? segbase + (size_t)(blockIdx.x / kSegChunks) * g.L * nb : nullptr;
   const uint32_t mask = (1u << g.log2T) - 1u;
   const uint32_t tsmask = (1u << log2TS) - 1u;
-  constexpr int NV = PAIR ? 2 * F : F, RW = NV + 1;  // values per record, record length in dwords
   for (int l = blockIdx.y; l < g.L; l += gridDim.y) {
     const float sc = g.scal[l];
-    __syncthreads();  // previous level's ranks consumed
+    __syncthreads();  // pos[] loaded / previous level's ranks consumed
     for (int b = tid; b < nb; b += nt) {
       rank[b] = 0;
       base[b] = offsets[l * nb + b] + bases[((size_t)blockIdx.x * g.L + l) * nb + b] + (seg ? seg[l * nb + b] : 0u);
     }
     __syncthreads();
     float vmax = 0.f;
-    Corners c[nit];
-    float gv[nit][F];
 #pragma unroll
-    for (int j = 0; j < nit; ++j) {
-      c[j] = Corners{};
+    for (int it = 0; it < nit; ++it) {
+      if (it >= nit_live) break;  // block-uniform
+      const bool live = it * nt + tid < nl;
+      if (__ballot(live) == 0ull) continue;
+      const float4 p = pos[live ? it * nt + tid : 0];
+      const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
+      float w[8];
+      corner_weights(c, w);
+      float gv[F];
+      src.template grad<F>(live ? src_i[it] : i_off, l, sc, p.w, pre[it], gv);
+      if (!live) {
 #pragma unroll
-      for (int q = 0; q < F; ++q) gv[j][q] = 0.f;
-      if (__ballot(live[j]) != 0ull) {  // wave-uniform: a slot no lane of the wave fills costs nothing
-        const float4 p = pos[live[j] ? j * nt + tid : tid];
-        c[j] = hash_corners(p.x, p.y, p.z, sc, mask);
-        src.template grad<F>(live[j] ? src_i[j] : i_off, l, sc, p.w, pre[j], gv[j]);
-        if (!live[j]) {
-#pragma unroll
-          for (int q = 0; q < F; ++q) gv[j][q] = 0.f;
-        }
+        for (int k = 0; k < F; ++k) gv[k] = 0.f;
       }
-    }
+      constexpr int NV = PAIR ? 2 * F : F, RW = NV + 1;  // values per record, record length in dwords
 #pragma unroll
-    for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
-      uint32_t kf[nit], kc[nit];
-      bool th[nit];
-      float v[nit][NV];  // (floor-corner terms, then ceil-corner terms)
-#pragma unroll
-      for (int j = 0; j < nit; ++j) {
-        kf[j] = c[j].idx[PAIR ? kPairF[k] : k];
-        kc[j] = PAIR ? c[j].idx[kPairC[k]] : kf[j];
-        const float ox = c[j].ox, oy = c[j].oy, oz = c[j].oz;
-        // trilinear weight of corner (x, y, z) in {c, f}^3 (common.h corner order): c -> offset, f -> 1 - offset
-        const int kk = PAIR ? kPairF[k] : k;
-        const float wy = (kk == 0 || kk == 3 || kk == 4 || kk == 7) ? oy : 1.f - oy;
-        const float wz = kk < 4 ? oz : 1.f - oz;
-        const float wx = (kk == 0 || kk == 1 || kk == 4 || kk == 5) ? ox : 1.f - ox;
-        if constexpr (PAIR) {  // floor-x corner kPairF[k], ceil-x corner kPairC[k] of the same (y, z)
-          const float wf = ((1.f - ox) * wy) * wz, wc = (ox * wy) * wz;
-#pragma unroll
-          for (int q = 0; q < F; ++q) v[j][q] = wf * gv[j][q], v[j][F + q] = wc * gv[j][q];
-        } else {
-          const float w = (wx * wy) * wz;
-#pragma unroll
-          for (int q = 0; q < F; ++q) v[j][q] = w * gv[j][q];
-        }
-      }
-      // own previous slot first (registers): a joined slot hands its terms down the chain of its thread's slots
-#pragma unroll
-      for (int j = 0; j < nit; ++j)
-        th[j] = live[j] && !(j > 0 && live[j > 0 ? j - 1 : 0] && kf[j] == kf[j > 0 ? j - 1 : 0] && kc[j] == kc[j > 0 ? j - 1 : 0]);
-#pragma unroll
-      for (int j = nit - 1; j > 0; --j) {
-        if (live[j] && !th[j]) {
-#pragma unroll
-          for (int q = 0; q < NV; ++q) v[j - 1][q] += v[j][q];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < nit; ++j) {
-        if (!th[j]) {
-#pragma unroll
-          for (int q = 0; q < NV; ++q) v[j][q] = 0.f;
-        }
-        const uint32_t ef = th[j] ? kf[j] : 0xffffffffu, ec = th[j] ? kc[j] : 0xffffffffu;
-        const bool head = th[j] && (dpp_row_shr<1>(ef, ~ef) != ef || (PAIR && dpp_row_shr<1>(ec, ~ec) != ec));
+      for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
+        const uint32_t kf = live ? c.idx[PAIR ? kPairF[k] : k] : 0xffffffffu;
+        const uint32_t kc = PAIR ? (live ? c.idx[kPairC[k]] : 0xffffffffu) : kf;
+        const bool head = dpp_row_shr<1>(kf, ~kf) != kf || (PAIR && dpp_row_shr<1>(kc, ~kc) != kc);
         const unsigned long long hm = __ballot(head);
-        if (hm == 0ull) continue;  // wave-uniform: no record from this slot of any lane
-        if (hm != __ballot(th[j])) {
+        float v[NV];  // (floor-corner terms, then ceil-corner terms)
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+          v[j] = w[PAIR ? kPairF[k] : k] * gv[j];
+          if constexpr (PAIR) v[F + j] = w[kPairC[k]] * gv[j];
+        }
+        if (hm != ~0ull) {
           // some run is longer than 1: segmented suffix sum onto the run heads, inside each 16-lane row, on DPP
-          // row shifts (VALU rate; a 64-lane __shfl version goes through the LDS crossbar 18x per corner).  Lanes
-          // without a slot of their own (silent, or joined to their own previous slot) carry zeros.
+          // row shifts (VALU rate; a 64-lane __shfl version goes through the LDS crossbar 18x per corner)
           const uint32_t run = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull));
 #define NR_SEG_STEP(OFF)                                                   \
   {                                                                        \
     const bool same = dpp_row_shl<OFF>(run, 0xffffffffu) == run;           \
-    _Pragma("unroll") for (int q = 0; q < NV; ++q) {                       \
-      const float t = dpp_row_shl<OFF>(v[j][q], 0.f);                      \
-      if (same) v[j][q] += t;                                              \
+    _Pragma("unroll") for (int j = 0; j < NV; ++j) {                       \
+      const float t = dpp_row_shl<OFF>(v[j], 0.f);                         \
+      if (same) v[j] += t;                                                 \
     }                                                                      \
   }
           NR_SEG_STEP(1)
@@ -686,33 +565,33 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
           NR_SEG_STEP(8)
 #undef NR_SEG_STEP
         }
-        if (head) {
-          const uint32_t b = kf[j] >> log2TS;
+        if (head && live) {
+          const uint32_t b = kf >> log2TS;
           // (one LDS atomic per record.  A wave-aggregated add -- one atomic for all lanes that share the first lane's slice --
           //  was measured SLOWER: emit<1> 293 -> 341 us, emit<4> 693 -> 752 us; the hashed levels scatter a wave's records
           //  over the slices, so the two ballots and the readlanes buy nothing there)
           const uint32_t my_rank = atomicAdd(&rank[b], 1u);
 #pragma unroll
-          for (int q = 0; q < NV; ++q) {
-            const float av = fabsf(v[j][q]);
+          for (int j = 0; j < NV; ++j) {
+            const float av = fabsf(v[j]);
             if (av <= 3.402823466e38f) vmax = fmaxf(vmax, av);  // Inf/NaN do not set the scale; they poison in `reduce`
           }
-          const uint32_t xm = kf[j] ^ kc[j];  // (0 without pairs)
+          const uint32_t xm = kf ^ kc;  // (0 without pairs)
           float out[RW];
           if ((xm >> log2TS) == 0) {  // (always, unless the level's resolution reaches the slice length)
-            out[0] = __uint_as_float((kf[j] & tsmask) | (xm << 16));
+            out[0] = __uint_as_float((kf & tsmask) | (xm << 16));
 #pragma unroll
-            for (int q = 0; q < NV; ++q) out[1 + q] = v[j][q];
+            for (int j = 0; j < NV; ++j) out[1 + j] = v[j];
             store_record<RW>(qrec + (size_t)(base[b] + my_rank) * RW, out);
           } else if constexpr (PAIR) {  // the ceil corner lives in another slice: two records, each with a zero second half
-            out[0] = __uint_as_float(kf[j] & tsmask);
+            out[0] = __uint_as_float(kf & tsmask);
 #pragma unroll
-            for (int q = 0; q < F; ++q) out[1 + q] = v[j][q], out[1 + F + q] = 0.f;
+            for (int j = 0; j < F; ++j) out[1 + j] = v[j], out[1 + F + j] = 0.f;
             store_record<RW>(qrec + (size_t)(base[b] + my_rank) * RW, out);
-            const uint32_t b2 = kc[j] >> log2TS;
-            out[0] = __uint_as_float(kc[j] & tsmask);
+            const uint32_t b2 = kc >> log2TS;
+            out[0] = __uint_as_float(kc & tsmask);
 #pragma unroll
-            for (int q = 0; q < F; ++q) out[1 + q] = v[j][F + q];
+            for (int j = 0; j < F; ++j) out[1 + j] = v[F + j];
             store_record<RW>(qrec + (size_t)(base[b2] + atomicAdd(&rank[b2], 1u)) * RW, out);
           }
         }
@@ -891,7 +770,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     const dim3 grid_a((unsigned)chunks, (unsigned)p.lgroups);
     // qmax slots of chunks this round does not have stay from an earlier round otherwise
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
-    bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive, coherent_walk_mode());
+    bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive, transposed_walk_enabled() ? 1 : 0);
     if (p.pair)
       bin_count_kernel<true><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     else
@@ -906,8 +785,8 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
       uint32_t total = 0;
       (void)hipStreamSynchronize(st);
       (void)hipMemcpy(&total, offsets + cols, sizeof(total), hipMemcpyDeviceToHost);
-      fprintf(stderr, "[nrhip bin stats] %s: %lld samples x %d levels, F=%d, walk %d: %u records (%.3f per corner%s term)\n", what,
-              (long long)cnt, gd.L, gd.F, coherent_walk_mode(), total,
+      fprintf(stderr, "[nrhip bin stats] %s: %lld samples x %d levels, F=%d, transposed walk %d: %u records (%.3f per corner%s term)\n",
+              what, (long long)cnt, gd.L, gd.F, transposed_walk_enabled() ? 1 : 0, total,
               (double)total / ((double)cnt * gd.L * (p.pair ? 4 : 8)), p.pair ? "-pair" : "");
     }
 #define CALL2(F, P)                                                                                                 \

@@ -430,14 +430,15 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
     assert np.allclose(rw_go, host(atomic).reshape(L, -1, F).sum(1), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"], ids=["ray-major", "sample-index-major", "quads"])
+@pytest.mark.parametrize("mode", ["0", "1"], ids=["ray-major", "sample-index-major"])
 @pytest.mark.parametrize("cfg", [(6, 1, 14, 128), (6, 1, 14, 64), (8, 4, 15, 32), (8, 4, 15, 16), (16, 2, 14, 64)])
 def test_table_gradient_on_coherent_chunks_every_walk(ops, cfg, mode, monkeypatch):
     """Camera-patch rays (one origin, directions a fraction of a degree apart): `prep` then walks a 4096-sample chunk
-    sample-index-major or, round 5, as QUADS -- four consecutive samples of a ray per thread, neighbouring rays in
-    neighbouring lanes, equal entries merged first inside the thread and then across the row (NRHIP_BIN_TRANSPOSE = 0 / 1 / 2).
-    Every walk sends the same terms: the result equals the atomic scatter-add, with silent samples (opaque tails, scattered
-    zeros, whole silent quads and rays) and a ragged last chunk, for the encode path and the proposal-density path."""
+    sample-index-major (a 16-lane row = 16 neighbouring rays at one sample index) instead of ray-major
+    (NRHIP_BIN_TRANSPOSE = 1 / 0).  Either walk sends the same terms: the result equals the atomic scatter-add, with silent
+    samples (opaque tails, scattered zeros, whole silent rays) and a ragged last chunk, for the encode path and the
+    proposal-density path.  (The coherent walk had no test of its own before round 5; the round's third walk, quads, was
+    held to this test too before it was measured slower and reverted: profiles/r05_quad_walk_rejected.diff.)"""
     L, F, lg, S = cfg
     monkeypatch.setenv("NRHIP_BIN_TRANSPOSE", mode)
     spec = ops.GridSpec(L, F, lg, 16, 2048)
