@@ -91,6 +91,64 @@ __global__ __launch_bounds__(256) void hashgrid_multi_bwd_kernel(GridDev g, cons
     for (int j = 0; j < F; ++j) unsafeAtomicAdd(base + (size_t)c.idx[k] * F + j, w[k] * go[t * F + j]);
 }
 
+// The same scatter-add with run combining (round 5).  The rows of the actor branch are (sample, actor) pairs in sample
+// order: consecutive rows are consecutive samples of one ray inside one box, which share a cell of the coarse actor levels
+// (62 / 25 cm cells against samples a few cm apart).  One lane = one row, looping over the levels; equal (grid, entry) in
+// neighbouring lanes of a 16-lane row form a run that is summed onto its first lane on DPP row shifts, and only run heads
+// issue the memory-side atomics -- the whole cost of this pass (config[4] training: 12.8 M atomics, 0.72 + 2 x 0.31 ms).
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_multi_bwd_runs_kernel(GridDev g, const int32_t* __restrict__ grid_id,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ go, int64_t n,
+                                                                       float* const* __restrict__ gts) {
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i0 < n;
+  const int64_t i = live ? i0 : n - 1;
+  const int lane = threadIdx.x & 63;
+  const uint32_t gid = live ? (uint32_t)grid_id[i] : 0xffffffffu;
+  const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
+  const uint32_t mask = (1u << g.log2T) - 1u;
+  float* const table = live ? gts[grid_id[i]] : nullptr;
+  for (int l = 0; l < g.L; ++l) {
+    const Corners c = hash_corners(px, py, pz, g.scal[l], mask);
+    float w[8];
+    corner_weights(c, w);
+    float gv[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) gv[j] = live ? go[(i * g.L + l) * F + j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t key = live ? c.idx[k] : 0xffffffffu;
+      const bool head = live && (dpp_row_shr<1>(key, ~key) != key || dpp_row_shr<1>(gid, ~gid) != gid);
+      const unsigned long long hm = __ballot(head);
+      float v[F];
+#pragma unroll
+      for (int j = 0; j < F; ++j) v[j] = w[k] * gv[j];
+      if (hm != __ballot(live)) {  // some run is longer than 1: segmented suffix sum onto the run heads, inside each row
+        const uint32_t run = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull));
+#define NR_SEG_STEP(OFF)                                                   \
+  {                                                                        \
+    const bool same = dpp_row_shl<OFF>(run, 0xffffffffu) == run;           \
+    _Pragma("unroll") for (int j = 0; j < F; ++j) {                        \
+      const float t = dpp_row_shl<OFF>(v[j], 0.f);                         \
+      if (same) v[j] += t;                                                 \
+    }                                                                      \
+  }
+        NR_SEG_STEP(1)
+        NR_SEG_STEP(2)
+        NR_SEG_STEP(4)
+        NR_SEG_STEP(8)
+#undef NR_SEG_STEP
+      }
+      if (head) {
+        float* e = table + (((size_t)l << g.log2T) + c.idx[k]) * F;
+#pragma unroll
+        for (int j = 0; j < F; ++j) unsafeAtomicAdd(e + j, v[j]);
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // encode: H2 -> H3 -> H1 -> H4, thread per (sample, level)
 template <int F, bool HALF>
@@ -597,9 +655,17 @@ extern "C" int nrhip_hashgrid_multi_bwd(const nrhip_grid* g, int32_t n_grids, co
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(grid_id && x && grad_out && grad_tables, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd: null pointer");
   const GridDev gd = to_dev(*g);
-  const int blocks = grid_for(n * gd.L, 256);
+  const char* rc = getenv("NRHIP_MULTI_BWD_RUNS");  // 0: one thread per (row, level), every corner term its own atomic (A/B)
+  if (rc && rc[0] == '0') {
+    const int blocks = grid_for(n * gd.L, 256);
 #define CALL(F) hashgrid_multi_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables)
-  DISPATCH_F(gd.F, CALL);
+    DISPATCH_F(gd.F, CALL);
 #undef CALL
+  } else {
+    const int blocks = grid_for(n, 256);
+#define CALL(F) hashgrid_multi_bwd_runs_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables)
+    DISPATCH_F(gd.F, CALL);
+#undef CALL
+  }
   return check_launch("hashgrid_multi_bwd");
 }
