@@ -160,6 +160,9 @@ int nrhip_encode_bwd_rays(const nrhip_grid* g, const void* table, float static_s
  * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  overwrite = 0: grad_table
  * is ACCUMULATED into, as above; overwrite = 1: every element of grad_table is WRITTEN (no zero-fill needed before,
  * and the pass over the table is a store instead of a read-modify-write). */
+/* Round 5: g->param_dtype describes GRAD_TABLE in the _binned entry points (the partition never reads the table): with
+ * param_dtype = 1 the gradient is written as fp16 [L*T,F] -- the dtype autograd wants for an fp16-storage table, without an
+ * fp32 image and a cast pass; overwrite = 1 and at most 2^23 samples (one round) only, NRHIP_ERR_UNSUPPORTED otherwise. */
 int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_samples, int64_t* bytes);
 /* The same scratch size serves the two other table gradients below (it depends on the grid and the sample count
  * only): nrhip_hashgrid_bwd_binned == nrhip_hashgrid_bwd, nrhip_proposal_density_bwd_binned ==

@@ -152,7 +152,7 @@ class EncodeFn(torch.autograd.Function):
     def backward(ctx, g):
         o, d, a, s, e, *tab = ctx.saved_tensors
         g = g.contiguous()
-        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, g) if ctx.needs_input_grad[0] else None
+        gt = ops.encode_bwd(ctx.spec, ctx.scale, o, d, a, s, e, g, out_dtype=ctx.table_dtype) if ctx.needs_input_grad[0] else None
         go, gd = (None, None) if not ctx.rays else _ray_grads(ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.spec,
                                                               tab[0], ctx.scale, o, d, a, s, e, g)
         return _like_param(gt, ctx.table_dtype), None, None, go, gd, None, None, None
@@ -219,7 +219,8 @@ def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends,
         ovr_row, pair_idx = override
         g_rows = genc.index_select(0, pair_idx)
         genc.masked_fill_((ovr_row >= 0)[:, None], 0.0)  # exactly-zero rows send no records (encode_bwd_binned: prep)
-    gt = _like_param(ops.encode_bwd(spec, scale, o, d, a, starts, ends, genc), table_dtype) if need_table else None
+    gt = _like_param(ops.encode_bwd(spec, scale, o, d, a, starts, ends, genc, out_dtype=table_dtype), table_dtype) \
+        if need_table else None
     grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
     god = (None, None) if rays is None else _ray_grads(rays[1], rays[2], spec, rays[0], scale, o, d, a, starts, ends, genc)
     return gt, grads, g_rows, god

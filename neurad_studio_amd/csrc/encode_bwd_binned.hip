@@ -609,7 +609,8 @@ template <int F, bool PAIR>
 __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __restrict__ offsets,
                                                            const float* __restrict__ qrec,
                                                            const float* __restrict__ qmax_all, float* __restrict__ gt,
-                                                           int log2T, int log2TS, int nb, int nmax, int overwrite) {
+                                                           int log2T, int log2TS, int nb, int nmax, int overwrite,
+                                                           int out_half) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];
   __shared__ float smax[16];
   __shared__ uint32_t poisoned;
@@ -617,7 +618,11 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
   const uint32_t first = offsets[lb], cnt = offsets[lb + 1] - first;
   const int l = lb / nb, b = lb - l * nb;
   if (cnt == 0) {  // uniform: nothing was sent to this slice
-    if (overwrite) {  // the caller did not zero grad_table: this slice's part of it is ours to define
+    if (overwrite && out_half) {  // fp16 gradient (fp16-storage table): half the bytes, written as 8-byte groups
+      __half* z = reinterpret_cast<__half*>(gt) + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+      const int nz = F << log2TS;
+      for (int i = threadIdx.x; i < nz; i += 1024) z[i] = __float2half(0.f);
+    } else if (overwrite) {  // the caller did not zero grad_table: this slice's part of it is ours to define
       float* z = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
       const int nz = F << log2TS;
       if (nz % 4 == 0)
@@ -680,6 +685,17 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
   float* out = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
   const bool any_poison = poisoned != 0;
   const float nan = __uint_as_float(0x7fc00000u);
+  if (out_half) {
+    // the gradient of an fp16-storage table in the table's own type (overwrite mode only: the launcher refuses the rest):
+    // autograd wants it in the parameter's dtype, and the 537 MB fp32 image + its cast pass (0.2 ms on config[4]) never exist
+    __half* oh = reinterpret_cast<__half*>(gt) + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+    for (int i = threadIdx.x; i < nacc; i += 1024) {
+      float o = (float)ldexp((double)(long long)tile[i], -sh);
+      if (any_poison && ((pbits[i >> 5] >> (i & 31)) & 1)) o = nan;
+      oh[i] = __float2half(o);
+    }
+    return;
+  }
   if (nacc % 4 == 0) {
     for (int i = threadIdx.x * 4; i < nacc; i += 4096) {
       float4 o = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(out + i);
@@ -741,6 +757,11 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
              "%s: workspace of %lld bytes, need %zu", what, (long long)workspace_bytes, p.total_bytes);
   NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
              NRHIP_ERR_INVALID_ARG, "%s: workspace and grad_table must be 16-byte aligned", what);
+  // grid.param_dtype describes grad_table here (the partition never reads the table itself): 1 = an fp16 gradient for an
+  // fp16-storage table, written once -- overwrite mode and a single round only (no fp16 read-modify-write)
+  const bool out_half = gd.dtype == 1;
+  NR_REQUIRE(!out_half || (overwrite && n <= round_samples()), NRHIP_ERR_UNSUPPORTED,
+             "%s: an fp16 grad_table needs overwrite = 1 and at most %lld samples (one round)", what, (long long)round_samples());
   char* ws = static_cast<char*>(workspace);
   uint32_t* counts = reinterpret_cast<uint32_t*>(ws + p.off_counts);
   uint32_t* segtot = reinterpret_cast<uint32_t*>(ws + p.off_seg);
@@ -803,7 +824,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
                                                             nseg > 1 ? segtot : nullptr, offsets, gpos, gidx,       \
                                                             nlive, qrec, qmax, p.nmax);                             \
     bin_reduce_kernel<F, P><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,   \
-                                                       p.nmax, (overwrite && i_off == 0) ? 1 : 0);                  \
+                                                       p.nmax, (overwrite && i_off == 0) ? 1 : 0, out_half ? 1 : 0); \
   } while (0)
 #define CALL(F)              \
   do {                       \
@@ -852,7 +873,8 @@ int proposal_table_grad_binned(const nrhip_proposal* p, const nrhip_rays* rays, 
                                const float* grad_density, float* grad_table, bool overwrite, void* workspace,
                                int64_t workspace_bytes, void* stream) {
   const int64_t n = rays->n_rays * rays->n_samples;
-  const GridDev gd = to_dev(p->grid);
+  GridDev gd = to_dev(p->grid);
+  gd.dtype = 0;  // (here the descriptor's param_dtype is the TABLE's storage type; this entry point's grad_table is fp32)
   const ProposalSrc src{to_dev(*rays), p->static_scale, p->decoder_weight, density, grad_density};
   return run_binned("proposal_density_bwd_binned", gd, src, n, grad_table, overwrite, workspace, workspace_bytes,
                     (hipStream_t)stream);

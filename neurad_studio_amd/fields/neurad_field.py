@@ -200,7 +200,8 @@ class NeuRADField(nn.Module):
         return ops.render_fwd(self.field_spec(), origins, directions, pixel_area, starts, ends, return_weights,
                               early_stop_eps=early_stop_eps, order=order)
 
-    def render_train(self, origins, directions, pixel_area, edges, appearance=None, times: Optional[Tensor] = None):
+    def render_train(self, origins, directions, pixel_area, edges, appearance=None, times: Optional[Tensor] = None,
+                     actor_cand=None):
         """Training counterpart of ``render``: field -> learnable-beta SDF head -> weights -> compositing as ONE autograd
         node (autograd.NffRenderTrainFn) from the bin edges [R,S+1] (last edge = sky distance).  appearance: None or
         (embedding weight [E,A], sensor_idx [R,1] | None, times [R,1] | None, (duration, n_per_sensor, temporal)): the
@@ -222,7 +223,7 @@ class NeuRADField(nn.Module):
         if hg.has_actors():
             if times is None:
                 raise ValueError("dynamic actors need ray times")
-            ovr = self._actor_overrides(origins, directions, pixel_area.reshape(-1), edges, times.reshape(-1))
+            ovr = self._actor_overrides(origins, directions, pixel_area.reshape(-1), edges, times.reshape(-1), actor_cand)
         sd = self.sdf_to_density
         return ag.NffRenderTrainFn.apply(
             g.hash_table, g.spec, hg.static_scale, sd.beta, sd.beta_min_value, origins, directions,
@@ -230,7 +231,7 @@ class NeuRADField(nn.Module):
             *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
             *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])
 
-    def _actor_overrides(self, origins, directions, pixel_area, edges, times):
+    def _actor_overrides(self, origins, directions, pixel_area, edges, times, actor_cand=None):
         """-> (ovr_row int32 [N]: row of the sample's WINNING actor (highest index containing it) or -1, rows [P,32],
         box-frame view directions [P,3], pair_idx [P]: flat sample index of every (sample, actor) pair) or four Nones"""
         hg = self.hashgrid
@@ -238,7 +239,9 @@ class NeuRADField(nn.Module):
         N = starts.shape[0] * starts.shape[1]
         flip = hg.sample_ray_flip(origins)
         with torch.no_grad():
-            spec, cand = hg.prepare_actors(origins, directions, pixel_area, starts, ends, times)
+            # candidate lists depend on the ray's line only: one list per ray batch serves every field (as in eval)
+            spec, cand = (hg.actor_spec(), actor_cand) if actor_cand is not None else hg.prepare_actors(
+                origins, directions, pixel_area, starts, ends, times)
             scratch = torch.empty((N, hg.get_out_dim()), device=origins.device, dtype=torch.float32)  # (hit rows land here)
             dirs, hit = ops.actor_encode(spec, cand, origins, directions, pixel_area, starts, ends, scratch, flip)
             hits = ops.actor_hits(spec, cand, origins, directions, pixel_area, starts, ends)
@@ -364,8 +367,9 @@ class NeuRADProposalField(nn.Module):
         return ops.ProposalSpec(g.spec, g.hash_table.detach(), self.hashgrid.static_scale,
                                 self.density_decoder.weight.detach())
 
-    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
-        """neurad_field.py:208-213, one kernel: gaussian -> contraction -> 6-level lookup -> rescale -> dot -> exp."""
+    def get_density(self, ray_samples: RaySamples, actor_cand=None) -> Tuple[Tensor, None]:
+        """neurad_field.py:208-213, one kernel: gaussian -> contraction -> 6-level lookup -> rescale -> dot -> exp.
+        actor_cand: candidate lists already computed for these rays (they depend on the ray's line only)."""
         fr = ray_samples.frustums
         o, d, a = per_ray(fr)
         hg = self.hashgrid
@@ -383,7 +387,8 @@ class NeuRADProposalField(nn.Module):
                 raise ValueError("dynamic actors need ray times")
             flip = hg.sample_ray_flip(o)
             with torch.no_grad():  # geometry of the actor branch: never differentiated here (require_actor_grad=False)
-                spec, cand = hg.prepare_actors(o, d, a, starts, ends, times)
+                spec, cand = (hg.actor_spec(), actor_cand) if actor_cand is not None else hg.prepare_actors(
+                    o, d, a, starts, ends, times)
                 merged = dens.detach().clone()
                 hit_actor = ops.actor_density(spec, cand, o, d, a, starts, ends, self.density_decoder.weight.detach(), merged,
                                               flip, return_actor=True)

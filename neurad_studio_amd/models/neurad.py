@@ -177,6 +177,17 @@ class FusedTrainMixin:
         if getattr(self, "reproduce_late_binding_quirk", True):
             pfs = [pfs[-1]] * len(pfs)
         train_props = smp._proposals_train_this_step()
+        cand = None
+        if self.field.hashgrid.has_actors() or any(p.hashgrid.has_actors() for p in pfs):
+            # which actors a ray can meet depends on its LINE only (bounding-sphere cull, neurad_encoding.py:225-247): one
+            # candidate list per step serves both proposal rounds and the field, as in eval (was: one launch per field call)
+            if ray_bundle.times is None:
+                raise ValueError("dynamic actors need ray times")
+            n0 = ray_bundle.nears.reshape(-1)
+            hg0 = self.field.hashgrid if self.field.hashgrid.has_actors() else next(p.hashgrid for p in pfs if p.hashgrid.has_actors())
+            with torch.no_grad():
+                _, cand = hg0.prepare_actors(o, d, a, torch.stack([n0, n0 + 1], -1), torch.stack([n0 + 1, n0 + 2], -1),
+                                             ray_bundle.times.reshape(-1))
         nff: Dict[str, Tensor] = {}
         weights_list, samples_list = [], []
         lidar_terms = self.training and calc_lidar_losses
@@ -190,7 +201,7 @@ class FusedTrainMixin:
                 if pf.hashgrid.has_actors():
                     # dynamic actors: the field's own density (static kernel + the actor overlay, operator level), then
                     # weights and the round's depth from the edges
-                    dens = pf.get_density(_light_samples(ray_bundle, sp, eu, fn))[0][..., 0]
+                    dens = pf.get_density(_light_samples(ray_bundle, sp, eu, fn), actor_cand=cand)[0][..., 0]
                     w, pdepth = ag.PropWeightsFn.apply(eu, dens.contiguous())
                 else:
                     w, pdepth = ag.ProposalRoundFn.apply(g.hash_table, pf.density_decoder.weight, g.spec,
@@ -216,7 +227,8 @@ class FusedTrainMixin:
             assert sensor is not None, "sensor_idxs must be present in metadata during training"
             appearance = (self.appearance_embedding.weight, sensor, ray_bundle.times if cfg.use_temporal_appearance else None,
                           (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance)))
-        features, depth, accumulation, w_ns = self.field.render_train(o, d, a, eu, appearance, times=ray_bundle.times)
+        features, depth, accumulation, w_ns = self.field.render_train(
+            o, d, a, eu, appearance, times=ray_bundle.times, actor_cand=cand if self.field.hashgrid.has_actors() else None)
         nff.update(features=features, depth=depth, accumulation=accumulation)
         S = counts[-1]
         if self.training:

@@ -298,16 +298,29 @@ def encode_fwd(spec: GridSpec, table: Tensor, static_scale: float, origins, dire
     return out
 
 
-def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_area, starts, ends, grad_out):
+_BINNED_ROUND_SAMPLES = 1 << 23  # round_samples() of csrc/encode_bwd_binned.hip
+
+
+def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_area, starts, ends, grad_out,
+               out_dtype=torch.float32):
+    """-> grad table [L*T, F].  out_dtype=torch.float16 (an fp16-storage table): the binned path writes the gradient in fp16
+    itself where it can (one round, i.e. <= 2^23 samples) -- otherwise fp32 is returned and the caller casts."""
     r, keep = _c_rays(origins, directions, pixel_area, starts, ends)
     grad_out = _chk(grad_out, "grad_out")
-    gt = torch.empty((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
+    n = r.n_rays * r.n_samples
+    half = (out_dtype == torch.float16 and n <= _BINNED_ROUND_SAMPLES and not _FORCE_ATOMIC_SCATTER and n >= _BINNED_MIN_SAMPLES
+            and "NRHIP_BIN_ROUND_LOG2" not in os.environ)
+    gt = torch.empty((spec.table_rows, spec.features_per_level), device=origins.device,
+                     dtype=torch.float16 if half else torch.float32)
     g = spec.c_grid(gt)
-    ws = _table_grad_workspace(g, r.n_rays * r.n_samples, origins.device)
+    ws = _table_grad_workspace(g, n, origins.device)
     if ws is not None:  # overwrite = 1: the partition writes every element of the gradient, no zero-fill
         call("nrhip_encode_bwd_binned", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), 1,
              _ptr(ws), ws.numel(), _stream())
-    else:  # tables too large to cut into LDS slices, or a tiny batch: memory-side atomics
+    else:  # tables too large to cut into LDS slices, or a tiny batch: memory-side atomics (fp32 only)
+        if gt.dtype != torch.float32:
+            gt = torch.empty((spec.table_rows, spec.features_per_level), device=origins.device, dtype=torch.float32)
+            g = spec.c_grid(gt)
         call("nrhip_encode_bwd", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt.zero_()),
              _stream())
     return gt

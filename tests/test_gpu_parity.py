@@ -738,3 +738,25 @@ def test_embedding_lerp_kernels_vs_torch_embedding(cfg):
     assert torch.equal(out, ref.detach())
     out.backward(g)
     assert rel_l2(host(emb.weight.grad), host(want)) < 2e-6
+
+
+def test_encode_bwd_binned_writes_the_fp16_gradient_of_an_fp16_storage_table(ops, monkeypatch):
+    """round 5: with out_dtype = fp16 the partition's `reduce` writes the gradient in the table's own storage type (what
+    autograd wants for an fp16-storage table) instead of an fp32 image + a cast pass: every element equals the fp16 rounding
+    of the fp32 result -- identical integer accumulation, one rounding at the store"""
+    L, F, lg, R, S = 8, 4, 15, 1100, 32
+    spec = ops.GridSpec(L, F, lg, 16, 2048)
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=9)
+    do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
+    go = dev(synth.normal((R * S, L * F), 19))
+    go[::5] = 0  # silent samples; some slices stay empty at this size
+    st, en = edges[:, :-1], edges[:, 1:]
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
+    g32 = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    g16 = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go, out_dtype=torch.float16)
+    assert g32.dtype == torch.float32 and g16.dtype == torch.float16 and g16.shape == g32.shape
+    assert torch.equal(g16, g32.half())
+    bad = go.clone()
+    bad[3, 1] = float("nan")
+    assert not torch.isfinite(ops.encode_bwd(spec, 1.0, do, dd, da, st, en, bad, out_dtype=torch.float16).float()).all()
