@@ -516,10 +516,10 @@ int nrhip_actor_pair_positions_bwd_rays(const nrhip_actors* a, const nrhip_rays*
  * `(hits >= 0).nonzero()` + a gather produce in the reference's style of indexing (neurad_encoding.py:221-263 returns such index
  * lists from torch.nonzero), as two streaming passes.  count: block_offsets [ceil(N / 1024)] u32 (scratch, exclusive prefix
  * on return) and *total (DEVICE int64) = number of pairs; the caller reads total, allocates sample_idx int64 [P] / actor_idx
- * int32 [P], and calls write with the same block_offsets. */
+ * int32 [P], and calls write with the same block_offsets and total (device pointers). */
 int nrhip_actor_pairs_count(const int32_t* hits, int64_t n_samples, uint32_t* block_offsets, int64_t* total, void* stream);
-int nrhip_actor_pairs_write(const int32_t* hits, int64_t n_samples, const uint32_t* block_offsets, int64_t* sample_idx,
-                            int32_t* actor_idx, void* stream);
+int nrhip_actor_pairs_write(const int32_t* hits, int64_t n_samples, const uint32_t* block_offsets, const int64_t* total,
+                            int64_t* sample_idx, int32_t* actor_idx, void* stream);
 
 /* Proposal density of the in-box samples in TRAINING (fields/neurad_field.py:208-213 over neurad_encoding.py:150-187,
  * index_put order :184-185): rows [P, row_dim] = rescaled actor features of the P (sample, actor) pairs, decoder_weight

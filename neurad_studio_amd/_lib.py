@@ -186,7 +186,7 @@ PROTOTYPES = {
     "nrhip_actor_pair_positions_bwd": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P, P, P],
     "nrhip_actor_pair_positions_bwd_rays": [C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, I64, P, P, P, P, P, P, P],
     "nrhip_actor_pairs_count": [P, I64, P, P, P],
-    "nrhip_actor_pairs_write": [P, I64, P, P, P, P],
+    "nrhip_actor_pairs_write": [P, I64, P, P, P, P, P],
     "nrhip_actor_density_splice_fwd": [P, I32, P, P, P, I64, P, P, P],
     "nrhip_actor_density_splice_bwd": [P, I32, P, P, P, P, P, P, I64, P, P, P, P],
     "nrhip_render_fwd_actors": [C.POINTER(Field), C.POINTER(Actors), C.POINTER(Rays), P, P, P, P, P, P, P, F32, P, P],

@@ -753,20 +753,29 @@ __global__ __launch_bounds__(1024) void actor_pairs_scan_kernel(uint32_t* __rest
 
 __global__ __launch_bounds__(256) void actor_pairs_write_kernel(const int32_t* __restrict__ hits, int64_t n,
                                                                  const uint32_t* __restrict__ block_offsets,
+                                                                 const int64_t* __restrict__ total,
                                                                  int64_t* __restrict__ sample_idx,
                                                                  int32_t* __restrict__ actor_idx) {
   __shared__ uint32_t wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t base = block_offsets[blockIdx.x];
+  // most 1024-sample blocks hold no pair at all (5 % of the samples lie in a box, clustered along the rays that meet one)
+  const uint32_t next = blockIdx.x + 1 < gridDim.x ? block_offsets[blockIdx.x + 1] : (uint32_t)*total;
+  if (next == base) return;
   for (int u = 0; u < 4; ++u) {  // samples in order: pass u covers 256 consecutive samples
     const int64_t i = (int64_t)blockIdx.x * kPairBlock + u * 256 + threadIdx.x;
     int h[KH];
     uint32_t c = 0;
+    static_assert(KH == 8, "two 16-byte loads per row");
+    if (i < n) {
+      const int4 a = reinterpret_cast<const int4*>(hits + i * KH)[0], b = reinterpret_cast<const int4*>(hits + i * KH)[1];
+      h[0] = a.x, h[1] = a.y, h[2] = a.z, h[3] = a.w, h[4] = b.x, h[5] = b.y, h[6] = b.z, h[7] = b.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < KH; ++k) {
-      h[k] = i < n ? hits[i * KH + k] : -1;
-      c += h[k] >= 0 ? 1u : 0u;
+      for (int k = 0; k < KH; ++k) h[k] = -1;
     }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) c += h[k] >= 0 ? 1u : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -812,12 +821,14 @@ extern "C" int nrhip_actor_pairs_count(const int32_t* hits, int64_t n_samples, u
 }
 
 extern "C" int nrhip_actor_pairs_write(const int32_t* hits, int64_t n_samples, const uint32_t* block_offsets,
-                                       int64_t* sample_idx, int32_t* actor_idx, void* stream) {
+                                       const int64_t* total, int64_t* sample_idx, int32_t* actor_idx, void* stream) {
   NR_REQUIRE(n_samples >= 0, NRHIP_ERR_INVALID_ARG, "actor_pairs_write: bad argument");
   if (n_samples == 0) return NRHIP_OK;
-  NR_REQUIRE(hits && block_offsets && sample_idx && actor_idx, NRHIP_ERR_INVALID_ARG, "actor_pairs_write: NULL pointer");
+  NR_REQUIRE(hits && block_offsets && total && sample_idx && actor_idx, NRHIP_ERR_INVALID_ARG,
+             "actor_pairs_write: NULL pointer");
   const int nblk = (int)((n_samples + kPairBlock - 1) / kPairBlock);
-  actor_pairs_write_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(hits, n_samples, block_offsets, sample_idx, actor_idx);
+  actor_pairs_write_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(hits, n_samples, block_offsets, total, sample_idx,
+                                                                  actor_idx);
   return check_launch("actor_pairs_write");
 }
 

@@ -1012,7 +1012,7 @@ def actor_pairs(hits: Tensor) -> Tuple[Tensor, Tensor]:
     si = torch.empty((P_,), dtype=torch.int64, device=h.device)
     ai = torch.empty((P_,), dtype=torch.int32, device=h.device)
     if P_:
-        call("nrhip_actor_pairs_write", _ptr(h), n, _ptr(off), _ptr(si), _ptr(ai), _stream())
+        call("nrhip_actor_pairs_write", _ptr(h), n, _ptr(off), _ptr(total), _ptr(si), _ptr(ai), _stream())
     return si, ai
 
 
