@@ -985,8 +985,8 @@ def bench_c4(args, device, rank, world):
             for p in m.proposal_fields:
                 p.hashgrid.static_grid.hash_table.data = p.hashgrid.static_grid.hash_table.data.half()
     # NRHIP_C4_ORDER_RAYS=1: the render stage walks the (incoherent) batch in the order of ops.ray_order.  Measured round 5:
-    # traffic 1.73 -> 1.59 GB per launch but the single-workgroup ordering pass costs more at 65 536 rays than it returns
-    # (render stage 0.62 -> 0.69 ms, profiles/r05_ab.txt): off
+    # traffic of the ACT slice 1.73 -> 1.59 GB per launch, but the stage gets slower, 0.61 -> 0.69 ms -- also with the
+    # multi-workgroup ordering pass (profiles/r05_ab.txt, r05_ab_c4_order_large.txt): off
     m.order_rays = os.environ.get("NRHIP_C4_ORDER_RAYS", "0") == "1"
     gen.manual_seed(31 + rank)
     o = (torch.randn(R, 3, generator=gen) * torch.tensor([20.0, 20.0, 0.3]) + torch.tensor([0.0, 0.0, 1.5])).to(device)

@@ -383,6 +383,13 @@ int nrhip_ray_order(const float* origins /*[R,3]*/, const float* directions /*[R
                     float static_scale, int32_t key_bits /* per axis: 0 = default (4), 3..5 */, int32_t* order,
                     void* stream);
 
+/* The same permutation property (a counting sort by the same key; the order inside a bucket is unspecified in both) over
+ * many workgroups, for eval chunks of tens of thousands of rays where the single-workgroup pass (~2 us per 1024 rays) would
+ * cost more than the ordered kernels return.  workspace: (n_rays + 8^key_bits) uint32, see _workspace. */
+int nrhip_ray_order_workspace(int64_t n_rays, int32_t key_bits, int64_t* bytes /*host*/);
+int nrhip_ray_order_large(const float* origins, const float* directions, int64_t n_rays, float t_ref, float static_scale,
+                          int32_t key_bits, void* workspace, int64_t workspace_bytes, int32_t* order, void* stream);
+
 /* ---- S2: NeuRADProposalField.get_density (neurad_field.py:208-213) ----------------------------- */
 /* level_features (may be NULL): LEVEL-MAJOR [L, R*S] rescaled per-level features, saved for the decoder gradient;
  * when requested (training) the lookups run level-partitioned over the XCDs (csrc/hashgrid.hip) */

@@ -162,6 +162,8 @@ PROTOTYPES = {
     "nrhip_render_fwd": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_render_fwd_ex": [C.POINTER(Field), C.POINTER(Rays), P, P, P, P, F32, P],
     "nrhip_ray_order": [P, P, I64, F32, F32, I32, P, P],
+    "nrhip_ray_order_workspace": [I64, I32, C.POINTER(I64)],
+    "nrhip_ray_order_large": [P, P, I64, F32, F32, I32, P, I64, P, P],
     "nrhip_camera_rays": [C.POINTER(CameraTable), P, P, I64, P, P, P, P, P, P],
     "nrhip_lidar_rays": [C.POINTER(LidarTable), P, P, I32, I64, P, P, P, P, P, P, P],
     "nrhip_patch_sample": [P, P, I64, I32, I32, I32, I32, I32, I32, P, P, I32, P, P, P, P],

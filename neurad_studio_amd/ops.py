@@ -137,6 +137,9 @@ def _c_rays(origins: Tensor, directions: Tensor, pixel_area: Tensor, starts: Ten
     return r, (o, d, a, starts, ends, order)
 
 
+_RAY_ORDER_LARGE = 16384  # rays above which ray_order takes the multi-workgroup counting sort
+
+
 def ray_order(origins: Tensor, directions: Tensor, static_scale: float, t_ref: Optional[float] = None,
               key_bits: int = 0) -> Tensor:
     """Processing order that groups rays looking at the same region (csrc/rayorder.hip) -> int32 [R] permutation to pass
@@ -145,6 +148,13 @@ def ray_order(origins: Tensor, directions: Tensor, static_scale: float, t_ref: O
     t_ref = float(static_scale) if t_ref is None else t_ref
     o, d = _chk(origins, "origins"), _chk(directions, "directions")
     out = torch.empty((o.shape[0],), device=o.device, dtype=torch.int32)
+    if o.shape[0] > _RAY_ORDER_LARGE:  # many workgroups: the one-workgroup pass costs ~2 us per 1024 rays
+        need = C.c_int64(0)
+        call("nrhip_ray_order_workspace", o.shape[0], int(key_bits), C.byref(need))
+        ws = torch.empty((need.value,), device=o.device, dtype=torch.uint8)
+        call("nrhip_ray_order_large", _ptr(o), _ptr(d), o.shape[0], float(t_ref), float(static_scale), int(key_bits),
+             _ptr(ws), ws.numel(), _ptr(out), _stream())
+        return out
     call("nrhip_ray_order", _ptr(o), _ptr(d), o.shape[0], float(t_ref), float(static_scale), int(key_bits), _ptr(out),
          _stream())
     return out
