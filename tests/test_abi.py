@@ -104,6 +104,42 @@ def test_product_path_refuses_cpu_tensors():
         ops.hashgrid_fwd(spec, torch.zeros(4 * 256, 2), torch.rand(5, 3))
 
 
+def test_round5_entry_points_validate_on_the_host_and_refuse_cpu_tensors(lib):
+    """nrhip_encode_bwd_rays / nrhip_actor_pairs_* / nrhip_ray_order_large: argument checks run on the host before any launch
+    (no GPU needed), and their tensor-level wrappers have no CPU path"""
+    import torch
+
+    from neurad_studio_amd import _lib, ops
+
+    spec = ops.GridSpec(4, 2, 8, 16, 128)
+    z = torch.zeros
+    with pytest.raises(_lib.NeuradHipError):  # CPU tensors: refused, not computed on the host
+        ops.encode_bwd_rays(spec, z(4 * 256, 2), 1.0, z(3, 3), z(3, 3), z(3), z(3, 5), z(3, 5), z(15, 8))
+    with pytest.raises(_lib.NeuradHipError):
+        ops.actor_pairs(z((10, 8), dtype=torch.int32))
+    with pytest.raises(_lib.NeuradHipError):
+        ops.ray_order(z(20000, 3), z(20000, 3), 100.0)
+    need = ctypes.c_int64(0)
+    _lib.call("nrhip_ray_order_workspace", 70000, 0, ctypes.byref(need))
+    assert need.value == (70000 + 4096) * 4
+    _lib.call("nrhip_ray_order_workspace", 70000, 5, ctypes.byref(need))
+    assert need.value == (70000 + 32768) * 4
+    one = ctypes.c_void_p(0x1000)  # any non-null address: validation fails before anything is dereferenced
+    with pytest.raises(_lib.NeuradHipError, match="workspace"):  # workspace too small
+        _lib.call("nrhip_ray_order_large", one, one, 70000, 1.0, 100.0, 0, one, 16, one, None)
+    with pytest.raises(_lib.NeuradHipError, match="key_bits"):
+        _lib.call("nrhip_ray_order_large", one, one, 70000, 1.0, 100.0, 3, one, 1 << 30, one, None)
+    g = _grid(4, 2, 8)
+    r = _lib.Rays()
+    r.n_rays, r.n_samples = 3, 5
+    r.origins = r.directions = r.pixel_area = r.starts = r.ends = 0x1000
+    with pytest.raises(_lib.NeuradHipError, match="bad argument"):  # NULL gradient buffers
+        _lib.call("nrhip_encode_bwd_rays", ctypes.byref(g), one, 1.0, ctypes.byref(r), one, None, None, None)
+    total = ctypes.c_int64(0)
+    with pytest.raises(_lib.NeuradHipError):  # NULL hits with samples to look at
+        _lib.call("nrhip_actor_pairs_count", None, 10, one, one, None)
+
+
 def _grid(L, F, lg):
     from neurad_studio_amd import _lib
 
