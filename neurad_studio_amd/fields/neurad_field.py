@@ -98,8 +98,12 @@ class NeuRADField(nn.Module):
             raise ValueError("num_multisamples >= 1")
         if config.num_multisamples != 1 and actors is not None and int(getattr(actors, "n_actors", 0)) > 0 \
                 and not config.grid.disable_actors:
-            raise NotImplementedError("num_multisamples != 1 with dynamic actors (no NeuRAD config uses it, neurad_field.py:67): "
-                                      "the multisampled frustum is implemented for the static scene")
+            # the reference raises in this configuration too, in the first batch with a sample inside a box: [P, M, 3] probe
+            # positions meet one box transform per pair in a torch.bmm (neurad_encoding.py:197-198, cameras/lidars.py:559;
+            # reproduced by oracle/check_multisample_actors_reference.py) -- there is no behaviour to match
+            raise NotImplementedError("num_multisamples != 1 with dynamic actors: the reference fails on it as well "
+                                      "(neurad_encoding.py:197-198 -> cameras/lidars.py:559 bmm of P*M points with P "
+                                      "transforms; no NeuRAD config sets it, neurad_field.py:67)")
         self.config, self.implementation = config, implementation
         self.order_rays = False
         """Training forward: walk the batch in the cache-coherent order of ops.ray_order (computed per call).  Pays for
