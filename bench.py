@@ -700,8 +700,9 @@ def bench_c1(args, device, rank, world):
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S, "parallelism": f"rays sharded x{world}, no collective"},
             "per_gpu_value": n_samples * args.steps / elapsed,
             "target_per_gpu": 2e7,
-            "roofline": {"kernel": "nrhip::render_kernel<16,2,64,fp32,composite> (software-pipelined gathers, XCD-coherent "
-                                   "ray ranges over the nrhip_ray_order permutation)", "bound": "hbm",
+            "roofline": {"kernel": "nrhip::render_kernel<16,2,64,fp32,composite,pairs> (software-pipelined gathers, "
+                                   "XCD-coherent ray ranges over the nrhip_ray_order permutation, MLP products as fp16 "
+                                   "pairs with fp32 accumulation)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": n_samples * bytes_per,
                          "kernel_ms": kernel_ms},
@@ -722,6 +723,24 @@ def bench_c1(args, device, rank, world):
         import dataclasses
 
         fs16 = dataclasses.replace(fs, table=fs.table.half())
+        if os.environ.get("NRHIP_MLP_PAIRS", "1") == "1" and not args.no_variants:
+            # the same launch with the matrix products on the fp32 MFMA (the default up to round 4), and how far the two
+            # forms' outputs are apart on this batch (both are fp32 product sums to rounding: csrc/render.hip)
+            pair_us = kernel_us(fs)
+            f_pairs = ops.render_fwd(fs, origins, dirs, area, state["edges"][:, :-1], state["edges"][:, 1:], order=state["order"])
+            os.environ["NRHIP_MLP_PAIRS"] = "0"
+            try:
+                f32_us = kernel_us(fs)
+                f_f32 = ops.render_fwd(fs, origins, dirs, area, state["edges"][:, :-1], state["edges"][:, 1:], order=state["order"])
+            finally:
+                del os.environ["NRHIP_MLP_PAIRS"]
+            rl2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
+            out["mlp_products"] = {
+                "form": "fp16 pairs: x = fp16(x) + fp16(x - fp16(x)), three v_mfma_f32_16x16x32_f16 terms per 32 inputs, fp32 "
+                        "accumulation; tile in units of 2^6, weights staged x 2^7; tiles / weights that do not fit take the "
+                        "fp32 MFMA (NRHIP_MLP_PAIRS=0: the fp32 MFMA everywhere)",
+                "kernel_us_back_to_back": {"fp16_pairs": pair_us, "fp32_mfma": f32_us},
+                "rel_l2_pairs_vs_fp32_mfma": {k: rl2(a, b) for k, a, b in zip(("features", "depth", "accumulation"), f_pairs, f_f32)}}
         if not args.no_variants:
             out["variants_not_headline"] = {
                 "fp16_table_kernel_us": kernel_us(fs16),

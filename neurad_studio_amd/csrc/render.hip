@@ -67,11 +67,12 @@ struct SaveDev {
 
 // LDS carve (floats), H = hidden width.  Fragment-ordered weights use [mb][s/4][lane][s%4] so that one
 // ds_read_b128 fetches the A fragments of 4 consecutive k-steps.
-// SPLIT: the four per-tile matrices are stored as 3-way bf16 splits (6 bytes per weight instead of 4, see mfma_layer_split).
-template <int H, bool SPLIT = false>
+// SPLIT = 1: the four per-tile matrices are stored as 3-way bf16 splits (6 bytes per weight instead of 4, see
+// mfma_layer_split); SPLIT = 2: as fp16 pairs (hi image | lo image, 4 bytes per weight, see mfma_layer_pairs).
+template <int H, int SPLIT = 0>
 struct Lds {
   static constexpr int NB = H / 16;        // 16-neuron blocks of a hidden layer
-  static constexpr int WS(int n) { return SPLIT ? n + n / 2 : n; }
+  static constexpr int WS(int n) { return SPLIT == 1 ? n + n / 2 : n; }
   static constexpr int G0 = 0;             // geo L0 : NB blocks x 8 steps
   static constexpr int G1 = G0 + WS(H * 32);   // geo L1 (rows 1..32): 2 blocks x H/4 steps
   static constexpr int F0 = G1 + WS(32 * H);   // feat L0 (geo part): NB blocks x 8 steps
@@ -87,7 +88,8 @@ struct Lds {
   static constexpr int SCAL = BF2 + 32;    // per-level scalings
   static constexpr int RB = SCAL + NRHIP_MAX_LEVELS;  // per wave: this ray's bias of feat L0 (fb0 + SH part), 4 x H
   static constexpr int LAY = RB + 4 * H;   // RELAY: per-level {mulY, mulZ, mask, row0} (uint32), 16-byte aligned
-  static constexpr int TOTAL = LAY + 4 * NRHIP_MAX_LEVELS;
+  static constexpr int FLG = LAY + 4 * NRHIP_MAX_LEVELS;  // SPLIT = 2: a weight does not fit the fp16 pair (int, 0 / 1)
+  static constexpr int TOTAL = FLG + 4;
   // ACT instantiations only:
   static constexpr int SHF = TOTAL;             // feat L0 SH part in fragment order: NB blocks x 4 steps
   static constexpr int ASCAL = SHF + 16 * H;    // actor grid: per-level scalings
@@ -226,10 +228,110 @@ __device__ __forceinline__ void stage_split_matrix(float* __restrict__ dst, cons
   }
 }
 
+// ---- the matrix work on the matrix cores, second form: fp16 PAIRS -------------------------------------------------------
+// x = h + l with h = fp16(x) and l = fp16(x - h) (both round-to-nearest; the remainder is exact in fp32): 22-24 significant
+// bits, and the three products h.h, h.l, l.h carry every term above 2^-22 of the full product, each exact in the MFMA's
+// fp32 accumulation.  Against the 3-way bf16 split: one v_mfma_f32_16x16x32_f16 per 32 inputs and term (60 MFMAs per
+// 16-sample tile at H = 64 instead of 240 of K = 16) and 2.5 VALU instructions per activation instead of 5.4 (gfx950 converts
+// PAIRS: v_cvt_pk_f16_f32, v_pk_add_f32).  fp16's exponent range is the price: it is spent where the network lives --
+//   * the whole tile runs in units of kPairAct = 2^6 (ReLU MLPs are positively homogeneous: biases and the feature inputs are
+//     staged / blended x 2^6, the three exits -- sdf row, deferred last layer, embedding sum -- x 2^-6; all exact), so an
+//     activation keeps full precision from 6e-5 x 2^-6 up to 1000;
+//   * the weights are staged x kPairW = 2^7 and the product sum comes back through one fma per output (acc = bias + 2^-7 t);
+//   * a tile whose inputs do not fit (|x| >= 1000 in true units, NaN) or a matrix with |w| >= 500 takes the fp32 MFMA with
+//     the A fragments read from global memory: slow, and the same numbers as the default kernel.
+// numpy emulation (profiles/r05_pairs_emulation.txt): rel. error of a 64-term product sum 0.7-1.6e-7 for activations >= 1e-3
+// and |w| >= 0.004 -- the fp32 GEMM's own 1.0e-7 -- against 1.7e-6 .. 1.7e-4 without the two recentrings.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+constexpr float kPairAct = 64.f, kPairW = 128.f, kPairFit = 65000.f;
+constexpr bool kPairsDefault = true;  // NRHIP_MLP_PAIRS unset (=0: the fp32 MFMA)
+
+// source of element e of a pair image: [mb][q][lane][t] halves (lane (i, g) slot t of the K = 32 step q: row 16 mb + i,
+// input of (g, 8 q + t) in the layer's own order -- CHAIN: the previous layer's D tiles (lane (j, g) holds neurons
+// 16 kb + 4 g + v of block kb = 2 q + t / 4, v = t % 4), else the gathered features 8 g + t)
+template <bool CHAIN, int NBLK, int KQ>
+__device__ __forceinline__ float pair_src(const float* __restrict__ W, int ldw, int row_off, int e) {
+  const int t = e & 7, lane = (e >> 3) & 63, rest = e >> 9;
+  const int q = rest % KQ, mb = rest / KQ;
+  const int i = lane & 15, g = lane >> 4;
+  const int col = CHAIN ? (16 * (2 * q + (t >> 2)) + 4 * g + (t & 3)) : (8 * g + t);
+  return W[(size_t)(row_off + 16 * mb + i) * ldw + col];
+}
+// element e of a region of N weights: hi image at halves [0, N), lo image at [N, 2 N).  -> does not fit
+__device__ __forceinline__ bool pair_store(float* __restrict__ region, int N, int e, float w) {
+  _Float16* d16 = reinterpret_cast<_Float16*>(region);
+  const float ws = w * kPairW;
+  const _Float16 h = (_Float16)ws;
+  d16[e] = h;
+  d16[N + e] = (_Float16)(ws - (float)h);
+  return !(fabsf(ws) < kPairFit);
+}
+
+// One layer on a 16-sample tile: acc[mb] = (acc[mb] + kPairW W[row_off + 16 mb .. +15][:] . b) / kPairW, K = 32 KQ inputs
+// (b in the layer's own order, see pair_src); acc arrives holding kPairW x the bias (staged so), which makes the scaled
+// product sum accumulate in place: no second accumulator set in a kernel at 213 VGPRs.  The accumulation order (hi.hi,
+// lo.hi, hi.lo per K step) is immaterial: every addition rounds at 2^-24 of the running sum, as in any fp32 product sum.
+// W / ldw / row_off: the fp32 matrix in global memory for the tiles that do not fit.
+template <bool CHAIN, int NBLK, int KQ>
+__device__ __forceinline__ void mfma_layer_pairs(const float* __restrict__ wf, const float* __restrict__ W, int ldw,
+                                                 int row_off, bool wbad, int lane, const float (&b)[8 * KQ],
+                                                 f32x4 (&acc)[NBLK]) {
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8 * KQ; ++k) mx = fmaxf(mx, fabsf(b[k]));
+#ifdef NRHIP_EXP_NOSLOW
+  if (false) {
+#else
+  if (__builtin_expect(wbad || __builtin_amdgcn_ballot_w64(!(mx < kPairFit)) != 0ull, 0)) {  // wave-uniform, rare
+#endif
+    // (the fragment addresses depend on the lane only: without the opaque offset they are hoisted out of the TILE loop,
+    // 2 VGPRs each, and the fast path spills)
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const int g = lane >> 4;
+    const float* Wl = W + (size_t)(row_off + (lane & 15)) * ldw + opaque;
+#pragma unroll
+    for (int s = 0; s < 8 * KQ; ++s) {
+      const int col = CHAIN ? (16 * (s >> 2) + 4 * g + (s & 3)) : (8 * g + s);
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(size_t)16 * mb * ldw + col] * kPairW, b[s], acc[mb], 0, 0, 0);
+    }
+  } else {
+    const f16x8* w8 = reinterpret_cast<const f16x8*>(wf);
+    constexpr int LO = NBLK * KQ * 64;  // f16x8 units from the hi image to the lo image
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      f16x8 xh, xl;
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const f32x2 v = {b[8 * q + k], b[8 * q + k + 1]};
+        const f16x2 h = __builtin_convertvector(v, f16x2);
+        const f16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);  // (the remainder is exact)
+        xh[k] = h[0], xh[k + 1] = h[1], xl[k] = l[0], xl[k + 1] = l[1];
+      }
+      // consecutive MFMAs go to different accumulators (a dependent one waits for its predecessor's passes)
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w8[(mb * KQ + q) * 64 + lane], xh, acc[mb], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w8[LO + (mb * KQ + q) * 64 + lane], xh, acc[mb], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < NBLK; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w8[(mb * KQ + q) * 64 + lane], xl, acc[mb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < NBLK; ++mb) acc[mb] *= 1.f / kPairW;
+}
+
 // Stage all weights of the field into LDS (256-thread workgroup; caller barriers afterwards).  Every thread first
 // ISSUES all of its global loads (one register each, ~60 in flight), then stores: one memory round trip for the whole
 // 54 KB image instead of one per loop iteration.
-template <int H, bool SPLIT = false>
+template <int H, int SPLIT = 0>
 __device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* __restrict__ lds) {
   using Ld = Lds<H, SPLIT>;
   constexpr int NB = H / 16;
@@ -239,11 +341,23 @@ __device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* _
   static_assert((H * 32) % T == 0 && (H * H) % T == 0 && (16 * H) % T == 0, "regions are whole passes of the block");
   const int tid = threadIdx.x;
   float vg0[N_G0], vg1[N_G1], vf0[N_F0], vf1[N_F1], vf2[N_F2], vsh[N_SH], vs[7];
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT == 1) {
     stage_split_matrix<false, NB, 2>(lds + Ld::G0, fd.gw0, 32, 0);
     stage_split_matrix<true, 2, NB>(lds + Ld::G1, fd.gw1, H, 1);
     stage_split_matrix<true, NB, 2>(lds + Ld::F0, fd.fw0, 48, 0);
     stage_split_matrix<true, NB, NB>(lds + Ld::F1, fd.fw1, H, 0);
+  } else if constexpr (SPLIT == 2) {
+    static_assert(H % 32 == 0, "fp16 pairs: K = 32 steps");
+    if (tid == 0) reinterpret_cast<int*>(lds)[Ld::FLG] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < N_G0; ++it) vg0[it] = pair_src<false, NB, 1>(fd.gw0, 32, 0, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_G1; ++it) vg1[it] = pair_src<true, 2, H / 32>(fd.gw1, H, 1, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_F0; ++it) vf0[it] = pair_src<true, NB, 1>(fd.fw0, 48, 0, it * T + tid);
+#pragma unroll
+    for (int it = 0; it < N_F1; ++it) vf1[it] = pair_src<true, NB, H / 32>(fd.fw1, H, 0, it * T + tid);
   } else {
 #pragma unroll
     for (int it = 0; it < N_G0; ++it) vg0[it] = frag_src<false, NB, 8>(fd.gw0, 32, 0, it * T + tid);
@@ -269,7 +383,28 @@ __device__ __forceinline__ void stage_field_weights(const FieldDev& fd, float* _
   vs[4] = fd.gb1 ? fd.gb1[t33] : 0.f;
   vs[5] = fd.fb2 ? fd.fb2[t32] : 0.f;
   vs[6] = fd.grid.scal[t32];
-  if constexpr (!SPLIT) {
+  if constexpr (SPLIT == 2) {
+    // the tile runs in units of kPairAct (see mfma_layer_pairs): biases in, the three exits out -- all powers of two
+    // ... and the biases of the four pair layers x kPairW on top (mfma_layer_pairs accumulates onto them in place)
+    constexpr float kB = kPairAct * kPairW;
+    vs[0] *= 1.f / kPairAct, vs[1] *= kB, vs[2] *= kB, vs[3] *= kB;
+    if (t33 != 0) vs[4] *= kB;
+#pragma unroll
+    for (int it = 0; it < N_F2; ++it) vf2[it] *= 1.f / kPairAct;
+#pragma unroll
+    for (int it = 0; it < N_SH; ++it) vsh[it] *= kB;
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < N_G0; ++it) bad |= pair_store(lds + Ld::G0, H * 32, it * T + tid, vg0[it]);
+#pragma unroll
+    for (int it = 0; it < N_G1; ++it) bad |= pair_store(lds + Ld::G1, 32 * H, it * T + tid, vg1[it]);
+#pragma unroll
+    for (int it = 0; it < N_F0; ++it) bad |= pair_store(lds + Ld::F0, H * 32, it * T + tid, vf0[it]);
+#pragma unroll
+    for (int it = 0; it < N_F1; ++it) bad |= pair_store(lds + Ld::F1, H * H, it * T + tid, vf1[it]);
+    if (bad) reinterpret_cast<int*>(lds)[Ld::FLG] = 1;
+  }
+  if constexpr (SPLIT == 0) {
 #pragma unroll
     for (int it = 0; it < N_G0; ++it) lds[Ld::G0 + it * T + tid] = vg0[it];
 #pragma unroll
@@ -551,7 +686,7 @@ __device__ __forceinline__ void blend_tile(const TileFetch<LPL, F>& tf, const fl
 }
 
 // L levels, F features/level (L*F == 32), H hidden width, HALF = fp16 table, COMPOSITE = fuse C1+C2, ACT = dynamic actors.
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false,
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, int SPLIT = 0, bool RELAY = false,
           bool OVR = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(
     FieldDev fd, int64_t n_rays, int S, int stride, const int32_t* __restrict__ order, const float* __restrict__ ro,
@@ -590,6 +725,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     if (threadIdx.x < 4 * L) reinterpret_cast<uint32_t*>(lds + Ld::LAY)[threadIdx.x] = fd.lay[threadIdx.x];
   }
   __syncthreads();
+  bool wbad = false;  // SPLIT = 2: some weight does not fit its fp16 pair -> every tile takes the fp32 products
+  if constexpr (SPLIT == 2) wbad = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lds)[Ld::FLG]) != 0;
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -692,6 +829,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
                       rd[3 * ray + 1], rd[3 * ray + 2], cand_w2b, shb);
     } else {
       blend_tile<LPL, F>(tf, scal_l, feat);
+      if constexpr (SPLIT == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) feat[k] *= kPairAct;
+      }
       if constexpr (OVR) {
         tile_hit = __ballot(ta >= 0) != 0ull;  // wave-uniform; rare
         if (tile_hit) {
@@ -759,7 +900,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     f32x4 h[NB];
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BG0 + 16 * mb + 4 * g);
-    if constexpr (SPLIT) mfma_layer_split<NB, 2>(lw + Ld::G0, lane, feat, h);
+    if constexpr (SPLIT == 2) mfma_layer_pairs<false, NB, 1>(lw + Ld::G0, fd.gw0, 32, 0, wbad, lane, feat, h);
+    else if constexpr (SPLIT == 1) mfma_layer_split<NB, 2>(lw + Ld::G0, lane, feat, h);
     else mfma_layer<NB, 8>(lw + Ld::G0, lane, feat, h);
     float hb[H / 4];
 #pragma unroll
@@ -792,7 +934,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       const float* bp = lw + Ld::BG1 + 1 + 16 * mb + 4 * g;
       e[mb] = f32x4{bp[0], bp[1], bp[2], bp[3]};
     }
-    if constexpr (SPLIT) mfma_layer_split<2, NB>(lw + Ld::G1, lane, hb, e);
+    if constexpr (SPLIT == 2) mfma_layer_pairs<true, 2, H / 32>(lw + Ld::G1, fd.gw1, H, 1, wbad, lane, hb, e);
+    else if constexpr (SPLIT == 1) mfma_layer_split<2, NB>(lw + Ld::G1, lane, hb, e);
     else mfma_layer<2, H / 4>(lw + Ld::G1, lane, hb, e);
     float eb[8];
 #pragma unroll
@@ -816,7 +959,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF0 + 16 * mb + 4 * g);
       mfma_layer<NB, 4>(lw + Ld::SHF, lane, shb, h);
     }
-    if constexpr (SPLIT) mfma_layer_split<NB, 2>(lw + Ld::F0, lane, eb, h);
+    if constexpr (SPLIT == 2) mfma_layer_pairs<true, NB, 1>(lw + Ld::F0, fd.fw0, 48, 0, wbad, lane, eb, h);
+    else if constexpr (SPLIT == 1) mfma_layer_split<NB, 2>(lw + Ld::F0, lane, eb, h);
     else mfma_layer<NB, 8>(lw + Ld::F0, lane, eb, h);
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb)
@@ -832,7 +976,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     }
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) h[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF1 + 16 * mb + 4 * g);
-    if constexpr (SPLIT) mfma_layer_split<NB, NB>(lw + Ld::F1, lane, hb, h);
+    if constexpr (SPLIT == 2) mfma_layer_pairs<true, NB, H / 32>(lw + Ld::F1, fd.fw1, H, 0, wbad, lane, hb, h);
+    else if constexpr (SPLIT == 1) mfma_layer_split<NB, NB>(lw + Ld::F1, lane, hb, h);
     else mfma_layer<NB, H / 4>(lw + Ld::F1, lane, hb, h);
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb)
@@ -925,7 +1070,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
         for (int mb = 0; mb < 2; ++mb) {
           const f32x4 b2 = *reinterpret_cast<const f32x4*>(lw + Ld::BF2 + 16 * mb + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) of2[mb][r] = fmaf(b2[r], wsum, row_sum16(of2[mb][r] + fa[mb][r]));
+          for (int r = 0; r < 4; ++r) {
+            const float es = SPLIT == 2 ? fa[mb][r] * (1.f / kPairAct) : fa[mb][r];  // (the embedding sum ran in tile units)
+            of2[mb][r] = fmaf(b2[r], wsum, row_sum16(of2[mb][r] + es));
+          }
         }
         if (j == 0) {
           float* fp = out_feat + ray * 32;
@@ -993,7 +1141,7 @@ struct ActorLaunch {
   const void* const* tables;
 };
 
-template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, bool SPLIT = false, bool RELAY = false,
+template <int L, int F, int H, bool HALF, bool COMPOSITE, bool ACT = false, int SPLIT = 0, bool RELAY = false,
           bool OVR = false>
 static int launch_render(const FieldDev& fd, const RaysDev& rd, float* of, float* od, float* oa, float* ow, float* os,
                          float* oal, const SaveDev& sv, float stop_eps, hipStream_t st,
@@ -1034,12 +1182,27 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   // default because it measured no faster (163 vs 163 us on config[1]: the splitting costs the vector ALU what the matrix
   // pipe saves -- DESIGN.md §9).
   const bool split_bf16 = getenv("NRHIP_MLP_SPLIT_BF16") != nullptr;
+  // NRHIP_MLP_PAIRS=1: the same products as fp16 pairs (mfma_layer_pairs; 64-wide MLPs, composited output)
+  const char* pairs_env = getenv("NRHIP_MLP_PAIRS");
+  const bool pairs = pairs_env ? pairs_env[0] == '1' : kPairsDefault;
+  if constexpr (COMPOSITE) {
+    if (H == 64 && pairs && !split_bf16) {
+#define PCASE(L_, F_)                                                                                                  \
+  if (L == L_ && F == F_)                                                                                              \
+    return half ? launch_render<L_, F_, 64, true, true, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)      \
+                : launch_render<L_, F_, 64, false, true, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+      PCASE(16, 2)
+      PCASE(8, 4)
+      PCASE(4, 8)
+#undef PCASE
+    }
+  }
   if constexpr (COMPOSITE) {
     if (H == 64 && split_bf16) {
 #define SCASE(L_, F_)                                                                                                  \
   if (L == L_ && F == F_)                                                                                              \
-    return half ? launch_render<L_, F_, 64, true, true, false, true>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)   \
-                : launch_render<L_, F_, 64, false, true, false, true>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+    return half ? launch_render<L_, F_, 64, true, true, false, 1>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)      \
+                : launch_render<L_, F_, 64, false, true, false, 1>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
       SCASE(16, 2)
       SCASE(8, 4)
       SCASE(4, 8)

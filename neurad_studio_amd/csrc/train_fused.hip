@@ -300,6 +300,194 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_bwd_kernel(
   }
 }
 
+// ---- the same two kernels with TWO rays per wavefront (S <= 32, C == 32) ---------------------------------------------
+// At NeuRAD's 32 samples per ray the per-ray scans above leave lanes 32..63 idle; here each 32-lane half of a wave owns a
+// ray: the scans run over the halves independently (DPP inside the 16-lane rows, one readlane per half for the row below /
+// above), the feature passes take 4 samples per half and pass (8 lanes x 16 bytes per sample, as above).
+// NRHIP_SDF_RENDER_PAIR=1 selects them (see the launchers for what was measured).
+namespace half {
+template <class Op>
+__device__ __forceinline__ float incl(float v, int lane) {
+  const float e = Op::template id<float>();
+  v = Op::op(wscan::dpp<0x111>(e, v), v);
+  v = Op::op(wscan::dpp<0x112>(e, v), v);
+  v = Op::op(wscan::dpp<0x114>(e, v), v);
+  v = Op::op(wscan::dpp<0x118>(e, v), v);
+  const float t0 = wscan::lane_of(v, 15), t2 = wscan::lane_of(v, 47);
+  const int row = lane >> 4;
+  return Op::op(row == 1 ? t0 : (row == 3 ? t2 : e), v);
+}
+template <class Op>
+__device__ __forceinline__ float rincl(float v, int lane) {
+  const float e = Op::template id<float>();
+  v = Op::op(v, wscan::dpp<0x101>(e, v));
+  v = Op::op(v, wscan::dpp<0x102>(e, v));
+  v = Op::op(v, wscan::dpp<0x104>(e, v));
+  v = Op::op(v, wscan::dpp<0x108>(e, v));
+  const float s1 = wscan::lane_of(v, 16), s3 = wscan::lane_of(v, 48);
+  const int row = lane >> 4;
+  return Op::op(v, row == 0 ? s1 : (row == 2 ? s3 : e));
+}
+// the value of lane - 1 inside the half (lanes 0 and 32: `first`)
+__device__ __forceinline__ float shift_up1(float v, float first, int lane) {
+  float x = wscan::dpp<0x111>(first, v);
+  const float a = wscan::lane_of(v, 15), c = wscan::lane_of(v, 47);
+  x = lane == 16 ? a : x;
+  x = lane == 48 ? c : x;
+  return x;
+}
+// sum over the half, the same value in each of its lanes
+__device__ __forceinline__ float sum(float v, int lane) {
+  v += wscan::dpp<0x111>(0.f, v);
+  v += wscan::dpp<0x112>(0.f, v);
+  v += wscan::dpp<0x114>(0.f, v);
+  v += wscan::dpp<0x118>(0.f, v);
+  const float lo = wscan::lane_of(v, 15) + wscan::lane_of(v, 31), hi = wscan::lane_of(v, 47) + wscan::lane_of(v, 63);
+  return lane < 32 ? lo : hi;
+}
+}  // namespace half
+
+__global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_fwd_pair_kernel(
+    const float* __restrict__ sdf, const float* __restrict__ beta_ptr, float beta_min, const float* __restrict__ feat,
+    const float* __restrict__ edges, int es, int64_t R, int S, float* __restrict__ alpha_out, float* __restrict__ w_ns,
+    float* __restrict__ of, int of_stride, float* __restrict__ od, float* __restrict__ oa) {
+  constexpr int C = 32;
+  extern __shared__ float tf_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31;
+  const int64_t ray0 = (int64_t)blockIdx.x * (2 * kRaysPerBlock) + 2 * wave;
+  if (ray0 >= R) return;
+  const int64_t ray = ray0 + (lane >> 5);
+  const bool rv = ray < R;            // an odd ray count leaves the last wave's upper half without a ray: it computes on
+  const int64_t rc = rv ? ray : ray0;  // the lower half's data and stores nothing
+  float* wsh = tf_lds + (2 * wave + (lane >> 5)) * S;
+  const float beta = fabsf(*beta_ptr) + beta_min;
+  const float* e = edges + rc * es;
+  const int s = hl;
+  const bool live = s < S;
+  const float a = live ? sigmoidf_(-sdf[rc * S + s] * beta) : 0.f;
+  const float incl = half::incl<wscan::Mul>(1.f - a, lane);
+  const float w = a * half::shift_up1(incl, 1.f, lane);
+  float depth = 0.f;
+  if (live) {
+    wsh[s] = w;
+    if (rv) alpha_out[ray * S + s] = a;
+    if (s < S - 1) {
+      depth = w * ((e[s] + e[s + 1]) / 2.f);
+      if (rv) w_ns[ray * (S - 1) + s] = w;
+    }
+  }
+  const float acc = half::sum(live ? w : 0.f, lane);
+  depth = half::sum(depth, lane);
+  if (hl == 0) {
+    if (rv) oa[ray] = acc, od[ray] = depth;
+    wsh[S - 1] += 1.f - acc;  // what is left behind the last sample is sky
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* fr = feat + rc * (int64_t)S * C;
+  const int sub = lane & 7, sl = hl >> 3;
+  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < S; s0 += 4) {
+    const int sk = s0 + sl;
+    if (sk < S) {
+      const float4 f4 = *reinterpret_cast<const float4*>(fr + (int64_t)sk * C + 4 * sub);
+      const float ws = wsh[sk];
+      a4.x = fmaf(ws, f4.x, a4.x), a4.y = fmaf(ws, f4.y, a4.y), a4.z = fmaf(ws, f4.z, a4.z), a4.w = fmaf(ws, f4.w, a4.w);
+    }
+  }
+#pragma unroll
+  for (int off = 16; off >= 8; off >>= 1) {
+    a4.x += __shfl_xor(a4.x, off, 64), a4.y += __shfl_xor(a4.y, off, 64);
+    a4.z += __shfl_xor(a4.z, off, 64), a4.w += __shfl_xor(a4.w, off, 64);
+  }
+  if (sl == 0 && rv) *reinterpret_cast<float4*>(of + ray * of_stride + 4 * sub) = a4;
+}
+
+__global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_bwd_pair_kernel(
+    const float* __restrict__ sdf, const float* __restrict__ beta_ptr, float beta_min, const float* __restrict__ alpha,
+    const float* __restrict__ feat, const float* __restrict__ edges, int es, const float* __restrict__ gF, int gF_stride,
+    const float* __restrict__ gD, const float* __restrict__ gA, const float* __restrict__ gWns, int64_t R, int S,
+    float* __restrict__ gfeat, float* __restrict__ gsdf, float* __restrict__ gbeta_part) {
+  constexpr int C = 32;
+  extern __shared__ float tf_lds[];
+  __shared__ float gb_wave[kRaysPerBlock];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31;
+  const int64_t ray0 = (int64_t)blockIdx.x * (2 * kRaysPerBlock) + 2 * wave;
+  float gb = 0.f;
+  if (ray0 < R) {
+    const int64_t ray = ray0 + (lane >> 5);
+    const bool rv = ray < R;
+    const int64_t rc = rv ? ray : ray0;
+    float* w2 = tf_lds + (2 * wave + (lane >> 5)) * 3 * S;
+    float* Tsh = w2 + S;
+    float* gwsh = Tsh + S;
+    const float beta = fabsf(*beta_ptr) + beta_min;
+    const float* e = edges + rc * es;
+    const int s = hl;
+    const bool live = s < S;
+    // 1. transmittance and weights from the saved alphas
+    const float a = live ? alpha[rc * S + s] : 0.f;
+    const float incl = half::incl<wscan::Mul>(1.f - a, lane);
+    const float T = half::shift_up1(incl, 1.f, lane);
+    if (live) Tsh[s] = T, w2[s] = a * T;
+    const float acc = half::sum(live ? a * T : 0.f, lane);
+    if (hl == 0) w2[S - 1] += 1.f - acc;
+    __builtin_amdgcn_wave_barrier();
+    // 2. q_{S-1}: the half's 32 lanes are the 32 channels
+    const float* fr = feat + rc * (int64_t)S * C;
+    const float* gFr = gF + rc * gF_stride;
+    const float qlast = half::sum(gFr[hl] * fr[(int64_t)(S - 1) * C + hl], lane);
+    const float gacc = gA ? gA[rc] : 0.f, gdep = gD ? gD[rc] : 0.f;
+    // 3. feature gradient and dL/dw
+    const int sub = lane & 7, sl = hl >> 3;
+    const float4 g4 = *reinterpret_cast<const float4*>(gFr + 4 * sub);
+    for (int s0 = 0; s0 < S; s0 += 4) {
+      const int sk = s0 + sl;
+      const bool lv = sk < S;
+      const int sc = lv ? sk : S - 1;
+      const float4 f4 = *reinterpret_cast<const float4*>(fr + (int64_t)sc * C + 4 * sub);
+      float q = g4.x * f4.x;
+      q = fmaf(g4.y, f4.y, q);
+      q = fmaf(g4.z, f4.z, q);
+      q = fmaf(g4.w, f4.w, q);
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      q += __shfl_xor(q, 4, 64);
+      if (lv) {
+        const float ws = w2[sk];
+        if (rv)
+          *reinterpret_cast<float4*>(gfeat + (ray * S + sk) * (int64_t)C + 4 * sub) =
+              make_float4(ws * g4.x, ws * g4.y, ws * g4.z, ws * g4.w);
+        if (sub == 0) {
+          float g = q - qlast + gacc;
+          if (sk < S - 1) g += gdep * ((e[sk] + e[sk + 1]) / 2.f) + (gWns ? gWns[rc * (S - 1) + sk] : 0.f);
+          gwsh[sk] = g;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 4. alpha-mode weights backward, 5. the sigmoid head incl. d beta
+    const float gwi = live ? gwsh[s] : 0.f;
+    const float Tl = live ? T : 0.f;
+    const float term = gwi * a * Tl;
+    const float after = half::rincl<wscan::Add>(term, lane) - term;
+    if (live && rv) {
+      const float ga = gwi * Tl - after / fmaxf(1.f - a, 1e-10f);
+      const float ds = ga * a * (1.f - a);  // sigmoid'(x), x = -sdf * beta
+      gsdf[ray * S + s] = -ds * beta;
+      gb -= ds * sdf[ray * S + s];
+    }
+    gb = tf_sum(gb);
+  }
+  if (lane == 0) gb_wave[wave] = gb;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kRaysPerBlock; ++k) t += gb_wave[k];
+    gbeta_part[blockIdx.x] = t;
+  }
+}
+
 // d beta = sign(beta) * sum(partials): one workgroup, fixed summation order
 __global__ __launch_bounds__(1024) void beta_grad_reduce_kernel(const float* __restrict__ part, int n,
                                                                 const float* __restrict__ beta_ptr,
@@ -673,6 +861,12 @@ __global__ __launch_bounds__(256) void lidar_losses_bwd_kernel(LidarBwdArgs A) {
 
 using namespace nrhip;
 
+// two rays per wave (sdf_render_*_pair_kernel): NRHIP_SDF_RENDER_PAIR=1, rays of at most 32 samples with 32 channels
+static bool sdf_render_pair(int s, int c) {
+  const char* e = getenv("NRHIP_SDF_RENDER_PAIR");
+  return e && e[0] == '1' && s <= 32 && c == 32;
+}
+
 #define TF_LAUNCH_RAYS(KERNEL, R_, LDS_, stream, ...)                                                              \
   KERNEL<<<(int)(((R_) + kRaysPerBlock - 1) / kRaysPerBlock), 64 * kRaysPerBlock, LDS_, (hipStream_t)stream>>>( \
       __VA_ARGS__)
@@ -707,6 +901,14 @@ extern "C" int nrhip_sdf_render_fwd(const float* sdf, const float* beta, float b
              NRHIP_ERR_INVALID_ARG, "sdf_render_fwd: bad argument");
   NR_REQUIRE(s <= 2048, NRHIP_ERR_UNSUPPORTED, "sdf_render_fwd: %d samples per ray (max 2048)", s);
   if (r == 0) return NRHIP_OK;
+  if (sdf_render_pair(s, c) && out_stride % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(out_features)) & 15) == 0) {
+    sdf_render_fwd_pair_kernel<<<(int)((r + 2 * kRaysPerBlock - 1) / (2 * kRaysPerBlock)), 64 * kRaysPerBlock,
+                                 (size_t)2 * kRaysPerBlock * s * sizeof(float), (hipStream_t)stream>>>(
+        sdf, beta, beta_min, features, edges, edge_stride, r, s, alpha, weights_ns, out_features, out_stride, out_depth,
+        out_acc);
+    return check_launch("sdf_render_fwd");
+  }
   TF_LAUNCH_RAYS(sdf_render_fwd_kernel, r, (size_t)kRaysPerBlock * s * sizeof(float), stream, sdf, beta, beta_min,
                  features, edges, edge_stride, r, s, c, alpha, weights_ns, out_features, out_stride, out_depth, out_acc);
   return check_launch("sdf_render_fwd");
@@ -730,6 +932,17 @@ extern "C" int nrhip_sdf_render_bwd(const float* sdf, const float* beta, float b
   if (r == 0) {
     if (hipMemsetAsync(grad_beta, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("sdf_render_bwd");
     return NRHIP_OK;
+  }
+  if (sdf_render_pair(s, c) && g_stride % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(grad_features) |
+        reinterpret_cast<uintptr_t>(g_features)) & 15) == 0) {
+    const int pblocks = (int)((r + 2 * kRaysPerBlock - 1) / (2 * kRaysPerBlock));
+    sdf_render_bwd_pair_kernel<<<pblocks, 64 * kRaysPerBlock, (size_t)2 * kRaysPerBlock * 3 * s * sizeof(float),
+                                 (hipStream_t)stream>>>(sdf, beta, beta_min, alpha, features, edges, edge_stride, g_features,
+                                                        g_stride, g_depth, g_acc, g_weights_ns, r, s, grad_features, grad_sdf,
+                                                        workspace);
+    beta_grad_reduce_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(workspace, pblocks, beta, grad_beta);
+    return check_launch("sdf_render_bwd");
   }
   const int blocks = (int)((r + kRaysPerBlock - 1) / kRaysPerBlock);
   sdf_render_bwd_kernel<<<blocks, 64 * kRaysPerBlock, (size_t)kRaysPerBlock * 3 * s * sizeof(float), (hipStream_t)stream>>>(

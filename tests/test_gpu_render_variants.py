@@ -229,6 +229,7 @@ def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
         o, d, area, s, e, _ = _sample_rays(R, S, seed=11)
         args = (fs, dev(o), dev(d), dev(area), dev(s), dev(e))
         monkeypatch.delenv("NRHIP_MLP_SPLIT_BF16", raising=False)
+        monkeypatch.setenv("NRHIP_MLP_PAIRS", "0")  # (the default since round 5 is the fp16-pair form, tested below)
         f32 = ops.render_fwd(*args, return_weights=True)
         monkeypatch.setenv("NRHIP_MLP_SPLIT_BF16", "1")
         spl = ops.render_fwd(*args, return_weights=True)
@@ -237,3 +238,58 @@ def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
         assert not torch.equal(spl[0], f32[0])  # (a different kernel did run)
         ref = O.render_rays(p, o[:32], d[:32], area[:32], s[:32], e[:32])
         assert rel_l2(host(spl[0][:32]), ref["features"]) < 1e-5
+
+
+def test_fp16_pair_matrix_products_are_fp32_equivalent(monkeypatch):
+    """The default of the 64-wide composited kernel since round 5 (NRHIP_MLP_PAIRS=0 switches it off): the fused render
+    kernel's MLP layers as fp16 pairs on the matrix cores (x = fp16(x) + fp16(x - fp16(x)),
+    three v_mfma_f32_16x16x32_f16 per 32 inputs; the tile runs in units of 2^6 and the weights are staged x 2^7 so that the
+    pairs keep 22+ bits where the network lives).  Same outputs as the fp32-MFMA kernel to fp32 rounding and the same parity
+    against the oracle on all three 64-wide grid shapes, fp32 and fp16-storage tables; inputs that do not fit an fp16 pair
+    (activations beyond 1000, a weight beyond 500) take the fp32 products tile by tile and give the default kernel's numbers;
+    an untrained field (table entries of 1e-4, the Instant-NGP initialisation) stays within 2e-6."""
+    from neurad_studio_amd import ops
+
+    R, S = 300, 72
+    o, d, area, s, e, _ = _sample_rays(R, S, seed=11)
+    rays = (dev(o), dev(d), dev(area), dev(s), dev(e))
+
+    def both(fs):
+        monkeypatch.setenv("NRHIP_MLP_PAIRS", "0")
+        a = ops.render_fwd(fs, *rays, return_weights=True)
+        monkeypatch.setenv("NRHIP_MLP_PAIRS", "1")
+        b = ops.render_fwd(fs, *rays, return_weights=True)
+        monkeypatch.delenv("NRHIP_MLP_PAIRS")
+        return a, b
+
+    for L, F, mn, mx in ((16, 2, 16, 1024), (8, 4, 32, 8192), (4, 8, 32, 2048)):
+        p = field_params(L=L, F=F, lg=12, H=64, mn=mn, mx=mx)
+        ref = O.render_rays(p, o[:32], d[:32], area[:32], s[:32], e[:32])
+        for half in (False, True):
+            f32, prs = both(to_spec(ops, p, half=half))
+            for a, b in zip(f32, prs):
+                assert rel_l2(host(b), host(a)) < 1e-6, (L, F, half)
+            assert not torch.equal(prs[0], f32[0])  # (a different kernel did run)
+            if not half:
+                assert rel_l2(host(prs[0][:32]), ref["features"]) < 1e-5
+                assert rel_l2(host(prs[1][:32]), ref["depth"]) < 1e-5
+    # --- the exits of the fast path
+    p = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024)
+    # (1) activations beyond the pair's range in SOME tiles: one ray bundle half of whose table region is scaled up
+    big = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024)
+    big.grid.table[::2] *= 3.0e3
+    f32, prs = both(to_spec(ops, big))
+    for a, b in zip(f32, prs):  # (SDF values of 1e4 and more: the compositing amplifies fp32 rounding, 1.8e-6 measured)
+        assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-5
+    # (2) a weight that does not fit: every tile takes the fp32 products -> the default kernel's numbers, bit for bit in the
+    #     per-sample quantities the compositing consumes
+    wb = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024)
+    wb.feat_w[1][3, 5] = 600.0
+    f32, prs = both(to_spec(ops, wb))
+    for a, b in zip(f32, prs):
+        assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-6
+    # (3) an untrained field: every input of the first layer is ~1e-4
+    small = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024, scale=1e-4)
+    f32, prs = both(to_spec(ops, small))
+    for a, b in zip(f32, prs):
+        assert rel_l2(host(b), host(a)) < 2e-6
