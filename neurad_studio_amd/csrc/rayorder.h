@@ -2,6 +2,7 @@
 // (sampler.hip: nrhip_power_sampler_ordered) -- see rayorder.hip for what it computes and why.
 #pragma once
 #include "common.h"
+#include "wave_scan.h"
 
 namespace nrhip {
 
@@ -34,13 +35,19 @@ __device__ __forceinline__ void ray_order_body(const float* __restrict__ o, cons
   __shared__ uint32_t hist[kOrderKeys];
   __shared__ uint32_t wave_tot[kOrderThreads / 64];
   const int tid = threadIdx.x;
-  for (int k = tid; k < kOrderKeys; k += kOrderThreads) hist[k] = 0;
-  __syncthreads();
+  // (the whole pass is a latency chain on one CU in front of the render kernel: the rays' global loads are issued before the
+  //  histogram is cleared, so the clear and its barrier run under them)
   uint32_t cached[kOrderCached];  // batches up to 8192 rays: the second pass needs no global reads
 #pragma unroll
   for (int it = 0; it < kOrderCached; ++it) {
     const int64_t i = tid + (int64_t)it * kOrderThreads;
     cached[it] = i < n ? order_key<BITS>(o, d, i, t_ref, scale) : 0u;
+  }
+  for (int k = tid; k < kOrderKeys; k += kOrderThreads) hist[k] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kOrderCached; ++it) {
+    const int64_t i = tid + (int64_t)it * kOrderThreads;
     if (i < n) atomicAdd(&hist[cached[it]], 1u);
   }
   for (int64_t i = tid + (int64_t)kOrderCached * kOrderThreads; i < n; i += kOrderThreads)
@@ -51,16 +58,12 @@ __device__ __forceinline__ void ray_order_body(const float* __restrict__ o, cons
   uint32_t v[PER], sum = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) v[k] = hist[PER * tid + k], sum += v[k];
-  uint32_t incl = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = __shfl_up(incl, off, 64);
-    if ((tid & 63) >= off) incl += up;
-  }
+  const uint32_t incl = wscan::incl<wscan::Add>(sum, tid & 63);  // DPP row shifts + 3 readlanes, not 6 ds_bpermute
   if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
   __syncthreads();
   uint32_t base = incl - sum;
-  for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+#pragma unroll
+  for (int w = 0; w < kOrderThreads / 64; ++w) base += w < (tid >> 6) ? wave_tot[w] : 0u;  // (independent broadcast reads)
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     hist[PER * tid + k] = base;

@@ -109,8 +109,30 @@ __global__ __launch_bounds__(kOrderThreads) void power_sampler_order_kernel(
     ray_order_body<BITS>(o, d, R, t_ref, scale, order);
     return;
   }
-  const int64_t t = ((int64_t)blockIdx.x - 1) * kOrderThreads + threadIdx.x;
-  if (t < R * (S + 1)) power_sampler_bin(nears, fars, t, S, lam, scaling, t_rand, last_edge, sp, eu);
+  // the block's 1024 consecutive edges belong to a handful of rays: their spacing (two powf per RAY) once, in LDS, as in
+  // power_sampler_kernel -- evaluated per edge it was 2/3 of the arithmetic, and the bins, not the ordering chain (5.7 us
+  // alone), set this launch's 15 us in front of the render kernel.  Same expressions on the same inputs: bit-identical bins.
+  __shared__ float s_near[kOrderThreads], s_far[kOrderThreads];
+  const int E = S + 1;
+  const int64_t t0 = ((int64_t)blockIdx.x - 1) * kOrderThreads, n_edges = R * E;
+  const int64_t ray_first = t0 / E, t_last = min(t0 + kOrderThreads, n_edges) - 1;
+  const int n_rays = (int)(t_last / E - ray_first) + 1;  // <= kOrderThreads (E >= 1)
+  if ((int)threadIdx.x < n_rays) {
+    const int64_t ray = ray_first + threadIdx.x;
+    const Spacing spc = make_spacing(nears ? nears[ray] : 0.f, fars[ray], lam, scaling);
+    s_near[threadIdx.x] = spc.s_near;
+    s_far[threadIdx.x] = spc.s_far;
+  }
+  __syncthreads();
+  const int64_t t = t0 + threadIdx.x;
+  if (t < n_edges) {
+    const int64_t ray = t / E;
+    const int k = (int)(t - ray * E), r = (int)(ray - ray_first);
+    const Spacing spc{s_near[r], s_far[r], lam, scaling};
+    const float b = power_bin(k, S, t_rand ? t_rand + ray * E : nullptr);
+    sp[t] = b;
+    eu[t] = (k == S && last_edge > 0.f) ? last_edge : spc.to_euclid(b);
+  }
 }
 
 // wave-wide sum / scan on DPP row shifts + readlane (wave_scan.h), not on ds_bpermute shuffles

@@ -53,11 +53,11 @@ NRHIP_BENCH_DECODER_MODES=hip prof decoder python $R/scripts/bench_decoder.py
 cd $R
 # the round's A/B re-measurements on this box
 {
-echo "== split-bf16 MLP products in the headline kernel (NRHIP_MLP_SPLIT_BF16=1) vs the fp32 MFMA default"
-for v in 0 1; do if [ $v = 1 ]; then export NRHIP_MLP_SPLIT_BF16=1; else unset NRHIP_MLP_SPLIT_BF16; fi
+echo "== MLP products of the headline kernel: fp16 pairs (default, NRHIP_MLP_PAIRS=1) vs the fp32 MFMA (0) vs 3-way bf16 split, alternating"
+for v in 1 0 1 0 bf16; do if [ $v = bf16 ]; then export NRHIP_MLP_SPLIT_BF16=1 NRHIP_MLP_PAIRS=0; else unset NRHIP_MLP_SPLIT_BF16; export NRHIP_MLP_PAIRS=$v; fi
   timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants 2>/dev/null | python -c "
 import sys, json
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('split_bf16=$v', 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline'].get('kernel_ms'), 'frac', d['roofline']['frac'], 'parity', d.get('parity_rel_l2_vs_oracle'))"; done; unset NRHIP_MLP_SPLIT_BF16
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('pairs=$v', 'ms_per_step', round(d['ms_per_step'],4), 'value', '%.4g'%d['value'], 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'frac', round(d['roofline']['frac'],4))"; done; unset NRHIP_MLP_SPLIT_BF16 NRHIP_MLP_PAIRS
 echo "== c4 eval: render stage in ray_order (default) vs data-loader order; fused sampler's in-box pass dense (default) vs inline"
 for e in "NRHIP_C4_ORDER_RAYS=1" "NRHIP_C4_ORDER_RAYS=0" "NRHIP_SAMPLER_ACTOR_INLINE=1"; do env $e timeout 300 python bench.py --config c4 --steps 8 --warmup 2 --train-steps 0 2>/dev/null | python -c "
 import sys, json

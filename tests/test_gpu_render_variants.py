@@ -112,6 +112,10 @@ def test_power_sampler_and_ordering_pass_in_one_launch(ops):
         key_pts = o + 20.0 * d
         spread = lambda od: float((key_pts[od.long()][1:] - key_pts[od.long()][:-1]).norm(dim=-1).mean())  # noqa: E731
         assert abs(spread(order) / spread(sep) - 1) < 0.05
+    for S2 in (1, 7, 1500):  # a workgroup's 1024 edges span 512 rays / 128 rays / less than one ray
+        sp0, eu0 = ops.power_sampler(nears, fars, S2, last_edge=20000.0)
+        sp1, eu1, _ = ops.power_sampler_ordered(nears, fars, S2, o, d, 100.0, last_edge=20000.0)
+        assert torch.equal(sp0, sp1) and torch.equal(eu0, eu1), S2
     sp, eu, order = ops.power_sampler_ordered(None, fars[:3], 7, o[:3], d[:3], 100.0)  # fewer rays than one workgroup
     assert sp.shape == (3, 8) and sorted(order.tolist()) == [0, 1, 2]
     assert ops.power_sampler_ordered(None, fars[:0], 7, o[:0], d[:0], 100.0)[2].shape == (0,)
