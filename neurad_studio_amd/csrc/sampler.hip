@@ -10,17 +10,22 @@ namespace nrhip {
 constexpr int kSMax = 512;  // max samples per ray per round handled by the LDS slabs
 
 // ZipNeRF power transform (utils/math.py:541-579) as used by PowerSampler (ray_samplers.py:838-852)
+// The reference raises with torch.pow(tensor, python float), and ATen evaluates the exponent -1 -- NeuRAD's lambda, and its
+// own inverse -- as the RECIPROCAL (pow_tensor_scalar: reciprocal kernel; torch.pow(x, -1.0) == 1 / x bit for bit, checked in
+// the build container).  So does this: one IEEE division instead of a generic powf, which was what bound the kernels below
+// (one powf per bin edge).
+__device__ __forceinline__ float pow_like_aten(float base, float e) { return e == -1.f ? 1.f / base : powf(base, e); }
 __device__ __forceinline__ float power_fn(float x, float lam) {
   if (lam == 1.f) return x;
   if (lam == 0.f) return log1pf(x);
   const float lam_1 = fabsf(lam - 1.f);
-  return (lam_1 / lam) * (powf(x / lam_1 + 1.f, lam) - 1.f);
+  return (lam_1 / lam) * (pow_like_aten(x / lam_1 + 1.f, lam) - 1.f);
 }
 __device__ __forceinline__ float inv_power_fn(float x, float lam) {
   if (lam == 1.f) return x;
   if (lam == 0.f) return expm1f(x);
   const float lam_1 = fabsf(lam - 1.f);
-  return (powf(fmaxf(x * lam / lam_1 + 1.f, 1e-10f), 1.f / lam) - 1.f) * lam_1;
+  return (pow_like_aten(fmaxf(x * lam / lam_1 + 1.f, 1e-10f), 1.f / lam) - 1.f) * lam_1;
 }
 struct Spacing {
   float s_near, s_far, lam, scaling;

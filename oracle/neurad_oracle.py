@@ -465,17 +465,25 @@ def depth_expected(weights, starts, ends):
 # --------------------------------------------------------------------------------------
 # S1  SpacedSampler / PowerSampler (ray_samplers.py:80-132,838-852; utils/math.py:541-579)
 # --------------------------------------------------------------------------------------
+def _pow_like_aten(base, e: float):
+    """``tensor ** python_float``: ATen evaluates the exponent -1 (NeuRAD's lambda and its inverse) as the reciprocal --
+    torch.pow(x, -1.0) == 1 / x bit for bit -- where numpy's power is an ulp off on a fifth of the inputs"""
+    if e == -1.0:
+        return (f32(1) / base).astype(f32)
+    return np.power(base, f32(e), dtype=f32)
+
+
 def power_fn(x, lam: float):
     x = np.asarray(x, f32)
     lam_1 = abs(lam - 1)
-    return (f32(lam_1 / lam) * (np.power(x / f32(lam_1) + f32(1), f32(lam), dtype=f32) - f32(1))).astype(f32)
+    return (f32(lam_1 / lam) * (_pow_like_aten(x / f32(lam_1) + f32(1), lam) - f32(1))).astype(f32)
 
 
 def inv_power_fn(x, lam: float, eps: float = 1e-10):
     x = np.asarray(x, f32)
     lam_1 = abs(lam - 1)
     base = np.maximum(x * f32(lam) / f32(lam_1) + f32(1), f32(eps))
-    return ((np.power(base, f32(1 / lam), dtype=f32) - f32(1)) * f32(lam_1)).astype(f32)
+    return ((_pow_like_aten(base, 1 / lam) - f32(1)) * f32(lam_1)).astype(f32)
 
 
 @dataclass

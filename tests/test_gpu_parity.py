@@ -295,6 +295,8 @@ def test_sampler_pieces_vs_reference_golden(ops):
     R = g["o"].shape[0]
     sp0, eu0 = ops.power_sampler(None, dev(g["fars"]), 128)
     assert rel_l2(host(sp0), g["sp0"]) < 1e-6 and rel_l2(host(eu0), g["eu0"]) < TOL
+    # PowerSampler's bins are the reference's bit for bit since the exponent -1 is evaluated the way ATen does (a reciprocal)
+    assert np.array_equal(host(sp0), g["sp0"]) and np.array_equal(host(eu0), g["eu0"])
     ps = to_pspec(ops, prop_params(95))
     e0 = dev(g["eu0"])
     dens = ops.proposal_density_fwd(ps, dev(g["o"]), dev(g["d"]), dev(g["area"]), e0[:, :-1], e0[:, 1:])
@@ -307,6 +309,7 @@ def test_sampler_pieces_vs_reference_golden(ops):
     gt = load_golden("sampler_train")
     sp0t, eu0t = ops.power_sampler(None, dev(gt["fars"]), 128, t_rand=dev(gt["t_rand"]))
     assert rel_l2(host(sp0t), gt["sp0"]) < 1e-6 and rel_l2(host(eu0t), gt["eu0"]) < TOL
+    assert np.array_equal(host(sp0t), gt["sp0"]) and np.array_equal(host(eu0t), gt["eu0"])
     sp1t, eu1t = ops.pdf_sample(dev(gt["w0"]), dev(gt["sp0"]), None, dev(gt["fars"]), 64, rand=dev(gt["rand1"]))
     assert rel_l2(host(sp1t), gt["sp1"]) < TOL and rel_l2(host(eu1t), gt["eu1"]) < TOL
 

@@ -190,6 +190,7 @@ def test_sampler_train_mode_injected_jitter():
     R = g["fars"].shape[0]
     bins, eu, sp = O.power_sampler(np.zeros(R), g["fars"], 128, t_rand=g["t_rand"])
     assert rel_l2(bins, g["sp0"]) < 1e-6 and rel_l2(eu, g["eu0"]) < TOL
+    assert np.array_equal(bins, g["sp0"]) and np.array_equal(eu, g["eu0"])  # bit for bit: x ** -1 as ATen's reciprocal
     nb, neu = O.pdf_sample(g["w0"], g["sp0"], 64, sp, rand=g["rand1"])
     assert rel_l2(nb, g["sp1"]) < TOL and rel_l2(neu, g["eu1"]) < TOL
 
