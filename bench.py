@@ -454,6 +454,63 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     el = timed(step, steps, 1, world, device)
     allocs1 = _device_allocs()
     assert torch.isfinite(state["loss"]), "non-finite loss"
+    if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
+        # diagnostic (not part of any line): which part of the step launches its torch library kernels (fills, adds, copies)
+        from torch.profiler import ProfilerActivity, profile, record_function
+
+        def marked_step():
+            with record_function("S:get_nff_outputs"):
+                rb = RayBundle(origins=o, directions=d, pixel_area=area.clone(), nears=nears, fars=None, times=times,
+                               metadata=dict(md))
+                out = m.get_nff_outputs(rb, calc_lidar_losses=True)
+            with record_function("S:lidar_head+metrics"):
+                rows = lidar_rows(is_lidar, n_lidar)
+                out["intensity"], out["ray_drop_logits"] = m.decode_lidar(out["features"], rows=rows[0])
+                terms = lidar_metrics(out, is_lidar, did_return, distance, intensity_t, lcfg, rows=rows)
+            with record_function("S:interlevel+distortion"):
+                terms["interlevel"] = zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
+                terms["distortion"] = distortion_loss(out["weights_list"], out["ray_samples_list"])
+            with record_function("S:decoder+rgb_loss"):
+                if dec is not None:
+                    terms["rgb"] = torch.nn.functional.mse_loss(decode(out["features"][:n_cam]), image)
+                else:
+                    terms["feature"] = (out["features"][:n_cam] - target).square().mean()
+            with record_function("S:total_loss"):
+                loss = total_loss(terms)
+            with record_function("S:zero_grad"):
+                opt.zero_grad(set_to_none=True)
+            with record_function("S:backward_call"):
+                loss.backward()
+            with record_function("S:sync"):
+                sync.sync()
+            with record_function("S:opt.step"):
+                opt.step()
+                m.sampler.step_cb(0)
+
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(2):
+                marked_step()
+            torch.cuda.synchronize()
+        agg = {}
+        for ev in prof.events():
+            self_us = getattr(ev, "self_device_time_total", None)
+            if self_us is None:
+                self_us = getattr(ev, "self_cuda_time_total", 0)
+            if not ev.name.startswith("aten::") or self_us <= 0:
+                continue  # aten ops whose own launches took device time
+            where, p = [], ev.cpu_parent
+            while p is not None:
+                if p.name.startswith("S:") or "evaluate_function" in p.name or p.name.endswith("Backward") or "Fn" in p.name:
+                    where.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
+                p = p.cpu_parent
+            key = (ev.name, " <- ".join(where[:3]), str(getattr(ev, "input_shapes", "")))
+            c = agg.setdefault(key, [0, 0.0])
+            c[0] += 1
+            c[1] += self_us
+        with open(os.environ["NRHIP_BENCH_TORCH_PROFILE"], "w") as f:
+            f.write("# aten ops with device time of their own over 2 steps of train_full: calls, device us, op, enclosing step part / autograd node\n")
+            for (name, where, shp), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{n:5d} {us:9.1f}  {name:24s} {where}\n")
     s = m.config.sampling
     # roofline of the step's largest single kernel, the fused training forward of the main field (render_kernel storing its
     # activations): timed standalone, after the timed region, on this batch's rays and 32 PowerSampler samples per ray

@@ -27,13 +27,13 @@ def ray_samples_to_sdist(ray_samples: RaySamples) -> Tensor:
 
 def zipnerf_interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: List[RaySamples]) -> Tensor:
     c = ray_samples_to_sdist(ray_samples_list[-1]).detach()
-    w = weights_list[-1][..., 0].detach()
-    loss = c.new_zeros(())
+    w = weights_list[-1].squeeze(-1).detach()
+    loss = None
     for i, (ray_samples, weights) in enumerate(zip(ray_samples_list[:-1], weights_list[:-1])):
-        loss = loss + ag.InterlevelLossFn.apply(c, w, ray_samples_to_sdist(ray_samples).detach(), weights[..., 0],
-                                                PULSE_WIDTHS[i])
-    return loss
+        term = ag.InterlevelLossFn.apply(c, w, ray_samples_to_sdist(ray_samples).detach(), weights.squeeze(-1), PULSE_WIDTHS[i])
+        loss = term if loss is None else loss + term
+    return c.new_zeros(()) if loss is None else loss
 
 
 def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list: List[RaySamples]) -> Tensor:
-    return ag.DistortionLossFn.apply(ray_samples_to_sdist(ray_samples_list[-1]).detach(), weights_list[-1][..., 0])
+    return ag.DistortionLossFn.apply(ray_samples_to_sdist(ray_samples_list[-1]).detach(), weights_list[-1].squeeze(-1))

@@ -489,7 +489,7 @@ class NeuRADHotPath(FusedEvalMixin, FusedTrainMixin, nn.Module):
         for i, (pw, prs) in enumerate(zip(proposal_weights, proposal_ray_samples)):
             nff[f"prop_depth_{i}"] = self.renderer_depth(pw, prs)
             if lidar_terms:  # carving: lidar weight away from the measured surface
-                nff[f"prop_weights_loss_{i}"] = ag.CarvingLossFn.apply(pw[..., 0], *self._carving_inputs(prs))
+                nff[f"prop_weights_loss_{i}"] = ag.CarvingLossFn.apply(pw.squeeze(-1), *self._carving_inputs(prs))
         if self.training:
             nff["weights_list"] = proposal_weights + [weights]
             nff["ray_samples_list"] = proposal_ray_samples + [ray_samples]
