@@ -31,8 +31,8 @@ pmc c4static_fetch "render_kernel<8, 4, 32, true, true, false" FETCH_SIZE $C4
 pmc c4s_fetch "proposal_sampler_kernel" FETCH_SIZE $C4
 pmc c4s_write "proposal_sampler_kernel" WRITE_SIZE $C4
 C4T="python $R/bench.py --config c4 --steps 2 --warmup 1 --train-steps 36"
-pmc c4t_fetch "render_kernel<8, 4, 32, true, false, false, false, false, true" FETCH_SIZE $C4T
-pmc c4t_write "render_kernel<8, 4, 32, true, false, false, false, false, true" WRITE_SIZE $C4T
+pmc c4t_fetch "render_kernel<8, 4, 32, true, false, false, 0, false, true" FETCH_SIZE $C4T
+pmc c4t_write "render_kernel<8, 4, 32, true, false, false, 0, false, true" WRITE_SIZE $C4T
 } > $OUT/${tag}_pmc_traffic.txt 2>&1
 cat $OUT/${tag}_pmc_traffic.txt
 python $R/scripts/traffic_from_pmc.py $OUT/${tag}_pmc_traffic.txt $tag; cp $R/profiles/traffic_*.json $OUT/
