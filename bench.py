@@ -104,6 +104,9 @@ def recorded_traffic(name):
 TRAFFIC_NOTES = {}
 
 
+LAST_ISSUE = {}
+
+
 def timed(step, steps, warmup, world, device):
     """the contract's timing: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks"""
     import torch.distributed as dist
@@ -116,6 +119,7 @@ def timed(step, steps, warmup, world, device):
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
+    LAST_ISSUE["s_per_step"] = (time.perf_counter() - t0) / max(steps, 1)  # host time to ENQUEUE a step (diagnostic)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -453,6 +457,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     allocs0 = _device_allocs()
     el = timed(step, steps, 1, world, device)
     allocs1 = _device_allocs()
+    host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
     assert torch.isfinite(state["loss"]), "non-finite loss"
     if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
         # diagnostic (not part of any line): which part of the step launches its torch library kernels (fills, adds, copies)
@@ -557,6 +562,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     return {"roofline": roof, "iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
+            "host_enqueue_ms_per_step": host_issue_ms,  # Python + autograd + ctypes time to issue a step, GPU not waited for
             "device_allocations_during_the_timed_steps": allocs1[0] - allocs0[0],  # hipMalloc calls: 0 in steady state
             "allocator_retries_during_the_timed_steps": allocs1[1] - allocs0[1],
             "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
