@@ -359,6 +359,38 @@ def joint_batch(device, rank, n_cam, n_lidar):
     return o, d, area, times, md
 
 
+def torch_op_attribution(step_fn, path, n=2):
+    """diagnostic (not part of any line): which part of a step / which autograd node launches its torch library kernels
+    (fills, adds, copies) -- aten ops with device time of their own over n steps, grouped by the enclosing record_function
+    ("S:...") ranges and autograd nodes, with their input shapes"""
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(n):
+            step_fn()
+        torch.cuda.synchronize()
+    agg = {}
+    for ev in prof.events():
+        self_us = getattr(ev, "self_device_time_total", None)
+        if self_us is None:
+            self_us = getattr(ev, "self_cuda_time_total", 0)
+        if not ev.name.startswith("aten::") or self_us <= 0:
+            continue
+        where, p = [], ev.cpu_parent
+        while p is not None:
+            if p.name.startswith("S:") or "evaluate_function" in p.name or p.name.endswith("Backward") or "Fn" in p.name:
+                where.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
+            p = p.cpu_parent
+        shapes = str([sh for sh in (getattr(ev, "input_shapes", None) or []) if sh])[:60]
+        c = agg.setdefault((ev.name, " <- ".join(where[:3]), shapes), [0, 0.0])
+        c[0] += 1
+        c[1] += self_us
+    with open(path, "w") as f:
+        f.write(f"# aten ops with device time of their own over {n} steps: calls, device us, op, enclosing step part / autograd node, input shapes\n")
+        for (name, where, shapes), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{cnt:5d} {us:9.1f}  {name:24s} {where}  {shapes}\n")
+
+
 def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, rgb_decoder=True,
                        cfg_edit=None, sharded_adam=False, sparse_exchange=False, torch_decoder=False):
     """The whole training step at the reference's default sizes (models/neurad.py defaults: static grid L=8, F=4, T=2^22;
@@ -461,7 +493,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     assert torch.isfinite(state["loss"]), "non-finite loss"
     if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
         # diagnostic (not part of any line): which part of the step launches its torch library kernels (fills, adds, copies)
-        from torch.profiler import ProfilerActivity, profile, record_function
+        from torch.profiler import record_function
 
         def marked_step():
             with record_function("S:get_nff_outputs"):
@@ -492,30 +524,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
                 opt.step()
                 m.sampler.step_cb(0)
 
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            for _ in range(2):
-                marked_step()
-            torch.cuda.synchronize()
-        agg = {}
-        for ev in prof.events():
-            self_us = getattr(ev, "self_device_time_total", None)
-            if self_us is None:
-                self_us = getattr(ev, "self_cuda_time_total", 0)
-            if not ev.name.startswith("aten::") or self_us <= 0:
-                continue  # aten ops whose own launches took device time
-            where, p = [], ev.cpu_parent
-            while p is not None:
-                if p.name.startswith("S:") or "evaluate_function" in p.name or p.name.endswith("Backward") or "Fn" in p.name:
-                    where.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
-                p = p.cpu_parent
-            key = (ev.name, " <- ".join(where[:3]), str(getattr(ev, "input_shapes", "")))
-            c = agg.setdefault(key, [0, 0.0])
-            c[0] += 1
-            c[1] += self_us
-        with open(os.environ["NRHIP_BENCH_TORCH_PROFILE"], "w") as f:
-            f.write("# aten ops with device time of their own over 2 steps of train_full: calls, device us, op, enclosing step part / autograd node\n")
-            for (name, where, shp), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                f.write(f"{n:5d} {us:9.1f}  {name:24s} {where}\n")
+        torch_op_attribution(marked_step, os.environ["NRHIP_BENCH_TORCH_PROFILE"])
     s = m.config.sampling
     # roofline of the step's largest single kernel, the fused training forward of the main field (render_kernel storing its
     # activations): timed standalone, after the timed region, on this batch's rays and 32 PowerSampler samples per ray
@@ -1221,6 +1230,8 @@ def bench_c4(args, device, rank, world):
         el = timed(tstep, tsteps, 3, world, device)
     finally:
         ops.field_fwd_train = real_field_train
+    if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
+        torch_op_attribution(tstep, os.environ["NRHIP_BENCH_TORCH_PROFILE"])
     if rank == 0:
         f_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_t[:tsteps]]))
         # the fused training forward moves, per field sample: fp16 table reads (8 levels x 8 corners x 4 features x 2 B; the

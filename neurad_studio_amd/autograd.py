@@ -218,7 +218,9 @@ def _field_backward(spec, scale, table_dtype, need_table, o, d, a, starts, ends,
     if override is not None:
         ovr_row, pair_idx = override
         g_rows = genc.index_select(0, pair_idx)
-        genc.masked_fill_((ovr_row >= 0)[:, None], 0.0)  # exactly-zero rows send no records (encode_bwd_binned: prep)
+        # exactly-zero rows send no records (encode_bwd_binned: prep).  The overridden samples are the pair list's samples
+        # (every sample of a pair has a winning pair): P rows written, not a pass over all N (85 us at 2 M samples)
+        genc.index_fill_(0, pair_idx, 0.0)
     gt = _like_param(ops.encode_bwd(spec, scale, o, d, a, starts, ends, genc, out_dtype=table_dtype), table_dtype) \
         if need_table else None
     grads = [ggw[0], ggb[0], ggw[1], ggb[1], gfw[0], gfb[0], gfw[1], gfb[1], gfw[2], gfb[2]]
