@@ -1182,7 +1182,7 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   // default because it measured no faster (163 vs 163 us on config[1]: the splitting costs the vector ALU what the matrix
   // pipe saves -- DESIGN.md §9).
   const bool split_bf16 = getenv("NRHIP_MLP_SPLIT_BF16") != nullptr;
-  // NRHIP_MLP_PAIRS=1: the same products as fp16 pairs (mfma_layer_pairs; 64-wide MLPs, composited output)
+  // NRHIP_MLP_PAIRS (default 1): the same products as fp16 pairs (mfma_layer_pairs; composited output)
   const char* pairs_env = getenv("NRHIP_MLP_PAIRS");
   const bool pairs = pairs_env ? pairs_env[0] == '1' : kPairsDefault;
   if constexpr (COMPOSITE) {
@@ -1191,6 +1191,18 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   if (L == L_ && F == F_)                                                                                              \
     return half ? launch_render<L_, F_, 64, true, true, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)      \
                 : launch_render<L_, F_, 64, false, true, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+      PCASE(16, 2)
+      PCASE(8, 4)
+      PCASE(4, 8)
+#undef PCASE
+    }
+    // ... and at NeuRAD's own width, where the arithmetic mostly hid under the memory time already (c2's render stage
+    // 72 -> 60-67 us)
+    if (H == 32 && pairs && !split_bf16) {
+#define PCASE(L_, F_)                                                                                                  \
+  if (L == L_ && F == F_)                                                                                              \
+    return half ? launch_render<L_, F_, 32, true, true, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)      \
+                : launch_render<L_, F_, 32, false, true, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
       PCASE(16, 2)
       PCASE(8, 4)
       PCASE(4, 8)

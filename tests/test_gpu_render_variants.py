@@ -245,7 +245,7 @@ def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
 
 
 def test_fp16_pair_matrix_products_are_fp32_equivalent(monkeypatch):
-    """The default of the 64-wide composited kernel since round 5 (NRHIP_MLP_PAIRS=0 switches it off): the fused render
+    """The default of the composited kernels since round 5 (NRHIP_MLP_PAIRS=0 switches it off): the fused render
     kernel's MLP layers as fp16 pairs on the matrix cores (x = fp16(x) + fp16(x - fp16(x)),
     three v_mfma_f32_16x16x32_f16 per 32 inputs; the tile runs in units of 2^6 and the weights are staged x 2^7 so that the
     pairs keep 22+ bits where the network lives).  Same outputs as the fp32-MFMA kernel to fp32 rounding and the same parity
@@ -266,34 +266,34 @@ def test_fp16_pair_matrix_products_are_fp32_equivalent(monkeypatch):
         monkeypatch.delenv("NRHIP_MLP_PAIRS")
         return a, b
 
-    for L, F, mn, mx in ((16, 2, 16, 1024), (8, 4, 32, 8192), (4, 8, 32, 2048)):
-        p = field_params(L=L, F=F, lg=12, H=64, mn=mn, mx=mx)
+    for L, F, mn, mx, H in ((16, 2, 16, 1024, 64), (8, 4, 32, 8192, 64), (4, 8, 32, 2048, 64), (8, 4, 32, 8192, 32),
+                            (16, 2, 16, 1024, 32), (4, 8, 32, 2048, 32)):
+        p = field_params(L=L, F=F, lg=12, H=H, mn=mn, mx=mx)
         ref = O.render_rays(p, o[:32], d[:32], area[:32], s[:32], e[:32])
         for half in (False, True):
             f32, prs = both(to_spec(ops, p, half=half))
             for a, b in zip(f32, prs):
-                assert rel_l2(host(b), host(a)) < 1e-6, (L, F, half)
+                assert rel_l2(host(b), host(a)) < 1e-6, (L, F, H, half)
             assert not torch.equal(prs[0], f32[0])  # (a different kernel did run)
             if not half:
                 assert rel_l2(host(prs[0][:32]), ref["features"]) < 1e-5
                 assert rel_l2(host(prs[1][:32]), ref["depth"]) < 1e-5
-    # --- the exits of the fast path
-    p = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024)
-    # (1) activations beyond the pair's range in SOME tiles: one ray bundle half of whose table region is scaled up
-    big = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024)
-    big.grid.table[::2] *= 3.0e3
-    f32, prs = both(to_spec(ops, big))
-    for a, b in zip(f32, prs):  # (SDF values of 1e4 and more: the compositing amplifies fp32 rounding, 1.8e-6 measured)
-        assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-5
-    # (2) a weight that does not fit: every tile takes the fp32 products -> the default kernel's numbers, bit for bit in the
-    #     per-sample quantities the compositing consumes
-    wb = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024)
-    wb.feat_w[1][3, 5] = 600.0
-    f32, prs = both(to_spec(ops, wb))
-    for a, b in zip(f32, prs):
-        assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-6
-    # (3) an untrained field: every input of the first layer is ~1e-4
-    small = field_params(L=16, F=2, lg=12, H=64, mn=16, mx=1024, scale=1e-4)
-    f32, prs = both(to_spec(ops, small))
-    for a, b in zip(f32, prs):
-        assert rel_l2(host(b), host(a)) < 2e-6
+    # --- the exits of the fast path, at both widths
+    for H in (64, 32):
+        # (1) activations beyond the pair's range in SOME tiles: half of the table's rows scaled up
+        big = field_params(L=16, F=2, lg=12, H=H, mn=16, mx=1024)
+        big.grid.table[::2] *= 3.0e3
+        f32, prs = both(to_spec(ops, big))
+        for a, b in zip(f32, prs):  # (SDF values of 1e4 and more: the compositing amplifies fp32 rounding, 1.8e-6 measured)
+            assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-5, H
+        # (2) a weight that does not fit: every tile takes the fp32 products -> the default kernel's numbers
+        wb = field_params(L=16, F=2, lg=12, H=H, mn=16, mx=1024)
+        wb.feat_w[1][3, 5] = 600.0
+        f32, prs = both(to_spec(ops, wb))
+        for a, b in zip(f32, prs):
+            assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-6, H
+        # (3) an untrained field: every input of the first layer is ~1e-4
+        small = field_params(L=16, F=2, lg=12, H=H, mn=16, mx=1024, scale=1e-4)
+        f32, prs = both(to_spec(ops, small))
+        for a, b in zip(f32, prs):
+            assert rel_l2(host(b), host(a)) < 2e-6, H
