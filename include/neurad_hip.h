@@ -270,7 +270,10 @@ int nrhip_composite_bwd(const float* weights, const float* features, const float
 
 /* ---- F1+C1+C2 fused: the headline kernel -- hash lookup + MLPs + compositing per ray -----------
  * (NeuRADModel.get_nff_outputs minus sampling, models/neurad.py:373-395).  Optional per-sample
- * outputs (may be NULL): weights [R,S] (pre sky residual, as returned by C1).                       */
+ * outputs (may be NULL): weights [R,S] (pre sky residual, as returned by C1).
+ * The MLPs' product sums are fp32 sums: formed from fp16 pairs on the matrix cores (x = fp16(x) + fp16(x - fp16(x)), fp32
+ * accumulation; inputs that do not fit a pair take the fp32 MFMA tile by tile), 1e-7 from the fp32 MFMA's, which the
+ * environment variable NRHIP_MLP_PAIRS=0 selects everywhere.                                        */
 int nrhip_render_fwd(const nrhip_field* f, const nrhip_rays* rays, float* out_features /*[R,C]*/,
                      float* out_depth /*[R]*/, float* out_acc /*[R]*/, float* out_weights /*[R,S] or NULL*/,
                      void* stream);

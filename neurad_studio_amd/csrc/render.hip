@@ -230,18 +230,21 @@ __device__ __forceinline__ void stage_split_matrix(float* __restrict__ dst, cons
 
 // ---- the matrix work on the matrix cores, second form: fp16 PAIRS -------------------------------------------------------
 // x = h + l with h = fp16(x) and l = fp16(x - h) (both round-to-nearest; the remainder is exact in fp32): 22-24 significant
-// bits, and the three products h.h, h.l, l.h carry every term above 2^-22 of the full product, each exact in the MFMA's
-// fp32 accumulation.  Against the 3-way bf16 split: one v_mfma_f32_16x16x32_f16 per 32 inputs and term (60 MFMAs per
-// 16-sample tile at H = 64 instead of 240 of K = 16) and 2.5 VALU instructions per activation instead of 5.4 (gfx950 converts
-// PAIRS: v_cvt_pk_f16_f32, v_pk_add_f32).  fp16's exponent range is the price: it is spent where the network lives --
-//   * the whole tile runs in units of kPairAct = 2^6 (ReLU MLPs are positively homogeneous: biases and the feature inputs are
-//     staged / blended x 2^6, the three exits -- sdf row, deferred last layer, embedding sum -- x 2^-6; all exact), so an
-//     activation keeps full precision from 6e-5 x 2^-6 up to 1000;
-//   * the weights are staged x kPairW = 2^7 and the product sum comes back through one fma per output (acc = bias + 2^-7 t);
-//   * a tile whose inputs do not fit (|x| >= 1000 in true units, NaN) or a matrix with |w| >= 500 takes the fp32 MFMA with
-//     the A fragments read from global memory: slow, and the same numbers as the default kernel.
-// numpy emulation (profiles/r05_pairs_emulation.txt): rel. error of a 64-term product sum 0.7-1.6e-7 for activations >= 1e-3
-// and |w| >= 0.004 -- the fp32 GEMM's own 1.0e-7 -- against 1.7e-6 .. 1.7e-4 without the two recentrings.
+// bits, and the three products h.h, l.h, h.l carry every term above 2^-22 of the full product, each exact in the MFMA's
+// fp32 accumulation.  One v_mfma_f32_16x16x32_f16 per 32 inputs and term: 60 MFMAs per 16-sample tile at H = 64, on a pipe of
+// their own, where the fp32 form issues 160 v_mfma_f32_16x16x4_f32 on the vector ALU and the 3-way bf16 split 240 of K = 16;
+// 2.5 VALU instructions per activation for the split instead of the bf16 split's 5.4 (gfx950 converts and subtracts PAIRS:
+// v_cvt_pk_f16_f32, v_pk_add_f32).  fp16's exponent range is the price; it is spent where the network lives --
+//   * the whole tile runs in units of kPairAct = 2^6 (ReLU MLPs are positively homogeneous: the biases and the feature inputs
+//     are staged / blended x 2^6, the three exits -- sdf row, deferred last layer, embedding sum -- x 2^-6; all exact), so an
+//     activation keeps its full precision from 1e-6 up to 1000;
+//   * the weights are staged x kPairW = 2^7 and the biases x 2^7 on top, so that the scaled sum accumulates onto the bias in
+//     place and comes back through one multiplication by 2^-7 per output;
+//   * a tile with an input that does not fit (|x| >= 1000 in true units, infinities) or a matrix with |w| >= 500 takes the
+//     fp32 MFMA with its A fragments read from global memory: slow, and the fp32-MFMA kernel's numbers.
+// numpy emulation (scripts/pairs_emulation.py, profiles/r05_pairs_emulation.txt): rel. error of a 64-term product sum
+// 0.7-1.0e-7 for activations >= 1e-2 (2.7e-7 at 1e-3) -- the fp32 product sum's own 1.0e-7 -- against 1.7e-6 .. 1.7e-4
+// without the two recentrings.  On the bench batch the two forms' outputs are 1.0e-7 apart (bench.py: mlp_products).
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -281,11 +284,7 @@ __device__ __forceinline__ void mfma_layer_pairs(const float* __restrict__ wf, c
   float mx = 0.f;
 #pragma unroll
   for (int k = 0; k < 8 * KQ; ++k) mx = fmaxf(mx, fabsf(b[k]));
-#ifdef NRHIP_EXP_NOSLOW
-  if (false) {
-#else
   if (__builtin_expect(wbad || __builtin_amdgcn_ballot_w64(!(mx < kPairFit)) != 0ull, 0)) {  // wave-uniform, rare
-#endif
     // (the fragment addresses depend on the lane only: without the opaque offset they are hoisted out of the TILE loop,
     // 2 VGPRs each, and the fast path spills)
     int opaque = 0;
