@@ -774,6 +774,8 @@ def bench_c1(args, device, rank, world):
     out = None
     if rank == 0:
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        if os.environ.get("NRHIP_BENCH_DUMP_EVENTS"):
+            print("kernel us per timed event:", [round(a.elapsed_time(b) * 1e3, 1) for a, b in events], file=sys.stderr)
         bytes_per = algorithmic_bytes_per_sample(GRID["num_levels"], GRID["features_per_level"], 4, S)
         achieved = n_samples * bytes_per / (kernel_ms * 1e-3) / 1e9
         traffic = recorded_traffic("render_kernel")
