@@ -107,21 +107,6 @@ TRAFFIC_NOTES = {}
 LAST_ISSUE = {}
 
 
-def settle_clocks(device, seconds=None):
-    """A short GEMM spin right before the W warm-up steps: building the workload leaves the device idle for tens of ms and its
-    clocks fall back; a 3 ms timed region (20 steps of 0.15 ms) then runs on the ramp (measured: 153.9 vs 142 us for the same
-    kernel at 20 vs 200 timed steps).  Device preparation, not steps of the workload; NRHIP_BENCH_SETTLE_S=0 switches it off."""
-    seconds = float(os.environ.get("NRHIP_BENCH_SETTLE_S", "0.25")) if seconds is None else seconds
-    if seconds <= 0:
-        return
-    a = torch.randn((4096, 4096), device=device, dtype=torch.float16)
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(10):
-            a @ a
-        torch.cuda.synchronize()
-
-
 def timed(step, steps, warmup, world, device):
     """the contract's timing: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks"""
     import torch.distributed as dist
@@ -767,7 +752,6 @@ def bench_c1(args, device, rank, world):
             events[i // ev_every][1].record()
         state["edges"], state["order"] = eu, order
 
-    settle_clocks(device)
     elapsed = timed(step, args.steps, args.warmup, world, device)
     assert torch.isfinite(feats).all() and torch.isfinite(acc).all()
     n_samples = R_RAYS * S
@@ -795,8 +779,6 @@ def bench_c1(args, device, rank, world):
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S, "parallelism": f"rays sharded x{world}, no collective"},
             "per_gpu_value": n_samples * args.steps / elapsed,
             "target_per_gpu": 2e7,
-            "device_prewarm": f"{os.environ.get('NRHIP_BENCH_SETTLE_S', '0.25')} s GEMM spin before the {args.warmup} warm-up steps "
-                              "(clocks fall back while the workload is built; NRHIP_BENCH_SETTLE_S=0: off, 1-2 % slower at 20 timed steps)",
             "roofline": {"kernel": "nrhip::render_kernel<16,2,64,fp32,composite,pairs> (software-pipelined gathers, "
                                    "XCD-coherent ray ranges over the nrhip_ray_order permutation, MLP products as fp16 "
                                    "pairs with fp32 accumulation)", "bound": "hbm",
