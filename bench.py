@@ -1267,6 +1267,23 @@ def bench_c4(args, device, rank, world):
     return out
 
 
+def self_launch(n: int) -> int:
+    """re-run this command line as n ranks of one node (torch.distributed.run, rendezvous on 127.0.0.1 at a free port) and
+    return the launcher's exit code"""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")  # (what torch.distributed.run would set itself, with a warning)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only form this host driver supports
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1296,6 +1313,12 @@ def main():
     global WIRE_DTYPE
     WIRE_DTYPE = torch.bfloat16 if args.wire_bf16 else None
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a PLAIN command: spawn the N ranks here, as the reference's own entry point does
+        # (scripts/train.py:167-230 launches its workers itself) -- one process per GPU under torch.distributed.run on a free
+        # local port; rank 0 of the children prints the one JSON line on this process's stdout.  The explicit
+        # `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE and never reaches this branch.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

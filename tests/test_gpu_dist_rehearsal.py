@@ -144,3 +144,25 @@ def test_two_ranks_on_one_gpu_end_with_the_parameters_of_one_process_on_the_mean
         # ... through csrc/grad_rows.hip (GPU gradients), and the levels that went densely in the previous step start their
         # reduce-scatter from the table's hook (20 levels in the three tables; the never-evaluated proposal table has none)
         assert level_runs[0] == 0 and (lists[0] >= 14 or min(level_runs[1:]) >= 1), (lists, level_runs)
+
+
+def test_bench_gpus_2_as_a_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (WORLD_SIZE unset): bench.py spawns its two ranks itself
+    (scripts/train.py:167-230 is the reference's own self-launch) and rank 0 prints the one JSON line.  Over gloo on this
+    box's one GPU -- the labelled rehearsal, not a scaling number."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env["NRHIP_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-train"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["dist"]["devices"]) == 2 and out["dist"]["backend"] == "gloo"
+    assert "rehearsal" in out and out["value"] > 0
