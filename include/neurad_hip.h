@@ -377,6 +377,34 @@ typedef struct nrhip_adam_tensor {
 int nrhip_adam_step_many(const nrhip_adam_tensor* tensors /* HOST array */, int32_t n_tensors, double lr, double beta1,
                          double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
+/* The device-controlled form of the same update: torch.amp.GradScaler's optimizer protocol (engine/trainer.py:550-576 steps
+ * every optimizer through GradScaler.step; optimizers with `_step_supports_amp_scaling` get the scale and the found-inf flag
+ * as DEVICE scalars, torch/amp/grad_scaler.py) and the form a captured step (HIP graph) replays.
+ *   step       DEVICE fp32 scalar per tensor (torch's capturable=True state layout), advanced by the launch itself;
+ *   found_inf  DEVICE fp32 scalar or NULL: != 0 -> NOTHING is touched (parameters, moments, images, step counts);
+ *   grad_scale DEVICE fp32 scalar or NULL: GradScaler's scale S, gradients are divided by it inside the update (no unscale
+ *              pass over the table gradients); host_grad_scale multiplies on top (1 = off);
+ *   lr_dev     DEVICE fp32 scalar or NULL: overrides lr (a scheduler fills it between graph replays);
+ *   workspace  DEVICE, nrhip_adam_step_many_workspace(n_tensors) bytes: the per-tensor arguments a one-thread-per-tensor
+ *              kernel derives (in double, rounded once -- the host form's arithmetic) for the streaming kernel.
+ * No host read anywhere; every argument of a replay is behind a pointer. */
+typedef struct nrhip_adam_tensor_dev {
+  float* param;
+  const void* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  void* image_fp16;
+  int64_t n;
+  float* step;         /* DEVICE fp32 scalar: the count BEFORE this update                */
+  int32_t grad_dtype;  /* 0 fp32, 1 fp16                                                  */
+  int32_t reserved;
+} nrhip_adam_tensor_dev;
+int nrhip_adam_step_many_workspace(int32_t n_tensors, int64_t* bytes);
+int nrhip_adam_step_many_dev(const nrhip_adam_tensor_dev* tensors /* HOST array */, int32_t n_tensors, double lr,
+                             const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                             double host_grad_scale, const float* grad_scale, const float* found_inf, void* workspace,
+                             void* stream);
+
 /* Processing order for cache locality (fills nrhip_rays.order): a permutation that groups rays looking at the same
  * region -- counting sort by the Morton code of the contracted position (ScaledSceneContraction, static_scale as in
  * nrhip_field) of the point origin + direction * t_ref, t_ref = a representative sample distance (the sampler's

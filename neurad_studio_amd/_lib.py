@@ -75,6 +75,12 @@ class AdamTensor(C.Structure):  # nrhip_adam_tensor
                 ("reserved", C.c_int32)]
 
 
+class AdamTensorDev(C.Structure):  # nrhip_adam_tensor_dev
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("image_fp16", C.c_void_p), ("n", C.c_int64), ("step", C.c_void_p), ("grad_dtype", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class OccGrid(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
 
@@ -171,6 +177,9 @@ PROTOTYPES = {
     "nrhip_adam_step": [P, P, P, P, I64, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P],
     "nrhip_adam_step_many": [C.POINTER(AdamTensor), I32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                              P],
+    "nrhip_adam_step_many_workspace": [I32, C.POINTER(I64)],
+    "nrhip_adam_step_many_dev": [C.POINTER(AdamTensorDev), I32, C.c_double, P, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_double, P, P, P, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],

@@ -122,6 +122,76 @@ __global__ __launch_bounds__(256) void adam_many_kernel(AdamMany many) {
   else adam_tensor<false>(t, first, stride);
 }
 
+// ---- device-controlled form: torch.amp.GradScaler's optimizer protocol + HIP-graph capture ------------------------------
+// engine/trainer.py:550-576 drives every optimizer through GradScaler.step(); an optimizer that sets
+// `_step_supports_amp_scaling` receives the scale S and the found-inf flag as DEVICE tensors (torch/amp/grad_scaler.py: what
+// torch's fused Adam consumes) and must, without a host read: leave everything untouched when found_inf != 0 (step counts
+// included), otherwise divide the gradients by S inside the update.  The same form serves a captured step (HIP graph): the
+// step counts live on the device (torch's capturable=True layout: one fp32 scalar per tensor), the learning rate may be a
+// device scalar (a scheduler fills it between replays), so a replay needs no new kernel arguments.
+// `adam_prepare_kernel` (one thread per tensor) advances the counts and derives each tensor's AdamArgs in double, rounded
+// once, exactly like make_args on the host; the streaming kernel reads them from the workspace.
+struct AdamCtl {
+  AdamArgs a;
+  int32_t skip;  // found_inf != 0: this launch must not touch anything
+  int32_t pad;
+};
+
+struct AdamPrepare {
+  float* step[kAdamMany];
+  AdamCtl* ctl;  // [count]
+  const float* lr_dev;
+  const float* grad_scale;
+  const float* found_inf;
+  double lr, beta1, beta2, eps, weight_decay, host_grad_scale;
+  int32_t count;
+};
+
+__global__ void adam_prepare_kernel(AdamPrepare pr) {
+  const int k = threadIdx.x;
+  if (k >= pr.count) return;
+  AdamCtl c;
+  c.pad = 0;
+  c.skip = (pr.found_inf && *pr.found_inf != 0.f) ? 1 : 0;
+  double step = (double)*pr.step[k];
+  if (!c.skip) {
+    step += 1.0;
+    *pr.step[k] = (float)step;
+  }
+  if (step < 1.0) step = 1.0;  // (skipped very first step: the arguments are never used)
+  const double lr = pr.lr_dev ? (double)*pr.lr_dev : pr.lr;
+  const double bc1 = 1.0 - pow(pr.beta1, step), bc2 = 1.0 - pow(pr.beta2, step);
+  c.a.step_size = (float)(lr / bc1);
+  c.a.b2 = (float)pr.beta2;
+  c.a.omb1 = (float)(1.0 - pr.beta1), c.a.omb2 = (float)(1.0 - pr.beta2);
+  c.a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  c.a.eps = (float)pr.eps;
+  c.a.decay = (float)(1.0 - lr * pr.weight_decay);
+  // GradScaler's scales are powers of two (init 2^16, growth 2, backoff 1/2): the reciprocal is exact, g * (1/S) == g / S
+  c.a.grad_scale = (float)(pr.host_grad_scale / (pr.grad_scale ? (double)*pr.grad_scale : 1.0));
+  pr.ctl[k] = c;
+}
+
+struct AdamManyDev {
+  AdamTensor t[kAdamMany];  // (t[k].a unused: the arguments come from ctl[k])
+  const AdamCtl* ctl;
+  int32_t count;
+  int32_t total_blocks;
+};
+
+__global__ __launch_bounds__(256) void adam_many_dev_kernel(AdamManyDev many) {
+  int k = 0;
+  while (k + 1 < many.count && (int)blockIdx.x >= many.t[k + 1].block0) ++k;
+  const AdamCtl c = many.ctl[k];
+  if (c.skip) return;
+  AdamTensor t = many.t[k];
+  t.a = c.a;
+  const int nblk = (k + 1 < many.count ? many.t[k + 1].block0 : many.total_blocks) - t.block0;
+  const int64_t first = (int64_t)((int)blockIdx.x - t.block0) * 256 + threadIdx.x, stride = (int64_t)nblk * 256;
+  if (t.grad_half) adam_tensor<true>(t, first, stride);
+  else adam_tensor<false>(t, first, stride);
+}
+
 }  // namespace nrhip
 
 using namespace nrhip;
@@ -205,6 +275,58 @@ extern "C" int nrhip_adam_step_many(const nrhip_adam_tensor* tensors, int32_t n_
     many.total_blocks = blocks;
     adam_many_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(many);
     if (int e = check_launch("adam_step_many")) return e;
+  }
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_adam_step_many_workspace(int32_t n_tensors, int64_t* bytes) {
+  NR_REQUIRE(n_tensors >= 0 && bytes, NRHIP_ERR_INVALID_ARG, "adam_step_many_workspace: bad argument");
+  *bytes = (int64_t)sizeof(AdamCtl) * (n_tensors > 0 ? n_tensors : 1);
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_adam_step_many_dev(const nrhip_adam_tensor_dev* tensors, int32_t n_tensors, double lr, const float* lr_dev,
+                                        double beta1, double beta2, double eps, double weight_decay, double host_grad_scale,
+                                        const float* grad_scale, const float* found_inf, void* workspace, void* stream) {
+  NR_REQUIRE(n_tensors >= 0 && (tensors || n_tensors == 0), NRHIP_ERR_INVALID_ARG, "adam_step_many_dev: bad argument");
+  NR_REQUIRE(workspace || n_tensors == 0, NRHIP_ERR_INVALID_ARG, "adam_step_many_dev: workspace required");
+  NR_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., NRHIP_ERR_INVALID_ARG,
+             "adam_step_many_dev: bad hyper-parameter");
+  AdamCtl* ctl = reinterpret_cast<AdamCtl*>(workspace);
+  int k = 0, slot = 0;
+  while (k < n_tensors) {
+    AdamManyDev many;
+    AdamPrepare pr;
+    many.count = 0;
+    int blocks = 0;
+    int live = 0;
+    for (int j = k; j < n_tensors && live < kAdamMany; ++j) live += tensors[j].n > 0 ? 1 : 0;
+    for (; k < n_tensors && many.count < kAdamMany; ++k) {
+      const nrhip_adam_tensor_dev& in = tensors[k];
+      NR_REQUIRE(in.n >= 0 && (in.grad_dtype == 0 || in.grad_dtype == 1) && in.step, NRHIP_ERR_INVALID_ARG,
+                 "adam_step_many_dev: tensor %d: n >= 0, grad_dtype 0 (fp32) or 1 (fp16), a device step scalar", k);
+      if (in.n == 0) continue;
+      if (int e = check_tensor("adam_step_many_dev", in.param, in.grad, in.exp_avg, in.exp_avg_sq, in.image_fp16)) return e;
+      pr.step[many.count] = in.step;
+      AdamTensor& t = many.t[many.count++];
+      t = AdamTensor{in.param, in.grad, in.exp_avg, in.exp_avg_sq, reinterpret_cast<__half*>(in.image_fp16), in.n, {},
+                     in.grad_dtype, blocks};
+      int b = blocks_for(in.n);
+      if (b > 1024 && live > 1) b = 1024;
+      blocks += b;
+    }
+    if (many.count == 0) continue;
+    many.total_blocks = blocks;
+    many.ctl = ctl + slot;
+    pr.ctl = ctl + slot;
+    pr.count = many.count;
+    pr.lr = lr, pr.lr_dev = lr_dev, pr.beta1 = beta1, pr.beta2 = beta2, pr.eps = eps, pr.weight_decay = weight_decay;
+    pr.host_grad_scale = host_grad_scale, pr.grad_scale = grad_scale, pr.found_inf = found_inf;
+    slot += many.count;
+    adam_prepare_kernel<<<1, 64, 0, (hipStream_t)stream>>>(pr);
+    if (int e = check_launch("adam_step_many_dev (prepare)")) return e;
+    adam_many_dev_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(many);
+    if (int e = check_launch("adam_step_many_dev")) return e;
   }
   return NRHIP_OK;
 }

@@ -24,11 +24,12 @@ import contextlib
 import dataclasses
 from copy import deepcopy
 from dataclasses import dataclass
-from typing import Type
+from typing import Literal, Type
 
 import torch
 
 import nerfstudio.models.neurad as _ref_neurad
+from nerfstudio.engine.optimizers import AdamOptimizerConfig
 from nerfstudio.field_components.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig
 from nerfstudio.fields.neurad_field import NeuRADFieldConfig, NeuRADProposalFieldConfig
 from nerfstudio.models.neurad import NeuRADModel, NeuRADModelConfig, SamplingSettings
@@ -41,7 +42,21 @@ from ..model_components import losses as hip_losses
 from ..model_components import ray_samplers as hip_samplers
 from ..model_components import renderers as hip_renderers
 from ..models.neurad import FusedEvalMixin, FusedTrainMixin
+from ..optim import HashGridAdam
 from ..shims import nerfacc as hip_nerfacc
+
+
+@dataclass
+class HashGridAdamConfig(AdamOptimizerConfig):
+    """``hashgrids`` group of the method (configs/method_configs.py:423-426: Adam, lr 1e-2, eps 1e-15) on csrc/adam.hip.  The
+    reference builds every optimizer as ``config._target(params, **fields)`` (engine/optimizers.py:39-62) and steps it through
+    ``grad_scaler.step`` (engine/optimizers.py:160-181): HashGridAdam takes the scale and the found-inf flag from the
+    GradScaler on the device (optim.py), so neither the 0.6 GB of table gradients get an unscale pass nor do fp16 gradients
+    (``table_dtype="float16"``) trip ``GradScaler.unscale_``."""
+
+    _target: Type = HashGridAdam
+    capturable: bool = False
+    """step counts on the device from the first step (a training step captured in a HIP graph)"""
 
 
 def _field_config() -> NeuRADFieldConfig:
@@ -77,6 +92,12 @@ class NeuRADHipModelConfig(NeuRADModelConfig):
     fused_training: bool = True
     """Training steps of a static scene on the fused nodes (models/neurad.py FusedTrainMixin); False: the reference's own
     get_nff_outputs over the HIP modules."""
+    table_dtype: Literal["float32", "float16"] = "float32"
+    """Storage of the main field's hash tables (static grid + actor grids).  "float16" (BASELINE config[4]; what tiny-cuda-nn
+    stores): half the gather bytes; gradients arrive in fp16 and HashGridAdam keeps fp32 master copies (optim.py).  State
+    dicts load into either (load_state_dict casts), so fp32 neurad checkpoints interchange."""
+    proposal_table_dtype: Literal["float32", "float16"] = "float32"
+    """... and of the proposal fields' static tables (their actor grids stay fp32: the fused sampler reads those as fp32)."""
 
 
 class _NchwDecoderAdapter(torch.nn.Module):
@@ -128,6 +149,15 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
         self.renderer_depth = (hip_renderers.DepthRenderer(method="expected") if cfg.normalize_depth
                                else hip_renderers.render_depth_simple)
         self.interlevel_loss = hip_losses.zipnerf_interlevel_loss
+        for what, name in ((cfg.table_dtype, "table_dtype"), (cfg.proposal_table_dtype, "proposal_table_dtype")):
+            if what not in ("float32", "float16"):
+                raise ValueError(f"{name} must be 'float32' or 'float16', got {what!r}")
+        if cfg.table_dtype == "float16":
+            for gr in [self.field.hashgrid.static_grid, *self.field.hashgrid.actor_grids]:
+                gr.hash_table.data = gr.hash_table.data.half()
+        if cfg.proposal_table_dtype == "float16":
+            for pf in self.proposal_fields:
+                pf.hashgrid.static_grid.hash_table.data = pf.hashgrid.static_grid.hash_table.data.half()
 
     def _render_weights(self, outputs, ray_samples):
         """models/neurad.py:711-724 without the cpu placeholder and independent of which ``nerfacc`` is importable"""
@@ -165,11 +195,15 @@ def _trainer_config():
     # imported before the method table
     from nerfstudio.configs.method_configs import method_configs
 
-    cfg = deepcopy(method_configs["neurad"])  # optimizers, schedules, data manager: the reference's own
+    cfg = deepcopy(method_configs["neurad"])  # schedules, data manager, the small groups' optimizers: the reference's own
     cfg.method_name = "neurad-hip"
     ref_model = cfg.pipeline.model
     cfg.pipeline.model = NeuRADHipModelConfig(eval_num_rays_per_chunk=ref_model.eval_num_rays_per_chunk,
                                               camera_optimizer=ref_model.camera_optimizer)
+    # the tables' optimizer on the HIP kernel, with the group's own hyper-parameters (configs/method_configs.py:423-426)
+    ref_opt = cfg.optimizers["hashgrids"]["optimizer"]
+    cfg.optimizers["hashgrids"]["optimizer"] = HashGridAdamConfig(lr=ref_opt.lr, eps=ref_opt.eps, max_norm=ref_opt.max_norm,
+                                                                  weight_decay=ref_opt.weight_decay)
     return cfg
 
 

@@ -1156,6 +1156,69 @@ def adam_step_many(items, lr: float, beta1: float = 0.9, beta2: float = 0.999, e
          float(grad_scale), _stream())
 
 
+_ADAM_CTL_BYTES = None
+
+
+def adam_workspace_floats(n_tensors: int) -> int:
+    """size of adam_step_many_dev's workspace for ``n_tensors`` tensors, in fp32 elements"""
+    global _ADAM_CTL_BYTES
+    if _ADAM_CTL_BYTES is None:
+        nb = C.c_int64()
+        call("nrhip_adam_step_many_workspace", 1, C.byref(nb))
+        _ADAM_CTL_BYTES = int(nb.value)
+    return (_ADAM_CTL_BYTES * max(int(n_tensors), 1) + 3) // 4
+
+
+def adam_workspace(n_tensors: int, device) -> Tensor:
+    """device workspace of adam_step_many_dev for up to ``n_tensors`` tensors (the caller keeps it across steps)"""
+    return torch.empty((adam_workspace_floats(n_tensors),), device=device, dtype=torch.float32)
+
+
+def adam_step_many_dev(items, lr, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15, weight_decay: float = 0.0,
+                       grad_scale: Optional[Tensor] = None, found_inf: Optional[Tensor] = None,
+                       workspace: Optional[Tensor] = None, host_grad_scale: float = 1.0) -> None:
+    """adam_step_many with everything a step decides ON THE DEVICE (csrc/adam.hip: GradScaler's protocol, graph capture).
+    items: (param fp32, grad fp32 | fp16, exp_avg, exp_avg_sq, step = fp32 device scalar holding the count BEFORE this
+    update, image | None).  lr: float, or an fp32 device scalar.  grad_scale / found_inf: fp32 device scalars (the
+    GradScaler's scale and its found-inf flag): gradients are divided by the scale; a non-zero flag leaves parameters, moments
+    and step counts untouched.  No host read."""
+    items = list(items)
+    if not items:
+        return
+    dev = items[0][0].device
+    arr = (_lib.AdamTensorDev * len(items))()
+    for k, (param, grad, m, v, step, image) in enumerate(items):
+        for t, n in ((param, "param"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            if _chk(t, n).data_ptr() != t.data_ptr() or t.shape != param.shape:
+                raise ValueError(f"adam_step_many_dev: {n} must be a contiguous fp32 GPU tensor of the parameter's shape")
+        if grad.dtype not in (torch.float32, torch.float16) or not grad.is_contiguous() or not grad.is_cuda or grad.shape != param.shape:
+            raise ValueError("adam_step_many_dev: grad must be a contiguous fp32 / fp16 GPU tensor of the parameter's shape")
+        if image is not None and (image.dtype != torch.float16 or not image.is_contiguous() or image.shape != param.shape):
+            raise ValueError("adam_step_many_dev: image must be a contiguous fp16 tensor of the parameter's shape")
+        if not (isinstance(step, Tensor) and step.is_cuda and step.dtype == torch.float32 and step.numel() == 1):
+            raise ValueError("adam_step_many_dev: step must be an fp32 GPU scalar")
+        a = arr[k]
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq = param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.image_fp16 = image.data_ptr() if image is not None else None
+        a.n, a.step, a.grad_dtype = param.numel(), step.data_ptr(), 1 if grad.dtype == torch.float16 else 0
+
+    def scalar(t, what):
+        if t is None:
+            return None
+        if not (isinstance(t, Tensor) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+            raise ValueError(f"adam_step_many_dev: {what} must be an fp32 GPU scalar")
+        return t.data_ptr()
+
+    lr_dev = scalar(lr, "lr") if isinstance(lr, Tensor) else None
+    if workspace is None:
+        workspace = adam_workspace(len(items), dev)
+    if workspace.numel() < adam_workspace_floats(len(items)) or not workspace.is_cuda or workspace.dtype != torch.float32:
+        raise ValueError("adam_step_many_dev: workspace too small (ops.adam_workspace)")
+    call("nrhip_adam_step_many_dev", arr, len(items), 0.0 if lr_dev is not None else float(lr), lr_dev, float(beta1),
+         float(beta2), float(eps), float(weight_decay), float(host_grad_scale), scalar(grad_scale, "grad_scale"),
+         scalar(found_inf, "found_inf"), workspace.data_ptr(), _stream())
+
+
 def device_info():
     cus, xcds, hbm = C.c_int32(), C.c_int32(), C.c_int64()
     call("nrhip_device_info", C.byref(cus), C.byref(xcds), C.byref(hbm))

@@ -6,10 +6,19 @@
 one launch per 24 small ones (the per-actor grids) that skips the rows whose update is provably a no-op (csrc/adam.hip).
 fp16-storage tables: the kernel reads the fp16 gradient, updates the fp32 master copy in the optimizer state and writes the
 rounded fp16 table in the same pass.  The reference's settings for its ``hashgrids`` group
-are ``AdamOptimizerConfig(lr=1e-2, eps=1e-15)`` (configs/method_configs.py:423-426)."""
+are ``AdamOptimizerConfig(lr=1e-2, eps=1e-15)`` (configs/method_configs.py:423-426).
+
+Under the reference's trainer (engine/trainer.py:550-576: ``torch.autocast`` + ``grad_scaler.step(optimizer)`` for every
+group, ``mixed_precision=True`` is the ``neurad`` default) the optimizer speaks torch.amp.GradScaler's protocol for
+optimizers that handle the scale themselves (``_step_supports_amp_scaling``, what torch's fused Adam does): GradScaler hands
+``self.grad_scale`` / ``self.found_inf`` as device scalars, the kernel divides the gradients by the scale inside the update
+and leaves everything untouched -- step counts included -- when an inf was found; no host read, no unscale pass over the
+table gradients, and fp16 gradients (fp16-storage tables) are accepted, which ``GradScaler.unscale_`` refuses.
+``capturable=True`` keeps the step counts on the device from the first step (torch's capturable layout) so that a whole
+training step can be captured in a HIP graph; ``lr`` may then be an fp32 device scalar that a scheduler fills."""
 from __future__ import annotations
 
-from typing import Iterable, Optional, Tuple
+from typing import Iterable, Optional, Tuple, Union
 
 import torch
 
@@ -17,41 +26,54 @@ from . import ops
 
 
 class HashGridAdam(torch.optim.Optimizer):
-    def __init__(self, params: Iterable, lr: float = 1e-2, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-15,
-                 weight_decay: float = 0.0, decoupled_weight_decay: bool = True) -> None:
+    _step_supports_amp_scaling = True  # torch/amp/grad_scaler.py: GradScaler.step registers grad_scale / found_inf on us
+
+    def __init__(self, params: Iterable, lr: Union[float, torch.Tensor] = 1e-2, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-15, weight_decay: float = 0.0, decoupled_weight_decay: bool = True,
+                 capturable: bool = False) -> None:
         if weight_decay and not decoupled_weight_decay:
             raise NotImplementedError("L2-in-gradient weight decay; use decoupled (AdamW) decay or 0")
         # the remaining keys are torch.optim.Adam's own group entries, carried so that a state_dict saved here loads into
         # torch.optim.Adam / AdamW with the same meaning (and the other way round)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
-                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      foreach=None, capturable=bool(capturable), differentiable=False, fused=None,
                                       decoupled_weight_decay=bool(weight_decay)))
+        self._workspace = {}
+
+    def _ws(self, n: int, device) -> torch.Tensor:
+        ws = self._workspace.get(device)
+        if ws is None or ws.numel() < ops.adam_workspace_floats(n):
+            ws = self._workspace[device] = ops.adam_workspace(max(n, 32), device)
+        return ws
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: Optional[float] = None):
-        """grad_scale: multiply every gradient by it inside the kernel (1 / GradScaler scale when the caller does not
-        want a separate unscale pass over 600 MB of gradients)."""
+        """grad_scale (host float): multiply every gradient by it inside the kernel.  GradScaler's device-side scale arrives
+        as the attribute ``self.grad_scale`` instead (see the module docstring) and divides."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        amp_scale = getattr(self, "grad_scale", None)  # set and removed by GradScaler.step around this call
+        found_inf = getattr(self, "found_inf", None)
+        amp = isinstance(amp_scale, torch.Tensor) or isinstance(found_inf, torch.Tensor)
         for group in self.param_groups:
             if group.get("amsgrad") or group.get("maximize") or (group["weight_decay"] and not group.get("decoupled_weight_decay", True)):
                 raise NotImplementedError("HashGridAdam: amsgrad / maximize / L2-in-gradient weight decay")
             b1, b2 = group["betas"]
-            items = []
+            lr = group["lr"]
+            items, on_device = [], amp or bool(group.get("capturable")) or isinstance(lr, torch.Tensor)
             for p in group["params"]:
                 if p.grad is None:
                     continue  # untouched tables (an actor no ray hit): state must not decay, as in torch
                 st = self.state[p]
                 if not st:
-                    # the step count is kept as a host int beside torch's 0-d tensor: no tensor arithmetic and no .item() per
-                    # table and step (66 tables on a 32-actor scene)
-                    st["step"] = torch.tensor(0.0)  # host scalar, like torch.optim.Adam(capturable=False)
+                    # capturable=False: a host scalar like torch.optim.Adam's -- no tensor arithmetic and no .item() per table
+                    # and step (66 tables on a 32-actor scene); device form: torch's capturable layout, an fp32 device scalar
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if on_device else torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
-                step = int(st["step"]) + 1
-                st["step"] = torch.tensor(float(step))  # (a new tensor: a state_dict loaded from a live optimizer shares this scalar)
+                on_device = on_device or st["step"].is_cuda  # a count that lives on the device stays there (no host read)
                 image = None
                 target = p
                 if p.dtype != torch.float32:
@@ -69,20 +91,52 @@ class HashGridAdam(torch.optim.Optimizer):
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if grad.dtype not in (torch.float32, torch.float16):
                     grad = grad.float()
-                items.append((target, grad, st["exp_avg"], st["exp_avg_sq"], step, image))
-            # one launch per 24 tensors (csrc/adam.hip): the large tables get the machine to themselves in their own launch
-            big = [it for it in items if it[0].numel() >= 1 << 24]
-            small = [it for it in items if it[0].numel() < 1 << 24]
-            for it in big:
-                ops.adam_step_many([it], group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                                   1.0 if grad_scale is None else grad_scale)
-            ops.adam_step_many(small, group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                               1.0 if grad_scale is None else grad_scale)
+                items.append((target, grad, st["exp_avg"], st["exp_avg_sq"], st, image))
+            if not items:
+                continue
+            host_scale = 1.0 if grad_scale is None else grad_scale
+            if on_device:
+                dev_items = []
+                for (target, grad, m, v, st, image) in items:
+                    if not st["step"].is_cuda or st["step"].dtype != torch.float32:  # (a host count from an earlier mode / a checkpoint)
+                        st["step"] = st["step"].detach().to(device=target.device, dtype=torch.float32).reshape(())
+                    dev_items.append((target, grad, m, v, st["step"], image))
+                dev = dev_items[0][0].device
+                if isinstance(lr, torch.Tensor) and (not lr.is_cuda or lr.dtype != torch.float32):
+                    lr = float(lr)
+                scale_t = amp_scale if isinstance(amp_scale, torch.Tensor) else None
+                inf_t = found_inf if isinstance(found_inf, torch.Tensor) else None
+                if scale_t is not None and (scale_t.dtype != torch.float32 or scale_t.device != dev):
+                    scale_t = scale_t.to(device=dev, dtype=torch.float32)
+                if inf_t is not None and (inf_t.dtype != torch.float32 or inf_t.device != dev):
+                    inf_t = inf_t.to(device=dev, dtype=torch.float32)
+                ws = self._ws(len(dev_items), dev)
+                # the large tables get the machine to themselves in their own launch (csrc/adam.hip); each launch takes its own
+                # slice of the workspace
+                big = [it for it in dev_items if it[0].numel() >= 1 << 24]
+                small = [it for it in dev_items if it[0].numel() < 1 << 24]
+                off = 0
+                for batch in [[it] for it in big] + ([small] if small else []):
+                    n_floats = ops.adam_workspace_floats(len(batch))
+                    ops.adam_step_many_dev(batch, lr, b1, b2, group["eps"], group["weight_decay"], scale_t, inf_t,
+                                           ws[off:off + n_floats], host_scale)
+                    off += n_floats
+            else:
+                host_items = []
+                for (target, grad, m, v, st, image) in items:
+                    step = int(st["step"]) + 1
+                    st["step"] = torch.tensor(float(step))  # (a new tensor: a state_dict loaded from a live optimizer shares this scalar)
+                    host_items.append((target, grad, m, v, step, image))
+                # one launch per 24 tensors (csrc/adam.hip): the large tables get the machine to themselves in their own launch
+                big = [it for it in host_items if it[0].numel() >= 1 << 24]
+                small = [it for it in host_items if it[0].numel() < 1 << 24]
+                for it in big:
+                    ops.adam_step_many([it], float(lr), b1, b2, group["eps"], group["weight_decay"], host_scale)
+                ops.adam_step_many(small, float(lr), b1, b2, group["eps"], group["weight_decay"], host_scale)
             # the kernel wrote the tables through raw pointers: the parameters' version counters did not move.  Caches keyed
             # on a table's version (ops.eval_table under NRHIP_EVAL_RELAYOUT=1: the re-laid-out coarse levels) would serve
             # the old values to an eval that stays in train mode; dropping them here costs nothing when none exist.
-            if items:
-                ops.clear_eval_tables()
+            ops.clear_eval_tables()
         return loss
 
     def load_state_dict(self, state_dict) -> None:
@@ -99,4 +153,3 @@ class HashGridAdam(torch.optim.Optimizer):
             for k in ("master", "exp_avg", "exp_avg_sq"):
                 if k in saved[i]:
                     self.state[p][k] = saved[i][k].detach().to(device=p.device, dtype=torch.float32).clone()
-

