@@ -597,6 +597,114 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
                     "path, SURVEY §8) -- so this figure must not be set beside the reference's it/s of its full trainer"}
 
 
+def train_via_plugin_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, mixed_precision=True,
+                             fused_losses=True, table_dtype="float32"):
+    """The c3 training step as `ns-train neurad-hip` runs it (--via-plugin): the reference's OWN iteration --
+    ``Trainer.train_iteration`` (engine/trainer.py:535-579: zero_grad_some -> torch.autocast -> pipeline.get_train_loss_dict ->
+    grad_scaler.scale(loss).backward() -> optimizer_scaler_step_some(grad_scaler) -> grad_scaler.update() -> schedulers) --
+    over ``NeuRADHipModel`` (integration/neurad_hip.py, a subclass of the reference's NeuRADModel: its get_outputs,
+    decode_features, get_loss_dict are the reference's code), the reference's ``Optimizers`` built from the method's own
+    optimizer table (HashGridAdam for `hashgrids` through GradScaler's device-side protocol, torch AdamW / Adam for the rest,
+    the reference's schedulers) and ``ADHipPipeline.get_train_loss_dict``; mixed precision on, as the `neurad` method ships.
+    Same batch, same sizes, same loss terms as `train_full` (no VGG term in either).  Needs a neurad-studio installation:
+    `nerfstudio` must be importable -- on the bench box the only copy is the byte-compiled tree under oracle/_ref, used here
+    as the HOST framework the plugin subclasses (never as a checker, and nothing of it is the thing measured apart from its
+    own Python glue, which is the point of this figure)."""
+    import types
+    from collections import defaultdict
+    from copy import deepcopy
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+    import ref_import
+
+    if not ref_import.reference_available():
+        return {"error": "nerfstudio is not importable (no /root/reference, no oracle/_ref): --via-plugin needs neurad-studio"}
+    ref_import.install()
+    os.environ.setdefault("NERFSTUDIO_METHOD_CONFIGS", "neurad-hip=neurad_studio_amd.integration.neurad_hip:neurad_hip")
+    import nerfstudio.configs.method_configs as ref_methods
+    import nerfstudio.models.neurad as ref_neurad
+    from nerfstudio.cameras.rays import RayBundle
+    from nerfstudio.data.scene_box import SceneBox
+    from nerfstudio.engine.optimizers import Optimizers
+    from nerfstudio.engine.trainer import Trainer
+    from nerfstudio.plugins.registry import discover_methods
+    from torch.cuda.amp.grad_scaler import GradScaler
+
+    from neurad_studio_amd.integration.pipeline import ADHipPipeline
+    from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
+
+    methods = dict(ref_methods.all_methods)
+    if "neurad-hip" not in methods:
+        methods.update(discover_methods()[0])
+    method = deepcopy(methods["neurad-hip"])
+    mcfg = method.pipeline.model
+    mcfg.loss.vgg_mult = 0.0  # (the VGG term needs torchvision's weights; train_full leaves it out too)
+    mcfg.fused_losses, mcfg.table_dtype = fused_losses, table_dtype
+    ref_neurad.VGGPerceptualLossPix2Pix = torch.nn.Identity
+    torch.manual_seed(11)  # identical replicas
+    m = mcfg.setup(scene_box=SceneBox(aabb=torch.tensor([[-STATIC_SCALE] * 3, [STATIC_SCALE] * 3])), num_train_data=7,
+                   metadata={"duration": 8.0, "sensor_idx_to_name": {i: f"s{i}" for i in range(7)}, "trajectories": []})
+    m = m.to(device).train()
+    m.psnr = lambda x, y: -10.0 * torch.log10(torch.nn.functional.mse_loss(x, y))  # (torchmetrics is absent on this box)
+    with torch.no_grad():  # O(1) features, as in train_full
+        m.field.hashgrid.static_grid.hash_table.mul_(1000.0)
+        for p in m.proposal_fields:
+            p.hashgrid.static_grid.hash_table.mul_(2000.0)
+    o, d, area, times, md = joint_batch(device, rank, n_cam, n_lidar)
+    g = torch.Generator(device=device)
+    g.manual_seed(5 + rank)
+    up = mcfg.rgb_upsample_factor
+    image = torch.rand((n_cam // 1024, 32 * up, 32 * up, 3), device=device, generator=g)
+    torch.rand((n_cam, 48), device=device, generator=g)  # (train_full's feature target: the same generator stream after it)
+    is_lidar = md["is_lidar"]
+    points = torch.cat([torch.zeros((n_lidar, 3), device=device), torch.rand((n_lidar, 1), device=device, generator=g),
+                        torch.zeros((n_lidar, 1), device=device)], -1)
+    batch = {"image": image, "lidar": points, "is_lidar": is_lidar, "did_return": md["did_return"],
+             "distance": md["directions_norm"][is_lidar[:, 0]].reshape(-1, 1).contiguous()}
+    cam_idx = torch.zeros((n_cam + n_lidar, 1), dtype=torch.long, device=device)
+
+    def next_train(step):
+        rb = RayBundle(origins=o, directions=d, pixel_area=area.clone(), camera_indices=cam_idx, times=times,
+                       metadata=dict(md))
+        return rb, dict(batch)
+
+    pipe = types.SimpleNamespace(_model=m, model=m, datamanager=types.SimpleNamespace(next_train=next_train),
+                                 config=types.SimpleNamespace(ray_patch_size=(32, 32)))
+    pipe.get_train_loss_dict = lambda step: ADHipPipeline.get_train_loss_dict(pipe, step)
+    groups = {k: v for k, v in m.get_param_groups().items() if len(v)}
+    loop = types.SimpleNamespace(config=types.SimpleNamespace(log_gradients=False), device=f"cuda:{device.index or 0}",
+                                 mixed_precision=bool(mixed_precision), grad_scaler=GradScaler(enabled=bool(mixed_precision)),
+                                 gradient_accumulation_steps=defaultdict(lambda: 1), pipeline=pipe,
+                                 optimizers=Optimizers(deepcopy({k: method.optimizers[k] for k in groups}), groups))
+    params = [p for p in m.parameters() if p.requires_grad]
+    sync = GradientSynchronizer(params, average=True, usage="static", overlap=world > 1, auto_sync=True,
+                                wire_dtype=WIRE_DTYPE) if world > 1 else None
+    state = {}
+
+    def step(i=None):
+        loss, loss_dict, _ = Trainer.train_iteration(loop, 0 if i is None else i)
+        m.sampler.step_cb(0)  # the model's AFTER_TRAIN_ITERATION callback (models/neurad.py:291-300)
+        state["loss"] = loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    el = timed(step, steps, 1, world, device)
+    host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
+    assert torch.isfinite(state["loss"]), "non-finite loss"
+    if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
+        torch_op_attribution(step, os.environ["NRHIP_BENCH_TORCH_PROFILE"] + ".via_plugin")
+    return {"iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
+            "rays_per_sec": world * (n_cam + n_lidar) * steps / el, "host_enqueue_ms_per_step": host_issue_ms,
+            "mixed_precision": bool(mixed_precision), "grad_scaler_scale": loop.grad_scaler.get_scale() if mixed_precision else None,
+            "fused_losses": bool(fused_losses), "table_dtype": table_dtype,
+            "optimizers": {k: type(v).__name__ for k, v in loop.optimizers.optimizers.items()},
+            "grad_exchange_bytes_per_rank": sync.last_sync_bytes if sync is not None else 0,
+            "what": "the c3 step as `ns-train neurad-hip` executes it: the reference's Trainer.train_iteration (autocast + "
+                    "GradScaler + Optimizers + schedulers) over NeuRADHipModel / ADHipPipeline.get_train_loss_dict with the "
+                    "method's own optimizer table; same batch, sizes and loss terms as train_full"}
+
+
 def device_state(device_index=0):
     """clocks / power state of the GPU UNDER LOAD when the run starts (rocm-smi sampled while a matmul loop keeps the device
     busy: the idle sclk says nothing): the pool's boxes differ by ~10 % on the same kernel (round 3: 169 us on the builder's
@@ -1307,6 +1415,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true",
                     help="c1: skip the two labelled non-headline launches of the render kernel (profiling runs: their "
                          "launches would enter the per-kernel averages)")
+    ap.add_argument("--via-plugin", action="store_true",
+                    help="c3: ALSO time the step as `ns-train neurad-hip` executes it -- the reference's Trainer.train_iteration "
+                         "(autocast + GradScaler + Optimizers) over the plugin model (needs nerfstudio importable)")
     ap.add_argument("--train-steps", type=int, default=60)
     ap.add_argument("--train-full-steps", type=int, default=30, help="0 skips the train_full section")
     args = ap.parse_args()
@@ -1379,6 +1490,15 @@ def main():
                "config": {"workload": tf["what"], "rays_per_gpu": tf["rays_per_gpu"],
                           "parallelism": f"dp{world}: rays sharded, table gradients reduce-scatter + all-gather"},
                "iters_per_sec": tf["iters_per_sec"], "roofline": tf.pop("roofline"), "train_full": tf}
+        if args.via_plugin:
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            vp = train_via_plugin_section(device, rank, world, steps, max(2, min(args.warmup, 5)))
+            if "ms_per_iter" in vp:
+                vp["ratio_to_train_full"] = vp["ms_per_iter"] / tf["ms_per_iter"]
+            out["train_via_plugin"] = vp
         if rank == 0 and world == 1:
             out["parity_rel_l2_vs_oracle"] = c3_parity(device)
     else:

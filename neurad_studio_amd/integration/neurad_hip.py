@@ -92,6 +92,11 @@ class NeuRADHipModelConfig(NeuRADModelConfig):
     fused_training: bool = True
     """Training steps of a static scene on the fused nodes (models/neurad.py FusedTrainMixin); False: the reference's own
     get_nff_outputs over the HIP modules."""
+    fused_losses: bool = True
+    """Training steps: the lidar terms of get_metrics_dict (models/neurad.py:485-521) on csrc/losses.hip (one launch each way,
+    the quantile as a radix select) and every per-step metric without boolean-mask indexing -- the reference's formulation
+    costs ~15 `x[mask]` (a nonzero + a device->host read each) and a `float(beta)` per step, which serialise the host with the
+    GPU.  Same keys, same values (tests/test_gpu_reference_plugin.py); False: the reference's own get_metrics_dict."""
     table_dtype: Literal["float32", "float16"] = "float32"
     """Storage of the main field's hash tables (static grid + actor grids).  "float16" (BASELINE config[4]; what tiny-cuda-nn
     stores): half the gather bytes; gradients arrive in fp16 and HashGridAdam keeps fp32 master copies (optim.py).  State
@@ -171,9 +176,32 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
             return self._fused_train_nff_outputs(ray_bundle, calc_lidar_losses)
         return super().get_nff_outputs(ray_bundle, calc_lidar_losses)
 
+    _batch_layout = None
+
+    def set_batch_layout(self, n_camera_rays, n_lidar_rays) -> None:
+        """The caller vouches that the NEXT bundle is [n_camera_rays camera rays; n_lidar_rays lidar rays] in this order --
+        what ``_merge_img_lidar`` builds (data/datamanagers/image_lidar_datamanager.py:379-423).  ``decode_features`` then
+        splits the rendered features with two views instead of two boolean-mask gathers (each a nonzero + a host read).
+        Set by integration/pipeline.py:ADHipPipeline, which owns the batch; consumed once."""
+        self._batch_layout = None if n_camera_rays is None else (int(n_camera_rays), int(n_lidar_rays))
+
     def decode_features(self, features, patch_size, is_lidar=None, intensity_for_cam=False):
         """the reference's method (models/neurad.py:337-366) with the RGB CNN decoder on the HIP kernels: fp16 operands, fp32
         accumulation -- what the reference's mixed-precision trainer runs through MIOpen"""
+        layout, self._batch_layout = self._batch_layout, None
+        if (layout is not None and is_lidar is not None and not intensity_for_cam and features.is_cuda
+                and sum(layout) == features.shape[0] and layout[0] > 0 and layout[1] > 0):
+            # models/neurad.py:345-366 with the two masks replaced by the layout's views
+            n_cam = layout[0]
+            intensity, ray_drop_logit = self.lidar_decoder(features[n_cam:]).split(1, dim=-1)
+            cam = features[:n_cam]
+            if self.config.fused_decoder:
+                from neurad_studio_amd.model_components.cnns import decode_rgb
+
+                rgb = decode_rgb(self._modules["rgb_decoder"], cam.float(), tuple(patch_size))
+            else:
+                rgb = self.rgb_decoder(cam.view(-1, *patch_size, cam.shape[-1]).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            return rgb, intensity.sigmoid(), ray_drop_logit
         if not (self.config.fused_decoder and features.is_cuda):
             return super().decode_features(features, patch_size, is_lidar, intensity_for_cam)
         decoder = self._modules["rgb_decoder"]
@@ -184,9 +212,53 @@ class NeuRADHipModel(FusedEvalMixin, FusedTrainMixin, NeuRADModel):
             self._modules["rgb_decoder"] = decoder
 
     def get_metrics_dict(self, outputs, batch):
+        if (self.training and self.config.fused_losses and "lidar" in batch and "image" in batch
+                and outputs["depth"].is_cuda and "weights_list" in outputs):
+            return self._fused_metrics_dict(outputs, batch)
         # the reference calls the module-level distortion_loss (models/neurad.py:524): the HIP one for this call only
         with _patched(_ref_neurad, "distortion_loss", hip_losses.distortion_loss):
             return super().get_metrics_dict(outputs, batch)
+
+    def _fused_metrics_dict(self, outputs, batch):
+        """get_metrics_dict (models/neurad.py:461-529) of a training step without a device->host read: same keys, same
+        values.  The number of lidar rays comes with the batch (``batch["lidar"]`` has one row per lidar ray), so their
+        positions are a compaction with a known size (ops.mask_compact) instead of a nonzero; the depth / intensity / ray-drop
+        terms of the final samples and the depth terms of both proposal rounds are one launch each way (csrc/losses.hip); the
+        four logging metrics are masked reductions."""
+        from ..model_components.lidar_losses import LidarLossSettings, lidar_metrics, lidar_rows
+
+        loss = self.config.loss
+        m = {"psnr": self.psnr(outputs["rgb"].detach(), batch["image"])}
+        is_lidar = batch["is_lidar"][:, 0]
+        n_lidar = batch["lidar"].shape[0]
+        rows = lidar_rows(is_lidar, n_lidar)
+        did_return = batch["did_return"].index_select(0, rows[0])[:, 0]
+        target_i, distance = batch["lidar"][..., 3:4], batch["distance"]
+        with torch.no_grad():  # the four eval metrics the reference logs every step (models/neurad.py:477-483)
+            ret = did_return[:, None]
+            n_ret = ret.sum().clamp_min(1)
+            pred = outputs["depth"].detach().index_select(0, rows[0])
+            sq = (pred - distance) ** 2
+            # median over the returned rays: the lower of the two middle values (torch.median), via a sort with the others at
+            # +inf and a device-side index
+            srt = torch.where(ret, sq, torch.full_like(sq, float("inf"))).reshape(-1).sort().values
+            m["depth_median_l2"] = srt.gather(0, ((n_ret - 1) // 2).reshape(1))[0]
+            m["depth_mean_rel_l2"] = (torch.where(ret, ((pred - distance) / distance) ** 2, torch.zeros_like(sq))).sum() / n_ret
+            m["intensity_rmse"] = (torch.where(ret, (outputs["intensity"].detach() - target_i) ** 2,
+                                               torch.zeros_like(sq)).sum() / n_ret).sqrt()
+            m["ray_drop_accuracy"] = ((outputs["ray_drop_logits"].detach().sigmoid() > 0.5).squeeze(-1) == ~did_return).float().mean()
+        cfg = LidarLossSettings(depth_mult=loss.depth_mult, intensity_mult=loss.intensity_mult, carving_mult=loss.carving_mult,
+                                quantile_threshold=loss.quantile_threshold,
+                                non_return_lidar_distance=loss.non_return_lidar_distance,
+                                non_return_loss_mult=loss.non_return_loss_mult, ray_drop_loss_mult=loss.ray_drop_loss_mult,
+                                prop_lidar_loss_mult=loss.prop_lidar_loss_mult)
+        m.update(lidar_metrics(outputs, is_lidar, did_return, distance, target_i, cfg,
+                               num_proposal_rounds=self.config.num_proposal_rounds, rows=rows))
+        m["distortion"] = hip_losses.distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+        if self.config.field.use_sdf:
+            m["sdf_to_density"] = self.field.sdf_to_density.beta.detach()  # (the reference: float(beta), a host read per step)
+        self.camera_optimizer.get_metrics_dict(m)
+        return m
 
 
 def _trainer_config():
@@ -200,6 +272,15 @@ def _trainer_config():
     ref_model = cfg.pipeline.model
     cfg.pipeline.model = NeuRADHipModelConfig(eval_num_rays_per_chunk=ref_model.eval_num_rays_per_chunk,
                                               camera_optimizer=ref_model.camera_optimizer)
+    # the pipeline: batches drawn on the device, gradients exchanged by GradientSynchronizer instead of DDP
+    # (integration/pipeline.py); every field of the reference's pipeline / data manager config is carried over
+    from .pipeline import ADHipDataManagerConfig, ADHipPipelineConfig
+
+    ref_pipe, ref_dm = cfg.pipeline, cfg.pipeline.datamanager
+    dm = ADHipDataManagerConfig(**{f.name: getattr(ref_dm, f.name) for f in dataclasses.fields(ref_dm)
+                                   if f.name not in ("_target", "num_processes")})
+    cfg.pipeline = ADHipPipelineConfig(**{f.name: getattr(ref_pipe, f.name) for f in dataclasses.fields(ref_pipe)
+                                          if f.name not in ("_target", "datamanager")}, datamanager=dm)
     # the tables' optimizer on the HIP kernel, with the group's own hyper-parameters (configs/method_configs.py:423-426)
     ref_opt = cfg.optimizers["hashgrids"]["optimizer"]
     cfg.optimizers["hashgrids"]["optimizer"] = HashGridAdamConfig(lr=ref_opt.lr, eps=ref_opt.eps, max_norm=ref_opt.max_norm,

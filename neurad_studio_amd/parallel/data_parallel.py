@@ -103,7 +103,7 @@ class GradientSynchronizer:
                  large_threshold_bytes: int = 8 << 20, usage: str = "dynamic", overlap: bool = False,
                  skip: Iterable[torch.nn.Parameter] = (),
                  level_tables: Optional[Dict[torch.nn.Parameter, int]] = None, profile: bool = False,
-                 wire_dtype: Optional[torch.dtype] = None) -> None:
+                 wire_dtype: Optional[torch.dtype] = None, auto_sync: bool = False) -> None:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         if overlap and usage != "static":
@@ -145,6 +145,17 @@ class GradientSynchronizer:
         self.profile = profile
         self._ev_first_hook = None
         self._ev_steps: List[Tuple[object, object, object]] = []  # (first hook | None, sync entry, sync exit)
+        # auto_sync=True: sync() runs by itself at the END of every backward pass (autograd's queue_callback, the mechanism DDP
+        # finalises its buckets with) -- for callers that own neither the backward call nor the optimizer step: the reference's
+        # trainer goes `grad_scaler.scale(loss).backward()` straight into `grad_scaler.step(optimizer)` (engine/trainer.py:553-
+        # 558), and the GradScaler's inf check must already see the REDUCED gradients, or one rank would skip a step the
+        # others take.
+        self.auto_sync = auto_sync
+        self._callback_queued = False
+        self.last_sync_bytes = 0
+        if auto_sync:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._queue_end_of_backward))
         if overlap:
             for i, p in enumerate(self.params):
                 if i in self._levels:  # counts + the previously dense levels start from the hook (_start_level_table)
@@ -154,6 +165,17 @@ class GradientSynchronizer:
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _queue_end_of_backward(self, _param) -> None:
+        """first gradient of a backward pass -> one callback at the end of that pass"""
+        if self._callback_queued or self.world_size() == 1:
+            return
+        self._callback_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self) -> None:
+        self._callback_queued = False
+        self.last_sync_bytes = self.sync()
 
     def _is_large(self, t: Tensor) -> bool:
         n = t.numel()

@@ -453,3 +453,45 @@ def test_bf16_wire_format_keeps_replicas_identical_world2_gloo():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_wire16_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _auto_sync_worker(rank, world, port, ret):
+    """the shape of the reference's iteration (engine/trainer.py:553-558): `grad_scaler.scale(loss).backward()` goes
+    straight into `grad_scaler.step(optimizer)` -- nobody calls sync(); GradientSynchronizer(auto_sync=True) runs it at the
+    end of the backward pass, BEFORE the scaler looks for infs.  Rank 1's batch overflows in step 1: both ranks must skip."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _TinyField()
+    params = [p for p in m.parameters()]
+    sync = GradientSynchronizer(params, average=True, large_threshold_bytes=1 << 14, usage="dynamic", auto_sync=True)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    scaler = torch.amp.GradScaler("cpu", init_scale=8.0, growth_interval=1000)
+    skipped = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        idx = torch.randint(0, 4096, (256,), generator=g)
+        x = m.table[idx] + m.prop_table[idx % 2048]
+        loss = m.mlp(x).square().mean()
+        if step == 1 and rank == 1:
+            loss = loss * float("inf")
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        before = m.table.detach().clone()
+        scaler.step(opt)
+        scaler.update()
+        skipped.append(bool(torch.equal(before, m.table.detach())))
+    ret[rank] = (skipped, [p.detach().clone() for p in params], scaler.get_scale(), sync.last_sync_bytes)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_auto_sync_reduces_before_the_gradscaler_looks_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_auto_sync_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        (s0, p0, sc0, b0), (s1, p1, sc1, b1) = ret[0], ret[1]
+    assert s0 == s1 == [False, True, False], (s0, s1)  # the overflow on rank 1 skipped the step on BOTH ranks
+    assert sc0 == sc1 == 4.0 and b0 == b1 > 0
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)  # replicas bit-identical

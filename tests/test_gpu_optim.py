@@ -156,6 +156,7 @@ def test_hashgrid_adam_speaks_the_gradscaler_protocol(table_dtype):
         rows = torch.randint(0, n_rows // 2, (2000,), device="cuda")
         g[rows] = (torch.randn(2000, F, device="cuda") * 0.1).half().float()  # (exactly representable once scaled by 2^k)
         poison = step == 3
+        scaler.scale(torch.zeros((), device="cuda"))  # (what grad_scaler.scale(loss) does first: the lazy scale tensor)
         scale = scaler.get_scale()
         a.grad = (g * scale).to(table_dtype)
         if poison:

@@ -81,7 +81,7 @@ class _Loop:
     """the attributes ``Trainer.train_iteration`` reads (engine/trainer.py:176-189,535-579), set as ``Trainer.__init__`` /
     ``Trainer.setup`` set them; the iteration itself is the reference's own function"""
 
-    def __init__(self, method_config, model, pipeline, device, mixed_precision):
+    def __init__(self, method_config, model, pipeline, device, mixed_precision, warmup=True):
         from nerfstudio.engine.optimizers import Optimizers
         from torch.cuda.amp.grad_scaler import GradScaler  # engine/trainer.py:40
 
@@ -93,7 +93,11 @@ class _Loop:
         self.pipeline = pipeline
         # Trainer.setup_optimizers (engine/trainer.py:264-275): the method's optimizer table x the model's parameter groups
         groups = {k: v for k, v in model.get_param_groups().items() if len(v)}
-        self.optimizers = Optimizers(deepcopy({k: method_config.optimizers[k] for k in groups}), groups)
+        table = deepcopy({k: method_config.optimizers[k] for k in groups})
+        if not warmup:  # full learning rates from the first iteration (the shipped schedules ramp up over 500 - 2500 steps:
+            for v in table.values():  # ten iterations of those move the parameters by 1e-4 only)
+                v["scheduler"].warmup_steps = 0
+        self.optimizers = Optimizers(table, groups)
 
     def run(self, n):
         from nerfstudio.engine.trainer import Trainer
@@ -121,6 +125,8 @@ def _param_report(models, init):
     ref32 = dict(models["ref32"].named_parameters())
     rep = {}
     for n, p0 in init.items():
+        if t._analytically_zero(n):  # (gradient = rounding noise, which Adam at eps = 1e-15 turns into +-lr steps)
+            continue
         r = ref32[n].detach().double().cpu()
         upd = float((r - p0.double()).norm())
         if upd == 0.0:
@@ -134,33 +140,36 @@ def _param_report(models, init):
     return rep
 
 
-def _run_all(ref, with_actors, fp16_tables=False, n_actors=3, with_amp_reference=True):
+def _run_all(ref, with_actors, fp16_tables=False, n_actors=3, with_amp_reference=True, warmup=True):
     methods = _methods()
     hip, ref32 = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
     init = {n: p.detach().float().cpu().clone() for n, p in ref32.named_parameters()}
     _, ref64 = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
     ref64 = ref64.double()
-    models = {"hip": hip, "ref32": ref32, "ref64": ref64}
+    hip32, _ = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
+    models = {"hip": hip, "hip32": hip32, "ref32": ref32, "ref64": ref64}
     if with_amp_reference:  # the reference's torch model on the GPU, under the reference's AMP loop
         _, refamp = t._build_pair(ref, with_actors, n_actors=n_actors, fp16_tables=fp16_tables)
         models["refamp"] = refamp.to("cuda")
         models["refamp"].camera_optimizer.to("cuda")
-    spec = {"hip": ("neurad-hip", "cuda:0", torch.float32, True), "ref32": ("neurad", "cpu", torch.float32, True),
+    spec = {"hip": ("neurad-hip", "cuda:0", torch.float32, True), "hip32": ("neurad-hip", "cuda:0", torch.float32, False),
+            "ref32": ("neurad", "cpu", torch.float32, True),
             "ref64": ("neurad", "cpu", torch.float64, True), "refamp": ("neurad", "cuda:0", torch.float32, True)}
     losses = {}
     for who, m in models.items():
         method, device, dtype, mp = spec[who]
         t._deterministic(m, True)
         pipe = _Pipeline(m, with_actors, device.split(":")[0], dtype, n_actors)
-        loop = _Loop(methods[method], m, pipe, device, mp)
+        loop = _Loop(methods[method], m, pipe, device, mp, warmup=warmup)
         if who == "hip":
             from neurad_studio_amd.optim import HashGridAdam
 
             assert isinstance(loop.optimizers.optimizers["hashgrids"], HashGridAdam)  # what ns-train neurad-hip builds
             assert loop.mixed_precision and loop.grad_scaler.is_enabled()
         losses[who] = loop.run(K)
-        if who == "hip":
+        if who.startswith("hip"):
             assert m.fused_training_possible()
+        if who == "hip":
             scale = loop.grad_scaler.get_scale()
             assert scale >= 1.0
             losses["_hip_scale"] = scale
@@ -191,43 +200,46 @@ def _check(models, init, losses, tag):
     _dump(f"r06_train_loop_{tag}.json", {"loss_rel_err_vs_ref32_per_iteration": lrep, "param_err_over_update": prep,
                                          "losses_ref32": losses["ref32"], "losses_hip": losses["hip"],
                                          "grad_scaler_scale_after_K": losses.get("_hip_scale")})
-    # every loss term of every iteration: within 1e-3 of the reference's fp32 loop -- or, for the terms mixed precision
-    # itself moves (the fp16 decoder under autocast, the fp16-storage tables' rounded gradients), within 1.5 x what the
-    # reference's own AMP loop differs from its fp32 loop by
-    bad = []
-    for k, row in enumerate(lrep):
-        for term, e in row.items():
-            tol = max(1e-3, 1.5 * e.get("refamp", 0.0), 3.0 * e["ref64"])
-            if e["hip"] > tol:
-                bad.append((k, term, e))
+    # Every loss term of every iteration against the reference's fp32 loop.  The yardsticks are the reference's own, per term,
+    # worst over the K iterations (with full learning rates the runs separate chaotically: an error at iteration k is the
+    # amplified rounding of all iterations before it):
+    #   * the plugin's fp32 loop (mixed precision off, GradScaler disabled as the trainer disables it): within 1e-3, or 2 x
+    #     the reference's fp32-vs-fp64 drift;
+    #   * the plugin's AMP loop: within 1e-3, or 3 x what the reference's own AMP loop / fp64 run differ from its fp32 loop
+    #     by (the fp16 CNN decoder under autocast is in both AMP runs).
+    yard = {term: {who: max(r[term].get(who, 0.0) for r in lrep) for who in ("ref64", "refamp")} for term in lrep[0]}
+    bad = [(k, term, e["hip"], yard[term]) for k, row in enumerate(lrep) for term, e in row.items()
+           if e["hip"] > max(1e-3, 3.0 * yard[term]["refamp"], 3.0 * yard[term]["ref64"])]
     assert not bad, bad[:6]
-    # parameters after K steps, relative to the size of the update the reference made: the plugin is as close to the
-    # reference's fp32 run as the reference's own fp64 / AMP runs are (x 2, + 2 %)
+    bad32 = [(k, term, e["hip32"], yard[term]) for k, row in enumerate(lrep) for term, e in row.items()
+             if e["hip32"] > max(1e-3, 2.0 * yard[term]["ref64"])]
+    assert not bad32, bad32[:6]
+    # parameters after K iterations, relative to the size of the update the reference made
     worst = {}
     for n, e in prep.items():
         kind = t._kind(n)
-        w = worst.setdefault(kind, {"hip": 0.0, "ref64": 0.0, "refamp": 0.0})
+        w = worst.setdefault(kind, {"hip": 0.0, "hip32": 0.0, "ref64": 0.0, "refamp": 0.0})
         for who in w:
             w[who] = max(w[who], e.get(who, 0.0))
     print(f"[{tag}] parameters after {K} iterations, worst ||p - p_ref32|| / ||update|| per kind:",
           {k: {a: float(f"{b:.2e}") for a, b in v.items()} for k, v in worst.items()})
     print(f"[{tag}] worst loss-term error over the iterations:",
           {term: {who: float(f"{max(r[term][who] for r in lrep):.2e}") for who in lrep[0][term]} for term in lrep[0]})
+    # AMP loop: as close to the reference's fp32 run as the reference's own AMP / fp64 runs are (x 2, + 2 % of the update);
+    # fp32 loop: as close as the reference's own fp64 run (x 2, + 1 %)
     badp = [(k, v) for k, v in worst.items() if v["hip"] > 2.0 * max(v["ref64"], v["refamp"]) + 0.02]
     assert not badp, badp
+    badp32 = [(k, v) for k, v in worst.items() if v["hip32"] > 2.0 * v["ref64"] + 0.01]
+    assert not badp32, badp32
     return worst
 
 
+@pytest.mark.parametrize("warmup", [True, False], ids=["shipped-schedules", "no-warmup"])
 @pytest.mark.parametrize("with_actors", [False, True], ids=["static", "actors3"])
-def test_plugin_trains_like_the_reference_under_the_references_own_amp_loop(ref, with_actors):
-    models, init, losses = _run_all(ref, with_actors)
-    _check(models, init, losses, "actors3" if with_actors else "static")
-    hg = models["hip"]
-    # the tables really trained through HashGridAdam's device-side protocol: counts on the device, K steps (or fewer if the
-    # scaler skipped some -- then the same number for every table)
-    from neurad_studio_amd.optim import HashGridAdam  # noqa: F401
-
-    assert losses["hip"][-1]["rgb_loss"] == losses["hip"][-1]["rgb_loss"]  # finite
+def test_plugin_trains_like_the_reference_under_the_references_own_amp_loop(ref, with_actors, warmup):
+    models, init, losses = _run_all(ref, with_actors, warmup=warmup)
+    _check(models, init, losses, ("actors3" if with_actors else "static") + ("" if warmup else "_no_warmup"))
+    assert all(np.isfinite(v) for row in losses["hip"] for v in row.values())
 
 
 def test_fp16_storage_tables_train_under_mixed_precision(ref):
@@ -251,7 +263,11 @@ def test_fp16_storage_tables_train_under_mixed_precision(ref):
     opt = loops["hip"].optimizers.optimizers["hashgrids"]
     table = hip.field.hashgrid.static_grid.hash_table
     st = opt.state[table]
-    assert st["master"].dtype == torch.float32 and st["step"].is_cuda and 1 <= float(st["step"]) <= 6
+    steps, scale = float(st["step"]), loops["hip"].grad_scaler.get_scale()
+    print("fp16-storage tables under the AMP loop: optimizer steps taken", steps, "of 6; GradScaler scale", scale)
+    assert st["master"].dtype == torch.float32 and st["step"].is_cuda and 1 <= steps <= 6
     assert torch.equal(table.detach(), st["master"].half())
-    moved = float((table.detach().float().cpu() - init["field.hashgrid.static_grid.hash_table"]).abs().max())
-    assert moved > 1e-3, moved
+    # a skipped iteration (an fp16 gradient overflowing at scale 2^16) halves the scale and leaves the count: both consistent
+    assert scale == 65536.0 * 0.5 ** (6 - steps), (steps, scale)
+    moved = float((st["master"].cpu() - init["field.hashgrid.static_grid.hash_table"]).abs().max())
+    assert moved > 1e-5, moved  # (the shipped schedule's warm-up: lr ~ 1e-2 * k / 500 in these first iterations)
