@@ -29,7 +29,7 @@ from typing import Literal, Type
 import torch
 
 import nerfstudio.models.neurad as _ref_neurad
-from nerfstudio.engine.optimizers import AdamOptimizerConfig
+from nerfstudio.engine.optimizers import AdamOptimizerConfig, AdamWOptimizerConfig
 from nerfstudio.field_components.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig
 from nerfstudio.fields.neurad_field import NeuRADFieldConfig, NeuRADProposalFieldConfig
 from nerfstudio.models.neurad import NeuRADModel, NeuRADModelConfig, SamplingSettings
@@ -74,6 +74,21 @@ def _proposal_config() -> NeuRADProposalFieldConfig:
 
 def _sampling() -> SamplingSettings:
     return SamplingSettings(proposal_field_1=_proposal_config(), proposal_field_2=_proposal_config())
+
+
+@dataclass
+class FusedAdamConfig(AdamOptimizerConfig):
+    """the small groups' torch.optim.Adam with ``fused=True``: one multi-tensor launch per group, and -- like HashGridAdam --
+    an optimizer that takes the GradScaler's scale / found-inf on the device, where the reference's default (foreach) Adam
+    makes ``GradScaler.step`` read found-inf back to the host for every optimizer and iteration (torch/amp/grad_scaler.py
+    `_maybe_opt_step`: a ``.item()``)"""
+
+    fused: bool = True
+
+
+@dataclass
+class FusedAdamWConfig(AdamWOptimizerConfig):
+    fused: bool = True
 
 
 @dataclass
@@ -285,6 +300,12 @@ def _trainer_config():
     ref_opt = cfg.optimizers["hashgrids"]["optimizer"]
     cfg.optimizers["hashgrids"]["optimizer"] = HashGridAdamConfig(lr=ref_opt.lr, eps=ref_opt.eps, max_norm=ref_opt.max_norm,
                                                                   weight_decay=ref_opt.weight_decay)
+    # the small groups (MLPs, CNN decoder, trajectories, camera poses): the reference's optimizers and hyper-parameters, fused
+    for name, group in cfg.optimizers.items():
+        opt = group["optimizer"]
+        if name != "hashgrids" and type(opt) in (AdamOptimizerConfig, AdamWOptimizerConfig):
+            fused = FusedAdamWConfig if isinstance(opt, AdamWOptimizerConfig) else FusedAdamConfig
+            group["optimizer"] = fused(lr=opt.lr, eps=opt.eps, max_norm=opt.max_norm, weight_decay=opt.weight_decay)
     return cfg
 
 
