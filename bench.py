@@ -919,11 +919,13 @@ def bench_c1(args, device, rank, world):
             pair_us = kernel_us(fs)
             f_pairs = ops.render_fwd(fs, origins, dirs, area, state["edges"][:, :-1], state["edges"][:, 1:], order=state["order"])
             os.environ["NRHIP_MLP_PAIRS"] = "0"
+            ops.reload_tuning()  # (the library reads its switches at load: csrc/common.h struct Tuning)
             try:
                 f32_us = kernel_us(fs)
                 f_f32 = ops.render_fwd(fs, origins, dirs, area, state["edges"][:, :-1], state["edges"][:, 1:], order=state["order"])
             finally:
                 del os.environ["NRHIP_MLP_PAIRS"]
+                ops.reload_tuning()
             rl2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
             out["mlp_products"] = {
                 "form": "fp16 pairs: x = fp16(x) + fp16(x - fp16(x)), three v_mfma_f32_16x16x32_f16 terms per 32 inputs, fp32 "

@@ -108,6 +108,10 @@ const char* nrhip_last_error(void);
 int nrhip_version(void);
 /* number of CUs / XCDs of the current device (host out-pointers) */
 int nrhip_device_info(int32_t* n_cus, int32_t* n_xcds, int64_t* hbm_bytes);
+/* The library's A/B switches (NRHIP_* environment variables, csrc/common.h: struct Tuning) are read once, when the library is
+ * loaded; a process that changes one afterwards calls this to have them read again.  Every switch selects between two
+ * implementations of the same result. */
+int nrhip_tuning_reload(void);
 
 /* ---- eval-time layout of the coarse levels (csrc/eval_layout.hip) ----------------------------------------------
  * Levels whose lattice (0 .. ceil(scalings[l]))^3, padded to 2^s per axis, fits the table size are copied into a shadow
@@ -160,9 +164,12 @@ int nrhip_encode_bwd_rays(const nrhip_grid* g, const void* table, float static_s
  * nrhip_encode_bwd), hand in a 16-byte aligned device buffer of at least that many bytes.  overwrite = 0: grad_table
  * is ACCUMULATED into, as above; overwrite = 1: every element of grad_table is WRITTEN (no zero-fill needed before,
  * and the pass over the table is a store instead of a read-modify-write). */
-/* Round 5: g->param_dtype describes GRAD_TABLE in the _binned entry points (the partition never reads the table): with
- * param_dtype = 1 the gradient is written as fp16 [L*T,F] -- the dtype autograd wants for an fp16-storage table, without an
- * fp32 image and a cast pass; overwrite = 1 and at most 2^23 samples (one round) only, NRHIP_ERR_UNSUPPORTED otherwise. */
+/* grad_table of the _binned entry points is ALWAYS fp32 [L*T,F]; g->param_dtype keeps its meaning (the TABLE's storage type)
+ * and is not looked at (the partition never reads the table).  (ABI 500 read it as the gradient's type; 510 does not: a caller
+ * that passes the descriptor of its fp16-storage table together with an fp32 grad_table gets fp32 again.)
+ * nrhip_encode_bwd_binned_f16 writes the gradient as fp16 [L*T,F] instead -- the dtype autograd wants for an fp16-storage
+ * table, without an fp32 image and a cast pass: every element is WRITTEN (overwrite semantics), at most 2^23 samples (one
+ * round), NRHIP_ERR_UNSUPPORTED otherwise. */
 int nrhip_encode_bwd_binned_workspace(const nrhip_grid* g, int64_t n_samples, int64_t* bytes);
 /* The same scratch size serves the two other table gradients below (it depends on the grid and the sample count
  * only): nrhip_hashgrid_bwd_binned == nrhip_hashgrid_bwd, nrhip_proposal_density_bwd_binned ==
@@ -173,6 +180,9 @@ int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, const float* 
 int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
                             const float* grad_out /*[N,L*F]*/, float* grad_table, int32_t overwrite, void* workspace,
                             int64_t workspace_bytes, void* stream);
+int nrhip_encode_bwd_binned_f16(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
+                                const float* grad_out /*[N,L*F]*/, void* grad_table_fp16, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 
 /* ---- F3: SHEncoding(levels=4) (encodings.py:797-805 -> utils/math.py:31-94) -------------------- */
 int nrhip_sh4_fwd(const float* dirs /*[N,3]*/, int64_t n, float* out /*[N,16]*/, void* stream);

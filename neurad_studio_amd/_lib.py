@@ -145,6 +145,7 @@ PROTOTYPES = {
     "nrhip_encode_bwd_rays": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P, P, P],
     "nrhip_encode_bwd_binned_workspace": [C.POINTER(Grid), I64, C.POINTER(I64)],
     "nrhip_encode_bwd_binned": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, I32, P, I64, P],
+    "nrhip_encode_bwd_binned_f16": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P, I64, P],
     "nrhip_hashgrid_bwd_binned": [C.POINTER(Grid), P, P, I64, P, I32, P, I64, P],
     "nrhip_sh4_fwd": [P, I64, P, P],
     "nrhip_mlp_fwd": [C.POINTER(Mlp), P, I64, P, P, P],
@@ -174,6 +175,7 @@ PROTOTYPES = {
     "nrhip_lidar_rays": [C.POINTER(LidarTable), P, P, I32, I64, P, P, P, P, P, P, P],
     "nrhip_patch_sample": [P, P, I64, I32, I32, I32, I32, I32, I32, P, P, I32, P, P, P, P],
     "nrhip_lidar_point_sample": [P, P, P, P, P, I32, I32, I32, I64, P, P, P],
+    "nrhip_tuning_reload": [],
     "nrhip_adam_step": [P, P, P, P, I64, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P],
     "nrhip_adam_step_many": [C.POINTER(AdamTensor), I32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                              P],

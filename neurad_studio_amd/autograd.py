@@ -408,13 +408,15 @@ class ProposalDensityFn(torch.autograd.Function):
     def backward(ctx, g):
         o, d, a, s, e, dens, lf = ctx.saved_tensors
         g = g.contiguous()
-        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g, level_features=lf)
+        gt = gdec = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # (frozen tables under a camera optimizer: rays only)
+            gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, s, e, dens, g, level_features=lf)
+            gt, gdec = _like_param(gt, ctx.ps.table.dtype), gdec.reshape(ctx.ps.decoder_weight.shape)
         go, gd = (None, None)
         if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
             go, gd = _ray_grads(ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.ps.grid, ctx.ps.table,
                                 ctx.ps.static_scale, o, d, a, s, e, _proposal_genc(dens, g, ctx.ps.decoder_weight))
-        return (_like_param(gt, ctx.ps.table.dtype), gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None,
-                None)
+        return gt, gdec, None, None, go, gd, None, None, None
 
 
 class InterlevelLossFn(torch.autograd.Function):
@@ -485,12 +487,15 @@ class ProposalRoundFn(torch.autograd.Function):
             return (None,) * 8
         gdens = ops.prop_weights_bwd(edges, dens, None if gw is None else gw.contiguous(), gdepth)
         starts, ends = edges[:, :-1], edges[:, 1:]
-        gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, starts, ends, dens, gdens, level_features=lf)
+        gt = gdec = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # (frozen tables under a camera optimizer: rays only)
+            gt, gdec = ops.proposal_density_bwd(ctx.ps, o, d, a, starts, ends, dens, gdens, level_features=lf)
+            gt, gdec = _like_param(gt, ctx.ps.table.dtype), gdec.reshape(ctx.ps.decoder_weight.shape)
         go, gd = (None, None)
         if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:  # the rays moved with a camera optimizer
             go, gd = _ray_grads(ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.ps.grid, ctx.ps.table,
                                 ctx.ps.static_scale, o, d, a, starts, ends, _proposal_genc(dens, gdens, ctx.ps.decoder_weight))
-        return _like_param(gt, ctx.ps.table.dtype), gdec.reshape(ctx.ps.decoder_weight.shape), None, None, go, gd, None, None
+        return gt, gdec, None, None, go, gd, None, None
 
 
 class PropWeightsFn(torch.autograd.Function):

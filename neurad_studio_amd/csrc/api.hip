@@ -1,6 +1,7 @@
 // Library plumbing: thread-local error string, argument validation, device info.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -23,6 +24,35 @@ int check_launch(const char* what) {
   }
   return NRHIP_OK;
 }
+
+static Tuning read_tuning() {
+  Tuning t;
+  auto env = [](const char* name) { return getenv(name); };
+  auto is = [&](const char* name, char c) {
+    const char* e = env(name);
+    return e && e[0] == c;
+  };
+  t.bin_round_log2 = 23;
+  if (const char* e = env("NRHIP_BIN_ROUND_LOG2")) {
+    const int x = atoi(e);
+    if (x >= 15 && x <= 24) t.bin_round_log2 = x;
+  }
+  t.bin_pairs = is("NRHIP_BIN_PAIRS", 'a') ? 1 : is("NRHIP_BIN_PAIRS", 'n') ? 0 : -1;
+  t.bin_transpose = !is("NRHIP_BIN_TRANSPOSE", '0');
+  t.bin_stats = env("NRHIP_BIN_STATS") != nullptr;
+  t.multi_bwd_runs = !is("NRHIP_MULTI_BWD_RUNS", '0');
+  t.mlp_generic = env("NRHIP_MLP_GENERIC") != nullptr;
+  t.mlp_split_wgrad = env("NRHIP_MLP_SPLIT_WGRAD") != nullptr;
+  t.mlp_split_bf16 = env("NRHIP_MLP_SPLIT_BF16") != nullptr;
+  t.mlp_pairs = env("NRHIP_MLP_PAIRS") ? (is("NRHIP_MLP_PAIRS", '1') ? 1 : 0) : -1;
+  t.sampler_actor_inline = is("NRHIP_SAMPLER_ACTOR_INLINE", '1');
+  t.sdf_render_pair = is("NRHIP_SDF_RENDER_PAIR", '1');
+  return t;
+}
+
+static Tuning g_tuning = read_tuning();  // at library load
+
+const Tuning& tuning() { return g_tuning; }
 
 int validate_grid(const nrhip_grid* g) {
   NR_REQUIRE(g, NRHIP_ERR_INVALID_ARG, "grid descriptor is NULL");
@@ -55,7 +85,14 @@ int validate_rays(const nrhip_rays* r) {
 extern "C" const char* nrhip_last_error(void) { return nrhip::g_err; }
 // 200: nrhip_rays.order, render_fwd_ex, ray_order.  300: nrhip_field grew eval_table / eval_layout (trailing), the training
 // glue of train_fused.hip, nrhip_field_fwd_train_ovr, nrhip_eval_layout_*.
-extern "C" int nrhip_version(void) { return 500; }
+// 510: nrhip_encode_bwd_binned / nrhip_hashgrid_bwd_binned write fp32 gradients whatever g->param_dtype says (the fp16 form
+// is nrhip_encode_bwd_binned_f16); nrhip_adam_step_many_dev (+ _workspace), nrhip_tuning_reload.
+extern "C" int nrhip_version(void) { return 510; }
+
+extern "C" int nrhip_tuning_reload(void) {
+  nrhip::g_tuning = nrhip::read_tuning();
+  return NRHIP_OK;
+}
 
 extern "C" int nrhip_device_info(int32_t* n_cus, int32_t* n_xcds, int64_t* hbm_bytes) {
   int dev = 0;

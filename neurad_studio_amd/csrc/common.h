@@ -11,6 +11,24 @@ namespace nrhip {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// A/B switches of the library (NRHIP_* environment variables): read ONCE, when the library is loaded, into this struct --
+// no getenv on any dispatch path.  A process that flips a switch afterwards (the parity tests, scripts/final_measure.sh's
+// alternating runs) calls nrhip_tuning_reload().  Every switch selects between two implementations of the SAME result.
+struct Tuning {
+  int bin_round_log2;        // NRHIP_BIN_ROUND_LOG2 in 15..24: samples per round of the binned table gradient; default 23
+  int bin_pairs;             // NRHIP_BIN_PAIRS: 1 "all", 0 "none", -1 unset (x-pair records at F = 1 only)
+  bool bin_transpose;        // NRHIP_BIN_TRANSPOSE != "0": sample-index-major walk of coherent chunks (default on)
+  bool bin_stats;            // NRHIP_BIN_STATS: print the record count of every round (synchronises; diagnostic)
+  bool multi_bwd_runs;       // NRHIP_MULTI_BWD_RUNS != "0": run combining in the actor-grid gradient (default on)
+  bool mlp_generic;          // NRHIP_MLP_GENERIC: per-layer MLP kernels instead of the chained ones
+  bool mlp_split_wgrad;      // NRHIP_MLP_SPLIT_WGRAD: weight gradients outside the chained backward
+  bool mlp_split_bf16;       // NRHIP_MLP_SPLIT_BF16: 3-way bf16 split products in the composited render kernels
+  int mlp_pairs;             // NRHIP_MLP_PAIRS: 1 / 0, -1 unset (fp16-pair products: the default)
+  bool sampler_actor_inline; // NRHIP_SAMPLER_ACTOR_INLINE == "1": per-chunk in-box lookup in the fused sampler
+  bool sdf_render_pair;      // NRHIP_SDF_RENDER_PAIR == "1": two rays per wave in sdf_render_fwd/bwd
+};
+const Tuning& tuning();
+
 #define NR_REQUIRE(cond, code, ...)  \
   do {                               \
     if (!(cond)) {                   \
@@ -385,28 +403,11 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ wf, int lan
 #pragma unroll
     for (int mb = 0; mb < NBLK; ++mb)
       a[mb] = *reinterpret_cast<const f32x4*>(wf + ((mb * (NS / 4) + s4) * 64 + lane) * 4);
-#ifdef NRHIP_EXP_BF16_PROXY
-    // experiment (scripts/build_variant.sh): the matrix-pipe load of a split-bf16 formulation -- six 8-cycle bf16 MFMAs per
-    // (16 outputs x 16 inputs) block on whatever bits the fp32 operands hold: WRONG results, realistic timing
-    using s16x4 = __attribute__((ext_vector_type(4))) short;
-    const s16x4 bb0 = __builtin_bit_cast(s16x4, float2{b[4 * s4], b[4 * s4 + 1]});
-    const s16x4 bb1 = __builtin_bit_cast(s16x4, float2{b[4 * s4 + 2], b[4 * s4 + 3]});
-#pragma unroll
-    for (int rep = 0; rep < 3; ++rep)
-#pragma unroll
-      for (int mb = 0; mb < NBLK; ++mb) {
-        const s16x4 aa0 = __builtin_bit_cast(s16x4, float2{a[mb][0], a[mb][1]});
-        const s16x4 aa1 = __builtin_bit_cast(s16x4, float2{a[mb][2], a[mb][3]});
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aa0, bb0, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aa1, bb1, acc[mb], 0, 0, 0);
-      }
-#else
 #pragma unroll
     for (int s3 = 0; s3 < 4; ++s3)
 #pragma unroll
       for (int mb = 0; mb < NBLK; ++mb)
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][s3], b[4 * s4 + s3], acc[mb], 0, 0, 0);
-#endif
   }
 }
 

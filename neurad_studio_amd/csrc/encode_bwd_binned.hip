@@ -58,23 +58,13 @@ __device__ constexpr int kPairC[4] = {0, 1, 4, 5};
 // round (memset, two scan launches, the tails of five kernels) is paid once, and with >= 1024 chunks a count / emit
 // workgroup walks all levels of its samples instead of one (positions and per-sample factors loaded once).
 // NRHIP_BIN_ROUND_LOG2 (15..24) overrides, for A/B runs.
-int64_t round_samples() {  // (read per call: a getenv is nothing next to seven launches, and tests flip it)
-  int lg = 23;
-  if (const char* e = getenv("NRHIP_BIN_ROUND_LOG2")) {
-    const int x = atoi(e);
-    if (x >= 15 && x <= 24) lg = x;
-  }
-  return (int64_t)1 << lg;
-}
+int64_t round_samples() { return (int64_t)1 << tuning().bin_round_log2; }
 
 // X-pair records pay where the record is small: F = 1 (12 instead of 2 x 8 bytes per corner pair, half the LDS rank atomics:
 // emit<1> 539 -> 393 us per c3 call).  At F = 4 they were measured SLOWER (emit 754 -> 848, reduce 592 -> 858 us: 36-byte
 // records, 8 values per DPP chain), so wider grids keep one corner term per record.  NRHIP_BIN_PAIRS=all|none overrides (A/B).
 bool use_pairs(int F) {
-  if (const char* e = getenv("NRHIP_BIN_PAIRS")) {
-    if (e[0] == 'a') return true;
-    if (e[0] == 'n') return false;
-  }
+  if (tuning().bin_pairs >= 0) return tuning().bin_pairs == 1;
   return F == 1;
 }
 
@@ -305,10 +295,7 @@ __device__ __forceinline__ int coherent_rays_of(const RaysDev& r, int64_t first_
   return (same_o && c1 > 0.9999f && c2 > 0.99f) ? nr : 0;  // (unit directions: < 0.8 deg to the next ray, < 8 deg across the chunk)
 }
 
-bool transposed_walk_enabled() {  // NRHIP_BIN_TRANSPOSE=0: ray-major everywhere (A/B)
-  const char* e = getenv("NRHIP_BIN_TRANSPOSE");
-  return !(e && e[0] == '0');
-}
+bool transposed_walk_enabled() { return tuning().bin_transpose; }  // NRHIP_BIN_TRANSPOSE=0: ray-major everywhere (A/B)
 
 template <class Src>
 __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, int64_t n, int64_t n_total,
@@ -757,8 +744,9 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
              "%s: workspace of %lld bytes, need %zu", what, (long long)workspace_bytes, p.total_bytes);
   NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
              NRHIP_ERR_INVALID_ARG, "%s: workspace and grad_table must be 16-byte aligned", what);
-  // grid.param_dtype describes grad_table here (the partition never reads the table itself): 1 = an fp16 gradient for an
-  // fp16-storage table, written once -- overwrite mode and a single round only (no fp16 read-modify-write)
+  // gd.dtype describes GRAD_TABLE here -- set by the entry point, never taken from the caller's descriptor (the partition
+  // does not read the table, whose storage type the descriptor's param_dtype names): 1 = an fp16 gradient for an fp16-storage
+  // table, written once -- overwrite mode and a single round only (no fp16 read-modify-write)
   const bool out_half = gd.dtype == 1;
   NR_REQUIRE(!out_half || (overwrite && n <= round_samples()), NRHIP_ERR_UNSUPPORTED,
              "%s: an fp16 grad_table needs overwrite = 1 and at most %lld samples (one round)", what, (long long)round_samples());
@@ -802,7 +790,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     if (nseg > 1) bin_scan_segments_kernel<<<(cols + 255) / 256, 256, 0, st>>>(segtot, nseg, cols, totals);
     bin_scan_totals_kernel<<<1, 1024, 0, st>>>(totals, cols, offsets);
     if (int e = check_launch(what)) return e;
-    if (getenv("NRHIP_BIN_STATS")) {  // diagnostic (synchronises): how many records this round sends
+    if (tuning().bin_stats) {  // diagnostic (synchronises): how many records this round sends
       uint32_t total = 0;
       (void)hipStreamSynchronize(st);
       (void)hipMemcpy(&total, offsets + cols, sizeof(total), hipMemcpyDeviceToHost);
@@ -849,10 +837,26 @@ extern "C" int nrhip_encode_bwd_binned(const nrhip_grid* g, float static_scale, 
   NR_REQUIRE(grad_out && grad_table && static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "encode_bwd_binned: bad argument");
   const int64_t n = rays->n_rays * rays->n_samples;
   if (n == 0) return NRHIP_OK;
-  const GridDev gd = to_dev(*g);
+  GridDev gd = to_dev(*g);
+  gd.dtype = 0;  // fp32 grad_table, whatever the table's storage type (g->param_dtype) is
   const EncodeSrc src{to_dev(*rays), static_scale, grad_out, gd.L, gd.L * gd.F};
   return run_binned("encode_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
                     (hipStream_t)stream);
+}
+
+extern "C" int nrhip_encode_bwd_binned_f16(const nrhip_grid* g, float static_scale, const nrhip_rays* rays,
+                                           const float* grad_out, void* grad_table_fp16, void* workspace,
+                                           int64_t workspace_bytes, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  if (int e = validate_rays(rays)) return e;
+  NR_REQUIRE(grad_out && grad_table_fp16 && static_scale > 0.f, NRHIP_ERR_INVALID_ARG, "encode_bwd_binned_f16: bad argument");
+  const int64_t n = rays->n_rays * rays->n_samples;
+  NR_REQUIRE(n > 0, NRHIP_ERR_INVALID_ARG, "encode_bwd_binned_f16: every element is written: at least one sample");
+  GridDev gd = to_dev(*g);
+  gd.dtype = 1;  // fp16 grad_table
+  const EncodeSrc src{to_dev(*rays), static_scale, grad_out, gd.L, gd.L * gd.F};
+  return run_binned("encode_bwd_binned_f16", gd, src, n, static_cast<float*>(grad_table_fp16), true, workspace,
+                    workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, const float* grad_out, int64_t n,
@@ -861,7 +865,8 @@ extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, co
   if (int e = validate_grid(g)) return e;
   NR_REQUIRE(x && grad_out && grad_table && n >= 0, NRHIP_ERR_INVALID_ARG, "hashgrid_bwd_binned: bad argument");
   if (n == 0) return NRHIP_OK;
-  const GridDev gd = to_dev(*g);
+  GridDev gd = to_dev(*g);
+  gd.dtype = 0;  // fp32 grad_table
   const GridSrc src{x, grad_out, gd.L, gd.L * gd.F};
   return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
                     (hipStream_t)stream);

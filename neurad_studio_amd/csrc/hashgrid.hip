@@ -655,8 +655,7 @@ extern "C" int nrhip_hashgrid_multi_bwd(const nrhip_grid* g, int32_t n_grids, co
   if (n == 0) return NRHIP_OK;
   NR_REQUIRE(grid_id && x && grad_out && grad_tables, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd: null pointer");
   const GridDev gd = to_dev(*g);
-  const char* rc = getenv("NRHIP_MULTI_BWD_RUNS");  // 0: one thread per (row, level), every corner term its own atomic (A/B)
-  if (rc && rc[0] == '0') {
+  if (!tuning().multi_bwd_runs) {  // NRHIP_MULTI_BWD_RUNS=0: one thread per (row, level), every corner term its own atomic (A/B)
     const int blocks = grid_for(n * gd.L, 256);
 #define CALL(F) hashgrid_multi_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables)
     DISPATCH_F(gd.F, CALL);

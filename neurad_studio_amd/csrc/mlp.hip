@@ -336,10 +336,7 @@ int mlp_chain_bwd_residual(const nrhip_mlp* m, const float* x, const float* hidd
                            int64_t n, float* g_geo, float* dz, float* part, int64_t part_floats, float* const* gw,
                            float* const* gbias, int* done_mask, void* stream);
 int64_t mlp_chain_part_floats(const nrhip_mlp* m);
-static bool use_chain() {
-  static const bool off = getenv("NRHIP_MLP_GENERIC") != nullptr;  // A/B switch (tests run both paths)
-  return !off;
-}
+static bool use_chain() { return !tuning().mlp_generic; }  // NRHIP_MLP_GENERIC: A/B switch (tests run both paths)
 
 int validate_mlp(const nrhip_mlp* m) {
   NR_REQUIRE(m, NRHIP_ERR_INVALID_ARG, "mlp descriptor is NULL");
@@ -474,7 +471,7 @@ extern "C" int nrhip_mlp_bwd(const nrhip_mlp* m, const float* x, const float* hi
   if (use_chain() && d.nl > 1) {
     // room behind the dZ block (nrhip_mlp_bwd_workspace) lets the chained kernel produce the weight gradients too
     const int64_t part_off = (dz_floats(m, n) + 3) & ~(int64_t)3;
-    static const bool no_fused_wgrad = getenv("NRHIP_MLP_SPLIT_WGRAD") != nullptr;  // A/B switch
+    const bool no_fused_wgrad = tuning().mlp_split_wgrad;  // NRHIP_MLP_SPLIT_WGRAD: A/B switch
     const int64_t part_floats = no_fused_wgrad ? 0 : workspace_floats - part_off;
     chained = mlp_chain_bwd(m, x, hidden, grad_y, n, grad_x, workspace, part_floats > 0 ? workspace + part_off : nullptr,
                             part_floats > 0 ? part_floats : 0, grad_weight, grad_bias, &wgrad_done, stream);

@@ -138,10 +138,6 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t lo_src, uint32_t hi_src) 
 __device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3) {
   const float x[4] = {x0, x1, x2, x3};
   uint32_t h[4], m[4], l[4];
-#ifdef NRHIP_EXP_CHEAP_SPLIT  // experiment: no splitting arithmetic (wrong results) -- what does the VALU work of the split cost?
-#pragma unroll
-  for (int k = 0; k < 4; ++k) h[k] = m[k] = l[k] = __float_as_uint(x[k]);
-#else
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     h[k] = __float_as_uint(x[k]) & 0xffff0000u;
@@ -149,7 +145,6 @@ __device__ __forceinline__ Split4 split4(float x0, float x1, float x2, float x3)
     m[k] = __float_as_uint(r1) & 0xffff0000u;
     l[k] = __float_as_uint(r1 - __uint_as_float(m[k]));  // exact; its upper half is taken at the packing
   }
-#endif
   Split4 s;
   s.h = __builtin_bit_cast(bf16x4, uint2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])});
   s.m = __builtin_bit_cast(bf16x4, uint2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])});
@@ -1176,14 +1171,29 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
   const hipStream_t st = (hipStream_t)stream;
   const int L = f->grid.num_levels, F = f->grid.n_features, H = f->geo.hidden_dim;
   const bool half = f->grid.param_dtype == 1;
-  // NRHIP_MLP_SPLIT_BF16=1 (read per call; 64-wide MLPs, composited output): the per-tile matrix products run as 3-way
+  // NRHIP_MLP_SPLIT_BF16=1 (64-wide MLPs, composited output): the per-tile matrix products run as 3-way
   // split bf16 on the matrix cores (mfma_layer_split) instead of the fp32 MFMA.  Same results to fp32 accuracy; NOT the
   // default because it measured no faster (163 vs 163 us on config[1]: the splitting costs the vector ALU what the matrix
   // pipe saves -- DESIGN.md §9).
-  const bool split_bf16 = getenv("NRHIP_MLP_SPLIT_BF16") != nullptr;
+  const bool split_bf16 = tuning().mlp_split_bf16;
   // NRHIP_MLP_PAIRS (default 1): the same products as fp16 pairs (mfma_layer_pairs; composited output)
-  const char* pairs_env = getenv("NRHIP_MLP_PAIRS");
-  const bool pairs = pairs_env ? pairs_env[0] == '1' : kPairsDefault;
+  const bool pairs = tuning().mlp_pairs >= 0 ? tuning().mlp_pairs == 1 : kPairsDefault;
+  if constexpr (COMPOSITE) {
+    // eval table given (nrhip_field.eval_table / eval_layout): the coarse levels are read from their shadow copies.  Decided
+    // FIRST: a caller that hands the table over asked for this kernel; it exists with fp32-MFMA products only (the
+    // static_assert above: the relayout and the split / pair products do not combine), so it wins over the pair default.
+    if (f->eval_table && f->eval_layout) {
+      FieldDev fe = fd;
+      fe.table = f->eval_table;
+#define RCASE(L_, F_, H_)                                                                                              \
+  if (L == L_ && F == F_ && H == H_)                                                                                   \
+    return half ? launch_render<L_, F_, H_, true, true, false, false, true>(fe, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)  \
+                : launch_render<L_, F_, H_, false, true, false, false, true>(fe, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+      RCASE(16, 2, 64)
+      RCASE(8, 4, 32)
+      RCASE(8, 4, 64)
+#undef RCASE
+    }
   if constexpr (COMPOSITE) {
     if (H == 64 && pairs && !split_bf16) {
 #define PCASE(L_, F_)                                                                                                  \
@@ -1220,20 +1230,6 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
 #undef SCASE
     }
   }
-  if constexpr (COMPOSITE) {
-    // eval table given (nrhip_field.eval_table / eval_layout): the coarse levels are read from their shadow copies
-    if (f->eval_table && f->eval_layout) {
-      FieldDev fe = fd;
-      fe.table = f->eval_table;
-#define RCASE(L_, F_, H_)                                                                                              \
-  if (L == L_ && F == F_ && H == H_)                                                                                   \
-    return half ? launch_render<L_, F_, H_, true, true, false, false, true>(fe, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)  \
-                : launch_render<L_, F_, H_, false, true, false, false, true>(fe, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
-      RCASE(16, 2, 64)
-      RCASE(8, 4, 32)
-      RCASE(8, 4, 64)
-#undef RCASE
-    }
   }
 #define CASE(L_, F_, H_)                                                                                          \
   if (L == L_ && F == F_ && H == H_) {                                                                            \

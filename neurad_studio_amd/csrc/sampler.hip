@@ -695,8 +695,7 @@ static int sampler_fwd(const nrhip_sampler_cfg* cfg, const nrhip_proposal* props
                                                                            r, slab_len, cand_count, cand_actor, cand_w2b,
                                                                            bounds, 0);
   } else if (actors) {
-    const char* ia = getenv("NRHIP_SAMPLER_ACTOR_INLINE");  // 1: the round-2..4 per-chunk lookup (A/B against the dense pass)
-    const int inline_actors = (ia && ia[0] == '1') ? 1 : 0;
+    const int inline_actors = tuning().sampler_actor_inline ? 1 : 0;  // NRHIP_SAMPLER_ACTOR_INLINE=1: the round-2..4 per-chunk lookup (A/B)
     if (lt == 6)
       proposal_sampler_kernel<false, 6, true><<<(int)blocks, 256, lds, st>>>(sd, origins, directions, pixel_area, nears, fars,
                                                                             r, slab_len, cand_count, cand_actor, cand_w2b,

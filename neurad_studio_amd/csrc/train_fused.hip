@@ -862,10 +862,7 @@ __global__ __launch_bounds__(256) void lidar_losses_bwd_kernel(LidarBwdArgs A) {
 using namespace nrhip;
 
 // two rays per wave (sdf_render_*_pair_kernel): NRHIP_SDF_RENDER_PAIR=1, rays of at most 32 samples with 32 channels
-static bool sdf_render_pair(int s, int c) {
-  const char* e = getenv("NRHIP_SDF_RENDER_PAIR");
-  return e && e[0] == '1' && s <= 32 && c == 32;
-}
+static bool sdf_render_pair(int s, int c) { return tuning().sdf_render_pair && s <= 32 && c == 32; }
 
 #define TF_LAUNCH_RAYS(KERNEL, R_, LDS_, stream, ...)                                                              \
   KERNEL<<<(int)(((R_) + kRaysPerBlock - 1) / kRaysPerBlock), 64 * kRaysPerBlock, LDS_, (hipStream_t)stream>>>( \

@@ -324,7 +324,10 @@ def encode_bwd(spec: GridSpec, static_scale: float, origins, directions, pixel_a
                      dtype=torch.float16 if half else torch.float32)
     g = spec.c_grid(gt)
     ws = _table_grad_workspace(g, n, origins.device)
-    if ws is not None:  # overwrite = 1: the partition writes every element of the gradient, no zero-fill
+    if ws is not None and half:  # the fp16 gradient of an fp16-storage table, written by the partition itself
+        call("nrhip_encode_bwd_binned_f16", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), _ptr(ws),
+             ws.numel(), _stream())
+    elif ws is not None:  # overwrite = 1: the partition writes every element of the gradient, no zero-fill
         call("nrhip_encode_bwd_binned", C.byref(g), float(static_scale), C.byref(r), _ptr(grad_out), _ptr(gt), 1,
              _ptr(ws), ws.numel(), _stream())
     else:  # tables too large to cut into LDS slices, or a tiny batch: memory-side atomics (fp32 only)
@@ -1217,6 +1220,11 @@ def adam_step_many_dev(items, lr, beta1: float = 0.9, beta2: float = 0.999, eps:
     call("nrhip_adam_step_many_dev", arr, len(items), 0.0 if lr_dev is not None else float(lr), lr_dev, float(beta1),
          float(beta2), float(eps), float(weight_decay), float(host_grad_scale), scalar(grad_scale, "grad_scale"),
          scalar(found_inf, "found_inf"), workspace.data_ptr(), _stream())
+
+
+def reload_tuning() -> None:
+    """the library reads its NRHIP_* A/B switches once at load; call this after changing one inside a running process"""
+    call("nrhip_tuning_reload")
 
 
 def device_info():

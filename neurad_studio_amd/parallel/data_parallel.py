@@ -115,8 +115,16 @@ class GradientSynchronizer:
         self.large_threshold = large_threshold_bytes
         self.usage = usage
         self.overlap = overlap
-        if wire_dtype not in (None, torch.bfloat16, torch.float16):
-            raise ValueError("wire_dtype: None (fp32), torch.bfloat16 or torch.float16")
+        if wire_dtype not in (None, torch.bfloat16):
+            # fp16 is not offered: under the trainer's GradScaler the table gradients carry a 2^16 scale, a single rounding to
+            # fp16 overflows to inf on the wire and the step is skipped on every rank
+            raise ValueError("wire_dtype: None (fp32) or torch.bfloat16")
+        if wire_dtype is not None and level_tables:
+            import warnings
+
+            warnings.warn("GradientSynchronizer: wire_dtype applies to plain large gradients only; tables listed in "
+                          "level_tables keep fp32 on the wire (their dense level runs go through the fp32 reduce-scatter)",
+                          stacklevel=2)
         # 16-bit reduce-scatter leg of the LARGE fp32 gradients (scatter_16bit_*): rounded once per rank, summed in fp32 on
         # the owning rank, the fp32 mean all-gathered -- replicas stay bit-identical, 6 instead of 8 bytes per element on
         # the wire.  Level tables and small gradients keep fp32.
@@ -124,7 +132,7 @@ class GradientSynchronizer:
         self._agreed: Optional[List[bool]] = None      # usage == "static": the set agreed at the first sync
         self._agreed_all: Optional[List[bool]] = None  # ... and the parameters EVERY rank holds a local gradient for
         self._local_at_agreement: Optional[List[bool]] = None
-        self._inflight: Dict[int, Tuple[object, Tensor, Tensor]] = {}  # param index -> (work, flat grad, shard)
+        self._inflight: Dict[int, tuple] = {}  # param index -> (work, flat grad, shard | 16-bit receive buffer, is 16-bit)
         self._inflight_levels: Dict[int, tuple] = {}   # level table -> (counts, count all-reduce, compaction aux, dense runs)
         self._dense_prev: Dict[int, set] = {}          # level table -> the levels that went densely in the previous step
         self.overlapped_level_runs_last_step = 0       # dense level runs whose exchange a hook started (last sync())
@@ -214,19 +222,19 @@ class GradientSynchronizer:
             if not async_op:
                 self._finish_large(flat, scatter_16bit_finish(recv, self.wire_dtype))
                 return
-            self._inflight[i] = (work, flat, recv)
+            self._inflight[i] = (work, flat, recv, True)
             return
         work, shard = reduce_scatter_flat(flat, self.world_size(), self.group, async_op)
         if not async_op:
             self._finish_large(flat, shard)
             return
-        self._inflight[i] = (work, flat, shard)
+        self._inflight[i] = (work, flat, shard, False)
 
     def _wire16(self, g: Tensor) -> bool:
         return self.wire_dtype is not None and g.dtype == torch.float32
 
-    def _finish_large(self, flat: Tensor, shard: Optional[Tensor]) -> None:
-        if shard is not None and shard.dtype == torch.int16:  # hook-started 16-bit scatter: the owner's fp32 sum first
+    def _finish_large(self, flat: Tensor, shard: Optional[Tensor], wire16: bool = False) -> None:
+        if wire16:  # hook-started 16-bit scatter (tagged in _inflight): `shard` is the receive buffer, the owner's fp32 sum first
             shard = scatter_16bit_finish(shard, self.wire_dtype)
         if shard is None:  # the backend had no reduce-scatter for this device: `flat` already holds the full sum
             if self.average:
@@ -446,9 +454,9 @@ class GradientSynchronizer:
                 self.last_wire_bytes_by_param[i] = (world - 1) * g.numel() * per_elt // world
                 self.last_wire_bytes += self.last_wire_bytes_by_param[i]
             if i in self._inflight:  # started from the hook: wait for the scatter, finish with the gather
-                work, flat, shard = self._inflight.pop(i)
+                work, flat, shard, wire16 = self._inflight.pop(i)
                 work.wait()
-                self._finish_large(flat, shard)
+                self._finish_large(flat, shard, wire16)
             elif self._is_large(g):
                 # reduce-scatter + all-gather in place on the gradient's own storage: every link busy, no staging copy
                 self._start_large(i, async_op=False)

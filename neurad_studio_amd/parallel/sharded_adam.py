@@ -44,8 +44,8 @@ class ShardedTableAdam:
         if usage not in ("dynamic", "static"):
             raise ValueError("usage must be 'dynamic' or 'static'")
         self.usage = usage
-        if wire_dtype not in (None, torch.bfloat16, torch.float16):
-            raise ValueError("wire_dtype: None (fp32), torch.bfloat16 or torch.float16")
+        if wire_dtype not in (None, torch.bfloat16):  # (fp16 would overflow under a GradScaler's 2^16: data_parallel.py)
+            raise ValueError("wire_dtype: None (fp32) or torch.bfloat16")
         # 16-bit gradient leg (data_parallel.scatter_16bit_*): rounded once per rank, summed in fp32 on the owning rank, whose
         # Adam step then runs on that fp32 sum; the parameters come back in fp32: 6 instead of 8 bytes per element per step
         self.wire_dtype = wire_dtype

@@ -29,3 +29,32 @@ def rel_l2(a, b):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+class _Switches:
+    """The library reads its NRHIP_* A/B switches once, at load (csrc/common.h: struct Tuning); a test that flips one sets the
+    variable AND has the library read it again -- and once more when the test is over and the variable is restored."""
+
+    def __init__(self, monkeypatch):
+        self.mp = monkeypatch
+
+    def _reload(self):
+        from neurad_studio_amd import ops
+
+        ops.reload_tuning()
+
+    def set(self, name, value):
+        self.mp.setenv(name, value)
+        self._reload()
+
+    def unset(self, name):
+        self.mp.delenv(name, raising=False)
+        self._reload()
+
+
+@pytest.fixture
+def switches(monkeypatch):
+    s = _Switches(monkeypatch)
+    yield s
+    monkeypatch.undo()
+    s._reload()

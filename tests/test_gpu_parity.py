@@ -398,13 +398,13 @@ def test_full_size_properties_config2(ops):
 @pytest.mark.parametrize("cfg", [(16, 2, 19, 4096, 128), (8, 4, 16, 257, 33), (4, 8, 12, 64, 7), (6, 1, 20, 300, 48),
                                  (2, 4, 9, 5, 3), (6, 1, 14, 9001, 128),  # > 64 chunks: the two-level chunk prefix
                                  (6, 1, 14, 9001, 128, 18), (8, 4, 16, 2051, 33, 15)])  # rounds of 2^18 / 2^15 samples
-def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
+def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch, switches):
     """B1 table gradient: the owner-computes path (LDS slices, no memory-side atomics) against the atomic
     scatter-add, from BASELINE config 2 at full size down to ragged batches and tables smaller than one slice.
     Same terms, different summation order -> agreement to fp32 rounding; linearity in grad_out is exact-ish too.
     A sixth entry sets NRHIP_BIN_ROUND_LOG2: the batch then goes through in several rounds."""
     if len(cfg) == 6:
-        monkeypatch.setenv("NRHIP_BIN_ROUND_LOG2", str(cfg[5]))
+        switches.set("NRHIP_BIN_ROUND_LOG2", str(cfg[5]))
     L, F, lg, R, S = cfg[:5]
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     o, d, area, s, e, eu = _sample_rays(R, S, seed=5)
@@ -435,7 +435,7 @@ def test_encode_bwd_binned_equals_atomic_scatter(ops, cfg, monkeypatch):
 
 @pytest.mark.parametrize("mode", ["0", "1"], ids=["ray-major", "sample-index-major"])
 @pytest.mark.parametrize("cfg", [(6, 1, 14, 128), (6, 1, 14, 64), (8, 4, 15, 32), (8, 4, 15, 16), (16, 2, 14, 64)])
-def test_table_gradient_on_coherent_chunks_every_walk(ops, cfg, mode, monkeypatch):
+def test_table_gradient_on_coherent_chunks_every_walk(ops, cfg, mode, monkeypatch, switches):
     """Camera-patch rays (one origin, directions a fraction of a degree apart): `prep` then walks a 4096-sample chunk
     sample-index-major (a 16-lane row = 16 neighbouring rays at one sample index) instead of ray-major
     (NRHIP_BIN_TRANSPOSE = 1 / 0).  Either walk sends the same terms: the result equals the atomic scatter-add, with silent
@@ -443,7 +443,7 @@ def test_table_gradient_on_coherent_chunks_every_walk(ops, cfg, mode, monkeypatc
     proposal-density path.  (The coherent walk had no test of its own before round 5; the round's third walk, quads, was
     held to this test too before it was measured slower and reverted: profiles/r05_quad_walk_rejected.diff.)"""
     L, F, lg, S = cfg
-    monkeypatch.setenv("NRHIP_BIN_TRANSPOSE", mode)
+    switches.set("NRHIP_BIN_TRANSPOSE", mode)
     spec = ops.GridSpec(L, F, lg, 16, 2048)
     R = 4096 // S * 5 + 7  # five coherent chunks and a ragged one
     o = np.tile(np.array([[1.5, -2.0, 0.7]], np.float32), (R, 1))

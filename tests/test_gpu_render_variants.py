@@ -220,7 +220,7 @@ def test_early_ray_termination_bounded(ops, use_sdf):
         ops.render_fwd(*args, early_stop_eps=1.5)
 
 
-def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
+def test_split_bf16_matrix_products_are_fp32_equivalent(switches):
     """NRHIP_MLP_SPLIT_BF16: the fused render kernel's MLP layers as 3-way split bf16 on the matrix cores (six bf16 MFMAs
     per 16 x 16 block keep every product term above 2^-24).  Same outputs as the fp32-MFMA kernel to fp32 rounding, and the
     same parity against the oracle -- on config[1]'s shape (16 levels, 64-wide) and on 8 x 4 levels."""
@@ -232,10 +232,10 @@ def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
         R, S = 300, 72
         o, d, area, s, e, _ = _sample_rays(R, S, seed=11)
         args = (fs, dev(o), dev(d), dev(area), dev(s), dev(e))
-        monkeypatch.delenv("NRHIP_MLP_SPLIT_BF16", raising=False)
-        monkeypatch.setenv("NRHIP_MLP_PAIRS", "0")  # (the default since round 5 is the fp16-pair form, tested below)
+        switches.unset("NRHIP_MLP_SPLIT_BF16")
+        switches.set("NRHIP_MLP_PAIRS", "0")  # (the default since round 5 is the fp16-pair form, tested below)
         f32 = ops.render_fwd(*args, return_weights=True)
-        monkeypatch.setenv("NRHIP_MLP_SPLIT_BF16", "1")
+        switches.set("NRHIP_MLP_SPLIT_BF16", "1")
         spl = ops.render_fwd(*args, return_weights=True)
         for a, b in zip(f32, spl):
             assert rel_l2(host(b), host(a)) < 1e-6
@@ -244,7 +244,7 @@ def test_split_bf16_matrix_products_are_fp32_equivalent(monkeypatch):
         assert rel_l2(host(spl[0][:32]), ref["features"]) < 1e-5
 
 
-def test_fp16_pair_matrix_products_are_fp32_equivalent(monkeypatch):
+def test_fp16_pair_matrix_products_are_fp32_equivalent(switches):
     """The default of the composited kernels since round 5 (NRHIP_MLP_PAIRS=0 switches it off): the fused render
     kernel's MLP layers as fp16 pairs on the matrix cores (x = fp16(x) + fp16(x - fp16(x)),
     three v_mfma_f32_16x16x32_f16 per 32 inputs; the tile runs in units of 2^6 and the weights are staged x 2^7 so that the
@@ -259,11 +259,11 @@ def test_fp16_pair_matrix_products_are_fp32_equivalent(monkeypatch):
     rays = (dev(o), dev(d), dev(area), dev(s), dev(e))
 
     def both(fs):
-        monkeypatch.setenv("NRHIP_MLP_PAIRS", "0")
+        switches.set("NRHIP_MLP_PAIRS", "0")
         a = ops.render_fwd(fs, *rays, return_weights=True)
-        monkeypatch.setenv("NRHIP_MLP_PAIRS", "1")
+        switches.set("NRHIP_MLP_PAIRS", "1")
         b = ops.render_fwd(fs, *rays, return_weights=True)
-        monkeypatch.delenv("NRHIP_MLP_PAIRS")
+        switches.unset("NRHIP_MLP_PAIRS")
         return a, b
 
     for L, F, mn, mx, H in ((16, 2, 16, 1024, 64), (8, 4, 32, 8192, 64), (4, 8, 32, 2048, 64), (8, 4, 32, 8192, 32),

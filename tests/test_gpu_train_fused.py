@@ -80,10 +80,10 @@ def _torch_sdf_render(sdf, beta, beta_min, feat, edges):
 @pytest.mark.parametrize("pair", ["0", "1"], ids=["ray-per-wave", "two-rays-per-wave"])
 @pytest.mark.parametrize("cfg", [(23, 32, 32, 16, 2.5), (7, 70, 32, 0, -3.0), (9, 5, 12, 4, 0.7), (4, 2, 3, 0, 20.0),
                                  (10, 17, 32, 0, 1.5), (1, 32, 32, 0, 4.0)])
-def test_sdf_render_fwd_bwd_vs_torch(ops, cfg, pair, monkeypatch):
+def test_sdf_render_fwd_bwd_vs_torch(ops, cfg, pair, switches):
     """pair = "1": NRHIP_SDF_RENDER_PAIR, the kernels with one ray per 32-lane half (taken for S <= 32 and 32 channels; the
     odd ray counts leave a half without a ray)"""
-    monkeypatch.setenv("NRHIP_SDF_RENDER_PAIR", pair)
+    switches.set("NRHIP_SDF_RENDER_PAIR", pair)
     R, S, Cc, A, b = cfg
     sdf = dev(synth.normal((R, S), 1) * 0.5)
     feat = dev(synth.normal((R, S, Cc), 2))
