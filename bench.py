@@ -159,17 +159,20 @@ class _Optimizers:
     HashGridAdam (csrc/adam.hip, torch.optim.Adam arithmetic, one streaming kernel per table); `fields` AdamW(lr=1e-2,
     eps=1e-15, weight_decay=1e-7) and `cnn` AdamW(lr=1e-3, eps=1e-15, weight_decay=1e-6) -> torch's fused AdamW"""
 
-    def __init__(self, params, groups=None):
+    def __init__(self, params, groups=None, capturable=False):
+        """capturable: step counts on the device (HashGridAdam's device-controlled form, torch's capturable=True) so that the
+        whole step can be captured in a HIP graph"""
         from neurad_studio_amd.optim import HashGridAdam
 
         g = _split_groups(params, groups)
-        self.opts = [HashGridAdam(g["hashgrids"], lr=1e-2, eps=1e-15)] if g["hashgrids"] else []
+        kw = {"capturable": True} if capturable else {}
+        self.opts = [HashGridAdam(g["hashgrids"], lr=1e-2, eps=1e-15, **kw)] if g["hashgrids"] else []
         if g["fields"]:
-            self.opts.append(_fused(torch.optim.AdamW, g["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7))
+            self.opts.append(_fused(torch.optim.AdamW, g["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, **kw))
         if g["cnn"]:
-            self.opts.append(_fused(torch.optim.AdamW, g["cnn"], lr=1e-3, eps=1e-15, weight_decay=1e-6))
+            self.opts.append(_fused(torch.optim.AdamW, g["cnn"], lr=1e-3, eps=1e-15, weight_decay=1e-6, **kw))
         if g["trajectory_opt"]:
-            self.opts.append(_fused(torch.optim.Adam, g["trajectory_opt"], lr=1e-3, eps=1e-15))
+            self.opts.append(_fused(torch.optim.Adam, g["trajectory_opt"], lr=1e-3, eps=1e-15, **kw))
 
     def zero_grad(self, set_to_none=True):
         for o in self.opts:
@@ -256,7 +259,11 @@ _OPT_GROUPS = ("the reference's groups (configs/method_configs.py:415-426): hash
                "wd 1e-7), cnn AdamW(lr 1e-3, wd 1e-6); ")
 
 
-def make_optimizer(params, sharded=False, groups=None):
+def make_optimizer(params, sharded=False, groups=None, capturable=False):
+    if capturable and not sharded:
+        return _Optimizers(params, groups, capturable=True), (_OPT_GROUPS + "hash tables on nrhip_adam_step_many_dev (dense, "
+                                                              "torch.optim.Adam arithmetic, step counts on the device), the rest on "
+                                                              "torch's fused AdamW (capturable)")
     if sharded:
         return _ShardedOptimizers(params, groups), (_OPT_GROUPS + "hash tables on ShardedTableAdam (reduce-scatter of the "
                                                     "gradient, Adam on the rank's shard via nrhip_adam_step, all-gather of the "
@@ -392,7 +399,7 @@ def torch_op_attribution(step_fn, path, n=2):
 
 
 def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, rgb_decoder=True,
-                       cfg_edit=None, sharded_adam=False, sparse_exchange=False, torch_decoder=False):
+                       cfg_edit=None, sharded_adam=False, sparse_exchange=False, torch_decoder=False, graph=True):
     """The whole training step at the reference's default sizes (models/neurad.py defaults: static grid L=8, F=4, T=2^22;
     proposal grids L=6, F=1, T=2^20; 128+64 proposal samples, 32 field samples; 32-wide MLPs; 16-d appearance embedding;
     lidar head; RGB CNN decoder) on a camera+lidar joint batch: get_nff_outputs (training mode, jitter, lidar metadata) ->
@@ -423,7 +430,11 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             p.hashgrid.static_grid.hash_table.mul_(2000.0)
     params = [p for p in m.parameters() if p.requires_grad] + ([] if dec is None else list(dec.parameters()))
     groups = dict(m.get_param_groups(), cnn=[] if dec is None else list(dec.parameters()))
-    opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1, groups=groups)
+    # graph (one GPU): the static step -- no device->host read, no allocation in steady state, step counts and jitter draws on
+    # the device -- is captured ONCE in a HIP graph and the timed steps are replays of it: the ~400 launches of a step cost
+    # the host one hipGraphLaunch instead of 5-7 ms of Python + autograd + ctypes, and the GPU no longer idles between them
+    use_graph = bool(graph) and world == 1 and not torch_decoder
+    opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1, groups=groups, capturable=use_graph)
     # static scene: the used-parameter set is agreed once (no per-step host read); the proposal tables' exchange starts
     # from their gradient hooks, under the field backward
     level_tables = None
@@ -486,11 +497,32 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     for _ in range(warmup):  # the caching allocator reaches its steady state here, outside timed()'s own warm-up
         step()
     torch.cuda.synchronize()
+    eager = None
+    graph_note = "eager launches (one Python / autograd / ctypes call chain per kernel)"
+    if use_graph:
+        # the eager step first (fewer steps: the before-figure of the launch path), then the capture
+        el_e = timed(step, max(steps // 3, 5), 1, world, device)
+        eager = {"ms_per_iter": el_e / max(steps // 3, 5) * 1e3, "host_enqueue_ms_per_step": LAST_ISSUE.get("s_per_step", 0.0) * 1e3,
+                 "steps": max(steps // 3, 5)}
+        try:
+            cuda_graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(cuda_graph):
+                step()
+            eager_step, step = step, (lambda _i=None: cuda_graph.replay())
+            graph_note = ("HIP graph: the whole step (jitter draws, forward, losses, backward, optimizer) captured once with "
+                          "torch.cuda.graph, every timed step is one replay")
+        except Exception as e:  # noqa: BLE001  (a capture failure must not cost the line: the eager step is timed instead)
+            torch.cuda.synchronize()
+            use_graph = False
+            graph_note = f"eager launches (HIP graph capture failed: {type(e).__name__}: {e})"[:400]
     allocs0 = _device_allocs()
     el = timed(step, steps, 1, world, device)
     allocs1 = _device_allocs()
     host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
     assert torch.isfinite(state["loss"]), "non-finite loss"
+    if use_graph:
+        step = eager_step  # (the diagnostics below run the Python step)
     if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
         # diagnostic (not part of any line): which part of the step launches its torch library kernels (fills, adds, copies)
         from torch.profiler import record_function
@@ -572,6 +604,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
             "host_enqueue_ms_per_step": host_issue_ms,  # Python + autograd + ctypes time to issue a step, GPU not waited for
+            "launch": graph_note, "eager_launch": eager,
             "device_allocations_during_the_timed_steps": allocs1[0] - allocs0[0],  # hipMalloc calls: 0 in steady state
             "allocator_retries_during_the_timed_steps": allocs1[1] - allocs0[1],
             "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
@@ -1413,6 +1446,9 @@ def main():
                     help="train_full / c3: the RGB decoder on the torch modules (MIOpen, fp16 autocast) instead of the HIP kernels")
     ap.add_argument("--no-rgb-decoder", action="store_true", help="train_full / c3 without the RGB CNN decoder (round-2 step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="train_full / c3 on one GPU: time the eagerly launched step only (default: the step captured in a HIP "
+                         "graph, the eager figure reported beside it)")
     ap.add_argument("--no-train", action="store_true", help="skip the train iters/sec sections")
     ap.add_argument("--no-variants", action="store_true",
                     help="c1: skip the two labelled non-headline launches of the render kernel (profiling runs: their "
@@ -1485,7 +1521,7 @@ def main():
         steps = min(args.steps, 50)
         tf = train_full_section(device, rank, world, steps, max(2, min(args.warmup, 5)), rgb_decoder=not args.no_rgb_decoder,
                                 sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange,
-                                torch_decoder=args.torch_decoder)
+                                torch_decoder=args.torch_decoder, graph=not args.no_graph)
         out = {"metric": "train iters/sec (camera+lidar joint batch)", "value": tf["rays_per_sec"], "unit": "rays/s",
                "n_gpus": world, "steps": steps, "warmup": max(2, min(args.warmup, 5)), "ms_per_step": tf["ms_per_iter"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -1536,7 +1572,7 @@ def main():
                 train_full = guarded(lambda: train_full_section(device, rank, world, args.train_full_steps, 8,
                                                                 rgb_decoder=not args.no_rgb_decoder,
                                                                 sharded_adam=args.sharded_adam, sparse_exchange=args.sparse_exchange,
-                                                                torch_decoder=args.torch_decoder))
+                                                                torch_decoder=args.torch_decoder, graph=not args.no_graph))
                 if not args.no_rgb_decoder and isinstance(train_full, dict) and "error" not in train_full:
                     gc.collect()
                     torch.cuda.empty_cache()

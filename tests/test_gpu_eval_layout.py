@@ -28,8 +28,12 @@ CFGS = [  # (L, F, lg, min_res, max_res, H, n shadow levels expected)
 
 @pytest.mark.parametrize("half", [False, True], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("cfg", CFGS)
-def test_render_with_eval_layout_is_bit_identical(ops, cfg, half, monkeypatch):
+def test_render_with_eval_layout_is_bit_identical(ops, cfg, half, monkeypatch, switches):
+    """the eval-table kernel exists with fp32-MFMA products only (csrc/render.hip: the relayout and the pair products do not
+    combine) and is dispatched FIRST when a table is handed over; it is held bit for bit to the plain fp32-MFMA kernel
+    (NRHIP_MLP_PAIRS=0) -- and shown to be the kernel that ran: the default (pair) kernel's output differs in the last bits"""
     L, F, lg, mn, mx, H, n_shadow = cfg
+    switches.set("NRHIP_MLP_PAIRS", "0")
     p = field_params(use_sdf=True, L=L, F=F, lg=lg, H=H, mn=mn, mx=mx, scale=0.5)
     p.beta = 3.0
     fs = to_spec(ops, p, half=half)
@@ -50,6 +54,14 @@ def test_render_with_eval_layout_is_bit_identical(ops, cfg, half, monkeypatch):
     for a, b in zip(outs[False], outs[True]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+    switches.unset("NRHIP_MLP_PAIRS")  # pair products are the default of the composited kernels; a handed-over eval table wins
+    relay = ops.render_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], return_weights=True)
+    monkeypatch.setattr(ops, "_EVAL_RELAYOUT", False)
+    pairs = ops.render_fwd(fs, do, dd, da, edges[:, :-1], edges[:, 1:], return_weights=True)
+    monkeypatch.setattr(ops, "_EVAL_RELAYOUT", True)
+    assert torch.equal(relay[0], outs[True][0][0])  # the eval-table kernel ran, pairs or not
+    assert not torch.equal(pairs[0], relay[0]) and rel_l2(host(pairs[0]), host(relay[0])) < 1e-6
+    switches.set("NRHIP_MLP_PAIRS", "0")
     # and against the oracle on a slice (fp16: the oracle on the rounded table)
     if half:
         p.grid.table = host(fs.table.float())

@@ -763,3 +763,39 @@ def test_encode_bwd_binned_writes_the_fp16_gradient_of_an_fp16_storage_table(ops
     bad = go.clone()
     bad[3, 1] = float("nan")
     assert not torch.isfinite(ops.encode_bwd(spec, 1.0, do, dd, da, st, en, bad, out_dtype=torch.float16).float()).all()
+
+
+def test_binned_table_gradient_is_fp32_whatever_the_tables_storage_type(ops, monkeypatch):
+    """ABI 510 (include/neurad_hip.h): nrhip_encode_bwd_binned / nrhip_hashgrid_bwd_binned ignore g->param_dtype -- a C caller
+    that passes the descriptor of its fp16-storage TABLE with an fp32 grad_table gets an fp32 gradient (ABI 500 wrote fp16
+    halves into it); the fp16 form is the explicit nrhip_encode_bwd_binned_f16"""
+    import ctypes as C
+
+    from neurad_studio_amd import _lib
+
+    L, F, lg, R, S = 8, 4, 14, 300, 32
+    spec = ops.GridSpec(L, F, lg, 16, 2048)
+    o, d, area, s, e, eu = _sample_rays(R, S, seed=4)
+    do, dd, da, edges = dev(o), dev(d), dev(area), dev(eu)
+    go = dev(synth.normal((R * S, L * F), 23))
+    st, en = edges[:, :-1], edges[:, 1:]
+    monkeypatch.setattr(ops, "_FORCE_ATOMIC_SCATTER", False)
+    monkeypatch.setattr(ops, "_BINNED_MIN_SAMPLES", 1)
+    want = ops.encode_bwd(spec, 1.0, do, dd, da, st, en, go)
+    table16 = torch.zeros((spec.table_rows, F), device="cuda", dtype=torch.float16)
+    g = spec.c_grid(table16)  # param_dtype = 1: the TABLE is fp16 storage
+    assert g.param_dtype == 1
+    r, keep = ops._c_rays(do, dd, da, st, en)
+    ws = ops._table_grad_workspace(g, R * S, do.device)
+    gt = torch.full((spec.table_rows, F), float("nan"), device="cuda", dtype=torch.float32)
+    _lib.call("nrhip_encode_bwd_binned", C.byref(g), 1.0, C.byref(r), ops._ptr(go), ops._ptr(gt), 1, ops._ptr(ws), ws.numel(),
+              ops._stream())
+    assert torch.equal(gt, want)
+    x = dev(synth.uniform((500, 3), 0, 1, 5))
+    g2 = dev(synth.normal((500, L * F), 6))
+    want2 = ops.hashgrid_bwd(spec, None, x, g2)
+    gt2 = torch.full_like(gt, float("nan"))
+    ws2 = ops._table_grad_workspace(g, 500, x.device)
+    _lib.call("nrhip_hashgrid_bwd_binned", C.byref(g), ops._ptr(x), ops._ptr(g2), 500, ops._ptr(gt2), 1, ops._ptr(ws2),
+              ws2.numel(), ops._stream())
+    assert torch.equal(gt2, want2)
