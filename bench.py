@@ -430,9 +430,8 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             p.hashgrid.static_grid.hash_table.mul_(2000.0)
     params = [p for p in m.parameters() if p.requires_grad] + ([] if dec is None else list(dec.parameters()))
     groups = dict(m.get_param_groups(), cnn=[] if dec is None else list(dec.parameters()))
-    # graph (one GPU): the static step -- no device->host read, no allocation in steady state, step counts and jitter draws on
-    # the device -- is captured ONCE in a HIP graph and the timed steps are replays of it: the ~400 launches of a step cost
-    # the host one hipGraphLaunch instead of 5-7 ms of Python + autograd + ctypes, and the GPU no longer idles between them
+    # graph (one GPU): after the timed eager steps the static step -- no device->host read, no allocation in steady state, step
+    # counts and jitter draws on the device -- is also captured in a HIP graph and its replays are timed (`hip_graph_replay`)
     use_graph = bool(graph) and world == 1 and not torch_decoder
     opt, opt_name = make_optimizer(params, sharded=sharded_adam and world > 1, groups=groups, capturable=use_graph)
     # static scene: the used-parameter set is agreed once (no per-step host read); the proposal tables' exchange starts
@@ -497,66 +496,45 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     for _ in range(warmup):  # the caching allocator reaches its steady state here, outside timed()'s own warm-up
         step()
     torch.cuda.synchronize()
-    eager = None
-    graph_note = "eager launches (one Python / autograd / ctypes call chain per kernel)"
-    if use_graph:
-        # the eager step first (fewer steps: the before-figure of the launch path), then the capture
-        el_e = timed(step, max(steps // 3, 5), 1, world, device)
-        eager = {"ms_per_iter": el_e / max(steps // 3, 5) * 1e3, "host_enqueue_ms_per_step": LAST_ISSUE.get("s_per_step", 0.0) * 1e3,
-                 "steps": max(steps // 3, 5)}
-        try:
-            cuda_graph = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(cuda_graph):
-                step()
-            eager_step, step = step, (lambda _i=None: cuda_graph.replay())
-            graph_note = ("HIP graph: the whole step (jitter draws, forward, losses, backward, optimizer) captured once with "
-                          "torch.cuda.graph, every timed step is one replay")
-        except Exception as e:  # noqa: BLE001  (a capture failure must not cost the line: the eager step is timed instead)
-            torch.cuda.synchronize()
-            use_graph = False
-            graph_note = f"eager launches (HIP graph capture failed: {type(e).__name__}: {e})"[:400]
     allocs0 = _device_allocs()
     el = timed(step, steps, 1, world, device)
     allocs1 = _device_allocs()
     host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
     assert torch.isfinite(state["loss"]), "non-finite loss"
+    graph_replay = None
     if use_graph:
-        step = eager_step  # (the diagnostics below run the Python step)
-    if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
-        # diagnostic (not part of any line): which part of the step launches its torch library kernels (fills, adds, copies)
-        from torch.profiler import record_function
-
-        def marked_step():
-            with record_function("S:get_nff_outputs"):
-                rb = RayBundle(origins=o, directions=d, pixel_area=area.clone(), nears=nears, fars=None, times=times,
-                               metadata=dict(md))
-                out = m.get_nff_outputs(rb, calc_lidar_losses=True)
-            with record_function("S:lidar_head+metrics"):
-                rows = lidar_rows(is_lidar, n_lidar)
-                out["intensity"], out["ray_drop_logits"] = m.decode_lidar(out["features"], rows=rows[0])
-                terms = lidar_metrics(out, is_lidar, did_return, distance, intensity_t, lcfg, rows=rows)
-            with record_function("S:interlevel+distortion"):
-                terms["interlevel"] = zipnerf_interlevel_loss(out["weights_list"], out["ray_samples_list"])
-                terms["distortion"] = distortion_loss(out["weights_list"], out["ray_samples_list"])
-            with record_function("S:decoder+rgb_loss"):
-                if dec is not None:
-                    terms["rgb"] = torch.nn.functional.mse_loss(decode(out["features"][:n_cam]), image)
-                else:
-                    terms["feature"] = (out["features"][:n_cam] - target).square().mean()
-            with record_function("S:total_loss"):
-                loss = total_loss(terms)
-            with record_function("S:zero_grad"):
-                opt.zero_grad(set_to_none=True)
-            with record_function("S:backward_call"):
-                loss.backward()
-            with record_function("S:sync"):
-                sync.sync()
-            with record_function("S:opt.step"):
-                opt.step()
-                m.sampler.step_cb(0)
-
-        torch_op_attribution(marked_step, os.environ["NRHIP_BENCH_TORCH_PROFILE"])
+        # the same step captured ONCE in a HIP graph (torch's whole-step recipe: the previous iteration's autograd graph is
+        # released, a short warm-up runs on a side stream, then the capture) and replayed: what the launch path costs
+        try:
+            state.clear()
+            opt.zero_grad(set_to_none=True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            state.clear()
+            opt.zero_grad(set_to_none=True)
+            cuda_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cuda_graph):
+                step()
+            n_g = max(steps // 2, 5)
+            el_g = timed(lambda _i=None: cuda_graph.replay(), n_g, 2, world, device)
+            assert torch.isfinite(state["loss"]), "non-finite loss in the replayed step"
+            graph_replay = {"ms_per_iter": el_g / n_g * 1e3, "host_enqueue_ms_per_step": LAST_ISSUE.get("s_per_step", 0.0) * 1e3,
+                            "steps": n_g,
+                            "what": "the whole step (jitter draws, forward, losses, backward, optimizers with their step counts "
+                                    "on the device) captured once with torch.cuda.graph; every step is one hipGraphLaunch.  The "
+                                    "eager step above is GPU-bound already (its host enqueue time is below its duration), so "
+                                    "the replay cannot be faster than the kernels; where it is slower, that is the graph's "
+                                    "per-node dispatch"}
+            del cuda_graph
+        except Exception as e:  # noqa: BLE001  (a capture failure must not cost the line)
+            torch.cuda.synchronize()
+            graph_replay = {"error": f"{type(e).__name__}: {e}"[:400]}
+        state.clear()
+        opt.zero_grad(set_to_none=True)
     s = m.config.sampling
     # roofline of the step's largest single kernel, the fused training forward of the main field (render_kernel storing its
     # activations): timed standalone, after the timed region, on this batch's rays and 32 PowerSampler samples per ray
@@ -604,7 +582,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "rays_per_sec": world * R * steps / el, "rays_per_gpu": R, "camera_rays": n_cam, "lidar_rays": n_lidar,
             "field_samples_per_ray": s.num_nerf_samples, "proposal_samples_per_ray": list(s.num_proposal_samples),
             "host_enqueue_ms_per_step": host_issue_ms,  # Python + autograd + ctypes time to issue a step, GPU not waited for
-            "launch": graph_note, "eager_launch": eager,
+            "hip_graph_replay": graph_replay,
             "device_allocations_during_the_timed_steps": allocs1[0] - allocs0[0],  # hipMalloc calls: 0 in steady state
             "allocator_retries_during_the_timed_steps": allocs1[1] - allocs0[1],
             "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
