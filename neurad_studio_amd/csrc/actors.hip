@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void actor_pair_positions_bwd_kernel(
     ActorsDev a, RaysDev r, const float* __restrict__ times, const int64_t* __restrict__ sample_idx,
     const int32_t* __restrict__ actor_idx, const float* __restrict__ ray_flip, int64_t n_pairs,
     const float* __restrict__ g_x01, const float* __restrict__ g_cstd, float* __restrict__ g_positions,
-    float* __restrict__ g_rot6, float* __restrict__ g_origins, float* __restrict__ g_directions) {
+    float* __restrict__ g_rot6, float* __restrict__ g_origins, float* __restrict__ g_directions, int combine_runs) {
   // (no early exit: the lanes of a 16-lane row merge their contributions on DPP shifts below; lanes past the end work on the
   //  last pair with their values zeroed)
   const int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void actor_pair_positions_bwd_kernel(
       v[6 + c] = on ? wgt[e] * gt[c] : 0.f;
     }
     const uint32_t key = live ? (uint32_t)(tix[e] * a.A + act) : 0xffffffffu;
-    const bool head = live && dpp_row_shr<1>(key, ~key) != key;
+    const bool head = live && (!combine_runs || dpp_row_shr<1>(key, ~key) != key);
     const unsigned long long hm = __ballot(head);
     if (hm != __ballot(live)) {
       const uint32_t run = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull));
@@ -673,7 +673,7 @@ extern "C" int nrhip_actor_pair_positions_bwd(const nrhip_actors* a, const nrhip
              NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd: NULL pointer");
   actor_pair_positions_bwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
       d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, grad_x01, grad_cstd, grad_positions,
-      grad_rotations_6d, nullptr, nullptr);
+      grad_rotations_6d, nullptr, nullptr, tuning().pair_bwd_runs ? 1 : 0);
   return check_launch("actor_pair_positions_bwd");
 }
 
@@ -693,7 +693,7 @@ extern "C" int nrhip_actor_pair_positions_bwd_rays(const nrhip_actors* a, const 
              NRHIP_ERR_INVALID_ARG, "actor_pair_positions_bwd_rays: NULL pointer");
   actor_pair_positions_bwd_kernel<<<grid_for(n_pairs, 256), 256, 0, (hipStream_t)stream>>>(
       d, to_dev(*rays), times, sample_idx, actor_idx, ray_flip, n_pairs, grad_x01, grad_cstd, grad_positions,
-      grad_rotations_6d, grad_origins, grad_directions);
+      grad_rotations_6d, grad_origins, grad_directions, tuning().pair_bwd_runs ? 1 : 0);
   return check_launch("actor_pair_positions_bwd_rays");
 }
 

@@ -41,6 +41,7 @@ static Tuning read_tuning() {
   t.bin_transpose = !is("NRHIP_BIN_TRANSPOSE", '0');
   t.bin_stats = env("NRHIP_BIN_STATS") != nullptr;
   t.multi_bwd_runs = !is("NRHIP_MULTI_BWD_RUNS", '0');
+  t.pair_bwd_runs = !is("NRHIP_PAIR_BWD_RUNS", '0');
   t.mlp_generic = env("NRHIP_MLP_GENERIC") != nullptr;
   t.mlp_split_wgrad = env("NRHIP_MLP_SPLIT_WGRAD") != nullptr;
   t.mlp_split_bf16 = env("NRHIP_MLP_SPLIT_BF16") != nullptr;

@@ -20,6 +20,7 @@ struct Tuning {
   bool bin_transpose;        // NRHIP_BIN_TRANSPOSE != "0": sample-index-major walk of coherent chunks (default on)
   bool bin_stats;            // NRHIP_BIN_STATS: print the record count of every round (synchronises; diagnostic)
   bool multi_bwd_runs;       // NRHIP_MULTI_BWD_RUNS != "0": run combining in the actor-grid gradient (default on)
+  bool pair_bwd_runs;        // NRHIP_PAIR_BWD_RUNS != "0": run combining in the trajectory gradient (default on)
   bool mlp_generic;          // NRHIP_MLP_GENERIC: per-layer MLP kernels instead of the chained ones
   bool mlp_split_wgrad;      // NRHIP_MLP_SPLIT_WGRAD: weight gradients outside the chained backward
   bool mlp_split_bf16;       // NRHIP_MLP_SPLIT_BF16: 3-way bf16 split products in the composited render kernels

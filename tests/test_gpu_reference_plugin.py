@@ -607,3 +607,199 @@ def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
         report[n] = (float(f"{e:.1e}"), float(f"{y:.1e}"))
         assert e <= max(2.0 * y, 5e-3), (n, e, y)
     print("decoder gradients vs the reference fp32 model: (HIP decoder, torch autocast fp16):", report)
+
+
+# ---- where the gradient outliers come from: sample-level evidence --------------------------------------------------------------
+def _sample_level_gradients(hip, refm, b, terms):
+    """For each loss term: the gradient ENTERING the encodings, per sample, on both sides --
+      rows   [N, 32]  d term / d (encoding row of sample n), after the actor overwrite (neurad_encoding.py:184-185); plugin: the
+                      geometry MLP's input gradient inside autograd._field_backward; reference: .grad of NeuRADHashEncoding's output
+      pos    {(ray, sample, actor): [3]}  d term / d (contracted box-frame position of the pair); plugin: what
+                      ActorPairPositionsFn.backward receives; reference: .grad of actor_contraction's output
+    plus the reference's hidden pre-activations of the three ReLU layers, the pairs, and their contracted positions."""
+    from neurad_studio_amd import autograd as ag
+
+    ev = {"terms": {}}
+    # ---- reference side: retained gradients + pre-activations
+    hg = refm.field.hashgrid
+    cap = {}
+    real_fwd, real_idx = hg.forward, hg._get_actor_indices
+    con = hg.actor_contraction
+    real_con = con.forward
+
+    def spy_fwd(*a, **k):
+        feats, dirs = real_fwd(*a, **k)
+        feats.retain_grad()
+        cap["feats"] = feats
+        return feats, dirs
+
+    def spy_idx(*a):
+        cap["idx"] = real_idx(*a)
+        return cap["idx"]
+
+    def spy_con(x):
+        out = real_con(x)
+        out.mean.retain_grad()
+        cap["pos"] = out
+        return out
+
+    pre = {}
+    hooks = [refm.field.mlp_geo.layers[0].register_forward_hook(lambda m, i, o: pre.__setitem__("geo0", o.detach())),
+             refm.field.mlp_feature.layers[0].register_forward_hook(lambda m, i, o: pre.__setitem__("feat0", o.detach())),
+             refm.field.mlp_feature.layers[1].register_forward_hook(lambda m, i, o: pre.__setitem__("feat1", o.detach()))]
+    hg.forward, hg._get_actor_indices, con.forward = spy_fwd, spy_idx, spy_con
+    try:
+        w_out, w_loss = _losses(refm, b, "cpu")
+    finally:
+        hg.forward, hg._get_actor_indices, con.forward = real_fwd, real_idx, real_con
+        for h in hooks:
+            h.remove()
+    ri, si, ai = cap.get("idx", (torch.empty(0), torch.empty(0), torch.empty(0)))
+    keys = list(zip(ri.tolist(), si.tolist(), ai.tolist()))
+    ev["pairs"], ev["pre"] = keys, pre
+    ev["x01"] = {k: cap["pos"].mean[i].reshape(3).detach() for i, k in enumerate(keys)} if keys else {}
+    # ---- plugin side: capture inside the backward
+    rec = {}
+    real_mlp_bwd = ag.ops.mlp_bwd
+    real_pf, real_pb = ag.ActorPairPositionsFn.forward, ag.ActorPairPositionsFn.backward
+    S_main = hip.config.sampling.num_nerf_samples
+    N = len(b["o"]) * S_main
+
+    def spy_mlp_bwd(x, hidden, grad_y, weights, biases, need_grad_x=True):
+        out = real_mlp_bwd(x, hidden, grad_y, weights, biases, need_grad_x)
+        if x.shape == (N, 32) and out[0] is not None:
+            rec["rows"] = out[0].detach().clone()
+        return out
+
+    def spy_pf(ctx, positions, rot6, spec, o, d, a, starts, ends, times, idx, act, flip):
+        out = real_pf(ctx, positions, rot6, spec, o, d, a, starts, ends, times, idx, act, flip)
+        if starts.shape[1] == S_main:
+            ctx._main, rec["idx"], rec["act"], rec["x01"] = True, idx.cpu(), act.cpu(), out[0].detach().cpu()
+        return out
+
+    def spy_pb(ctx, g_x01, g_cstd):
+        if getattr(ctx, "_main", False):
+            rec["gpos"] = g_x01.detach().cpu().clone()
+        return real_pb(ctx, g_x01, g_cstd)
+
+    ag.ops.mlp_bwd = spy_mlp_bwd
+    ag.ActorPairPositionsFn.forward, ag.ActorPairPositionsFn.backward = staticmethod(spy_pf), staticmethod(spy_pb)
+    try:
+        g_out, g_loss = _losses(hip, b, "cuda")
+        hp = [p for p in hip.parameters() if p.requires_grad]
+        for term in terms:
+            rec.pop("rows", None), rec.pop("gpos", None)
+            torch.autograd.grad(g_loss[term], hp, retain_graph=True, allow_unused=True)
+            cap["feats"].grad = None
+            if keys:
+                cap["pos"].mean.grad = None
+            w_loss[term].backward(retain_graph=True)
+            t_ev = {"rows": (rec["rows"].cpu(), cap["feats"].grad.detach().clone())}
+            if keys and "gpos" in rec:
+                hipg = {(int(n) // S_main, int(n) % S_main, int(a)): rec["gpos"][k]
+                        for k, (n, a) in enumerate(zip(rec["idx"].tolist(), rec["act"].tolist()))}
+                t_ev["pos"] = (hipg, {k: cap["pos"].mean.grad[i].reshape(3).clone() for i, k in enumerate(keys)})
+                t_ev["x01_hip"] = {(int(n) // S_main, int(n) % S_main, int(a)): rec["x01"][k]
+                                   for k, (n, a) in enumerate(zip(rec["idx"].tolist(), rec["act"].tolist()))}
+            ev["terms"][term] = t_ev
+    finally:
+        ag.ops.mlp_bwd = real_mlp_bwd
+        ag.ActorPairPositionsFn.forward, ag.ActorPairPositionsFn.backward = real_pf, real_pb
+    ev["S"] = S_main
+    return ev
+
+
+def classify_gradient_outliers(hip, refm, b, terms, report_name=None):
+    """Every sample whose encoding-row gradient, and every (sample, actor) pair whose position gradient, differs between the
+    plugin and the reference by more than 1e-4 (rows) / 2e-3 (positions) of the term's largest one is put in a class:
+      kink       a hidden unit of the reference's geometry / feature MLP within rounding of the ReLU kink at that sample (its
+                 pre-activation is below 3e-5 of the layer's rms): the two roundings of the forward land on different sides and
+                 the unit's whole backward contribution is switched on or off for that sample;
+      duplicate  the sample lies in two overlapping boxes: index_put with duplicate indices keeps an unspecified one
+                 (neurad_encoding.py:256-263, "randomly" in the reference's own words);
+      cell       (positions) a coordinate of the contracted box-frame position within the two sides' position difference of a
+                 lattice plane of an actor-grid level: floor() picks neighbouring cells, the feature is continuous across the
+                 plane but its derivative is not (encodings.py:441-464);
+      inherited  (positions) the pair's sample is itself a kink / duplicate sample: its row gradient differs upstream.
+    -> report; raises on a sample or pair in NO class, and when the unflagged samples do not agree to 5e-4."""
+    ev = _sample_level_gradients(hip, refm, b, terms)
+    S = ev["S"]
+    pre = ev["pre"]
+    rms = {k: float(v.float().pow(2).mean().sqrt()) for k, v in pre.items()}
+    near_kink = torch.zeros(pre["geo0"].shape[0], dtype=torch.bool)
+    for k, v in pre.items():
+        near_kink |= (v.abs() < 3e-5 * rms[k]).any(-1)
+    count = {}
+    for (r, s, a) in ev["pairs"]:
+        count[(r, s)] = count.get((r, s), 0) + 1
+    dup = {r * S + s for (r, s), c in count.items() if c > 1}
+    scal = hip.field.hashgrid.actor_grids[0].scalings.detach().cpu().reshape(-1).tolist() if len(hip.field.hashgrid.actor_grids) else []
+    report, bad = {}, []
+    for term, t_ev in ev["terms"].items():
+        a, c = t_ev["rows"]
+        a, c = a.double(), c.double()
+        diff, scale = (a - c).norm(dim=-1), float(c.norm(dim=-1).max())
+        if scale == 0.0:
+            continue
+        out = (diff > 1e-4 * scale).nonzero().reshape(-1).tolist()
+        cls = {}
+        for n in out:
+            cls[n] = "kink" if bool(near_kink[n]) else ("duplicate" if n in dup else None)
+        rest = torch.ones(a.shape[0], dtype=torch.bool)
+        rest[out] = False
+        rest_err = float((a[rest] - c[rest]).norm() / (c[rest].norm() + 1e-300))
+        entry = {"row_outliers": len(out), "samples": a.shape[0], "classes": {k: sum(1 for v in cls.values() if v == k)
+                                                                                  for k in ("kink", "duplicate")},
+                 "unclassified": [n for n, v in cls.items() if v is None], "rest_rel_l2": float(f"{rest_err:.2e}")}
+        flagged = {n for n in out}
+        if "pos" in t_ev:
+            hipg, refg = t_ev["pos"]
+            pscale = max(float(v.norm()) for v in refg.values())
+            pc = {"cell": 0, "inherited": 0}
+            unexplained = []
+            for key, g in refg.items():
+                dg = float((hipg[key].double() - g.double()).norm())
+                x_ref, x_hip = ev["x01"][key].double(), t_ev["x01_hip"][key].double()
+                dx = float((x_ref - x_hip).abs().max())
+                # the two sides' positions differ by dx (fp32 rounding of the box-frame transform, ~1e-6 of the unit cube):
+                # the trilinear weights then differ by dx * scaling, and so does the position gradient -- that is noise, not
+                # an outlier
+                if pscale == 0.0 or dg <= max(2e-3, 4.0 * dx * max(scal)) * pscale:
+                    continue
+                n = key[0] * S + key[1]
+                on_plane = any(abs(float(x) * sc - round(float(x) * sc)) <= 2.0 * dx * sc + 1e-6 for x in x_ref for sc in scal)
+                if on_plane:
+                    pc["cell"] += 1
+                elif n in flagged or n in dup or bool(near_kink[n]):
+                    pc["inherited"] += 1
+                else:
+                    unexplained.append((key, dg / pscale))
+            entry["position_outliers"], entry["position_unclassified"] = pc, unexplained
+            if unexplained:
+                bad.append((term, "positions", unexplained[:4]))
+        report[term] = entry
+        if entry["unclassified"]:
+            bad.append((term, "rows", entry["unclassified"][:8]))
+        if rest_err > 5e-4:
+            bad.append((term, "rest", rest_err))
+    if report_name and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        import json
+
+        json.dump(report, open(os.path.join(ROOT, "gpurun_out", report_name), "w"), indent=1)
+    assert not bad, bad
+    return report
+
+
+@pytest.mark.parametrize("scene", ["actors3", "actors32_fp16"])
+def test_every_gradient_outlier_has_a_class(ref, scene):
+    """The (loss term, parameter kind) pairs that `check_gradients_against_floor` passes on the outlier-count criterion
+    only (profiles/r05_grad_outliers_*.json: a few table rows / trajectory elements far off, the rest tight) are traced to
+    their cause at the SAMPLE level: each differing sample is a ReLU-kink sample or a duplicate-index sample, each differing
+    pair position gradient sits on a lattice plane of an actor grid or inherits from such a sample; anything else fails."""
+    big = scene == "actors32_fp16"
+    hip, refm = _build_pair(ref, True, n_actors=32 if big else 3, fp16_tables=big)
+    b = _batch(True, n_actors=32 if big else 3)
+    _deterministic(hip, True), _deterministic(refm, True)
+    terms = ["rgb_loss", "distortion_loss", "depth_loss", "intensity_loss", "carving_loss", "ray_drop_loss"]
+    rep = classify_gradient_outliers(hip, refm, b, terms, f"r06_grad_outlier_classes_{scene}.json")
+    print(scene, {t_: {k: v for k, v in e.items() if k != "unclassified"} for t_, e in rep.items()})
