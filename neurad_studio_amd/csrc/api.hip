@@ -46,6 +46,7 @@ static Tuning read_tuning() {
   t.mlp_split_wgrad = env("NRHIP_MLP_SPLIT_WGRAD") != nullptr;
   t.mlp_split_bf16 = env("NRHIP_MLP_SPLIT_BF16") != nullptr;
   t.mlp_pairs = env("NRHIP_MLP_PAIRS") ? (is("NRHIP_MLP_PAIRS", '1') ? 1 : 0) : -1;
+  t.mlp_pairs_train = is("NRHIP_MLP_PAIRS_TRAIN", '1');
   t.sampler_actor_inline = is("NRHIP_SAMPLER_ACTOR_INLINE", '1');
   t.sdf_render_pair = is("NRHIP_SDF_RENDER_PAIR", '1');
   return t;

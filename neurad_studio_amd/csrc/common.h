@@ -24,7 +24,8 @@ struct Tuning {
   bool mlp_generic;          // NRHIP_MLP_GENERIC: per-layer MLP kernels instead of the chained ones
   bool mlp_split_wgrad;      // NRHIP_MLP_SPLIT_WGRAD: weight gradients outside the chained backward
   bool mlp_split_bf16;       // NRHIP_MLP_SPLIT_BF16: 3-way bf16 split products in the composited render kernels
-  int mlp_pairs;             // NRHIP_MLP_PAIRS: 1 / 0, -1 unset (fp16-pair products: the default)
+  int mlp_pairs;             // NRHIP_MLP_PAIRS: 1 / 0, -1 unset (fp16-pair products: the default of the composited kernels)
+  bool mlp_pairs_train;      // NRHIP_MLP_PAIRS_TRAIN == "1": pair products in the per-sample (training forward) kernel too
   bool sampler_actor_inline; // NRHIP_SAMPLER_ACTOR_INLINE == "1": per-chunk in-box lookup in the fused sampler
   bool sdf_render_pair;      // NRHIP_SDF_RENDER_PAIR == "1": two rays per wave in sdf_render_fwd/bwd
 };

@@ -694,7 +694,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
   static_assert(L * F == 32 && L % 4 == 0, "fused kernel needs L*F == 32, L % 4 == 0");
   static_assert(!ACT || COMPOSITE, "actors: composited eval kernel (static and actor tables share one storage type)");
   static_assert(H % 16 == 0 && H >= 16 && H <= 128, "hidden width");
-  static_assert(!SPLIT || (COMPOSITE && !ACT), "split-bf16 matrix products: the composited static-scene kernel");
+  // SPLIT = 1 (3-way bf16): the composited static-scene kernel.  SPLIT = 2 (fp16 pairs): also the per-sample kernel of the
+  // static scene -- the training forward: the tile runs in units of kPairAct, every store of an activation undoes it
+  static_assert(!SPLIT || ((COMPOSITE || SPLIT == 2) && !ACT), "split matrix products: static-scene kernels");
   static_assert(!RELAY || (COMPOSITE && !ACT && !SPLIT), "eval-table layout: the composited static-scene kernel");
   // OVR (training forward of a scene with dynamic actors): samples inside an actor box take their encoding row and view
   // direction from the caller (the differentiable actor branch computed them for the few hit samples) instead of the
@@ -884,9 +886,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       saving = sv.enc != nullptr && live;
       srow = ray * S + s;
       if (saving) {
+        constexpr float u = SPLIT == 2 ? 1.f / kPairAct : 1.f;  // (tile units -> true units: a power of two, exact)
         float* ep = sv.enc + srow * 32 + 8 * g;
-        stream_store(ep, f32x4{feat[0], feat[1], feat[2], feat[3]});
-        stream_store(ep + 4, f32x4{feat[4], feat[5], feat[6], feat[7]});
+        stream_store(ep, f32x4{feat[0] * u, feat[1] * u, feat[2] * u, feat[3] * u});
+        stream_store(ep + 4, f32x4{feat[4] * u, feat[5] * u, feat[6] * u, feat[7] * u});
       }
     }
 
@@ -905,9 +908,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
 
     if constexpr (!COMPOSITE) {
       if (saving) {
+        constexpr float u = SPLIT == 2 ? 1.f / kPairAct : 1.f;
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb)
-          stream_store(sv.hg + srow * H + 16 * mb + 4 * g, f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]});
+          stream_store(sv.hg + srow * H + 16 * mb + 4 * g,
+                       f32x4{hb[4 * mb] * u, hb[4 * mb + 1] * u, hb[4 * mb + 2] * u, hb[4 * mb + 3] * u});
       }
     }
 
@@ -938,9 +943,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
     // ---- feature MLP (32 [+16 SH folded into the per-ray bias] -> H -> H -> 32), residual add ------
     if constexpr (!COMPOSITE) {
       if (saving) {
+        constexpr float u = SPLIT == 2 ? 1.f / kPairAct : 1.f;
         float* xp = sv.xf + srow * 48;
-        stream_store(xp + 4 * g, e[0]);
-        stream_store(xp + 16 + 4 * g, e[1]);
+        stream_store(xp + 4 * g, e[0] * u);
+        stream_store(xp + 16 + 4 * g, e[1] * u);
         stream_store(xp + 32 + 4 * g, tile_hit ? f32x4{shb[0], shb[1], shb[2], shb[3]} : shq);
       }
     }
@@ -962,10 +968,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
     if constexpr (!COMPOSITE) {
       if (saving) {
+        constexpr float u = SPLIT == 2 ? 1.f / kPairAct : 1.f;
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb)
           stream_store(sv.hf + srow * (2 * H) + 16 * mb + 4 * g,
-                       f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]});
+                       f32x4{hb[4 * mb] * u, hb[4 * mb + 1] * u, hb[4 * mb + 2] * u, hb[4 * mb + 3] * u});
       }
     }
 #pragma unroll
@@ -979,10 +986,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       for (int r = 0; r < 4; ++r) hb[4 * mb + r] = fmaxf(h[mb][r], 0.f);
     if constexpr (!COMPOSITE) {
       if (saving) {
+        constexpr float u = SPLIT == 2 ? 1.f / kPairAct : 1.f;
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb)
           stream_store(sv.hf + srow * (2 * H) + H + 16 * mb + 4 * g,
-                       f32x4{hb[4 * mb], hb[4 * mb + 1], hb[4 * mb + 2], hb[4 * mb + 3]});
+                       f32x4{hb[4 * mb] * u, hb[4 * mb + 1] * u, hb[4 * mb + 2] * u, hb[4 * mb + 3] * u});
       }
     }
 
@@ -996,9 +1004,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel(
       f32x4 o[2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) o[mb] = *reinterpret_cast<const f32x4*>(lw + Ld::BF2 + 16 * mb + 4 * g);
-      mfma_layer<2, H / 4>(lw + Ld::F2, lane, hb, o);
-      o[0] += e[0];
-      o[1] += e[1];
+      mfma_layer<2, H / 4>(lw + Ld::F2, lane, hb, o);  // (SPLIT = 2: fw2 is staged x 1 / kPairAct -- true units)
+      if constexpr (SPLIT == 2) {
+        o[0] += e[0] * (1.f / kPairAct);
+        o[1] += e[1] * (1.f / kPairAct);
+      } else {
+        o[0] += e[0];
+        o[1] += e[1];
+      }
       if (live) {
         float* fp = out_feat + (ray * S + s) * 32;
         stream_store(fp + 4 * g, o[0]);
@@ -1194,6 +1207,7 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
       RCASE(8, 4, 64)
 #undef RCASE
     }
+  }
   if constexpr (COMPOSITE) {
     if (H == 64 && pairs && !split_bf16) {
 #define PCASE(L_, F_)                                                                                                  \
@@ -1218,6 +1232,23 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
 #undef PCASE
     }
   }
+  if constexpr (!COMPOSITE) {
+    // the per-sample kernel (field forward / training forward with saved activations): the same pair products, OPT-IN
+    // (NRHIP_MLP_PAIRS_TRAIN=1).  Round 6 measured no gain: the kernel stores 516 B of activations per sample beside its
+    // gathers and is bound by them -- 1.03-1.09 ms with pairs against 1.01-1.03 ms with the fp32 MFMA on the c3 batch,
+    // the step unchanged (profiles/r06_ab_pairs_train.txt)
+    if (pairs && tuning().mlp_pairs_train && !split_bf16) {
+#define TCASE(L_, F_, H_)                                                                                              \
+  if (L == L_ && F == F_ && H == H_)                                                                                   \
+    return half ? launch_render<L_, F_, H_, true, false, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al)     \
+                : launch_render<L_, F_, H_, false, false, false, 2>(fd, rd, of, od, oa, ow, os, oal, sv, stop_eps, st, al);
+      TCASE(8, 4, 32)
+      TCASE(16, 2, 64)
+      TCASE(8, 4, 64)
+      TCASE(16, 2, 32)
+#undef TCASE
+    }
+  }
   if constexpr (COMPOSITE) {
     if (H == 64 && split_bf16) {
 #define SCASE(L_, F_)                                                                                                  \
@@ -1229,7 +1260,6 @@ static int dispatch_render(const nrhip_field* f, const nrhip_rays* rays, float* 
       SCASE(4, 8)
 #undef SCASE
     }
-  }
   }
 #define CASE(L_, F_, H_)                                                                                          \
   if (L == L_ && F == F_ && H == H_) {                                                                            \

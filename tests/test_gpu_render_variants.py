@@ -297,3 +297,52 @@ def test_fp16_pair_matrix_products_are_fp32_equivalent(switches):
         f32, prs = both(to_spec(ops, small))
         for a, b in zip(f32, prs):
             assert rel_l2(host(b), host(a)) < 2e-6, H
+
+
+def test_fp16_pair_products_in_the_training_forward(switches):
+    """Round 6: the per-sample kernel (nrhip_field_fwd / nrhip_field_fwd_train: the training forward that stores its
+    activations) can form its matrix products as fp16 pairs too (NRHIP_MLP_PAIRS_TRAIN=1; opt-in: it measured no faster,
+    the kernel is bound by its stores and gathers).  The tile runs in units of 2^6; every store -- the three outputs
+    and the four saved activation tensors the backward reads -- undoes that exactly.  Held to the fp32-MFMA kernel
+    (the default) on everything it writes, fp32 and fp16-storage tables, both widths, and through the exits of the fast
+    path (activations / weights that do not fit an fp16 pair)."""
+    from neurad_studio_amd import ops
+
+    R, S = 200, 32
+    o, d, area, s, e, _ = _sample_rays(R, S, seed=13)
+    rays = (dev(o), dev(d), dev(area), dev(s), dev(e))
+
+    def both(fs):
+        switches.unset("NRHIP_MLP_PAIRS_TRAIN")
+        a = ops.field_fwd_train(fs, *rays)
+        a2 = ops.field_fwd(fs, *rays)
+        switches.set("NRHIP_MLP_PAIRS_TRAIN", "1")
+        b = ops.field_fwd_train(fs, *rays)
+        b2 = ops.field_fwd(fs, *rays)
+        switches.unset("NRHIP_MLP_PAIRS_TRAIN")
+        return (*a[0], *a[1], *a2), (*b[0], *b[1], *b2)
+
+    names = ("feature", "sdf", "head", "enc", "geo_hidden", "feat_in", "feat_hidden", "feature (field_fwd)", "sdf", "head")
+    for L, F, mn, mx, H in ((8, 4, 32, 8192, 32), (16, 2, 16, 1024, 64), (8, 4, 32, 8192, 64), (16, 2, 16, 1024, 32)):
+        p = field_params(L=L, F=F, lg=12, H=H, mn=mn, mx=mx)
+        for half in (False, True):
+            f32, prs = both(to_spec(ops, p, half=half))
+            for n, a, b in zip(names, f32, prs):
+                assert a.shape == b.shape and rel_l2(host(b), host(a)) < 1e-6, (L, F, H, half, n, rel_l2(host(b), host(a)))
+            assert torch.equal(prs[3], f32[3])  # the encoding rows: computed before any product, scaled by 2^6 and back
+            assert not torch.equal(prs[0], f32[0])  # (a different kernel did run)
+    for H in (32, 64):
+        big = field_params(L=8, F=4, lg=12, H=H, mn=32, mx=8192)
+        big.grid.table[::2] *= 3.0e3  # activations beyond the pair's range in some tiles
+        f32, prs = both(to_spec(ops, big))
+        for n, a, b in zip(names, f32, prs):
+            assert np.isfinite(host(b)).all() and rel_l2(host(b), host(a)) < 1e-5, (H, n)
+        wb = field_params(L=8, F=4, lg=12, H=H, mn=32, mx=8192)
+        wb.feat_w[1][3, 5] = 600.0  # a weight that does not fit: every tile takes the fp32 products
+        f32, prs = both(to_spec(ops, wb))
+        for n, a, b in zip(names, f32, prs):
+            assert rel_l2(host(b), host(a)) < 1e-6, (H, n)
+        small = field_params(L=8, F=4, lg=12, H=H, mn=32, mx=8192, scale=1e-4)  # an untrained field
+        f32, prs = both(to_spec(ops, small))
+        for n, a, b in zip(names, f32, prs):
+            assert rel_l2(host(b), host(a)) < 2e-6, (H, n)
