@@ -1434,6 +1434,7 @@ def main():
     ap.add_argument("--via-plugin", action="store_true",
                     help="c3: ALSO time the step as `ns-train neurad-hip` executes it -- the reference's Trainer.train_iteration "
                          "(autocast + GradScaler + Optimizers) over the plugin model (needs nerfstudio importable)")
+    ap.add_argument("--via-plugin-only", action="store_true", help="c3: time only the --via-plugin step (kernel traces)")
     ap.add_argument("--train-steps", type=int, default=60)
     ap.add_argument("--train-full-steps", type=int, default=30, help="0 skips the train_full section")
     args = ap.parse_args()
@@ -1495,6 +1496,14 @@ def main():
         out = bench_c2(args, device, rank, world)
     elif args.config == "c4":
         out = bench_c4(args, device, rank, world)
+    elif args.config == "c3" and args.via_plugin_only:  # (profiling runs: only the plugin's step in the kernel trace)
+        steps = min(args.steps, 50)
+        vp = train_via_plugin_section(device, rank, world, steps, max(2, min(args.warmup, 5)))
+        out = {"metric": "train iters/sec (camera+lidar joint batch), the step as `ns-train neurad-hip` executes it",
+               "value": vp.get("rays_per_sec"), "unit": "rays/s", "n_gpus": world, "steps": steps,
+               "warmup": max(2, min(args.warmup, 5)), "ms_per_step": vp.get("ms_per_iter"), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": vp.get("what")}, "train_via_plugin": vp}
     elif args.config == "c3":
         steps = min(args.steps, 50)
         tf = train_full_section(device, rank, world, steps, max(2, min(args.warmup, 5)), rgb_decoder=not args.no_rgb_decoder,

@@ -2,7 +2,7 @@
 # End-of-round measurements in one lease: GPU test suite, the PMC passes behind roofline.traffic (written to profiles/traffic_*.json
 # BEFORE the bench lines read them), bench lines c1-c4, kernel traces, the two-rank gloo rehearsals, the round's A/B re-measurements.
 # usage: scripts/final_measure.sh <tag>   (outputs under gpurun_out/<tag>_*)
-tag=${1:-r05}
+tag=${1:-r06}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd $R
@@ -39,14 +39,24 @@ python $R/scripts/traffic_from_pmc.py $OUT/${tag}_pmc_traffic.txt $tag; cp $R/pr
 fi
 cd $R
 timeout 600 python bench.py > $OUT/bench_${tag}_c1.json 2> $OUT/bench_${tag}_c1.err; echo "c1 rc=$?"
-for c in c2 c3 c4; do timeout 600 python bench.py --config $c > $OUT/bench_${tag}_$c.json 2> $OUT/bench_${tag}_$c.err; echo "$c rc=$?"; done
+for c in c2 c4; do timeout 600 python bench.py --config $c > $OUT/bench_${tag}_$c.json 2> $OUT/bench_${tag}_$c.err; echo "$c rc=$?"; done
+# c3: the hand-assembled step (eager + HIP-graph replay) and the same step as `ns-train neurad-hip` runs it (--via-plugin)
+timeout 900 python bench.py --config c3 --via-plugin > $OUT/bench_${tag}_c3.json 2> $OUT/bench_${tag}_c3.err; echo "c3 rc=$?"
+# `python bench.py --gpus 2` as a plain command (self-launch), over gloo on this box's one GPU: the labelled rehearsal
+NRHIP_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 > $OUT/${tag}_rehearsal_n2_self_launch_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2_self_launch.err; echo "self-launch rehearsal rc=$?"
 NRHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 > $OUT/${tag}_rehearsal_n2_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2.err; echo "rehearsal rc=$?"
 NRHIP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --train-steps 20 --train-full-steps 6 --wire-bf16 > $OUT/${tag}_rehearsal_n2_wire_bf16_gloo_one_gpu.json 2> $OUT/${tag}_rehearsal_n2_wire_bf16.err; echo "rehearsal wire-bf16 rc=$?"
 cd /tmp
 prof() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_$name -o t -- "$@" > $OUT/prof_${tag}_$name.log 2>&1
   python $R/scripts/prof_summary.py $(find $OUT/prof_${tag}_$name -name '*.db' | head -1) | head -64 > $OUT/${tag}_${name}_kernel_trace.txt; find $OUT/prof_${tag}_$name -name '*.db' -delete; }
 prof headline python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train --no-variants
-prof train_full_c3 python $R/bench.py --config c3 --steps 10 --warmup 3
+prof() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_${tag}_$name -o t -- "$@" > $OUT/prof_${tag}_$name.log 2>&1
+  db=$(find $OUT/prof_${tag}_$name -name '*.db' | head -1)
+  python $R/scripts/prof_summary.py $db | head -64 > $OUT/${tag}_${name}_kernel_trace.txt
+  if [ -n "$GAPS" ]; then python $R/scripts/gpu_gaps.py $db $GAPS 8 > $OUT/${tag}_${name}_gpu_gaps.txt 2>&1; fi
+  find $OUT/prof_${tag}_$name -name '*.db' -delete; }
+GAPS=60 prof train_full_c3 python $R/bench.py --config c3 --steps 10 --warmup 3 --no-graph
+GAPS=60 prof via_plugin_c3 python $R/bench.py --config c3 --steps 10 --warmup 3 --via-plugin-only
 prof c2 python $R/bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline
 prof c4 python $R/bench.py --config c4 --steps 4 --warmup 1 --train-steps 60
 NRHIP_BENCH_DECODER_MODES=hip prof decoder python $R/scripts/bench_decoder.py
