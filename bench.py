@@ -501,6 +501,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     allocs1 = _device_allocs()
     host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
     assert torch.isfinite(state["loss"]), "non-finite loss"
+    exchanged_bytes = state["bytes"]
     graph_replay = None
     if use_graph:
         # the same step captured ONCE in a HIP graph (torch's whole-step recipe: the previous iteration's autograd graph is
@@ -585,7 +586,7 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
             "hip_graph_replay": graph_replay,
             "device_allocations_during_the_timed_steps": allocs1[0] - allocs0[0],  # hipMalloc calls: 0 in steady state
             "allocator_retries_during_the_timed_steps": allocs1[1] - allocs0[1],
-            "grad_exchange_bytes_per_rank": state["bytes"], "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
+            "grad_exchange_bytes_per_rank": exchanged_bytes, "grad_exchange_wire_bytes_per_rank": sync.last_wire_bytes,
             "grad_exchange": ("level-sparse: table levels sent as (row, values) lists this step, by parameter index: "
                               f"{sync.last_list_levels}") if level_tables else
             ("dense; reduce-scatter leg in bf16 (rounded once per rank, all-to-all to the owner, fp32 sum), fp32 all-gather"

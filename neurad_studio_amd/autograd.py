@@ -524,6 +524,7 @@ class NffRenderTrainFn(torch.autograd.Function):
     (NeuRADField.forward) -> SigmoidDensity with the learnable beta -> render_weight_from_alpha -> accumulation, sky
     residual, features, depth -> appearance embedding written beside the features.
 
+    beta = None: the density head (use_sdf = False: trunc_exp -> render_weight_from_density, models/neurad.py:718-723).
     args: table, spec, static_scale, beta (raw parameter), beta_min, origins, directions, pixel_area, edges [R,S+1] (last
     edge = sky distance), emb_weight | None, sensor_idx | None, times | None, (duration, n_per_sensor, temporal), order |
     None, ovr_row | None, ovr_rows | None, ovr_dirs | None, pair_idx | None (dynamic actors: the rows of the samples
@@ -553,7 +554,9 @@ class NffRenderTrainFn(torch.autograd.Function):
         ctx.rays = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]  # a camera optimizer moved the rays
         opt = ([t for t in (sensor_idx, times) if t is not None] + ([ovr_row, pair_idx] if ctx.has_ovr else [])
                + ([table] if ctx.rays else []))
-        ctx.save_for_backward(origins, directions, pixel_area, edges, enc, hg, xf, hf, feature, sdf, alpha, beta, *params, *opt)
+        ctx.density_head = beta is None
+        ctx.save_for_backward(origins, directions, pixel_area, edges, enc, hg, xf, hf, feature, sdf, alpha,
+                              sdf.new_empty(0) if beta is None else beta, *params, *opt)
         return out, depth, acc, w_ns
 
     @staticmethod
@@ -567,8 +570,8 @@ class NffRenderTrainFn(torch.autograd.Function):
         C_ = feature.shape[-1]
         if g_out is None:
             g_out = torch.zeros((R, C_ + ctx.A), device=o.device, dtype=torch.float32)
-        gfeat, gsdf, gbeta = ops.sdf_render_bwd(sdf.view(R, S), beta, ctx.beta_min, alpha, feature.view(R, S, C_), edges,
-                                                g_out[:, :C_], g_depth, g_acc, g_wns)
+        gfeat, gsdf, gbeta = ops.sdf_render_bwd(sdf.view(R, S), None if ctx.density_head else beta, ctx.beta_min, alpha,
+                                                feature.view(R, S, C_), edges, g_out[:, :C_], g_depth, g_acc, g_wns)
         g_emb = None
         if ctx.A and ctx.needs_input_grad[9]:
             g_emb = ops.appearance_bwd(g_out[:, C_:], sensor_idx, times, ctx.emb_cfg[0], ctx.emb_cfg[1], ctx.emb_cfg[2],
@@ -580,7 +583,7 @@ class NffRenderTrainFn(torch.autograd.Function):
                                                       gfeat.view(R * S, C_), gsdf.view(-1), override=override, rays=rays)
         if not ctx.needs_input_grad[15]:
             g_rows = None
-        g_beta = gbeta.reshape(beta.shape) if ctx.needs_input_grad[3] else None
+        g_beta = gbeta.reshape(beta.shape) if (ctx.needs_input_grad[3] and not ctx.density_head) else None
         return (gt, None, None, g_beta, None, go, gd, None, None, g_emb, None, None, None, None, None, g_rows, None, None,
                 *grads)
 

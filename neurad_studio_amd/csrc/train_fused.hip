@@ -115,13 +115,20 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_fwd_kernel(
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= R) return;
   float* wsh = tf_lds + wave * S;
-  const float beta = fabsf(*beta_ptr) + beta_min;
+  // beta_ptr == NULL: the density head (use_sdf = False, fields/neurad_field.py:149-151): sigma = trunc_exp(x), and
+  // render_weight_from_density's alpha = 1 - exp(-sigma (t_end - t_start)) (models/neurad.py:718-723) -- the same compositing
+  const bool dens = beta_ptr == nullptr;
+  const float beta = dens ? 0.f : fabsf(*beta_ptr) + beta_min;
   const float* e = edges + ray * es;
   float carry = 1.f, acc = 0.f, depth = 0.f;
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int s = s0 + lane;
     const bool live = s < S;
-    const float a = live ? sigmoidf_(-sdf[ray * S + s] * beta) : 0.f;
+    float a = 0.f;
+    if (live) {
+      const float x = sdf[ray * S + s];
+      a = dens ? -expm1f(-expf(x) * (e[s + 1] - e[s])) : sigmoidf_(-x * beta);
+    }
     const float incl = tf_scan_mul(1.f - a, lane);
     const float excl = wscan::shift_up1(incl, 1.f, lane);
     const float w = a * (carry * excl);
@@ -195,7 +202,8 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_bwd_kernel(
     float* w2 = tf_lds + wave * 3 * S;
     float* Tsh = w2 + S;
     float* gwsh = Tsh + S;
-    const float beta = fabsf(*beta_ptr) + beta_min;
+    const bool dens = beta_ptr == nullptr;  // (the density head: see the forward)
+    const float beta = dens ? 0.f : fabsf(*beta_ptr) + beta_min;
     const float* e = edges + ray * es;
     const float* ar = alpha + ray * S;
     // 1. transmittance and weights from the saved alphas
@@ -280,11 +288,18 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void sdf_render_bwd_kernel(
       const float incl_r = tf_rscan_add(term, lane);
       const float after = incl_r - term + suffix;
       if (live) {
-        const float ga = gwi * T - after / fmaxf(1.f - a, 1e-10f);
-        const float ds = ga * a * (1.f - a);  // sigmoid'(x), x = -sdf * beta
         const float x = sdf[ray * S + s];
-        gsdf[ray * S + s] = -ds * beta;
-        gb -= ds * x;
+        if (dens) {
+          // d L / d sigma = delta (g_i T_i exp(-sigma delta) - sum_{j > i} g_j w_j), exp(-sigma delta) = 1 - alpha;
+          // trunc_exp's backward: exp(clamp(x, -15, 15)) (field_components/activations.py:37-41)
+          const float gsig = (gwi * T * (1.f - a) - after) * (e[s + 1] - e[s]);
+          gsdf[ray * S + s] = gsig * expf(fminf(fmaxf(x, -15.f), 15.f));
+        } else {
+          const float ga = gwi * T - after / fmaxf(1.f - a, 1e-10f);
+          const float ds = ga * a * (1.f - a);  // sigmoid'(x), x = -sdf * beta
+          gsdf[ray * S + s] = -ds * beta;
+          gb -= ds * x;
+        }
       }
       suffix += wscan::first(incl_r);
     }
@@ -893,12 +908,12 @@ extern "C" int nrhip_sdf_render_fwd(const float* sdf, const float* beta, float b
                                     const float* edges, int32_t edge_stride, int64_t r, int32_t s, int32_t c,
                                     float* alpha, float* weights_ns, float* out_features, int32_t out_stride,
                                     float* out_depth, float* out_acc, void* stream) {
-  NR_REQUIRE(sdf && beta && features && edges && alpha && weights_ns && out_features && out_depth && out_acc && r >= 0 &&
+  NR_REQUIRE(sdf && features && edges && alpha && weights_ns && out_features && out_depth && out_acc && r >= 0 &&
                  s >= 2 && c >= 1 && edge_stride >= s + 1 && out_stride >= c,
              NRHIP_ERR_INVALID_ARG, "sdf_render_fwd: bad argument");
   NR_REQUIRE(s <= 2048, NRHIP_ERR_UNSUPPORTED, "sdf_render_fwd: %d samples per ray (max 2048)", s);
   if (r == 0) return NRHIP_OK;
-  if (sdf_render_pair(s, c) && out_stride % 4 == 0 &&
+  if (beta && sdf_render_pair(s, c) && out_stride % 4 == 0 &&
       ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(out_features)) & 15) == 0) {
     sdf_render_fwd_pair_kernel<<<(int)((r + 2 * kRaysPerBlock - 1) / (2 * kRaysPerBlock)), 64 * kRaysPerBlock,
                                  (size_t)2 * kRaysPerBlock * s * sizeof(float), (hipStream_t)stream>>>(
@@ -922,15 +937,16 @@ extern "C" int nrhip_sdf_render_bwd(const float* sdf, const float* beta, float b
                                     const float* g_features, int32_t g_stride, const float* g_depth, const float* g_acc,
                                     const float* g_weights_ns, int64_t r, int32_t s, int32_t c, float* grad_features,
                                     float* grad_sdf, float* grad_beta, float* workspace, void* stream) {
-  NR_REQUIRE(sdf && beta && alpha && features && edges && g_features && grad_features && grad_sdf && grad_beta &&
+  NR_REQUIRE(sdf && alpha && features && edges && g_features && grad_features && grad_sdf && (grad_beta || !beta) &&
                  workspace && r >= 0 && s >= 2 && c >= 1 && edge_stride >= s + 1 && g_stride >= c,
              NRHIP_ERR_INVALID_ARG, "sdf_render_bwd: bad argument");
   NR_REQUIRE(s <= 1024, NRHIP_ERR_UNSUPPORTED, "sdf_render_bwd: %d samples per ray (max 1024)", s);
   if (r == 0) {
-    if (hipMemsetAsync(grad_beta, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("sdf_render_bwd");
+    if (grad_beta && hipMemsetAsync(grad_beta, 0, sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return check_launch("sdf_render_bwd");
     return NRHIP_OK;
   }
-  if (sdf_render_pair(s, c) && g_stride % 4 == 0 &&
+  if (beta && sdf_render_pair(s, c) && g_stride % 4 == 0 &&
       ((reinterpret_cast<uintptr_t>(features) | reinterpret_cast<uintptr_t>(grad_features) |
         reinterpret_cast<uintptr_t>(g_features)) & 15) == 0) {
     const int pblocks = (int)((r + 2 * kRaysPerBlock - 1) / (2 * kRaysPerBlock));
@@ -945,7 +961,7 @@ extern "C" int nrhip_sdf_render_bwd(const float* sdf, const float* beta, float b
   sdf_render_bwd_kernel<<<blocks, 64 * kRaysPerBlock, (size_t)kRaysPerBlock * 3 * s * sizeof(float), (hipStream_t)stream>>>(
       sdf, beta, beta_min, alpha, features, edges, edge_stride, g_features, g_stride, g_depth, g_acc, g_weights_ns, r, s,
       c, grad_features, grad_sdf, workspace);
-  beta_grad_reduce_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(workspace, blocks, beta, grad_beta);
+  if (beta) beta_grad_reduce_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(workspace, blocks, beta, grad_beta);
   return check_launch("sdf_render_bwd");
 }
 

@@ -218,8 +218,8 @@ class NeuRADField(nn.Module):
         the static lookup (nrhip_field_fwd_train_ovr).  The backward hands every (sample, actor) pair its sample's row
         gradient, as the reference's index_put does, and the static table nothing for those samples."""
         hg = self.hashgrid
-        if not (self.config.use_sdf and self.fused_supported(with_actors=True) and self._fused_train_ok()):
-            raise NotImplementedError("render_train: SDF head and a fused-kernel configuration only")
+        if not (self.fused_supported(with_actors=True) and self._fused_train_ok()):
+            raise NotImplementedError("render_train: a fused-kernel configuration only (L * F = 32, 32- or 64-wide MLPs)")
         g = hg.static_grid
         emb, sensor, etimes, emb_cfg = appearance if appearance is not None else (None, None, None, (1.0, 1, False))
         order = ops.ray_order(origins, directions, hg.static_scale) if self.order_rays else None
@@ -228,9 +228,10 @@ class NeuRADField(nn.Module):
             if times is None:
                 raise ValueError("dynamic actors need ray times")
             ovr = self._actor_overrides(origins, directions, pixel_area.reshape(-1), edges, times.reshape(-1), actor_cand)
-        sd = self.sdf_to_density
+        # use_sdf = False (fields/neurad_field.py:149-151): the density head -- beta = None selects it in the node
+        beta, beta_min = (self.sdf_to_density.beta, self.sdf_to_density.beta_min_value) if self.config.use_sdf else (None, 0.0)
         return ag.NffRenderTrainFn.apply(
-            g.hash_table, g.spec, hg.static_scale, sd.beta, sd.beta_min_value, origins, directions,
+            g.hash_table, g.spec, hg.static_scale, beta, beta_min, origins, directions,
             pixel_area.reshape(-1), edges, emb, sensor, etimes, emb_cfg, order, *ovr,
             *[t for l in self.mlp_geo.layers for t in (l.weight, l.bias)],
             *[t for l in self.mlp_feature.layers for t in (l.weight, l.bias)])

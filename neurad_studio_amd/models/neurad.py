@@ -144,9 +144,9 @@ class FusedTrainMixin:
 
     def fused_training_possible(self) -> bool:
         f = self.field
-        return (self.fused_training and self.training and torch.is_grad_enabled() and f.fused_training and f.config.use_sdf
+        return (self.fused_training and self.training and torch.is_grad_enabled() and f.fused_training
                 and f.fused_supported(with_actors=True) and f._fused_train_ok()
-                and isinstance(self.sampler.initial_sampler, PowerSampler) and not self.config.normalize_depth)
+                and isinstance(self.sampler.initial_sampler, PowerSampler))
 
     def _fused_train_nff_outputs(self, ray_bundle: RayBundle, calc_lidar_losses: bool) -> Dict[str, Tensor]:
         """get_nff_outputs (models/neurad.py:368-421) without the RaySamples plumbing: bin edges [R,S+1] go from kernel to
@@ -208,7 +208,7 @@ class FusedTrainMixin:
                                                          pf.hashgrid.static_scale, o, d, a, eu)
             weights_list.append(w[..., None])
             samples_list.append(_light_samples(ray_bundle, sp, eu, fn))
-            nff[f"prop_depth_{k}"] = pdepth
+            nff[f"prop_depth_{k}"] = _expected_depth(pdepth, w, eu) if cfg.normalize_depth else pdepth
             if lidar_terms:
                 nff[f"prop_weights_loss_{k}"] = ag.CarvingLossFn.apply(w, eu[:, :-1], eu[:, 1:], *carve)
             rand = None
@@ -229,8 +229,10 @@ class FusedTrainMixin:
                           (float(self._duration), int(self._num_embeds_per_sensor), bool(cfg.use_temporal_appearance)))
         features, depth, accumulation, w_ns = self.field.render_train(
             o, d, a, eu, appearance, times=ray_bundle.times, actor_cand=cand if self.field.hashgrid.has_actors() else None)
-        nff.update(features=features, depth=depth, accumulation=accumulation)
         S = counts[-1]
+        if cfg.normalize_depth:  # over the non-sky samples (models/neurad.py:386-391)
+            depth = _expected_depth(depth, w_ns, eu[:, :S])
+        nff.update(features=features, depth=depth, accumulation=accumulation)
         if self.training:
             nff["weights_list"] = weights_list + [w_ns[..., None]]
             # the sky sample plays no further role: the first S-1 samples = the first S edges
@@ -245,6 +247,14 @@ class FusedTrainMixin:
             else:
                 nff["non_nearby_weights_loss"] = ag.CarvingLossFn.apply(w_ns, eu[:, :S - 1], eu[:, 1:S], *carve)
         return nff
+
+
+def _expected_depth(depth: Tensor, w: Tensor, edges: Tensor) -> Tensor:
+    """DepthRenderer("expected") (model_components/renderers.py:398-416) from what the fused nodes return: depth = sum w * mid
+    [R,1], the weights w [R,S] of those samples and their bin edges [R,S+1] -> sum w * mid / (sum w + 1e-10), clipped to the
+    batch's range of sample midpoints"""
+    mid = (edges[:, :-1] + edges[:, 1:]) / 2
+    return torch.clip(depth / (w.sum(-1, keepdim=True) + 1e-10), mid.min(), mid.max())
 
 
 def _light_samples(rb: RayBundle, sp: Tensor, eu: Tensor, fn) -> RaySamples:

@@ -1297,11 +1297,13 @@ def prop_weights_bwd(edges: Tensor, densities: Tensor, grad_w: Optional[Tensor],
 def sdf_render_fwd(sdf: Tensor, beta: Tensor, beta_min: float, features: Tensor, edges: Tensor, extra_cols: int = 0):
     """SDF head + weights + compositing.  sdf [R,S], beta = the raw learnable parameter (device, 1 element), features
     [R,S,C], edges [R,S+1] (last edge = sky distance).  -> alpha [R,S], weights_ns [R,S-1], out [R,C+extra_cols] (the
-    first C columns written), depth [R,1], acc [R,1]"""
-    sdf, feat, b = _chk(sdf, "sdf"), _chk(features, "features"), _chk(beta.reshape(-1), "beta")
+    first C columns written), depth [R,1], acc [R,1].  beta = None: the density head (use_sdf = False) -- ``sdf`` is the
+    raw geometry output x, sigma = trunc_exp(x), alpha = 1 - exp(-sigma (end - start)) (render_weight_from_density)."""
+    sdf, feat = _chk(sdf, "sdf"), _chk(features, "features")
+    b = None if beta is None else _chk(beta.reshape(-1), "beta")
     R, S = sdf.shape
     C_ = feat.shape[-1]
-    if feat.numel() != R * S * C_ or b.numel() != 1:
+    if feat.numel() != R * S * C_ or (b is not None and b.numel() != 1):
         raise ValueError("sdf_render_fwd: features must be [R,S,C], beta one element")
     e, es = _edges(edges, S)
     dev = sdf.device
@@ -1326,9 +1328,10 @@ def _strided_rows(t: Tensor, name: str):
 
 def sdf_render_bwd(sdf, beta, beta_min, alpha, features, edges, g_out: Tensor, g_depth: Optional[Tensor],
                    g_acc: Optional[Tensor], g_weights_ns: Optional[Tensor]):
-    """-> grad_features [R,S,C], grad_sdf [R,S], grad_beta [1].  g_out: [R,C] view (row stride free) of the gradient of
-    the composited features."""
-    sdf, feat, b, alpha = _chk(sdf, "sdf"), _chk(features, "features"), _chk(beta.reshape(-1), "beta"), _chk(alpha, "alpha")
+    """-> grad_features [R,S,C], grad_sdf [R,S], grad_beta [1] (None for the density head, beta = None).  g_out: [R,C] view
+    (row stride free) of the gradient of the composited features."""
+    sdf, feat, alpha = _chk(sdf, "sdf"), _chk(features, "features"), _chk(alpha, "alpha")
+    b = None if beta is None else _chk(beta.reshape(-1), "beta")
     R, S = sdf.shape
     C_ = feat.shape[-1]
     e, es = _edges(edges, S)
@@ -1343,7 +1346,7 @@ def sdf_render_bwd(sdf, beta, beta_min, alpha, features, edges, g_out: Tensor, g
     dev = sdf.device
     gfeat = torch.empty_like(feat)
     gsdf = torch.empty_like(sdf)
-    gbeta = torch.empty((1,), device=dev, dtype=torch.float32)
+    gbeta = None if b is None else torch.empty((1,), device=dev, dtype=torch.float32)
     need = C.c_int64(0)
     call("nrhip_sdf_render_bwd_workspace", R, C.byref(need))
     ws = torch.empty((max(need.value, 1),), device=dev, dtype=torch.float32)

@@ -56,7 +56,14 @@ def _dense_nerfacc():
     def accumulate_along_rays(weights, values=None, ray_indices=None, n_rays=None):
         return weights.sum(-1, keepdim=True) if values is None else (weights[..., None] * values).sum(-2)
 
+    def render_weight_from_density(t_starts, t_ends, sigmas, **kw):
+        sd = sigmas * (t_ends - t_starts)
+        trans = torch.exp(-(torch.cumsum(sd, -1) - sd))
+        alphas = 1 - torch.exp(-sd)
+        return trans * alphas, trans, alphas
+
     m.render_weight_from_alpha, m.accumulate_along_rays = render_weight_from_alpha, accumulate_along_rays
+    m.render_weight_from_density = render_weight_from_density
     return m
 
 
@@ -149,7 +156,8 @@ def _shrink(c):
     return c
 
 
-def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_actors=3, fp16_tables=False):
+def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_actors=3, fp16_tables=False, use_sdf=True,
+                normalize_depth=False):
     """(the plugin on cuda:0, resolved through the registry; the reference's torch model on the CPU; same weights).
     pose_opt: camera_optimizer.mode = "SO3xR3" on both (the `*-scaleopt` methods, configs/method_configs.py:438-447), with
     non-zero pose adjustments so that the rays really move.  n_actors > 3: `_many_trajectories`.  fp16_tables: the plugin's
@@ -170,6 +178,7 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_
     mcfg.fused_decoder = fused_decoder
     if fp16_tables:  # the plugin's own switch (integration/neurad_hip.py: NeuRADHipModelConfig.table_dtype)
         mcfg.table_dtype = "float16"
+    mcfg.field.use_sdf, mcfg.normalize_depth = use_sdf, normalize_depth
     if pose_opt:
         mcfg.camera_optimizer = deepcopy(mcfg.camera_optimizer)
         mcfg.camera_optimizer.mode = "SO3xR3"
@@ -190,6 +199,7 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_
         c.grid.actor.use_4d_hashgrid = False
     if pose_opt:  # (the method table's camera optimizer carries its own penalties: the same object on both sides)
         ref_cfg.camera_optimizer = deepcopy(mcfg.camera_optimizer)
+    ref_cfg.field.use_sdf, ref_cfg.normalize_depth = use_sdf, normalize_depth
     refm = ref_cfg.setup(**kw())
     assert sorted(hip.state_dict()) == sorted(refm.state_dict())
     _fill(hip)
@@ -206,8 +216,13 @@ def _build_pair(ref_neurad, with_actors, fused_decoder=False, pose_opt=False, n_
     ref_neurad.nerfacc = na
     ref_renderers.nerfacc = na
     # (on the INSTANCE: the plugin class inherits from NeuRADModel and must keep the reference's method)
-    refm._render_weights = lambda outputs, rs: na.render_weight_from_alpha(
-        outputs[ref_neurad.FieldHeadNames.ALPHA].squeeze(-1))[0]
+    if use_sdf:
+        refm._render_weights = lambda outputs, rs: na.render_weight_from_alpha(
+            outputs[ref_neurad.FieldHeadNames.ALPHA].squeeze(-1))[0]
+    else:  # models/neurad.py:718-723
+        refm._render_weights = lambda outputs, rs: na.render_weight_from_density(
+            t_starts=rs.frustums.starts.squeeze(-1), t_ends=rs.frustums.ends.squeeze(-1),
+            sigmas=outputs[ref_neurad.FieldHeadNames.DENSITY].squeeze(-1))[0]
     return hip, refm
 
 
@@ -803,3 +818,36 @@ def test_every_gradient_outlier_has_a_class(ref, scene):
     terms = ["rgb_loss", "distortion_loss", "depth_loss", "intensity_loss", "carving_loss", "ray_drop_loss"]
     rep = classify_gradient_outliers(hip, refm, b, terms, f"r06_grad_outlier_classes_{scene}.json")
     print(scene, {t_: {k: v for k, v in e.items() if k != "unclassified"} for t_, e in rep.items()})
+
+
+@pytest.mark.parametrize("mode", ["density", "normalize_depth", "density+normalize_depth"])
+def test_plugin_training_step_in_the_non_default_modes_runs_fused_and_matches_the_reference(ref, mode):
+    """``use_sdf=False`` (fields/neurad_field.py:149-151: trunc_exp density -> render_weight_from_density,
+    models/neurad.py:718-723) and ``normalize_depth=True`` (DepthRenderer("expected"), model_components/renderers.py:398-416,
+    for the final samples and both proposal rounds) ran on the operator-level path up to round 5; round 6: the fused
+    training nodes cover them (the density head inside nrhip_sdf_render_fwd/bwd, the normalisation over the nodes' outputs).
+    Same checks as the default-mode step: every loss term, the outputs, every parameter gradient per loss term."""
+    hip, refm = _build_pair(ref, False, use_sdf="density" not in mode, normalize_depth="normalize_depth" in mode)
+    b = _batch(False)
+    _deterministic(hip, True), _deterministic(refm, True)
+    if "density" in mode:  # a translucent medium: raw densities around exp(-1.5) per metre
+        with torch.no_grad():
+            for m in (hip, refm):
+                m.field.mlp_geo.layers[-1].bias[0] = -1.5
+    assert hip.fused_training_possible()
+    g_out, g_loss = _losses(hip, b, "cuda")
+    w_out, w_loss = _losses(refm, b, "cpu")
+    assert set(g_loss) == set(w_loss)
+    for k in w_loss:
+        a, c = float(g_loss[k]), float(w_loss[k])
+        assert abs(a - c) <= 2e-4 * abs(c) + 1e-7, (k, a, c)
+    for k in ("rgb", "depth", "accumulation", "intensity", "ray_drop_logits", "prop_depth_0", "prop_depth_1"):
+        assert rel_l2(N(g_out[k]), N(w_out[k])) < 1e-4, (k, rel_l2(N(g_out[k]), N(w_out[k])))
+    errs = per_loss_gradient_errors(hip, g_loss, refm, w_loss, detail=True)
+    check_gradients_against_floor(errs, _floors("static"))
+    seen = {k for kinds in errs.values() for k in kinds}
+    assert {"table", "mlp", "embedding", "lidar_head", "decoder"} <= seen and ("beta" in seen) == ("density" not in mode)
+    for term in ("rgb_loss", "interlevel_loss"):
+        for kind, st in errs[term].items():
+            if kind in ("table", "mlp", "embedding", "decoder"):
+                assert st["rel_l2"] < 5e-4, (term, kind, st)
