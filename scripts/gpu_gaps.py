@@ -12,7 +12,8 @@ def main():
     cur = con.cursor()
     win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 60e6
     min_gap = float(sys.argv[3]) * 1e3 if len(sys.argv) > 3 else 8e3
-    rows = sorted(cur.execute("select start, end, name from kernels"))
+    # (hipBLASLt GEMMs are bench.py's clock warm-up spin, not part of any step: they would win the "densest window" contest)
+    rows = sorted(r for r in cur.execute("select start, end, name from kernels") if not r[2].startswith("Cijk_"))
     merged = []  # [start, end, last kernel name, first kernel name]
     for s, e, n in rows:
         if merged and s <= merged[-1][1]:

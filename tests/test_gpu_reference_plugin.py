@@ -847,7 +847,10 @@ def test_plugin_training_step_in_the_non_default_modes_runs_fused_and_matches_th
     check_gradients_against_floor(errs, _floors("static"))
     seen = {k for kinds in errs.values() for k in kinds}
     assert {"table", "mlp", "embedding", "lidar_head", "decoder"} <= seen and ("beta" in seen) == ("density" not in mode)
+    # ... and tight in absolute terms on the terms that reach every parameter (the density head's exp amplifies the ReLU-kink
+    # flips of the geometry MLP: 31 of 17 031 table rows carry the rgb term's 9e-4, the rest agrees to 1e-5)
     for term in ("rgb_loss", "interlevel_loss"):
         for kind, st in errs[term].items():
             if kind in ("table", "mlp", "embedding", "decoder"):
-                assert st["rel_l2"] < 5e-4, (term, kind, st)
+                assert st["rel_l2"] < (2e-3 if "density" in mode else 5e-4), (term, kind, st)
+                assert st["rest_rel_l2"] < 2e-4, (term, kind, st)
