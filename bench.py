@@ -904,7 +904,8 @@ def bench_c1(args, device, rank, world):
                                    "pairs with fp32 accumulation)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": n_samples * bytes_per,
-                         "kernel_ms": kernel_ms,
+                         "kernel_ms": kernel_ms, "kernel_ms_plain_mean": float(np.mean(ts)),
+                         "frac_at_the_plain_mean": n_samples * bytes_per / (float(np.mean(ts)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_how": f"HIP events around every 4th of the {args.steps} timed launches; the first one (right after "
                                           f"the synchronize, {ts[0] * 1e3:.1f} us) weighted 1 / {args.steps}, the others' mean "
                                           f"({float(np.mean(ts[1:]) if len(ts) > 1 else ts[0]) * 1e3:.1f} us) {args.steps - 1} / {args.steps}"},
