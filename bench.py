@@ -392,10 +392,29 @@ def torch_op_attribution(step_fn, path, n=2):
         c = agg.setdefault((ev.name, " <- ".join(where[:3]), shapes), [0, 0.0])
         c[0] += 1
         c[1] += self_us
+    # device-to-device copies (hipMemcpyAsync: `__amd_rocclr_copyBuffer` in a kernel trace) are not kernels of their op: they
+    # hang off the CPU op that issued them as `kernels` entries named Memcpy / Memset
+    mem = {}
+    for ev in prof.events():
+        for k in (getattr(ev, "kernels", None) or []):
+            if "emcpy" not in k.name and "emset" not in k.name:
+                continue
+            where, p = [], ev.cpu_parent
+            while p is not None:
+                if p.name.startswith("S:") or "evaluate_function" in p.name or p.name.endswith("Backward") or "Fn" in p.name:
+                    where.append(p.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
+                p = p.cpu_parent
+            shapes = str([sh for sh in (getattr(ev, "input_shapes", None) or []) if sh])[:60]
+            c = mem.setdefault((k.name[:28], ev.name, " <- ".join(where[:3]), shapes), [0, 0.0])
+            c[0] += 1
+            c[1] += k.duration
     with open(path, "w") as f:
         f.write(f"# aten ops with device time of their own over {n} steps: calls, device us, op, enclosing step part / autograd node, input shapes\n")
         for (name, where, shapes), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write(f"{cnt:5d} {us:9.1f}  {name:24s} {where}  {shapes}\n")
+        f.write(f"# device memcpy / memset nodes over {n} steps: calls, device us, kind, issuing op, enclosing part / node, input shapes\n")
+        for (kind, op, where, shapes), (cnt, us) in sorted(mem.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{cnt:5d} {us:9.1f}  {kind:28s} {op:22s} {where}  {shapes}\n")
 
 
 def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS, n_lidar=C3_LIDAR_RAYS, rgb_decoder=True,
