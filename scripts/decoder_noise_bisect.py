@@ -8,7 +8,8 @@ csrc/decoder.hip:1459-1566), every intermediate kept; then
   (2) SUBSTITUTION: the backward is re-run with one class of ops (BatchNorm backward / input-gradient convolution / weight-gradient
       convolution / residual add) replaced by that fp32 evaluation (rounded to fp16 where the chain carries fp16), and the error
       of every weight gradient against the reference's fp32 model is compared with torch autocast's.
-usage: python scripts/decoder_noise_bisect.py [patches] [patch_size]   -> a table on stdout"""
+usage: python scripts/decoder_noise_bisect.py [patches] [patch_size] [seed]   -> a table on stdout (+ a RATIOS line: HIP error /
+loss-scaled autocast error per weight tensor, for averaging over seeds)"""
 import os
 import sys
 
@@ -22,7 +23,8 @@ from neurad_studio_amd.model_components.cnns import _fused_decoder_args, decode_
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-torch.manual_seed(0)
+SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+torch.manual_seed(SEED)
 dev = "cuda"
 dec = make_rgb_decoder(48, 32, 3).to(dev).train()
 feats = torch.randn((B * P * P, 48), device=dev)
@@ -46,18 +48,19 @@ def loss_of(rgb):
     return F.mse_loss(rgb, image)
 
 
-def run_torch(autocast):
+def run_torch(autocast, loss_scale=1.0):
     for p in dec.parameters():
         p.grad = None
     f = feats.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
         rgb = decode_rgb(dec, f, (P, P), fused=False).float()
-    loss_of(rgb).backward()
-    return {n: p.grad.clone() for n, p in dec.named_parameters()}
+    (loss_of(rgb) * loss_scale).backward()
+    return {n: p.grad.clone() / loss_scale for n, p in dec.named_parameters()}
 
 
 ref = run_torch(False)
 auto = run_torch(True)
+auto_scaled = {k: run_torch(True, 2.0 ** k) for k in (8, 16)}  # what the trainer's GradScaler does for the torch modules
 params, states, bns = _fused_decoder_args(dec)
 names = [n for n, _ in dec.named_parameters()]
 pmap = {id(p): n for n, p in dec.named_parameters()}
@@ -148,21 +151,25 @@ def staged(substitute=()):
         if k == 2:
             dcur = D.upsample_bwd(up_in, dcur, wup, g[pn[34]], g[pn[35]], gs)
     D.conv1x1_in_bwd(feats, h0.view(-1, 32), dcur.view(-1, 32), w0, g[pn[0]], g[pn[1]], gs)
+    dh = dcur.view(-1, 32).float() * (h0.view(-1, 32) > 0)
+    iso["conv_in.wgrad"] = rel(g[pn[0]].view(32, -1), dh.t() @ feats * inv)
     return g, iso
 
 
 conv_w = [n for n in names if n.endswith(("main_branch.0.weight", "main_branch.3.weight"))]
+other_w = [n for n in names if n.endswith("weight") and n not in conv_w and "main_branch" not in n]  # 1x1 in, upsample, rgb head
 g0, iso = staged()
 print(f"# {B} patches of {P} x {P}; rel-L2 of d loss / d (7x7 weights) against the reference's fp32 modules")
 print("staged chain == monolithic call:", max(rel(g0[n], hip[n]) for n in conv_w))
 print("\n(1) each backward op against its fp32 evaluation on the SAME inputs (rel-L2 of the op's output):")
 for k, v in iso.items():
     print(f"   {k:26s} {v:.2e}")
-runs = {"HIP decoder": g0}
-for sub in (("bn",), ("dgrad",), ("wgrad",), ("add",), ("bn", "dgrad", "wgrad", "add")):
+runs = {"autocast x 2^8": auto_scaled[8], "autocast x 2^16": auto_scaled[16], "HIP decoder": g0}
+for sub in (("bn", "dgrad", "wgrad", "add"),):
     runs["HIP, fp32 " + "+".join(sub)] = staged(sub)[0]
 print("\n(2) weight-gradient error per 7x7 convolution (first = nearest the input), and the ratio to torch autocast's:")
-print(f"   {'layer':34s} {'autocast':>9s} " + " ".join(f"{k[:22]:>22s}" for k in runs))
-for n in conv_w:
+print(f"   {'layer':24s} {'autocast':>9s} " + " ".join(f"{k[:24]:>24s}" for k in runs))
+for n in other_w[:1] + conv_w + other_w[1:]:
     a = rel(auto[n], ref[n])
-    print(f"   {n:34s} {a:9.3f} " + " ".join(f"{rel(r[n], ref[n]):13.3f} ({rel(r[n], ref[n]) / a:4.2f}x)" for r in runs.values()))
+    print(f"   {n:24s} {a:9.3f} " + " ".join(f"{rel(r[n], ref[n]):15.3f} ({rel(r[n], ref[n]) / a:4.2f}x)" for r in runs.values()))
+print("RATIOS", SEED, " ".join(f"{rel(g0[n], ref[n]) / rel(auto_scaled[16][n], ref[n]):.3f}" for n in other_w[:1] + conv_w + other_w[1:2]))

@@ -575,9 +575,9 @@ def test_plugin_training_step_32_actors_fp16_tables_matches_the_reference_torch_
 def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
     """the same step with decode_features' CNN on csrc/decoder.hip (fp16 operands, fp32 accumulation: the arithmetic of the
     reference trainer's mixed precision, configs/method_configs.py:401).  The yardstick for that arithmetic is the trainer's
-    own path -- the SAME torch modules under torch.autocast(fp16) on the GPU: against the reference's fp32 CPU model the HIP
-    decoder may not be further off than 2 x what autocast is (+ a floor), output, loss and every decoder gradient
-    (both are fp16 noise of 1 - 5 % on three 24 x 24 patches: the ratio of two such numbers scatters)."""
+    own path -- the SAME torch modules under torch.autocast(fp16) with the GradScaler's loss scale on the GPU: against the
+    reference's fp32 CPU model the HIP decoder may not be further off than 1.5 x what that is (+ a floor): output, loss and
+    every decoder gradient."""
     hip, refm = _build_pair(ref, False, fused_decoder=True)
     b = _batch(False, patch=8, n_patches=3, n_lidar=24)  # 24 x 24 px patches: BatchNorm statistics over > 1000 pixels
     _deterministic(hip, True), _deterministic(refm, True)
@@ -585,9 +585,9 @@ def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
     sum(w_loss.values()).backward()
     want = {n: p.grad for n, p in refm.named_parameters() if n.startswith("rgb_decoder") and not _analytically_zero(n)}
 
-    def run():
+    def run(loss_scale=1.0):
         out, loss = _losses(hip, b, "cuda")
-        sum(loss.values()).backward()
+        (sum(loss.values()) * loss_scale).backward()
         return out, loss
 
     g_out, g_loss = run()
@@ -605,11 +605,14 @@ def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
     try:
         for p in dec.parameters():
             p.grad = None
-        a_out, a_loss = run()
+        # the yardstick runs as the trainer runs autocast: under a loss scale (GradScaler's 2^16, engine/trainer.py:553).
+        # Unscaled, fp16 gradients of a mean over 10^4 - 10^6 pixels are subnormal or zero (at the bench's 40 x 96 x 96 pixels
+        # EVERY autocast gradient underflows: scripts/decoder_noise_bisect.py) and the yardstick measures the underflow
+        a_out, a_loss = run(loss_scale=65536.0)
     finally:
         hip._modules["rgb_decoder"] = dec
         hip.config.fused_decoder = True
-    auto = {"rgb_decoder." + n: p.grad for n, p in dec.named_parameters()}
+    auto = {"rgb_decoder." + n: p.grad / 65536.0 for n, p in dec.named_parameters()}
     e_rgb, y_rgb = rel_l2(N(g_out["rgb"]), N(w_out["rgb"])), rel_l2(N(a_out["rgb"]), N(w_out["rgb"]))
     assert e_rgb <= max(2.0 * y_rgb, 3e-3), (e_rgb, y_rgb)
     for k in w_loss:
@@ -620,7 +623,14 @@ def test_plugin_training_step_with_the_hip_rgb_decoder(ref):
     for n, c in want.items():
         e, y = rel_l2(N(got[n]), N(c)), rel_l2(N(auto[n]), N(c))
         report[n] = (float(f"{e:.1e}"), float(f"{y:.1e}"))
-        assert e <= max(2.0 * y, 5e-3), (n, e, y)
+        # round 6: against the loss-scaled autocast yardstick (+ a floor).  scripts/decoder_noise_bisect.py: every HIP
+        # backward op agrees with its fp32 evaluation on the same inputs to the rounding of its fp16 output (2e-4; weight
+        # gradients 3e-7), replacing all of them by fp32 changes no weight gradient -- what is left is the forward's fp16
+        # activations, which autocast has too (HIP 0.069 / 0.061 / 0.060 against scaled autocast's 0.075 / 0.066 / 0.065 on the
+        # bench batch's first layers)
+        # (ONE batch: the ratio of two fp16-noise figures scatters -- over eight seeds of the standalone decoder the HIP / scaled
+        # autocast ratio is 0.93 +- 0.06 per layer, profiles/r06_decoder_noise_bisect.txt -- hence 1.5 x here, not 1.1 x)
+        assert e <= max(1.5 * y, 5e-3), (n, e, y)
     print("decoder gradients vs the reference fp32 model: (HIP decoder, torch autocast fp16):", report)
 
 
