@@ -662,6 +662,7 @@ def train_via_plugin_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA
     from torch.cuda.amp.grad_scaler import GradScaler
 
     from neurad_studio_amd.integration.pipeline import ADHipPipeline
+    from neurad_studio_amd.optim import TableGradScaler
     from neurad_studio_amd.parallel.data_parallel import GradientSynchronizer
 
     methods = dict(ref_methods.all_methods)
@@ -703,17 +704,22 @@ def train_via_plugin_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA
                                  config=types.SimpleNamespace(ray_patch_size=(32, 32)))
     pipe.get_train_loss_dict = lambda step: ADHipPipeline.get_train_loss_dict(pipe, step)
     groups = {k: v for k, v in m.get_param_groups().items() if len(v)}
-    loop = types.SimpleNamespace(config=types.SimpleNamespace(log_gradients=False), device=f"cuda:{device.index or 0}",
-                                 mixed_precision=bool(mixed_precision), grad_scaler=GradScaler(enabled=bool(mixed_precision)),
-                                 gradient_accumulation_steps=defaultdict(lambda: 1), pipeline=pipe,
-                                 optimizers=Optimizers(deepcopy({k: method.optimizers[k] for k in groups}), groups))
+    # the trainer class the method's config names (integration/trainer.py: HipTrainer, the reference's iteration with the
+    # schedulers' step deferred past its two get_scale() host reads), given the attributes Trainer.__init__ / setup set
+    trainer_cls = method._target
+    loop = object.__new__(trainer_cls)
+    loop.__dict__.update(config=types.SimpleNamespace(log_gradients=False, deferred_scheduler_step=True),
+                         device=f"cuda:{device.index or 0}", mixed_precision=bool(mixed_precision),
+                         grad_scaler=TableGradScaler(enabled=bool(mixed_precision)),  # (HipTrainer.__init__)
+                         gradient_accumulation_steps=defaultdict(lambda: 1), pipeline=pipe,
+                         optimizers=Optimizers(deepcopy({k: method.optimizers[k] for k in groups}), groups))
     params = [p for p in m.parameters() if p.requires_grad]
     sync = GradientSynchronizer(params, average=True, usage="static", overlap=world > 1, auto_sync=True,
                                 wire_dtype=WIRE_DTYPE) if world > 1 else None
     state = {}
 
-    def step(i=None):
-        loss, loss_dict, _ = Trainer.train_iteration(loop, 0 if i is None else i)
+    def step(i=None, iterate=trainer_cls.train_iteration):
+        loss, loss_dict, _ = iterate(loop, 0 if i is None else i)
         m.sampler.step_cb(0)  # the model's AFTER_TRAIN_ITERATION callback (models/neurad.py:291-300)
         state["loss"] = loss
 
@@ -723,17 +729,28 @@ def train_via_plugin_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA
     el = timed(step, steps, 1, world, device)
     host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
     assert torch.isfinite(state["loss"]), "non-finite loss"
+    # the same model, optimizers and scaler stepped by the reference's own Trainer.train_iteration (its two get_scale() reads)
+    loop._settle_schedulers()
+    hip_scaler, loop.grad_scaler = loop.grad_scaler, GradScaler(enabled=bool(mixed_precision))  # (engine/trainer.py:189)
+    loop.grad_scaler.load_state_dict(hip_scaler.state_dict())
+    el_ref = timed(lambda i=None: step(i, Trainer.train_iteration), steps, 1, world, device)
     if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
         torch_op_attribution(step, os.environ["NRHIP_BENCH_TORCH_PROFILE"] + ".via_plugin")
     return {"iters_per_sec": steps / el, "ms_per_iter": el / steps * 1e3, "steps": steps,
             "rays_per_sec": world * (n_cam + n_lidar) * steps / el, "host_enqueue_ms_per_step": host_issue_ms,
+            "trainer": trainer_cls.__name__, "ms_per_iter_under_the_reference_trainer": el_ref / steps * 1e3,
+            "grad_scaler": type(hip_scaler).__name__,
             "mixed_precision": bool(mixed_precision), "grad_scaler_scale": loop.grad_scaler.get_scale() if mixed_precision else None,
             "fused_losses": bool(fused_losses), "table_dtype": table_dtype,
             "optimizers": {k: type(v).__name__ for k, v in loop.optimizers.optimizers.items()},
             "grad_exchange_bytes_per_rank": sync.last_sync_bytes if sync is not None else 0,
-            "what": "the c3 step as `ns-train neurad-hip` executes it: the reference's Trainer.train_iteration (autocast + "
-                    "GradScaler + Optimizers + schedulers) over NeuRADHipModel / ADHipPipeline.get_train_loss_dict with the "
-                    "method's own optimizer table; same batch, sizes and loss terms as train_full"}
+            "what": "the c3 step as `ns-train neurad-hip` executes it: the method's trainer class (HipTrainer = the reference's "
+                    "Trainer.train_iteration -- autocast + GradScaler + Optimizers + schedulers -- with the schedulers' step "
+                    "deferred to the next iteration's optimizer step instead of two get_scale() host reads, and a GradScaler "
+                    "whose inf check over the table gradients is read-only) over NeuRADHipModel "
+                    "/ ADHipPipeline.get_train_loss_dict with the method's own optimizer table; same batch, sizes and loss "
+                    "terms as train_full; ms_per_iter_under_the_reference_trainer = the same objects stepped by the "
+                    "reference's Trainer.train_iteration itself with torch's GradScaler"}
 
 
 def device_state(device_index=0):

@@ -415,6 +415,20 @@ int nrhip_adam_step_many_dev(const nrhip_adam_tensor_dev* tensors /* HOST array 
                              double host_grad_scale, const float* grad_scale, const float* found_inf, void* workspace,
                              void* stream);
 
+/* GradScaler's inf check over gradients, READ-ONLY (ABI 511).  torch.amp.GradScaler.step runs `_check_inf_per_device` on an
+ * optimizer that consumes the scale itself (engine/optimizers.py:168-181 steps every group through it): torch's
+ * `_amp_foreach_non_finite_check_and_unscale_` with a scale of 1, which reads and re-writes every element.  This entry point
+ * only reads: *found_inf (DEVICE fp32 scalar) is set to 1 when any element of any tensor is +-inf or NaN and is left alone
+ * otherwise (the caller zeroes it; several calls may accumulate into one flag).  dtype 0 = fp32, 1 = fp16. */
+typedef struct nrhip_check_tensor {
+  const void* data;  /* [n], 16-byte aligned */
+  int64_t n;
+  int32_t dtype;
+  int32_t reserved;
+} nrhip_check_tensor;
+int nrhip_nonfinite_check_many(const nrhip_check_tensor* tensors /* HOST array */, int32_t n_tensors, float* found_inf,
+                               void* stream);
+
 /* Processing order for cache locality (fills nrhip_rays.order): a permutation that groups rays looking at the same
  * region -- counting sort by the Morton code of the contracted position (ScaledSceneContraction, static_scale as in
  * nrhip_field) of the point origin + direction * t_ref, t_ref = a representative sample distance (the sampler's

@@ -81,6 +81,10 @@ class AdamTensorDev(C.Structure):  # nrhip_adam_tensor_dev
                 ("reserved", C.c_int32)]
 
 
+class CheckTensor(C.Structure):  # nrhip_check_tensor
+    _fields_ = [("data", C.c_void_p), ("n", C.c_int64), ("dtype", C.c_int32), ("reserved", C.c_int32)]
+
+
 class OccGrid(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("resolution", C.c_int32), ("binaries", C.c_void_p)]
 
@@ -182,6 +186,7 @@ PROTOTYPES = {
     "nrhip_adam_step_many_workspace": [I32, C.POINTER(I64)],
     "nrhip_adam_step_many_dev": [C.POINTER(AdamTensorDev), I32, C.c_double, P, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_double, P, P, P, P],
+    "nrhip_nonfinite_check_many": [C.POINTER(CheckTensor), I32, P, P],
     "nrhip_proposal_density_fwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P],
     "nrhip_proposal_density_bwd": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P],
     "nrhip_proposal_density_bwd_binned": [C.POINTER(Proposal), C.POINTER(Rays), P, P, P, P, P, I32, P, I64, P],

@@ -89,7 +89,8 @@ extern "C" const char* nrhip_last_error(void) { return nrhip::g_err; }
 // glue of train_fused.hip, nrhip_field_fwd_train_ovr, nrhip_eval_layout_*.
 // 510: nrhip_encode_bwd_binned / nrhip_hashgrid_bwd_binned write fp32 gradients whatever g->param_dtype says (the fp16 form
 // is nrhip_encode_bwd_binned_f16); nrhip_adam_step_many_dev (+ _workspace), nrhip_tuning_reload.
-extern "C" int nrhip_version(void) { return 510; }
+// 511: nrhip_nonfinite_check_many.
+extern "C" int nrhip_version(void) { return 511; }
 
 extern "C" int nrhip_tuning_reload(void) {
   nrhip::g_tuning = nrhip::read_tuning();

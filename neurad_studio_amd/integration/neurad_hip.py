@@ -306,7 +306,10 @@ def _trainer_config():
         if name != "hashgrids" and type(opt) in (AdamOptimizerConfig, AdamWOptimizerConfig):
             fused = FusedAdamWConfig if isinstance(opt, AdamWOptimizerConfig) else FusedAdamConfig
             group["optimizer"] = fused(lr=opt.lr, eps=opt.eps, max_norm=opt.max_norm, weight_decay=opt.weight_decay)
-    return cfg
+    # the trainer: the reference's iteration without its two grad_scaler.get_scale() host reads (integration/trainer.py)
+    from .trainer import HipTrainerConfig
+
+    return HipTrainerConfig(**{f.name: getattr(cfg, f.name) for f in dataclasses.fields(cfg) if f.name != "_target"})
 
 
 _SPEC = None

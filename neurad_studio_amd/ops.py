@@ -1222,6 +1222,26 @@ def adam_step_many_dev(items, lr, beta1: float = 0.9, beta2: float = 0.999, eps:
          scalar(found_inf, "found_inf"), workspace.data_ptr(), _stream())
 
 
+def nonfinite_check(tensors, found_inf: Tensor) -> Tensor:
+    """GradScaler's inf check, read-only (csrc/adam.hip: nonfinite_check_kernel): ``found_inf`` (fp32 GPU scalar) becomes 1
+    when any element of any of ``tensors`` (contiguous fp32 / fp16 GPU tensors, 16-byte aligned) is inf or NaN; it is never
+    cleared here.  Same flag semantics as ``torch._amp_foreach_non_finite_check_and_unscale_`` at a scale of 1, without the
+    write-back."""
+    tensors = [t for t in tensors if t.numel()]
+    if not (found_inf.is_cuda and found_inf.dtype == torch.float32 and found_inf.numel() == 1):
+        raise ValueError("nonfinite_check: found_inf must be an fp32 GPU scalar")
+    if not tensors:
+        return found_inf
+    arr = (_lib.CheckTensor * len(tensors))()
+    for k, t in enumerate(tensors):
+        if (not t.is_cuda or t.dtype not in (torch.float32, torch.float16) or not t.is_contiguous() or t.data_ptr() % 16
+                or t.device != found_inf.device):
+            raise ValueError("nonfinite_check: tensors must be contiguous, 16-byte aligned fp32 / fp16 tensors on found_inf's GPU")
+        arr[k].data, arr[k].n, arr[k].dtype = t.data_ptr(), t.numel(), 1 if t.dtype == torch.float16 else 0
+    call("nrhip_nonfinite_check_many", arr, len(tensors), found_inf.data_ptr(), _stream())
+    return found_inf
+
+
 def reload_tuning() -> None:
     """the library reads its NRHIP_* A/B switches once at load; call this after changing one inside a running process"""
     call("nrhip_tuning_reload")

@@ -153,3 +153,34 @@ class HashGridAdam(torch.optim.Optimizer):
             for k in ("master", "exp_avg", "exp_avg_sq"):
                 if k in saved[i]:
                     self.state[p][k] = saved[i][k].detach().to(device=p.device, dtype=torch.float32).clone()
+
+
+class TableGradScaler(torch.amp.GradScaler):
+    """torch.amp.GradScaler whose inf check over a ``HashGridAdam``'s gradients only READS them.
+
+    ``GradScaler.step`` runs ``_check_inf_per_device`` on every optimizer that consumes the scale itself
+    (torch/amp/grad_scaler.py; the reference steps each group through it, engine/optimizers.py:168-181): torch's
+    ``_amp_foreach_non_finite_check_and_unscale_`` at a scale of 1 reads AND re-writes every gradient element -- 1.2 GB per
+    step for NeuRAD's 600 MB of table gradients.  For a HashGridAdam the same flag comes from ``ops.nonfinite_check`` (one
+    read); every other optimizer, and any gradient that kernel does not take (sparse, other devices, unaligned views), goes
+    through torch's own pass.  Scale growth / backoff, ``unscale_``, ``state_dict``: inherited unchanged.  (The override point
+    is the one torch's own ShardedGradScaler uses.)"""
+
+    def __init__(self, device: str = "cuda", **kwargs) -> None:
+        super().__init__(device, **kwargs)
+
+    def _check_inf_per_device(self, optimizer):
+        if isinstance(optimizer, HashGridAdam):
+            grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+            devices = {g.device for g in grads}
+            if grads and len(devices) == 1 and all(
+                    g.is_cuda and not g.is_sparse and g.dtype in (torch.float32, torch.float16) and g.is_contiguous()
+                    and g.data_ptr() % 16 == 0 for g in grads):
+                self._check_scale_growth_tracker("_check_inf_per_device")
+                device = grads[0].device
+                found_inf = torch.zeros((), dtype=torch.float32, device=device)
+                ops.nonfinite_check(grads, found_inf)
+                state = self._per_optimizer_states[id(optimizer)]
+                state["found_inf_per_device"] = {device: found_inf}
+                return state["found_inf_per_device"]
+        return super()._check_inf_per_device(optimizer)

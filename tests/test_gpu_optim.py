@@ -134,8 +134,9 @@ def test_sharded_table_adam_single_process_equals_torch_adam():
     assert float(other.state_dict()["state"][0]["step"]) == 4.0
 
 
+@pytest.mark.parametrize("scaler_cls", ["torch", "table"])
 @pytest.mark.parametrize("table_dtype", [torch.float32, torch.float16], ids=["fp32", "fp16-storage"])
-def test_hashgrid_adam_speaks_the_gradscaler_protocol(table_dtype):
+def test_hashgrid_adam_speaks_the_gradscaler_protocol(table_dtype, scaler_cls):
     """engine/trainer.py:550-576: every optimizer is stepped through ``grad_scaler.step``.  HashGridAdam declares
     ``_step_supports_amp_scaling`` and consumes ``grad_scale`` / ``found_inf`` on the device (csrc/adam.hip,
     nrhip_adam_step_many_dev): scaled gradients give torch.optim.Adam's trajectory on the unscaled ones, an inf skips the
@@ -149,7 +150,10 @@ def test_hashgrid_adam_speaks_the_gradscaler_protocol(table_dtype):
     b = torch.nn.Parameter(p0.clone())
     ours = HashGridAdam([a], lr=1e-2, eps=1e-15)
     ref = torch.optim.Adam([b], lr=1e-2, eps=1e-15)
-    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=1000)
+    from neurad_studio_amd.optim import TableGradScaler
+
+    # (TableGradScaler: the same protocol with the read-only inf check, what HipTrainer installs)
+    scaler = (TableGradScaler if scaler_cls == "table" else torch.amp.GradScaler)("cuda", init_scale=1024.0, growth_interval=1000)
     done = 0
     for step in range(8):
         g = torch.zeros_like(p0)
@@ -217,3 +221,50 @@ def test_hashgrid_adam_capturable_replays_in_a_hip_graph():
         ref.step()
         assert torch.allclose(a, b, rtol=3e-6, atol=3e-8), k
     assert float(ours.state[a]["step"]) == 6.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_nonfinite_check_is_torchs_found_inf(dtype):
+    """ops.nonfinite_check (nrhip_nonfinite_check_many) against torch._amp_foreach_non_finite_check_and_unscale_ at a scale of
+    1: the flag for +inf / -inf / NaN at the first element, the last, the scalar tail and in the middle of a 16-byte group;
+    the largest finite values, denormals and -0 do not raise it; 30 tensors (two launches); the tensors are not written."""
+    from neurad_studio_amd import ops
+
+    torch.manual_seed(0)
+    sizes = [1, 3, 4, 5, 7, 8, 9, 1023, 4096, 65537, (1 << 20) + 3] + [257 + 13 * k for k in range(19)]
+    big = torch.finfo(dtype).max
+    tiny = torch.finfo(dtype).smallest_normal / 4  # a denormal
+    base = []
+    for n in sizes:
+        t = torch.randn(n, device="cuda").to(dtype)
+        t[0], t[-1] = big, -big
+        if n > 4:
+            t[1], t[2], t[3] = tiny, -0.0, -tiny
+        base.append(t)
+    one = torch.ones((), device="cuda")
+
+    def both(tensors):
+        want = torch.zeros((), device="cuda")
+        torch._amp_foreach_non_finite_check_and_unscale_([t.clone() for t in tensors], want, one)
+        got = torch.zeros((), device="cuda")
+        keep = [t.clone() for t in tensors]
+        ops.nonfinite_check(tensors, got)
+        for a, b in zip(tensors, keep):
+            assert torch.equal(a.view(torch.int16 if dtype == torch.float16 else torch.int32),
+                               b.view(torch.int16 if dtype == torch.float16 else torch.int32))
+        return float(got), float(want)
+
+    assert both(base) == (0.0, 0.0)
+    assert both([]) == (0.0, 0.0)
+    for which, where in ((0, 0), (3, 4), (10, (1 << 20) + 2), (10, 1 << 19), (10, (1 << 19) + 1), (29, 100), (7, 1022), (9, 65536),
+                         (9, 65532), (24, 0), (23, 5)):
+        for bad in (float("inf"), float("-inf"), float("nan")):
+            tensors = [t.clone() for t in base]
+            tensors[which][where] = bad
+            assert both(tensors) == (1.0, 1.0), (which, where, bad)
+    # the flag accumulates: a call over clean tensors leaves a raised flag raised
+    flag = torch.ones((), device="cuda")
+    ops.nonfinite_check(base, flag)
+    assert float(flag) == 1.0
+    with pytest.raises(ValueError):
+        ops.nonfinite_check([base[10][1:]], torch.zeros((), device="cuda"))  # (a view off the 16-byte grid: the caller's job)
