@@ -137,11 +137,24 @@ int nrhip_hashgrid_bwd_input(const nrhip_grid* g, const void* table, const float
 /* Several grids of one shape in one launch -- the per-actor grids of NeuRADHashEncoding (the reference loops over
  * actor ids, `_get_actor_features_slow`, neurad_encoding.py:270-295).  tables / grad_tables: DEVICE arrays of n_grids
  * pointers to [L*T,F] fp32 tables; grid_id [N] int32 selects the grid of each sample.  grad_tables are ACCUMULATED
- * into. */
+ * into; a sample whose grid_id is outside [0, n_grids) or whose grad_tables entry is NULL sends nothing (ABI 511; the
+ * forward and _bwd_input need valid ids). */
 int nrhip_hashgrid_multi_fwd(const nrhip_grid* g, const void* const* tables, int32_t n_grids, const int32_t* grid_id,
                              const float* x /*[N,3]*/, int64_t n, float* out /*[N,L*F]*/, void* stream);
 int nrhip_hashgrid_multi_bwd(const nrhip_grid* g, int32_t n_grids, const int32_t* grid_id, const float* x,
                              const float* grad_out, int64_t n, float* const* grad_tables, void* stream);
+/* The same table gradients WITHOUT memory-side atomics (ABI 511): the radix partition of nrhip_encode_bwd_binned over
+ * (slot, level, slice) -- the gradients of the n_slots grids that have samples form ONE block [n_slots][L*T][F] (fp32, or
+ * fp16 for fp16-storage grids: block_dtype 1, at most 2^23 samples), EVERY element of which is written (no zero-fill by
+ * the caller).  slot_of [n_grids] int32 DEVICE: the grid's position in the block, < 0 = no gradient wanted (its samples
+ * send nothing, like samples with grid_id outside [0, n_grids)).  Same sums as nrhip_hashgrid_multi_bwd up to the order of
+ * the fp32 additions (this one is bit-reproducible).  _workspace gives 0 bytes when the shape cannot be partitioned
+ * (n_slots x T / slice length > 2048 columns per level): use the atomic entry point then. */
+int nrhip_hashgrid_multi_bwd_binned_workspace(const nrhip_grid* g, int32_t n_slots, int64_t n, int64_t* bytes /*host*/);
+int nrhip_hashgrid_multi_bwd_binned(const nrhip_grid* g, int32_t n_grids, const int32_t* grid_id, const int32_t* slot_of,
+                                    int32_t n_slots, const float* x /*[N,3]*/, const float* grad_out /*[N,L*F]*/, int64_t n,
+                                    void* grad_block, int32_t block_dtype, void* workspace, int64_t workspace_bytes,
+                                    void* stream);
 int nrhip_hashgrid_multi_bwd_input(const nrhip_grid* g, const void* const* tables, int32_t n_grids,
                                    const int32_t* grid_id, const float* x, const float* grad_out, int64_t n,
                                    float* grad_x /*[N,3]*/, void* stream);

@@ -144,6 +144,8 @@ PROTOTYPES = {
     "nrhip_hashgrid_multi_fwd": [C.POINTER(Grid), P, I32, P, P, I64, P, P],
     "nrhip_hashgrid_multi_bwd": [C.POINTER(Grid), I32, P, P, P, I64, P, P],
     "nrhip_hashgrid_multi_bwd_input": [C.POINTER(Grid), P, I32, P, P, P, I64, P, P],
+    "nrhip_hashgrid_multi_bwd_binned_workspace": [C.POINTER(Grid), I32, I64, C.POINTER(I64)],
+    "nrhip_hashgrid_multi_bwd_binned": [C.POINTER(Grid), I32, P, P, I32, P, P, I64, P, I32, P, I64, P],
     "nrhip_encode_fwd": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P],
     "nrhip_encode_bwd": [C.POINTER(Grid), F32, C.POINTER(Rays), P, P, P],
     "nrhip_encode_bwd_rays": [C.POINTER(Grid), P, F32, C.POINTER(Rays), P, P, P, P],

@@ -122,15 +122,18 @@ __device__ __forceinline__ void store_record(float* __restrict__ p, const float 
 }
 
 // Returns false when the grid can not be binned (too many slices per level).
-bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p) {
+// n_slots > 1: the MULTI-GRID form (the per-actor grids, MultiSrc below) -- n_slots tables of the shape `g` side by side; a
+// level's slices are then (slot, slice-of-that-table) pairs, nb = n_slots x the slices of one table, and everything downstream
+// (histograms, prefix sums, queues, one `reduce` workgroup per slice) is the single-grid machinery over those columns.
+bool make_plan(const GridDev& g, int64_t n_total, BinPlan* p, int n_slots = 1) {
   const int64_t n = n_total < round_samples() ? n_total : round_samples();  // larger batches go through in rounds
   int log2F = 0;
   while ((1 << log2F) < g.F) ++log2F;
   int log2TS = 14 - log2F;  // 8-byte accumulators: 16384 / F entries fill the 128 KB image
   if (log2TS > g.log2T) log2TS = g.log2T;
   // small tables: shrink the slices until `reduce` has ~2 workgroups per CU (one workgroup owns one slice)
-  while (((int64_t)g.L << (g.log2T - log2TS)) < 512 && log2TS > 9) --log2TS;
-  const int64_t nb = (int64_t)1 << (g.log2T - log2TS);
+  while ((((int64_t)g.L * n_slots) << (g.log2T - log2TS)) < 512 && log2TS > 9) --log2TS;
+  const int64_t nb = ((int64_t)1 << (g.log2T - log2TS)) * n_slots;
   if (nb > kMaxSlices) return false;
   p->log2TS = log2TS;
   p->nb = (int)nb;
@@ -230,6 +233,34 @@ struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   int width;  // L * F
   __device__ bool silent(int64_t w0, int64_t n_rows) const { return rows_are_zero(go, width, w0, n_rows); }
   __device__ int coherent_rays(int64_t, int64_t) const { return 0; }  // bare positions: no rays to compare
+};
+struct MultiSrc {  // H5's per-actor grids (nrhip_hashgrid_multi_bwd_binned): positions given, ONE of n_grids tables per sample
+  const float* x;
+  const float* go;
+  const int* gid;      // [N] grid of each sample (< 0 or >= n_grids: the sample sends nothing)
+  const int* slot_of;  // [n_grids] position of the grid's gradient in the output block, < 0: no gradient wanted
+  int n_grids;
+  int L;
+  int width;  // L * F
+  __device__ int slot(int64_t i) const {
+    const int g_ = gid[i];
+    return (g_ >= 0 && g_ < n_grids) ? slot_of[g_] : -1;
+  }
+  // (the fourth component is the std of the ray-sample sources; here it carries the slot to `count` / `emit`)
+  __device__ float4 position(int64_t i) const { return make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], __int_as_float(slot(i))); }
+  __device__ float pre(int64_t) const { return 0.f; }
+  template <int F>
+  __device__ void grad(int64_t i, int l, float, float, float, float (&gv)[F]) const {
+#pragma unroll
+    for (int k = 0; k < F; ++k) gv[k] = go[(i * L + l) * F + k];
+  }
+  __device__ bool silent(int64_t w0, int64_t n_rows) const {
+    bool z = rows_are_zero(go, width, w0, n_rows);
+    const int64_t i = w0 + (threadIdx.x & 63);
+    if (i < n_rows && slot(i) < 0) z = true;
+    return z;
+  }
+  __device__ int coherent_rays(int64_t, int64_t) const { return 0; }
 };
 struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(decoder . rescaled features), F = 1
   RaysDev r;
@@ -360,8 +391,8 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
 template <bool PAIR>
 __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, int nb, uint32_t* __restrict__ counts,
                                                           const float4* __restrict__ gpos,
-                                                          const uint32_t* __restrict__ nlive) {
-  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std of the block's samples
+                                                          const uint32_t* __restrict__ nlive, int multi) {
+  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std (multi: slot) of the block's samples
   uint32_t* hist = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
   const int tid = threadIdx.x;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
@@ -380,11 +411,12 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, 
       if (__ballot(live) == 0ull) continue;  // wave-uniform
       const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
+      const uint32_t sb = multi ? __float_as_uint(p.w) << g.log2T : 0u;  // multi-grid: entry = slot * T + hash
 #pragma unroll
       for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
         // a silent sample never joins a run of equal entries; the first lane of a 16-lane row always heads a run
-        const uint32_t kf = live ? c.idx[PAIR ? kPairF[k] : k] : 0xffffffffu;
-        const uint32_t kc = PAIR ? (live ? c.idx[kPairC[k]] : 0xffffffffu) : kf;
+        const uint32_t kf = live ? (c.idx[PAIR ? kPairF[k] : k] | sb) : 0xffffffffu;
+        const uint32_t kc = PAIR ? (live ? (c.idx[kPairC[k]] | sb) : 0xffffffffu) : kf;
         const bool head = dpp_row_shr<1>(kf, ~kf) != kf || (PAIR && dpp_row_shr<1>(kc, ~kc) != kc);
         if (live && head) {
           atomicAdd(&hist[kf >> log2TS], 1u);
@@ -477,7 +509,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
                                                          const float4* __restrict__ gpos,
                                                          const uint16_t* __restrict__ gidx,
                                                          const uint32_t* __restrict__ nlive, float* __restrict__ qrec,
-                                                         float* __restrict__ qmax, int nmax) {
+                                                         float* __restrict__ qmax, int nmax, int multi) {
   extern __shared__ __attribute__((aligned(16))) float4 pos[];
   uint32_t* rank = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
   uint32_t* base = rank + nb;
@@ -513,6 +545,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
       if (__ballot(live) == 0ull) continue;
       const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
+      const uint32_t sb = multi ? __float_as_uint(p.w) << g.log2T : 0u;
       float w[8];
       corner_weights(c, w);
       float gv[F];
@@ -524,8 +557,8 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
       constexpr int NV = PAIR ? 2 * F : F, RW = NV + 1;  // values per record, record length in dwords
 #pragma unroll
       for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
-        const uint32_t kf = live ? c.idx[PAIR ? kPairF[k] : k] : 0xffffffffu;
-        const uint32_t kc = PAIR ? (live ? c.idx[kPairC[k]] : 0xffffffffu) : kf;
+        const uint32_t kf = live ? (c.idx[PAIR ? kPairF[k] : k] | sb) : 0xffffffffu;
+        const uint32_t kc = PAIR ? (live ? (c.idx[kPairC[k]] | sb) : 0xffffffffu) : kf;
         const bool head = dpp_row_shr<1>(kf, ~kf) != kf || (PAIR && dpp_row_shr<1>(kc, ~kc) != kc);
         const unsigned long long hm = __ballot(head);
         float v[NV];  // (floor-corner terms, then ceil-corner terms)
@@ -597,20 +630,27 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
                                                            const float* __restrict__ qrec,
                                                            const float* __restrict__ qmax_all, float* __restrict__ gt,
                                                            int log2T, int log2TS, int nb, int nmax, int overwrite,
-                                                           int out_half) {
+                                                           int out_half, int nbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];
   __shared__ float smax[16];
   __shared__ uint32_t poisoned;
   const int lb = blockIdx.x;
   const uint32_t first = offsets[lb], cnt = offsets[lb + 1] - first;
   const int l = lb / nb, b = lb - l * nb;
+  // where the slice's entries start in grad_table, in entries.  One grid: [L][T].  Multi-grid (nbg = slices per table and
+  // level > 0): the block is grid-major, [slot][L][T] -- every slot's gradient a contiguous [L * T, F] tensor.
+  size_t entry0 = ((size_t)l << log2T) + ((size_t)b << log2TS);
+  if (nbg > 0) {
+    const int slot = b / nbg, L = (int)gridDim.x / nb;
+    entry0 = (((size_t)slot * L + l) << log2T) + ((size_t)(b - slot * nbg) << log2TS);
+  }
   if (cnt == 0) {  // uniform: nothing was sent to this slice
     if (overwrite && out_half) {  // fp16 gradient (fp16-storage table): half the bytes, written as 8-byte groups
-      __half* z = reinterpret_cast<__half*>(gt) + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+      __half* z = reinterpret_cast<__half*>(gt) + entry0 * F;
       const int nz = F << log2TS;
       for (int i = threadIdx.x; i < nz; i += 1024) z[i] = __float2half(0.f);
     } else if (overwrite) {  // the caller did not zero grad_table: this slice's part of it is ours to define
-      float* z = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+      float* z = gt + entry0 * F;
       const int nz = F << log2TS;
       if (nz % 4 == 0)
         for (int i = threadIdx.x * 4; i < nz; i += 4096) *reinterpret_cast<float4*>(z + i) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -669,13 +709,13 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint32_t* __rest
     }
   }
   __syncthreads();
-  float* out = gt + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+  float* out = gt + entry0 * F;
   const bool any_poison = poisoned != 0;
   const float nan = __uint_as_float(0x7fc00000u);
   if (out_half) {
     // the gradient of an fp16-storage table in the table's own type (overwrite mode only: the launcher refuses the rest):
     // autograd wants it in the parameter's dtype, and the 537 MB fp32 image + its cast pass (0.2 ms on config[4]) never exist
-    __half* oh = reinterpret_cast<__half*>(gt) + (((size_t)l << log2T) + ((size_t)b << log2TS)) * F;
+    __half* oh = reinterpret_cast<__half*>(gt) + entry0 * F;
     for (int i = threadIdx.x; i < nacc; i += 1024) {
       float o = (float)ldexp((double)(long long)tile[i], -sh);
       if (any_poison && ((pbits[i >> 5] >> (i & 31)) & 1)) o = nan;
@@ -735,11 +775,14 @@ namespace {
 // All four passes for one source of samples, in rounds of round_samples().  `what` names the entry point in errors.
 template <class Src>
 int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, bool overwrite,
-               void* workspace, int64_t workspace_bytes, hipStream_t st) {
+               void* workspace, int64_t workspace_bytes, hipStream_t st, int n_slots = 0) {
+  // n_slots > 0: the multi-grid form (MultiSrc): grad_table is a block of n_slots gradients, [slot][L * T][F]
+  const int multi = n_slots > 0 ? 1 : 0;
   BinPlan p;
-  NR_REQUIRE(make_plan(gd, n, &p), NRHIP_ERR_UNSUPPORTED,
-             "%s: 2^%d entries x %d features need more than %d slices per level; use the atomic entry point", what,
-             gd.log2T, gd.F, kMaxSlices);
+  NR_REQUIRE(make_plan(gd, n, &p, multi ? n_slots : 1), NRHIP_ERR_UNSUPPORTED,
+             "%s: %d table(s) of 2^%d entries x %d features need more than %d slices per level; use the atomic entry point", what,
+             multi ? n_slots : 1, gd.log2T, gd.F, kMaxSlices);
+  const int nbg = multi ? p.nb / n_slots : 0;  // slices per table and level
   NR_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total_bytes, NRHIP_ERR_INVALID_ARG,
              "%s: workspace of %lld bytes, need %zu", what, (long long)workspace_bytes, p.total_bytes);
   NR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_table) & 15) == 0,
@@ -781,9 +824,9 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
     bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive, transposed_walk_enabled() ? 1 : 0);
     if (p.pair)
-      bin_count_kernel<true><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
+      bin_count_kernel<true><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive, multi);
     else
-      bin_count_kernel<false><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
+      bin_count_kernel<false><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive, multi);
     if (int e = check_launch(what)) return e;
     // one segment: its sums ARE the column totals and there is no second level
     bin_scan_chunks_kernel<<<dim3((cols + 255) / 256, nseg), 256, 0, st>>>(counts, chunks, cols, nseg > 1 ? segtot : totals);
@@ -810,9 +853,10 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     }                                                                                                               \
     bin_emit_kernel<F, P, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,             \
                                                             nseg > 1 ? segtot : nullptr, offsets, gpos, gidx,       \
-                                                            nlive, qrec, qmax, p.nmax);                             \
+                                                            nlive, qrec, qmax, p.nmax, multi);                      \
     bin_reduce_kernel<F, P><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,   \
-                                                       p.nmax, (overwrite && i_off == 0) ? 1 : 0, out_half ? 1 : 0); \
+                                                       p.nmax, (overwrite && i_off == 0) ? 1 : 0, out_half ? 1 : 0, \
+                                                       nbg);                                                        \
   } while (0)
 #define CALL(F)              \
   do {                       \
@@ -870,6 +914,31 @@ extern "C" int nrhip_hashgrid_bwd_binned(const nrhip_grid* g, const float* x, co
   const GridSrc src{x, grad_out, gd.L, gd.L * gd.F};
   return run_binned("hashgrid_bwd_binned", gd, src, n, grad_table, overwrite != 0, workspace, workspace_bytes,
                     (hipStream_t)stream);
+}
+
+extern "C" int nrhip_hashgrid_multi_bwd_binned_workspace(const nrhip_grid* g, int32_t n_slots, int64_t n, int64_t* bytes) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(bytes && n >= 0 && n_slots >= 1, NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd_binned_workspace: bad argument");
+  BinPlan p;
+  *bytes = (n > 0 && make_plan(to_dev(*g), n, &p, n_slots)) ? (int64_t)p.total_bytes : 0;
+  return NRHIP_OK;
+}
+
+extern "C" int nrhip_hashgrid_multi_bwd_binned(const nrhip_grid* g, int32_t n_grids, const int32_t* grid_id,
+                                               const int32_t* slot_of, int32_t n_slots, const float* x, const float* grad_out,
+                                               int64_t n, void* grad_block, int32_t block_dtype, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+  if (int e = validate_grid(g)) return e;
+  NR_REQUIRE(grid_id && slot_of && x && grad_out && grad_block && n > 0 && n_grids >= 1 && n_slots >= 1 && n_slots <= n_grids &&
+                 (block_dtype == 0 || block_dtype == 1),
+             NRHIP_ERR_INVALID_ARG, "hashgrid_multi_bwd_binned: bad argument (every element of the block is written: n > 0)");
+  GridDev gd = to_dev(*g);
+  NR_REQUIRE(((int64_t)n_slots << gd.log2T) < ((int64_t)1 << 32) - 1, NRHIP_ERR_UNSUPPORTED,
+             "hashgrid_multi_bwd_binned: %d tables of 2^%d entries exceed 32-bit entry numbers", n_slots, gd.log2T);
+  gd.dtype = block_dtype;  // the block's type: 1 = fp16 gradients for fp16-storage tables (one round only)
+  const MultiSrc src{x, grad_out, grid_id, slot_of, n_grids, gd.L, gd.L * gd.F};
+  return run_binned("hashgrid_multi_bwd_binned", gd, src, n, static_cast<float*>(grad_block), true, workspace, workspace_bytes,
+                    (hipStream_t)stream, n_slots);
 }
 
 // grad_table part of nrhip_proposal_density_bwd (the decoder gradient stays with that entry point's kernel)

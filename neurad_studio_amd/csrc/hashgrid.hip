@@ -75,16 +75,18 @@ template <int F>
 __global__ __launch_bounds__(256) void hashgrid_multi_bwd_kernel(GridDev g, const int32_t* __restrict__ grid_id,
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ go, int64_t n,
-                                                                  float* const* __restrict__ gts) {
+                                                                  float* const* __restrict__ gts, int n_grids) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * g.L) return;
   const int64_t i = t / g.L;
   const int l = (int)(t - i * g.L);
+  const uint32_t gid = (uint32_t)grid_id[i];
+  if (gid >= (uint32_t)n_grids || gts[gid] == nullptr) return;  // no such grid / no gradient wanted: the row sends nothing
   const uint32_t mask = (1u << g.log2T) - 1u;
   const Corners c = hash_corners(x[3 * i], x[3 * i + 1], x[3 * i + 2], g.scal[l], mask);
   float w[8];
   corner_weights(c, w);
-  float* base = gts[grid_id[i]] + ((size_t)l << g.log2T) * F;
+  float* base = gts[gid] + ((size_t)l << g.log2T) * F;
 #pragma unroll
   for (int k = 0; k < 8; ++k)
 #pragma unroll
@@ -100,15 +102,17 @@ template <int F>
 __global__ __launch_bounds__(256) void hashgrid_multi_bwd_runs_kernel(GridDev g, const int32_t* __restrict__ grid_id,
                                                                        const float* __restrict__ x,
                                                                        const float* __restrict__ go, int64_t n,
-                                                                       float* const* __restrict__ gts) {
+                                                                       float* const* __restrict__ gts, int n_grids) {
   const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = i0 < n;
-  const int64_t i = live ? i0 : n - 1;
+  const int64_t i = i0 < n ? i0 : n - 1;
   const int lane = threadIdx.x & 63;
-  const uint32_t gid = live ? (uint32_t)grid_id[i] : 0xffffffffu;
+  const uint32_t gid0 = (uint32_t)grid_id[i];
+  // a row whose grid does not exist (id outside [0, n_grids)) or wants no gradient (NULL entry) sends nothing
+  float* const table = (i0 < n && gid0 < (uint32_t)n_grids) ? gts[gid0] : nullptr;
+  const bool live = table != nullptr;
+  const uint32_t gid = live ? gid0 : 0xffffffffu;
   const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
   const uint32_t mask = (1u << g.log2T) - 1u;
-  float* const table = live ? gts[grid_id[i]] : nullptr;
   for (int l = 0; l < g.L; ++l) {
     const Corners c = hash_corners(px, py, pz, g.scal[l], mask);
     float w[8];
@@ -657,12 +661,12 @@ extern "C" int nrhip_hashgrid_multi_bwd(const nrhip_grid* g, int32_t n_grids, co
   const GridDev gd = to_dev(*g);
   if (!tuning().multi_bwd_runs) {  // NRHIP_MULTI_BWD_RUNS=0: one thread per (row, level), every corner term its own atomic (A/B)
     const int blocks = grid_for(n * gd.L, 256);
-#define CALL(F) hashgrid_multi_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables)
+#define CALL(F) hashgrid_multi_bwd_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables, n_grids)
     DISPATCH_F(gd.F, CALL);
 #undef CALL
   } else {
     const int blocks = grid_for(n, 256);
-#define CALL(F) hashgrid_multi_bwd_runs_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables)
+#define CALL(F) hashgrid_multi_bwd_runs_kernel<F><<<blocks, 256, 0, (hipStream_t)stream>>>(gd, grid_id, x, grad_out, n, grad_tables, n_grids)
     DISPATCH_F(gd.F, CALL);
 #undef CALL
   }

@@ -229,6 +229,25 @@ def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor,
         present = grids_present(grid_id, n_grids)
     if not any(present):
         return [None] * n_grids
+    n, n_slots = x.shape[0], sum(present)
+    if n >= _BINNED_MIN_SAMPLES and not _FORCE_ATOMIC_SCATTER:
+        # the radix partition over (slot, level, slice) (csrc/encode_bwd_binned.hip, MultiSrc): no memory-side atomics, every
+        # element of the block written by the partition (no zero-fill), fp16-storage grids get their fp16 gradient directly
+        half = out_dtype == torch.float16 and n <= _BINNED_ROUND_SAMPLES and "NRHIP_BIN_ROUND_LOG2" not in os.environ
+        g = spec.c_grid(torch.empty((spec.table_rows, spec.features_per_level), device="meta"))  # (the shape only)
+        need = C.c_int64(0)
+        call("nrhip_hashgrid_multi_bwd_binned_workspace", C.byref(g), n_slots, n, C.byref(need))
+        if need.value > 0:
+            block = torch.empty((n_slots, spec.table_rows, spec.features_per_level), device=x.device,
+                                dtype=torch.float16 if half else torch.float32)
+            ws = torch.empty((need.value,), device=x.device, dtype=torch.uint8)
+            slot32 = _present_slots(tuple(present), x.device, torch.int32)
+            call("nrhip_hashgrid_multi_bwd_binned", C.byref(g), n_grids, _ptr(grid_id), _ptr(slot32), n_slots, _ptr(x),
+                 _ptr(grad_out), n, _ptr(block), 1 if half else 0, _ptr(ws), ws.numel(), _stream())
+            if block.dtype != out_dtype:
+                block = block.to(out_dtype)
+            views = iter(block.unbind(0))
+            return [next(views) if p else None for p in present]
     # one zero-filled block for all touched grids (a scene has ~100 actor grids: one fill, not one per grid)
     flat = torch.zeros((sum(present), spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
     views = iter(flat.unbind(0))
@@ -249,10 +268,10 @@ def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor,
 _SLOT_TABLES: dict = {}
 
 
-def _present_slots(present: Tuple[bool, ...], device) -> Tensor:
-    """int64 [n_grids]: position of each touched grid in the packed gradient block, -1 for untouched ones; uploaded once per
-    distinct pattern"""
-    key = (device, present)
+def _present_slots(present: Tuple[bool, ...], device, dtype=torch.int64) -> Tensor:
+    """int64 / int32 [n_grids]: position of each touched grid in the packed gradient block, -1 for untouched ones; uploaded once
+    per distinct pattern"""
+    key = (device, present, dtype)
     t = _SLOT_TABLES.get(key)
     if t is None:
         if len(_SLOT_TABLES) >= 64:
@@ -261,7 +280,7 @@ def _present_slots(present: Tuple[bool, ...], device) -> Tensor:
         for p in present:
             slots.append(k if p else -1)
             k += int(p)
-        t = _SLOT_TABLES[key] = torch.tensor(slots, dtype=torch.int64, device=device)
+        t = _SLOT_TABLES[key] = torch.tensor(slots, dtype=dtype, device=device)
     return t
 
 
