@@ -110,6 +110,59 @@ class MultiHashGridFn(torch.autograd.Function):
         return (gx, None, None, *gts)
 
 
+class TableBundle:
+    """what the consumers of one ``StackTablesFn`` output share: which grids ANY of their batches touched (a grid none
+    touched gets no gradient at all -- the reference's per-id loop never evaluates it, so torch.optim.Adam leaves its
+    moments alone), and whether the node's backward has run (its graph is gone: build a new one)"""
+
+    def __init__(self, n_grids: int) -> None:
+        self.present = [False] * n_grids
+        self.spent = False
+
+
+class StackTablesFn(torch.autograd.Function):
+    """tables of one shape -> ONE tensor [A, rows, F] (a copy), for a set of grids that several nodes of one step look into
+    (the proposal field's actor grids: once per sampler round).  The consumers' gradients then meet on the stacked tensor --
+    one add of the block -- instead of on each of the A parameters (autograd's AccumulateGrad: A adds per extra consumer; 32
+    per c4 step).  Backward: table a gets row a of the block, or None when no consumer's batch touched it."""
+
+    @staticmethod
+    def forward(ctx, bundle, *tables):
+        ctx.bundle = bundle
+        return torch.stack(tables)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.bundle.spent = True
+        return (None, *[g[a] if p else None for a, p in enumerate(ctx.bundle.present)])
+
+
+class MultiHashGridStackedFn(torch.autograd.Function):
+    """MultiHashGridFn over a stacked table set (StackTablesFn): the table gradient is ONE block [A, rows, F].
+    args: x [N,3], grid_id [N], spec, stacked [A, rows, F], bundle."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, grid_id, spec, stacked, bundle):
+        ctx.spec = spec
+        grid_id = grid_id.to(torch.int32)
+        ctx.present = ops.grids_present(grid_id, stacked.shape[0]) if ctx.needs_input_grad[3] else None  # (see MultiHashGridFn)
+        if ctx.present is not None:
+            bundle.present = [bool(a) or bool(b) for a, b in zip(bundle.present, ctx.present)]
+        ctx.save_for_backward(x, grid_id, stacked)
+        return ops.hashgrid_multi_fwd(spec, list(stacked.unbind(0)), grid_id, x)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, grid_id, stacked = ctx.saved_tensors
+        g = g.contiguous()
+        block = ops.hashgrid_multi_bwd(ctx.spec, stacked.shape[0], grid_id, x, g, present=ctx.present, out_dtype=stacked.dtype,
+                                       dense_block=True) if ctx.needs_input_grad[3] else None
+        gx = ops.hashgrid_multi_bwd_input(ctx.spec, list(stacked.unbind(0)), grid_id, x, g) if ctx.needs_input_grad[0] else None
+        return gx, None, None, block, None
+
+
 class ActorDensitySpliceFn(torch.autograd.Function):
     """Proposal density with the in-box samples' values spliced in (fields/neurad_field.py:208-213 over
     neurad_encoding.py:150-187): dens [N] static density, rows [P, La] rescaled actor features of the P (sample, actor)

@@ -11,6 +11,8 @@ backward) so actor grids and trajectories get the reference's gradients; rows ov
 table no gradient."""
 from __future__ import annotations
 
+import weakref
+
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -95,6 +97,9 @@ class _SpliceActorRowsFn(torch.autograd.Function):
         return g_feats, g_rows, None, None
 
 
+_STACKED_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()  # encoding -> (key, stacked tables, bundle)
+
+
 class NeuRADHashEncoding(nn.Module):
     def __init__(self, config: NeuRADHashEncodingConfig, dynamic_actors=None, static_scale: float = 1.0,
                  implementation: str = "hip") -> None:
@@ -119,6 +124,8 @@ class NeuRADHashEncoding(nn.Module):
                          log2_hashmap_size=a.log2_hashmap_size, features_per_level=a.hashgrid_dim,
                          implementation=implementation) for _ in range(n_actors)])
         self.scene_repr_dim = self.static_grid.get_out_dim()
+        # set by owners whose encoding is looked into several times per step (the proposal field: once per sampler round)
+        self.share_actor_table_grads = False
         if n_actors and a.num_levels * a.hashgrid_dim > self.scene_repr_dim:
             raise ValueError("actor feature dim exceeds the static feature dim (F.pad would be negative)")
 
@@ -236,9 +243,27 @@ class NeuRADHashEncoding(nn.Module):
         # _get_actor_features_slow loops over the actor ids; all actor grids share one shape, so one multi-grid
         # lookup (row i -> actor_grids[ids[i]]) does the same without the per-id launches and host syncs
         grid = self.actor_grids[0]
-        f = ag.MultiHashGridFn.apply(x01, ids, grid.spec, *[g.hash_table for g in self.actor_grids])
+        tables = [g.hash_table for g in self.actor_grids]
+        if self.share_actor_table_grads and len(tables) > 1 and torch.is_grad_enabled() and all(t.requires_grad for t in tables):
+            stacked, bundle = self._stacked_actor_tables(tables)
+            f = ag.MultiHashGridStackedFn.apply(x01, ids, grid.spec, stacked, bundle)
+        else:
+            f = ag.MultiHashGridFn.apply(x01, ids, grid.spec, *tables)
         w = 1 / (grid.scalings[None, :] * 2 * cstd[:, None]).clamp_min(1.0)
         return idx, winner, (f.view(-1, grid.num_levels, grid.features_per_level) * w[..., None]).flatten(1)
+
+    def _stacked_actor_tables(self, tables):
+        """the actor tables as one autograd-tracked tensor [A, rows, F] (ag.StackTablesFn), shared by every lookup of this
+        step: a proposal field is evaluated once per sampler round, and with one node per round autograd would add the
+        rounds' gradients on each of the A parameters (32 adds per c4 step); through the shared stack they meet in one add.
+        Rebuilt once its backward has run, and whenever the tables changed (in place, or under autograd's feet: the
+        optimizer kernels write through raw pointers and bump ops.TABLE_EPOCH)."""
+        key = (ops.TABLE_EPOCH[0], tuple((t.data_ptr(), t._version) for t in tables))
+        hit = _STACKED_TABLES.get(self)  # (not an attribute: a tensor with a grad_fn on the module would break deepcopy)
+        if hit is None or hit[0] != key or hit[2].spent:
+            bundle = ag.TableBundle(len(tables))
+            hit = _STACKED_TABLES[self] = (key, ag.StackTablesFn.apply(bundle, *tables), bundle)
+        return hit[1], hit[2]
 
     def _actor_rows_with_grad(self, feats, hit, hits, origins, directions, pixel_area, starts, ends, times, flip):
         """spliced in with index_put, whose autograd zeroes the static-table gradient of the replaced rows."""

@@ -350,6 +350,7 @@ class NeuRADProposalField(nn.Module):
         self.config, self.implementation = config, implementation
         self.hashgrid = NeuRADHashEncoding(config.grid, dynamic_actors=actors, static_scale=static_scale,
                                            implementation=implementation)
+        self.hashgrid.share_actor_table_grads = True  # evaluated once per sampler round: the rounds' gradients meet in one add
         self.density_decoder = nn.Linear(self.hashgrid.get_out_dim(), 1, bias=False)
 
     def get_param_groups(self, param_groups: Dict):

@@ -220,16 +220,36 @@ def grids_present(grid_id: Tensor, n_grids: int) -> List[bool]:
 
 
 def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, grad_out: Tensor,
-                       present: Optional[List[bool]] = None, out_dtype=torch.float32):
+                       present: Optional[List[bool]] = None, out_dtype=torch.float32, dense_block: bool = False):
     """-> one gradient per grid, None for grids no sample refers to (like the reference's per-id loop, which never
     touches them: their optimizer state must not decay).  present: ``grids_present(grid_id, n_grids)`` when the caller
-    already has it -- the backward then runs without a device->host read and without a host->device copy."""
+    already has it -- the backward then runs without a device->host read and without a host->device copy.
+    dense_block=True: -> ONE tensor [n_grids, rows, F] instead (zeros for the grids without samples)."""
     x, grid_id, grad_out = _chk(x, "x"), _chk(grid_id, "grid_id", torch.int32), _chk(grad_out, "grad_out")
     if present is None:
         present = grids_present(grid_id, n_grids)
+    present = [bool(p) for p in present]
+    if dense_block:
+        # slot a = grid a; a grid without samples keeps its (all-zero) slot
+        block = _multi_bwd_block(spec, n_grids, grid_id, x, grad_out, tuple(a if p else -1 for a, p in enumerate(present)), n_grids,
+                                 out_dtype) if any(present) else None
+        if block is None:
+            block = torch.zeros((n_grids, spec.table_rows, spec.features_per_level), device=x.device, dtype=out_dtype)
+        return block
     if not any(present):
         return [None] * n_grids
-    n, n_slots = x.shape[0], sum(present)
+    slots, k = [], 0
+    for p in present:
+        slots.append(k if p else -1)
+        k += int(p)
+    views = iter(_multi_bwd_block(spec, n_grids, grid_id, x, grad_out, tuple(slots), k, out_dtype).unbind(0))
+    return [next(views) if p else None for p in present]
+
+
+def _multi_bwd_block(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, grad_out: Tensor, slots: Tuple[int, ...],
+                     n_slots: int, out_dtype) -> Tensor:
+    """-> [n_slots, rows, F] of ``out_dtype``: slot slots[a] holds grid a's gradient (slots[a] < 0: grid a sends nothing)"""
+    n = x.shape[0]
     if n >= _BINNED_MIN_SAMPLES and not _FORCE_ATOMIC_SCATTER:
         # the radix partition over (slot, level, slice) (csrc/encode_bwd_binned.hip, MultiSrc): no memory-side atomics, every
         # element of the block written by the partition (no zero-fill), fp16-storage grids get their fp16 gradient directly
@@ -241,45 +261,34 @@ def hashgrid_multi_bwd(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor,
             block = torch.empty((n_slots, spec.table_rows, spec.features_per_level), device=x.device,
                                 dtype=torch.float16 if half else torch.float32)
             ws = torch.empty((need.value,), device=x.device, dtype=torch.uint8)
-            slot32 = _present_slots(tuple(present), x.device, torch.int32)
+            slot32 = _slot_table(slots, x.device, torch.int32)
             call("nrhip_hashgrid_multi_bwd_binned", C.byref(g), n_grids, _ptr(grid_id), _ptr(slot32), n_slots, _ptr(x),
                  _ptr(grad_out), n, _ptr(block), 1 if half else 0, _ptr(ws), ws.numel(), _stream())
-            if block.dtype != out_dtype:
-                block = block.to(out_dtype)
-            views = iter(block.unbind(0))
-            return [next(views) if p else None for p in present]
+            return block if block.dtype == out_dtype else block.to(out_dtype)
     # one zero-filled block for all touched grids (a scene has ~100 actor grids: one fill, not one per grid)
-    flat = torch.zeros((sum(present), spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
-    views = iter(flat.unbind(0))
-    gts = [next(views) if p else None for p in present]
+    flat = torch.zeros((n_slots, spec.table_rows, spec.features_per_level), device=x.device, dtype=torch.float32)
     g = spec.c_grid(flat[0])
     # device array of the gradient tables' addresses, computed ON the device (base + slot * stride; 0 for untouched grids):
     # a torch.tensor(list, device=...) here is a pageable host->device copy, i.e. a stream synchronisation per backward
-    slot = _present_slots(tuple(present), x.device)
+    slot = _slot_table(slots, x.device, torch.int64)
     ptrs = torch.where(slot >= 0, slot * (flat[0].numel() * 4) + flat.data_ptr(), torch.zeros_like(slot))
     call("nrhip_hashgrid_multi_bwd", C.byref(g), n_grids, _ptr(grid_id), _ptr(x), _ptr(grad_out), x.shape[0], _ptr(ptrs),
          _stream())
-    if out_dtype != torch.float32:  # fp16-storage grids: autograd wants the parameter's dtype -- ONE cast of the block
-        views = iter(flat.to(out_dtype).unbind(0))
-        gts = [next(views) if p else None for p in present]
-    return gts
+    # fp16-storage grids: autograd wants the parameter's dtype -- ONE cast of the block
+    return flat if out_dtype == torch.float32 else flat.to(out_dtype)
 
 
 _SLOT_TABLES: dict = {}
 
 
-def _present_slots(present: Tuple[bool, ...], device, dtype=torch.int64) -> Tensor:
-    """int64 / int32 [n_grids]: position of each touched grid in the packed gradient block, -1 for untouched ones; uploaded once
-    per distinct pattern"""
-    key = (device, present, dtype)
+def _slot_table(slots: Tuple[int, ...], device, dtype) -> Tensor:
+    """int64 / int32 [n_grids] on the device: position of each grid in the gradient block, -1 for grids without one; uploaded
+    once per distinct pattern"""
+    key = (device, slots, dtype)
     t = _SLOT_TABLES.get(key)
     if t is None:
         if len(_SLOT_TABLES) >= 64:
             _SLOT_TABLES.clear()
-        k, slots = 0, []
-        for p in present:
-            slots.append(k if p else -1)
-            k += int(p)
         t = _SLOT_TABLES[key] = torch.tensor(slots, dtype=dtype, device=device)
     return t
 
@@ -527,8 +536,13 @@ def eval_table(spec: GridSpec, table: Tensor):
     return None if hit[0] is None else hit
 
 
+TABLE_EPOCH = [0]  # bumped whenever a kernel has written tables behind autograd's back (the optimizer): copies made from
+                   # the tables before that (eval re-layouts, field_components/neurad_encoding.py's stacked actor tables) are stale
+
+
 def clear_eval_tables() -> None:
     _EVAL_TABLES.clear()
+    TABLE_EPOCH[0] += 1
 
 
 def field_fwd(fs: FieldSpec, origins, directions, pixel_area, starts, ends, order: Optional[Tensor] = None):

@@ -134,3 +134,49 @@ def test_multi_grid_partition_poisons_like_an_atomic_add_and_falls_back_when_too
     for a in range(n_grids):
         if present[a]:
             assert float((got[a] - single[a]).abs().max()) <= 2e-6 * float(single[a].abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("n", [3000, 50_000], ids=["atomics", "partition"])
+def test_shared_table_stack_gives_the_per_node_gradients(n):
+    """A grid set looked into by two nodes of one step (the proposal field's actor grids: once per sampler round): through
+    ag.StackTablesFn + MultiHashGridStackedFn the two gradients meet in one add of the block; every table must receive what
+    two MultiHashGridFn nodes give it, and a table neither batch touches must receive None (its Adam state must not move)."""
+    from neurad_studio_amd import autograd as ag
+    from neurad_studio_amd import ops
+
+    A, L, F, log2T = 6, 4, 1, 15
+    spec = ops.GridSpec(L, F, log2T, 16, 256)
+    torch.manual_seed(0)
+    tables = [torch.nn.Parameter(torch.randn((spec.table_rows, F), device="cuda") * 0.1) for _ in range(A)]
+    batches = []
+    for k in range(2):
+        x = torch.rand((n, 3), device="cuda", requires_grad=True)
+        ids = torch.randint(0, A, (n,), device="cuda")
+        ids[ids == 4] = 0           # grid 4: in neither batch
+        if k == 0:
+            ids[ids == 2] = 1       # grid 2: in the second batch only
+        batches.append((x, ids, torch.randn((n, L * F), device="cuda")))
+
+    def run(shared):
+        for t in tables:
+            t.grad = None
+        outs = []
+        if shared:
+            bundle = ag.TableBundle(A)
+            stacked = ag.StackTablesFn.apply(bundle, *tables)
+        for x, ids, w in batches:
+            x.grad = None
+            f = ag.MultiHashGridStackedFn.apply(x, ids, spec, stacked, bundle) if shared else ag.MultiHashGridFn.apply(x, ids, spec, *tables)
+            outs.append((f * w).sum())
+        (outs[0] + outs[1]).backward()
+        return [None if t.grad is None else t.grad.clone() for t in tables], [b[0].grad.clone() for b in batches], [float(o) for o in outs]
+
+    g_plain, gx_plain, v_plain = run(False)
+    g_shared, gx_shared, v_shared = run(True)
+    assert v_plain == v_shared
+    assert g_plain[4] is None and g_shared[4] is None
+    for a in range(A):
+        if a != 4:
+            assert float((g_plain[a] - g_shared[a]).abs().max()) <= 2e-6 * float(g_plain[a].abs().max()), a
+    for p, s_ in zip(gx_plain, gx_shared):
+        assert torch.equal(p, s_)
