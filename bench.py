@@ -521,6 +521,8 @@ def train_full_section(device, rank, world, steps, warmup, n_cam=C3_CAMERA_RAYS,
     host_issue_ms = LAST_ISSUE.get("s_per_step", 0.0) * 1e3
     assert torch.isfinite(state["loss"]), "non-finite loss"
     exchanged_bytes = state["bytes"]
+    if os.environ.get("NRHIP_BENCH_TORCH_PROFILE") and rank == 0:
+        torch_op_attribution(step, os.environ["NRHIP_BENCH_TORCH_PROFILE"] + ".train_full")
     graph_replay = None
     if use_graph:
         # the same step captured ONCE in a HIP graph (torch's whole-step recipe: the previous iteration's autograd graph is
