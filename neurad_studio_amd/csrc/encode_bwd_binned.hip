@@ -196,6 +196,7 @@ __device__ __forceinline__ bool rows_are_zero(const float* __restrict__ g, int w
 __device__ __forceinline__ int coherent_rays_of(const RaysDev& r, int64_t first_sample, int64_t count);  // (see `prep`)
 
 struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray samples, gradient of the rescaled features
+  static constexpr bool kMulti = false;
   RaysDev r;
   float scale;
   const float* go;
@@ -220,6 +221,7 @@ struct EncodeSrc {  // H2+H3+H1+H4 (nrhip_encode_bwd): positions from ray sample
   __device__ int coherent_rays(int64_t first, int64_t count) const { return coherent_rays_of(r, first, count); }
 };
 struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
+  static constexpr bool kMulti = false;
   const float* x;
   const float* go;
   int L;
@@ -235,6 +237,7 @@ struct GridSrc {  // H1 (nrhip_hashgrid_bwd): positions given
   __device__ int coherent_rays(int64_t, int64_t) const { return 0; }  // bare positions: no rays to compare
 };
 struct MultiSrc {  // H5's per-actor grids (nrhip_hashgrid_multi_bwd_binned): positions given, ONE of n_grids tables per sample
+  static constexpr bool kMulti = true;  // `count` / `emit` read the slot from the position's fourth component
   const float* x;
   const float* go;
   const int* gid;      // [N] grid of each sample (< 0 or >= n_grids: the sample sends nothing)
@@ -263,6 +266,7 @@ struct MultiSrc {  // H5's per-actor grids (nrhip_hashgrid_multi_bwd_binned): po
   __device__ int coherent_rays(int64_t, int64_t) const { return 0; }
 };
 struct ProposalSrc {  // S2 (nrhip_proposal_density_bwd): density = trunc_exp(decoder . rescaled features), F = 1
+  static constexpr bool kMulti = false;
   RaysDev r;
   float scale;
   const float* dec;
@@ -388,11 +392,11 @@ __global__ __launch_bounds__(1024) void bin_prep_kernel(Src src, int64_t i_off, 
 }
 
 // ---- count ---------------------------------------------------------------------------------------------------
-template <bool PAIR>
+template <bool PAIR, bool MULTI>
 __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, int nb, uint32_t* __restrict__ counts,
                                                           const float4* __restrict__ gpos,
-                                                          const uint32_t* __restrict__ nlive, int multi) {
-  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std (multi: slot) of the block's samples
+                                                          const uint32_t* __restrict__ nlive) {
+  extern __shared__ __attribute__((aligned(16))) float4 pos[];  // x, y, z, std (MULTI: slot) of the block's samples
   uint32_t* hist = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
   const int tid = threadIdx.x;
   constexpr int nt = 1024, nit = kSamplesPerBlock / nt;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(GridDev g, int log2TS, 
       if (__ballot(live) == 0ull) continue;  // wave-uniform
       const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
-      const uint32_t sb = multi ? __float_as_uint(p.w) << g.log2T : 0u;  // multi-grid: entry = slot * T + hash
+      const uint32_t sb = MULTI ? __float_as_uint(p.w) << g.log2T : 0u;  // multi-grid: entry = slot * T + hash
 #pragma unroll
       for (int k = 0; k < (PAIR ? 4 : 8); ++k) {
         // a silent sample never joins a run of equal entries; the first lane of a 16-lane row always heads a run
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
                                                          const float4* __restrict__ gpos,
                                                          const uint16_t* __restrict__ gidx,
                                                          const uint32_t* __restrict__ nlive, float* __restrict__ qrec,
-                                                         float* __restrict__ qmax, int nmax, int multi) {
+                                                         float* __restrict__ qmax, int nmax) {
   extern __shared__ __attribute__((aligned(16))) float4 pos[];
   uint32_t* rank = reinterpret_cast<uint32_t*>(pos + kSamplesPerBlock);
   uint32_t* base = rank + nb;
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(1024) void bin_emit_kernel(GridDev g, Src src, int 
       if (__ballot(live) == 0ull) continue;
       const float4 p = pos[live ? it * nt + tid : 0];
       const Corners c = hash_corners(p.x, p.y, p.z, sc, mask);
-      const uint32_t sb = multi ? __float_as_uint(p.w) << g.log2T : 0u;
+      const uint32_t sb = Src::kMulti ? __float_as_uint(p.w) << g.log2T : 0u;
       float w[8];
       corner_weights(c, w);
       float gv[F];
@@ -777,7 +781,8 @@ template <class Src>
 int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, float* grad_table, bool overwrite,
                void* workspace, int64_t workspace_bytes, hipStream_t st, int n_slots = 0) {
   // n_slots > 0: the multi-grid form (MultiSrc): grad_table is a block of n_slots gradients, [slot][L * T][F]
-  const int multi = n_slots > 0 ? 1 : 0;
+  const bool multi = n_slots > 0;
+  NR_REQUIRE(multi == Src::kMulti, NRHIP_ERR_INVALID_ARG, "%s: n_slots goes with the multi-grid source", what);
   BinPlan p;
   NR_REQUIRE(make_plan(gd, n, &p, multi ? n_slots : 1), NRHIP_ERR_UNSUPPORTED,
              "%s: %d table(s) of 2^%d entries x %d features need more than %d slices per level; use the atomic entry point", what,
@@ -810,8 +815,10 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
   const size_t lds_b = (size_t)nacc * sizeof(unsigned long long) + (size_t)((nacc + 31) / 32) * sizeof(uint32_t);
   static thread_local bool count_configured = false;
   if (!count_configured) {
-    (void)hipFuncSetAttribute((const void*)bin_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
-    (void)hipFuncSetAttribute((const void*)bin_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a_max);
     count_configured = true;
   }
   const int64_t round = round_samples();
@@ -824,9 +831,9 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     if (hipMemsetAsync(qmax, 0, (size_t)gd.L * p.nmax * sizeof(float), st) != hipSuccess) return check_launch(what);
     bin_prep_kernel<Src><<<chunks, 1024, 0, st>>>(src, i_off, cnt, n, gpos, gidx, nlive, transposed_walk_enabled() ? 1 : 0);
     if (p.pair)
-      bin_count_kernel<true><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive, multi);
+      bin_count_kernel<true, Src::kMulti><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     else
-      bin_count_kernel<false><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive, multi);
+      bin_count_kernel<false, Src::kMulti><<<grid_a, 1024, lds_a, st>>>(gd, p.log2TS, p.nb, counts, gpos, nlive);
     if (int e = check_launch(what)) return e;
     // one segment: its sums ARE the column totals and there is no second level
     bin_scan_chunks_kernel<<<dim3((cols + 255) / 256, nseg), 256, 0, st>>>(counts, chunks, cols, nseg > 1 ? segtot : totals);
@@ -853,7 +860,7 @@ int run_binned(const char* what, const GridDev& gd, const Src& src, int64_t n, f
     }                                                                                                               \
     bin_emit_kernel<F, P, Src><<<grid_a, 1024, lds_a, st>>>(gd, src, p.log2TS, p.nb, i_off, cnt, counts,             \
                                                             nseg > 1 ? segtot : nullptr, offsets, gpos, gidx,       \
-                                                            nlive, qrec, qmax, p.nmax, multi);                      \
+                                                            nlive, qrec, qmax, p.nmax);                             \
     bin_reduce_kernel<F, P><<<cols, 1024, lds_b, st>>>(offsets, qrec, qmax, grad_table, gd.log2T, p.log2TS, p.nb,   \
                                                        p.nmax, (overwrite && i_off == 0) ? 1 : 0, out_half ? 1 : 0, \
                                                        nbg);                                                        \
