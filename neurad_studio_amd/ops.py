@@ -250,7 +250,7 @@ def _multi_bwd_block(spec: GridSpec, n_grids: int, grid_id: Tensor, x: Tensor, g
                      n_slots: int, out_dtype) -> Tensor:
     """-> [n_slots, rows, F] of ``out_dtype``: slot slots[a] holds grid a's gradient (slots[a] < 0: grid a sends nothing)"""
     n = x.shape[0]
-    if n >= _BINNED_MIN_SAMPLES and not _FORCE_ATOMIC_SCATTER:
+    if n >= _BINNED_MIN_SAMPLES and not _FORCE_ATOMIC_SCATTER and _MULTI_BWD_BINNED:
         # the radix partition over (slot, level, slice) (csrc/encode_bwd_binned.hip, MultiSrc): no memory-side atomics, every
         # element of the block written by the partition (no zero-fill), fp16-storage grids get their fp16 gradient directly
         half = out_dtype == torch.float16 and n <= _BINNED_ROUND_SAMPLES and "NRHIP_BIN_ROUND_LOG2" not in os.environ
@@ -315,6 +315,7 @@ def hashgrid_bwd_input(spec: GridSpec, table: Tensor, x: Tensor, grad_out: Tenso
 # A/B switch for profiling and for the parity test of the atomic path
 _FORCE_ATOMIC_SCATTER = os.environ.get("NRHIP_ENCODE_BWD_ATOMIC") is not None
 _BINNED_MIN_SAMPLES = 1 << 15
+_MULTI_BWD_BINNED = os.environ.get("NRHIP_MULTI_BWD_BINNED", "1") != "0"  # 0: the actor grids' gradients by atomics (A/B)
 
 
 def _table_grad_workspace(c_grid, n_samples: int, device) -> Optional[Tensor]:

@@ -495,3 +495,44 @@ def test_plugin_decoder_adapter_is_the_reference_decoder_call_without_a_copy(ref
     assert x.permute(0, 2, 3, 1).reshape(-1, 48).data_ptr() == rows.data_ptr()
     with torch.no_grad():
         assert torch.equal(_NchwDecoderAdapter(dec)(x), dec(x))
+
+
+def test_neurad_hip_trainer_config_is_the_references_with_the_trainer_substituted(ref, monkeypatch):
+    """``ns-train neurad-hip`` instantiates ``config._target`` (scripts/train.py:96-107 -> TrainerConfig.setup): the method's
+    config is a HipTrainerConfig carrying EVERY field of the reference's ``neurad`` trainer config (schedules, logging, steps,
+    mixed_precision ...) and naming HipTrainer; the pending-scheduler-step bookkeeping of HipTrainer steps the schedulers
+    exactly when the scale did not go down."""
+    import dataclasses
+    import types
+
+    import nerfstudio.configs.method_configs as ref_methods
+    from nerfstudio.engine.trainer import Trainer, TrainerConfig
+
+    from neurad_studio_amd.integration.neurad_hip import neurad_hip
+    from neurad_studio_amd.integration.trainer import HipTrainer, HipTrainerConfig
+
+    cfg, ref_cfg = neurad_hip.config, ref_methods.method_configs["neurad"]
+    assert isinstance(cfg, HipTrainerConfig) and isinstance(cfg, TrainerConfig) and cfg._target is HipTrainer
+    assert issubclass(HipTrainer, Trainer) and cfg.deferred_scheduler_step and cfg.read_only_inf_check
+    substituted = {"_target", "method_name", "pipeline", "optimizers"}
+    for f in dataclasses.fields(ref_cfg):
+        if f.name not in substituted:
+            assert getattr(cfg, f.name) == getattr(ref_cfg, f.name), f.name
+    assert cfg.mixed_precision is True  # configs/method_configs.py:401
+    for name, group in ref_cfg.optimizers.items():  # same groups, same hyper-parameters and schedules
+        mine = cfg.optimizers[name]
+        assert mine["scheduler"] == group["scheduler"]
+        for k in ("lr", "eps", "weight_decay", "max_norm"):
+            assert getattr(mine["optimizer"], k) == getattr(group["optimizer"], k), (name, k)
+
+    stepped = []
+    loop = object.__new__(HipTrainer)
+    loop.optimizers = types.SimpleNamespace(scheduler_step_all=stepped.append)
+    done = types.SimpleNamespace(synchronize=lambda: None)
+    loop._settle_schedulers()                                   # nothing pending
+    loop._pending_scheduler_step = (7, torch.tensor(False), done)
+    loop._settle_schedulers()
+    loop._settle_schedulers()                                   # (settled once)
+    loop._pending_scheduler_step = (8, torch.tensor(True), done)  # the scale went down in iteration 8: no scheduler step
+    loop._settle_schedulers()
+    assert stepped == [7] and loop._pending_scheduler_step is None
