@@ -97,16 +97,14 @@ def make_parser_classes(root: Path):
     return SynthParserConfig
 
 
-@pytest.fixture()
-def pipeline(ref, tmp_path):
+def _method_config(tmp_path):
+    """the ``neurad-hip`` method's trainer config, pointed at the synthetic drive and shrunk to test size"""
     methods = dict(__import__("nerfstudio.configs.method_configs", fromlist=["all_methods"]).all_methods)
     if "neurad-hip" not in methods:
         from nerfstudio.plugins.registry import discover_methods
 
         methods.update(discover_methods()[0])
     cfg = deepcopy(methods["neurad-hip"])
-    from neurad_studio_amd.integration.pipeline import ADHipDataManager, ADHipPipeline
-
     pc = cfg.pipeline
     pc.ray_patch_size = (4, 4)
     pc.datamanager.dataparser = make_parser_classes(tmp_path)()
@@ -117,6 +115,15 @@ def pipeline(ref, tmp_path):
     pc.datamanager.pixel_sampler.patch_size, pc.datamanager.pixel_sampler.patch_scale = 4, pc.model.rgb_upsample_factor
     t._shrink(pc.model)
     pc.__post_init__()
+    return cfg
+
+
+@pytest.fixture()
+def pipeline(ref, tmp_path):
+    from neurad_studio_amd.integration.pipeline import ADHipDataManager, ADHipPipeline
+
+    cfg = _method_config(tmp_path)
+    pc = cfg.pipeline
     torch.manual_seed(0)
     pipe = pc.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, grad_scaler=None)
     assert isinstance(pipe, ADHipPipeline) and isinstance(pipe.datamanager, ADHipDataManager)
@@ -242,3 +249,80 @@ def test_fused_metrics_equal_the_references_get_metrics_dict(pipeline):
     for k, w in want.items():
         a, c = float(got[k]), float(w)
         assert abs(a - c) <= 2e-5 * abs(c) + 1e-7, (k, a, c)
+
+
+def test_ns_train_neurad_hip_from_config_setup_to_checkpoint(ref, tmp_path):
+    """What ``ns-train neurad-hip`` does after parsing its arguments (scripts/train.py:96-107,246-261): ``config.setup()`` ->
+    ``trainer.setup()`` -> ``trainer.train()`` -- here with the method's own config objects all the way: HipTrainer built by
+    ``TrainerConfig.setup``, its TableGradScaler, ``ADHipPipeline`` / ``ADHipDataManager`` built by ``trainer.setup()``, the
+    reference's ``Optimizers`` with HashGridAdam, the model's training callbacks, the reference's train loop with logging, and
+    checkpoints written by ``save_checkpoint`` (engine/trainer.py:499-533) mid-run and at the end.  The checkpoint must hold what
+    the reference's would: pipeline state, every optimizer's ``state_dict`` (HashGridAdam's in torch.optim.Adam's layout),
+    scheduler counts that match the optimizer steps taken, the scaler; a second trainer resumes from it."""
+    from nerfstudio.engine.optimizers import Optimizers
+
+    from neurad_studio_amd.integration.pipeline import ADHipDataManager, ADHipPipeline
+    from neurad_studio_amd.integration.trainer import HipTrainer
+    from neurad_studio_amd.optim import HashGridAdam, TableGradScaler
+
+    n_iter = 8
+    cfg = _method_config(tmp_path)
+    cfg.output_dir, cfg.experiment_name, cfg.timestamp = tmp_path / "outputs", "synthetic-drive", "run"
+    cfg.vis = "none"  # no viewer, no event writer (neither viser nor tensorboard is installed here); the local writer stays
+    cfg.max_num_iterations, cfg.steps_per_save = n_iter, 4
+    cfg.steps_per_eval_batch = cfg.steps_per_eval_image = cfg.steps_per_eval_all_images = 10 ** 9
+    cfg.logging.steps_per_log = 2
+    cfg.viewer.quit_on_train_completion = True
+    for group in cfg.optimizers.values():
+        group["scheduler"].warmup_steps = 0
+    cfg.get_base_dir().mkdir(parents=True)
+    torch.manual_seed(0)
+    trainer = cfg.setup(local_rank=0, world_size=1)
+    assert type(trainer) is HipTrainer and isinstance(trainer.grad_scaler, TableGradScaler) and trainer.mixed_precision
+    trainer.setup()
+    assert isinstance(trainer.pipeline, ADHipPipeline) and isinstance(trainer.pipeline.datamanager, ADHipDataManager)
+    assert isinstance(trainer.optimizers.optimizers["hashgrids"], HashGridAdam)
+    assert len(trainer.callbacks) >= 1  # the model's own (sampler anneal / step callbacks, models/neurad.py:291-300)
+    t._fill(trainer.pipeline.model)
+    table = trainer.pipeline.model.field.hashgrid.static_grid.hash_table
+    before = table.detach().clone()
+    trainer.train()
+    assert getattr(trainer, "_pending_scheduler_step", None) is None  # the last save_checkpoint settled it
+    ckpt = trainer.checkpoint_dir / f"step-{n_iter - 1:09d}.ckpt"
+    assert sorted(p.name for p in trainer.checkpoint_dir.glob("*.ckpt")) == [ckpt.name]  # save_only_latest_checkpoint
+    state = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert state["step"] == n_iter - 1 and set(state) >= {"pipeline", "optimizers", "schedulers", "scalers"}
+    hg = state["optimizers"]["hashgrids"]
+    idx = [i for i, p in enumerate(trainer.optimizers.optimizers["hashgrids"].param_groups[0]["params"]) if p is table][0]
+    steps = float(hg["state"][idx]["step"])
+    scale = state["scalers"]["scale"]
+    skipped = n_iter - steps
+    assert 1 <= steps <= n_iter and scale == 65536.0 * 0.5 ** skipped
+    for name, sched in state["schedulers"].items():
+        assert sched["last_epoch"] == steps, (name, sched["last_epoch"], steps)  # one scheduler step per optimizer step taken
+    assert not torch.equal(table.detach(), before)
+    assert torch.equal(state["pipeline"]["_model.field.hashgrid.static_grid.hash_table"], table.detach().cpu())
+
+    # resume (ns-train --load-dir): pipeline + scaler through Trainer._load_checkpoint, optimizers / schedulers through the
+    # reference's own loaders (its setup() calls _load_checkpoint before the optimizers exist: load_optimizer off there)
+    cfg2 = deepcopy(cfg)
+    cfg2.load_dir, cfg2.load_optimizer, cfg2.load_scheduler, cfg2.timestamp = trainer.checkpoint_dir, False, False, "resumed"
+    cfg2.get_base_dir().mkdir(parents=True)
+    resumed = cfg2.setup(local_rank=0, world_size=1)
+    # (the reference's schedulers compute their rates with numpy, so `_last_lr` in a checkpoint is a numpy scalar; its
+    #  `torch.load(path, map_location="cpu")` predates torch 2.6's weights_only default: allow-list what the file holds)
+    with torch.serialization.safe_globals([np.core.multiarray.scalar, np.dtype, type(np.dtype(np.float64)), type(np.dtype(np.int64))]):
+        resumed.setup()
+    assert resumed._start_step == n_iter and resumed.grad_scaler.get_scale() == scale
+    assert torch.equal(resumed.pipeline.model.field.hashgrid.static_grid.hash_table.detach(), table.detach())
+    assert isinstance(resumed.optimizers, Optimizers)
+    resumed.optimizers.load_optimizers(state["optimizers"])
+    resumed.optimizers.load_schedulers(state["schedulers"])
+    a, b = trainer.optimizers.optimizers["hashgrids"], resumed.optimizers.optimizers["hashgrids"]
+    for pa, pb in zip(a.param_groups[0]["params"], b.param_groups[0]["params"]):
+        if pa in a.state:
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(a.state[pa][k], b.state[pb][k].to(a.state[pa][k].device)), k
+            assert float(a.state[pa]["step"]) == float(b.state[pb]["step"])
+    loss, _, _ = resumed.train_iteration(n_iter)  # and it keeps training from there
+    assert torch.isfinite(loss)
