@@ -166,3 +166,37 @@ def test_bench_gpus_2_as_a_plain_command_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and len(out["dist"]["devices"]) == 2 and out["dist"]["backend"] == "gloo"
     assert "rehearsal" in out and out["value"] > 0
+
+
+def test_the_method_under_its_trainer_with_two_ranks():
+    """`ns-train neurad-hip` at world_size 2, rehearsed on one GPU over gloo: `bench.py --gpus 2 --config c3 --via-plugin-only`
+    steps NeuRADHipModel under HipTrainer (deferred scheduler step) + TableGradScaler on both ranks, with
+    GradientSynchronizer(auto_sync=True) exchanging every gradient at the end of backward -- BEFORE the scaler's inf check, so
+    that both ranks skip or step together -- and the reference's own Trainer.train_iteration over the same objects after it.
+    Needs the reference (oracle/_ref).  Not a scaling number."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("no reference (oracle/_ref ships with the lease)")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env["NRHIP_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c3", "--via-plugin-only",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    via = out["train_via_plugin"]
+    assert out["n_gpus"] == 2 and out["dist"]["backend"] == "gloo" and "error" not in via
+    assert via["trainer"] == "HipTrainer" and via["grad_scaler"] == "TableGradScaler"
+    assert via["optimizers"]["hashgrids"] == "HashGridAdam"
+    assert via["grad_exchange_bytes_per_rank"] > 5e8  # the table gradients went through the exchange (0.56 GB per rank)
+    assert via["grad_scaler_scale"] == 65536.0 and via["ms_per_iter"] > 0 and via["ms_per_iter_under_the_reference_trainer"] > 0
